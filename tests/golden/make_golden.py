@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REAL reference Python
+(/root/reference/lib, py2 code) under small py3 shims, plus the reference's
+Cython NMS/IoU compiled into oracle/_ref (oracle/build_ref.py).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes tests/golden/*.npz.  The shims do not change any arithmetic:
+  * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
+    cPickle -> pickle, bytes config defaults decoded to str;
+  * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
+    NumPy functions living in files that import them can be imported.
+"""
+import builtins
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        full = self.__name__ + '.' + name
+        m = _Stub(full)
+        sys.modules[full] = m
+        setattr(self, name, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return _Stub(self.__name__ + '()')
+
+
+def _install_shims():
+    np.float = float
+    np.int = int
+    builtins.basestring = str
+    builtins.unicode = str
+    sys.modules['cPickle'] = pickle
+    for root in ('caffe2', 'cv2', 'pycocotools', 'h5py'):
+        sys.modules[root] = _Stub(root)
+    for sub in ('caffe2.python', 'caffe2.python.core', 'caffe2.python.workspace', 'caffe2.python.scope',
+                'caffe2.python.cnn', 'caffe2.python.muji', 'caffe2.python.utils', 'caffe2.proto',
+                'caffe2.proto.caffe2_pb2', 'pycocotools.mask', 'pycocotools.coco', 'pycocotools.cocoeval',
+                'caffe2.python.modeling', 'caffe2.python.modeling.parameter_info', 'caffe2.python.memonger',
+                'caffe2.python.dyndep'):
+        parent, _, leaf = sub.rpartition('.')
+        getattr(sys.modules[parent], leaf)
+    from oracle import build_ref
+    build_ref.build()
+    nms_mod, bbox_mod = build_ref.load()
+    sys.path.insert(0, '/root/reference/lib')
+    import utils  # noqa  (reference package)
+    sys.modules['utils.cython_nms'] = nms_mod
+    sys.modules['utils.cython_bbox'] = bbox_mod
+    from core.config import cfg
+
+    def fix(d):
+        for k, v in d.items():
+            if isinstance(v, bytes):
+                d[k] = v.decode()
+            elif isinstance(v, dict):
+                fix(v)
+    fix(cfg)
+    return cfg
+
+
+class _Blob(object):
+    def __init__(self, data=None):
+        self.data = data
+        self.shape = None if data is None else data.shape
+
+    def reshape(self, shape):
+        self.data = np.zeros(shape, dtype=np.float32)
+        self.shape = tuple(shape)
+
+    def init(self, shape, dtype_code):  # utils/blob.py py_op_copy_blob int32 path
+        self.data = np.zeros(shape, dtype=np.int32)
+        self.shape = tuple(shape)
+
+
+def main():
+    cfg = _install_shims()
+    from modeling.generate_anchors import generate_anchors
+    import utils.boxes as box_utils
+    from core.nms_wrapper import nms
+    from ops.generate_proposals import GenerateProposalsOp
+    from ops.roi_blob_transforms import RoIToBatchFormatOp
+    rs = np.random.RandomState(3)
+    out = {}
+
+    # ---- anchors -------------------------------------------------------------------
+    out['anchors_s16_3x3'] = generate_anchors(16, (128, 256, 512), (0.5, 1, 2))
+    out['anchors_c4_default'] = generate_anchors(16., cfg.RPN.SIZES, cfg.RPN.ASPECT_RATIOS, time_dim=1)
+    out['anchors_c4_T3'] = generate_anchors(16., cfg.RPN.SIZES, cfg.RPN.ASPECT_RATIOS, time_dim=3)
+    for lvl in range(2, 7):
+        out['anchors_fpn%d' % lvl] = generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2), time_dim=1)
+
+    # ---- bbox transforms ---------------------------------------------------------------
+    def rand_boxes(n, T=1, W=320., H=256.):
+        b = np.zeros((n, 4 * T), dtype=np.float32)
+        for t in range(T):
+            x1 = rs.uniform(0, W - 20, n)
+            y1 = rs.uniform(0, H - 20, n)
+            b[:, 4 * t + 0] = x1
+            b[:, 4 * t + 1] = y1
+            b[:, 4 * t + 2] = x1 + rs.uniform(4, 120, n)
+            b[:, 4 * t + 3] = y1 + rs.uniform(4, 120, n)
+        return b
+    boxes = rand_boxes(64)
+    deltas = (rs.randn(64, 4) * 0.5).astype(np.float32)
+    out['bt_boxes'], out['bt_deltas'] = boxes, deltas
+    out['bt_out_w1'] = box_utils.bbox_transform(boxes.astype(np.float64), deltas, (1., 1., 1., 1.))
+    out['bt_out_w10'] = box_utils.bbox_transform(boxes.astype(np.float64), deltas, (10., 10., 5., 5.))
+    tb = rand_boxes(32, T=3)
+    td = (rs.randn(32, 2 * 3 * 4) * 0.5).astype(np.float32)  # 2 classes x 3 frames
+    out['tt_boxes'], out['tt_deltas'] = tb, td
+    out['tt_out'] = box_utils.bbox_transform(tb.astype(np.float64), td, (10., 10., 5., 5.))
+    out['clip_out'] = box_utils.clip_tiled_boxes(out['tt_out'].copy(), (256, 320))
+    gt = rand_boxes(64)
+    out['inv_gt'] = gt
+    out['inv_out'] = box_utils.bbox_transform_inv(boxes, gt, (10., 10., 5., 5.))
+
+    # ---- IoU + NMS (reference Cython, compiled) ----------------------------------------------
+    a = rand_boxes(50)
+    b = rand_boxes(70)
+    out['iou_a'], out['iou_b'] = a, b
+    out['iou_out'] = box_utils.bbox_overlaps(a, b)
+    ta, tb2 = rand_boxes(20, T=3), rand_boxes(30, T=3)
+    out['iou_ta'], out['iou_tb'] = ta, tb2
+    out['iou_tube_out'] = box_utils.bbox_overlaps(ta, tb2)
+    for n, thr in ((300, 0.3), (300, 0.5), (1000, 0.7), (1, 0.5), (2, 0.5)):
+        d = np.hstack((rand_boxes(n, W=200., H=160.), rs.uniform(0, 1, (n, 1)).astype(np.float32))).astype(np.float32)
+        key = 'nms_n%d_t%d' % (n, int(thr * 10))
+        out[key + '_dets'] = d
+        out[key + '_keep'] = np.asarray(nms(d, thr), dtype=np.int64)
+    for n, T, thr in ((200, 3, 0.5), (120, 8, 0.7), (1, 3, 0.5)):
+        d = rand_boxes(n, T=1, W=200., H=160.)
+        jit = [d + rs.uniform(-6, 6, d.shape).astype(np.float32) for _ in range(T)]
+        d = np.hstack(jit + [rs.uniform(0, 1, (n, 1)).astype(np.float32)]).astype(np.float32)
+        key = 'tnms_n%d_T%d_t%d' % (n, T, int(thr * 10))
+        out[key + '_dets'] = d
+        out[key + '_keep'] = np.asarray(nms(d, thr), dtype=np.int64)
+
+    # ---- GenerateProposalsOp (the real op class) -------------------------------------------------
+    def run_gp(name, A_anchors, H, W, T, stride, pre, post, thr, min_size, im_hw):
+        cfg.TEST.RPN_PRE_NMS_TOP_N = pre
+        cfg.TEST.RPN_POST_NMS_TOP_N = post
+        cfg.TEST.RPN_NMS_THRESH = thr
+        cfg.TEST.RPN_MIN_SIZE = min_size
+        A = A_anchors.shape[0]
+        scores = rs.uniform(0, 1, (1, A, H, W)).astype(np.float32)
+        deltas = (rs.randn(1, 4 * A * T, H, W) * 0.3).astype(np.float32)
+        im_info = np.array([[im_hw[0], im_hw[1], 1.25]], dtype=np.float32)
+        op = GenerateProposalsOp(A_anchors, 1. / stride, False)
+        outs = [_Blob(), _Blob()]
+        op.forward([_Blob(scores), _Blob(deltas), _Blob(im_info)], outs)
+        out[name + '_scores'], out[name + '_deltas'], out[name + '_im_info'] = scores, deltas, im_info
+        out[name + '_anchors'] = A_anchors
+        out[name + '_cfg'] = np.array([stride, pre, post, thr, min_size], dtype=np.float64)
+        out[name + '_rois'], out[name + '_probs'] = outs[0].data, outs[1].data
+    run_gp('gp_fpn3', out['anchors_fpn3'], 32, 40, 1, 8., 1000, 300, 0.7, 0, (256, 320))
+    run_gp('gp_fpn2_min', out['anchors_fpn2'], 24, 28, 1, 4., 500, 200, 0.7, 16, (96, 112))
+    run_gp('gp_c4_T3', out['anchors_c4_T3'], 16, 20, 3, 16., 600, 150, 0.7, 0, (256, 320))
+
+    # ---- RoIToBatchFormat (real op) ------------------------------------------------------------------
+    tr = np.hstack((np.zeros((5, 1), np.float32), rand_boxes(5, T=3)))
+    ob = [_Blob()]
+    RoIToBatchFormatOp().forward([_Blob(tr)], ob)
+    out['r2b_in'], out['r2b_out'] = tr, ob[0].data
+
+    # ---- FPN level mapping + collect/distribute (real functions; caffe2 stubbed) ----------------------
+    import modeling.FPN as fpn
+    import ops.collect_and_distribute_fpn_rpn_proposals as cd
+    rois = np.hstack((np.zeros((400, 1), np.float32), rand_boxes(400, W=1300., H=740.)))
+    rois[:, 3] = rois[:, 1] + rs.uniform(4, 700, 400)
+    rois[:, 4] = rois[:, 2] + rs.uniform(4, 600, 400)
+    out['lvl_rois'] = rois
+    out['lvl_out'] = fpn.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    cfg.FPN.RPN_MAX_LEVEL, cfg.FPN.RPN_MIN_LEVEL = 6, 2
+    rl = [np.hstack((np.zeros((n, 1), np.float32), rand_boxes(n, W=1300., H=740.))) for n in (120, 100, 80, 40, 10)]
+    sl = [rs.uniform(0, 1, (r.shape[0], 1)).astype(np.float32) for r in rl]
+    for i in range(5):
+        out['cd_rois%d' % i], out['cd_scores%d' % i] = rl[i], sl[i]
+    collected = cd.collect([_Blob(r) for r in rl] + [_Blob(s) for s in sl], False)
+    outs = [_Blob() for _ in range(6)]
+    # blob_utils.py_op_copy_blob is a caffe2-stubbed import here; replicate its int32 copy by hand
+    import utils.blob as blob_utils
+    blob_utils.py_op_copy_blob = lambda arr, blob: setattr(blob, 'data', np.array(arr))
+    cd.blob_utils = blob_utils
+    cd.distribute(collected, None, outs, False)
+    out['cd_out_rois'] = outs[0].data
+    for i in range(4):
+        out['cd_out_fpn%d' % (i + 2)] = outs[1 + i].data
+    out['cd_out_restore'] = np.asarray(outs[5].data, dtype=np.int32)
+
+    # ---- weight inflation (utils/net.py:95-161) ---------------------------------------------------------
+    import utils.net as net_utils
+    w2d = rs.randn(8, 4, 3, 3).astype(np.float32)
+    for mode in ('mean-repeat', 'repeat', 'center-only'):
+        cfg.VIDEO.WEIGHTS_INFLATE_MODE = mode
+        out['inflate_' + mode.replace('-', '_')] = net_utils.inflate_weights(
+            w2d, np.zeros((8, 4, 3, 3, 3), np.float32), 'x_w', {'x_w': w2d})
+    out['inflate_src'] = w2d
+
+    np.savez_compressed(os.path.join(HERE, 'reference_host.npz'), **out)
+    print('wrote', os.path.join(HERE, 'reference_host.npz'), len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()
