@@ -1,0 +1,79 @@
+// Context, error text and per-launch profiling of libdat_hip (see include/dat_hip.h).
+#include "dat_common.h"
+
+extern "C" {
+
+int dat_version(void) { return 1; }
+
+int dat_ctx_create(dat_ctx** out, int device) {
+    if (!out) return DAT_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DAT_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return DAT_ERR_ARG;
+    dat_ctx* c = new dat_ctx();
+    c->device = device;
+    c->prof_enabled = 0;
+    c->prof_ev = nullptr;
+    c->prof_cap = c->prof_n = 0;
+    c->prof_flops = nullptr;
+    c->prof_tag = nullptr;
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    *out = c;
+    return DAT_OK;
+}
+
+void dat_ctx_destroy(dat_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i) hipEventDestroy(ctx->prof_ev[i]);
+        delete[] ctx->prof_ev;
+        delete[] ctx->prof_flops;
+        delete[] ctx->prof_tag;
+    }
+    if (ctx->ws) hipFree(ctx->ws);
+    delete ctx;
+}
+
+const char* dat_last_error(dat_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null dat_ctx"; }
+
+int dat_prof_enable(dat_ctx* ctx, int capacity) {
+    if (!ctx) return DAT_ERR_ARG;
+    if (capacity <= 0) {
+        ctx->prof_enabled = 0;
+        return DAT_OK;
+    }
+    if (capacity > ctx->prof_cap) {
+        if (ctx->prof_ev) {
+            for (int i = 0; i < 2 * ctx->prof_cap; ++i) hipEventDestroy(ctx->prof_ev[i]);
+            delete[] ctx->prof_ev;
+            delete[] ctx->prof_flops;
+            delete[] ctx->prof_tag;
+        }
+        ctx->prof_ev = new hipEvent_t[2 * capacity];
+        for (int i = 0; i < 2 * capacity; ++i) hipEventCreate(&ctx->prof_ev[i]);
+        ctx->prof_flops = new double[capacity];
+        ctx->prof_tag = new int[capacity];
+        ctx->prof_cap = capacity;
+    }
+    ctx->prof_n = 0;
+    ctx->prof_enabled = 1;
+    return DAT_OK;
+}
+
+int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float* ms) {
+    if (!ctx) return DAT_ERR_ARG;
+    const int n = ctx->prof_n < max_records ? ctx->prof_n : max_records;
+    for (int i = 0; i < n; ++i) {
+        hipEventSynchronize(ctx->prof_ev[2 * i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]);
+        if (tags) tags[i] = ctx->prof_tag[i];
+        if (flops) flops[i] = ctx->prof_flops[i];
+        if (ms) ms[i] = t;
+    }
+    ctx->prof_n = 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,520 @@
+// Fused 3D convolution as an MFMA implicit GEMM for gfx950 (CDNA4).
+//
+//   y[f, oh, ow, co] = act( sum_{kt,kh,kw,ci} x[f+kt-pt, oh*sh+kh-ph, ow*sw+kw-pw, ci] * w[kt,kh,kw][co][ci]
+//                           * scale[co] + bias[co] + residual )
+//
+// Replaces the reference's ConvNd -> AffineChannelNd -> (Sum) -> Relu op chains
+// (lib/modeling/ResNet3D.py:21-154, FPN3D.py:109-222, detector.py:410-438; elementwise semantics of
+// lib/ops/affine_channel_nd_op.cu:20-32) with ONE kernel: the affine/bias, the residual Sum (also the FPN
+// nearest-2x top-down Sum) and the ReLU live in the epilogue, so a conv output crosses HBM once.
+//
+// Design (MI355X-first, not a cuDNN translation):
+//   * activations NDHWC, so the GEMM K axis (input channels of one tap) is contiguous: every LDS row is
+//     one 128-byte line = 64 bf16 / 32 fp32 channels of one input position;
+//   * the block stages an INPUT PATCH (output tile + halo) in LDS once per (kt, channel chunk) and reuses it
+//     for all KH*KW spatial taps — the im2col matrix never exists, and global->LDS traffic for activations
+//     drops by ~KH*KW versus a tap-by-tap implicit GEMM; only the weight tile streams per tap
+//     (double-buffered, prefetched into registers one tap ahead);
+//   * MFMA operands: A = weights (rows = output channels), B = activations (cols = output positions), both
+//     read from LDS as one ds_read_b128 per lane per k-slice with an XOR swizzle ((row>>1)&7) that makes
+//     the 16-lane read groups conflict-free for consecutive rows;
+//   * bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate); fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact
+//     fp32 fma chain) consuming the same 16-byte LDS reads as 4 k-steps;
+//   * D layout (col = lane&31 = position, rows = 4 consecutive channels per register quad) gives 8/16-byte
+//     channel-contiguous NDHWC stores in the epilogue;
+//   * blockIdx -> tile mapping is XCD-aware: output-channel blocks of one spatial tile and neighbouring
+//     tiles land on the same XCD (shared L2 for patch + weights).
+#include "dat_common.h"
+
+namespace {
+
+constexpr int ROWB = 128;   // bytes per LDS row (one 128-B line of channels)
+constexpr int NTHREADS = 256;
+
+struct ConvParams {
+    const char* x;
+    const char* w;
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int frames, T, H, W, Cin;
+    int Ho, Wo, Cout, out_cs, Cout_pad;
+    int KT, KH, KW, sh, sw, pt, ph, pw;
+    int relu, res_mode;
+    int th_log2, tw_log2;     // output tile = 2^th x 2^tw positions
+    int tiles_h, tiles_w;
+    int PH, PW;               // patch rows/cols (LDS rows = PH*PW)
+    int psh, psw;             // patch sampling step in the input (stride for 1x1 kernels, else 1)
+    int ash, asw;             // patch-row step per output position (stride for KxK kernels, else 1)
+    int n_cchunks;            // Cin / CK
+    int nblk_n;               // Cout_pad / BN
+    unsigned nblocks;
+};
+
+template <int DT> struct Mma;
+template <> struct Mma<DAT_BF16> {
+    static constexpr int CK = 64;  // channels per 128-B row
+    __device__ static __forceinline__ void step(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                    c, 0, 0, 0);
+    }
+};
+template <> struct Mma<DAT_F32> {
+    static constexpr int CK = 32;
+    __device__ static __forceinline__ void step(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + (((slot ^ (row >> 1)) & 7) << 4); }
+
+// BN = output channels per block, BP = output positions per block, WAVES_N x WAVES_P = 4 waves.
+template <int DT, int BN, int BP, int WAVES_N>
+__global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams p) {
+    constexpr int ES = ElemOf<DT>::size;
+    constexpr int CK = Mma<DT>::CK;
+    constexpr int WAVES_P = 4 / WAVES_N;
+    constexpr int WN = BN / WAVES_N;      // channels per wave
+    constexpr int WP = BP / WAVES_P;      // positions per wave
+    constexpr int MT = WN / 32;
+    constexpr int PT = WP / 32;
+    constexpr int W_ITEMS = BN * 8 / NTHREADS;  // 16-B items of the weight tile per thread
+    static_assert(MT >= 1 && PT >= 1 && W_ITEMS >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wbuf = smem;                       // 2 x BN x 128 B
+    char* patch = smem + 2 * BN * ROWB;      // PH*PW x 128 B
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_n = wave % WAVES_N;
+    const int wave_p = wave / WAVES_N;
+
+    // ---- XCD-aware block -> (channel block, tile) map (bijective for any grid size) ----
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nx = 8, q = p.nblocks / nx, r = p.nblocks % nx;
+        const unsigned xcd = bid % nx, k = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int nb = bid % p.nblk_n;
+    unsigned tile = bid / p.nblk_n;
+    const int tw_i = tile % p.tiles_w;
+    tile /= p.tiles_w;
+    const int th_i = tile % p.tiles_h;
+    const int f = tile / p.tiles_h;          // output frame (n*T + t)
+    const int t = f % p.T;
+    const int n0 = nb * BN;
+    const int TW = 1 << p.tw_log2;
+    const int oh0 = th_i << p.th_log2;
+    const int ow0 = tw_i << p.tw_log2;
+    // input coordinate of patch cell (0,0)
+    const int ih0 = oh0 * p.sh - p.ph;
+    const int iw0 = ow0 * p.sw - p.pw;
+
+    // per-lane patch row of each position sub-tile (tap offset added per tap)
+    int rowbase[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int pos = wave_p * WP + j * 32 + (lane & 31);
+        const int ohl = pos >> p.tw_log2, owl = pos & (TW - 1);
+        rowbase[j] = ohl * p.ash * p.PW + owl * p.asw;
+    }
+    const int khalf = lane >> 5;
+
+    f32x16_t acc[MT][PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // valid temporal taps for this output frame
+    int kt_lo = 0, kt_hi = p.KT - 1;
+    while (kt_lo < p.KT && (t + kt_lo - p.pt) < 0) ++kt_lo;
+    while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.T) --kt_hi;
+    const int n_kt = kt_hi - kt_lo + 1;
+    const int ntap = p.KH * p.KW;
+    const int total = n_kt * p.n_cchunks * ntap;
+
+    const size_t w_tap_stride = (size_t)p.Cout_pad * p.Cin * ES;  // bytes between taps
+    const int npatch_items = p.PH * p.PW * 8;
+
+    // weight tile prefetch registers
+    uint4 wreg[W_ITEMS];
+    auto w_prefetch = [&](int kt, int cc, int tap) {
+        const char* base = p.w + (size_t)(kt * ntap + tap) * w_tap_stride + (size_t)cc * CK * ES;
+#pragma unroll
+        for (int i = 0; i < W_ITEMS; ++i) {
+            const int it = tid + i * NTHREADS;
+            const int row = it >> 3, slot = it & 7;
+            wreg[i] = *(const uint4*)(base + (size_t)(n0 + row) * p.Cin * ES + slot * 16);
+        }
+    };
+    auto w_commit = [&](int buf) {
+        char* dst = wbuf + buf * BN * ROWB;
+#pragma unroll
+        for (int i = 0; i < W_ITEMS; ++i) {
+            const int it = tid + i * NTHREADS;
+            const int row = it >> 3, slot = it & 7;
+            *(uint4*)(dst + swz(row, slot)) = wreg[i];
+        }
+    };
+    auto patch_load = [&](int kt, int cc) {
+        const int fin = f + kt - p.pt;
+        const char* base = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+        for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * 4) {
+            uint4 v[4];
+            int rows[4], slots[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * NTHREADS;
+                const int row = it >> 3, slot = it & 7;
+                rows[u] = row;
+                slots[u] = slot;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (it < npatch_items) {
+                    const int prow = row / p.PW, pcol = row - prow * p.PW;
+                    const int ih = ih0 + prow * p.psh, iw = iw0 + pcol * p.psw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        v[u] = *(const uint4*)(base + ((size_t)ih * p.W + iw) * p.Cin * ES + slot * 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (it0 + u * NTHREADS < npatch_items) *(uint4*)(patch + swz(rows[u], slots[u])) = v[u];
+        }
+    };
+
+    if (total > 0) {
+        int kt = kt_lo, cc = 0, tap = 0;
+        w_prefetch(kt, cc, tap);
+        for (int step = 0; step < total; ++step) {
+            if (tap == 0) {
+                __syncthreads();  // all waves finished reading the previous patch
+                patch_load(kt, cc);
+            }
+            w_commit(step & 1);
+            __syncthreads();
+            // advance to the next (kt, cc, tap) and prefetch its weight tile
+            int ntap_i = tap + 1, ncc = cc, nkt = kt;
+            if (ntap_i == ntap) {
+                ntap_i = 0;
+                if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
+            }
+            if (step + 1 < total) w_prefetch(nkt, ncc, ntap_i);
+
+            // ---- compute this tap: 4 k-slices of 16 B per row ----
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int tapoff = (p.psh == 1 ? kh : 0) * p.PW + (p.psw == 1 ? kw : 0);
+            const char* wb = wbuf + (step & 1) * BN * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int slot = ks * 2 + khalf;
+                uint4 a[MT], b[PT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(wb + swz(wave_n * WN + i * 32 + (lane & 31), slot));
+#pragma unroll
+                for (int j = 0; j < PT; ++j) b[j] = *(const uint4*)(patch + swz(rowbase[j] + tapoff, slot));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) Mma<DT>::step(a[i], b[j], acc[i][j]);
+            }
+            tap = ntap_i;
+            cc = ncc;
+            kt = nkt;
+        }
+    }
+
+    // ---- epilogue: affine/bias + residual + relu, channel-contiguous stores ----
+    // D[i = channel][j = position]: lane holds position lane&31; register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int pos = wave_p * WP + j * 32 + (lane & 31);
+        const int oh = oh0 + (pos >> p.tw_log2), ow = ow0 + (pos & (TW - 1));
+        if (oh >= p.Ho || ow >= p.Wo) continue;
+        const size_t opos = ((size_t)f * p.Ho + oh) * p.Wo + ow;
+        size_t rpos = opos;
+        if (p.res_mode == 2) rpos = ((size_t)f * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = n0 + wave_n * WN + i * 32 + g * 8 + khalf * 4;
+                if (c >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+                if (p.scale) {
+                    const float4 s = *(const float4*)(p.scale + c);
+                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                }
+                if (p.bias) {
+                    const float4 b = *(const float4*)(p.bias + c);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (p.res_mode) {
+                    if (DT == DAT_BF16) {
+                        const uint2 r = *(const uint2*)(p.res + (rpos * p.out_cs + c) * 2);
+                        v[0] += bf2f((uint16_t)(r.x & 0xffff)); v[1] += bf2f((uint16_t)(r.x >> 16));
+                        v[2] += bf2f((uint16_t)(r.y & 0xffff)); v[3] += bf2f((uint16_t)(r.y >> 16));
+                    } else {
+                        const float4 r = *(const float4*)(p.res + (rpos * p.out_cs + c) * 4);
+                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (DT == DAT_BF16) {
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *(uint2*)(p.y + (opos * p.out_cs + c) * 2) = o;
+                } else {
+                    *(float4*)(p.y + (opos * p.out_cs + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 [Cout_real, Cin_real, KT, KH, KW] -> [tap][Cout_pad][Cin] in dtype, zero padded
+template <int DT>
+__global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real, int Cin_real,
+                                    int ntap, int Cout_pad, int Cin) {
+    const size_t total = (size_t)ntap * Cout_pad * Cin;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = i % Cin;
+        const int co = (i / Cin) % Cout_pad;
+        const int tap = i / ((size_t)Cin * Cout_pad);
+        float v = 0.f;
+        if (co < Cout_real && ci < Cin_real) v = w[((size_t)co * Cin_real + ci) * ntap + tap];
+        ElemOf<DT>::st(out, i, v);
+    }
+}
+
+// stem packing (see dat_hip.h: dat_stem_pack)
+template <int DT>
+__global__ void stem_pack_kernel(const float* __restrict__ data, void* __restrict__ out, int N, int T, int H, int W,
+                                 int Ho, int Wo) {
+    const int R = Ho + 3;
+    const size_t total = (size_t)N * T * R * Wo * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = i & 63;
+        size_t q = i >> 6;
+        const int ow = q % Wo; q /= Wo;
+        const int r = q % R; q /= R;
+        const int t = q % T;
+        const int n = q / T;
+        const int dkh = ch >> 5, rem = ch & 31;
+        float v = 0.f;
+        if (rem < 21) {
+            const int kw = rem / 3, c = rem - kw * 3;
+            const int ih = 2 * r - 3 + dkh, iw = 2 * ow - 3 + kw;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                v = data[((((size_t)n * 3 + c) * T + t) * H + ih) * W + iw];
+        }
+        ElemOf<DT>::st(out, i, v);
+    }
+}
+
+// conv1_w [Cout,3,1,7,7] -> [Cout,64,1,4,1]; channel dkh*32 + kw*3 + c of tap j holds w[co,c,0,2j+dkh,kw]
+__global__ void stem_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout) {
+    const int total = Cout * 64 * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 3;
+        const int ch = (i >> 2) & 63;
+        const int co = i >> 8;
+        const int dkh = ch >> 5, rem = ch & 31;
+        float v = 0.f;
+        const int kh = 2 * j + dkh;
+        if (rem < 21 && kh < 7) {
+            const int kw = rem / 3, c = rem - kw * 3;
+            v = w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw];
+        }
+        out[i] = v;
+    }
+}
+
+struct TileChoice {
+    int th_log2, tw_log2;
+};
+
+// pick the 2^a x 2^b tile (a+b = log2(BP)) that wastes the fewest output positions, tie -> squarer patch
+TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int KW) {
+    TileChoice best{0, bp_log2};
+    double best_cost = 1e30;
+    for (int a = 0; a <= bp_log2; ++a) {
+        const int b = bp_log2 - a;
+        const long long th = 1 << a, tw = 1 << b;
+        const long long tiles = cdiv_ll(Ho, th) * cdiv_ll(Wo, tw);
+        const double waste = (double)(tiles * th * tw) / ((double)Ho * Wo);
+        const long long PH = (KH == 1) ? th : (th - 1) * sh + KH;
+        const long long PW = (KW == 1) ? tw : (tw - 1) * sw + KW;
+        const double halo = (double)(PH * PW) / (double)(th * tw);
+        const double cost = waste * (1.0 + 0.15 * (halo - 1.0));
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = TileChoice{a, b};
+        }
+    }
+    return best;
+}
+
+template <int DT, int BN, int BP, int WAVES_N>
+int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
+    const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW);
+    p.th_log2 = tc.th_log2;
+    p.tw_log2 = tc.tw_log2;
+    const int th = 1 << tc.th_log2, tw = 1 << tc.tw_log2;
+    p.tiles_h = (p.Ho + th - 1) / th;
+    p.tiles_w = (p.Wo + tw - 1) / tw;
+    p.psh = (p.KH == 1) ? p.sh : 1;
+    p.psw = (p.KW == 1) ? p.sw : 1;
+    p.ash = (p.KH == 1) ? 1 : p.sh;
+    p.asw = (p.KW == 1) ? 1 : p.sw;
+    p.PH = (p.KH == 1) ? th : (th - 1) * p.sh + p.KH;
+    p.PW = (p.KW == 1) ? tw : (tw - 1) * p.sw + p.KW;
+    p.n_cchunks = p.Cin / Mma<DT>::CK;
+    p.nblk_n = p.Cout_pad / BN;
+    const long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
+    DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
+    p.nblocks = (unsigned)nblocks;
+    const size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * ROWB;
+    DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
+                th, tw, p.sh, p.sw);
+    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NTHREADS), lds, st, p);
+    DAT_CHECK_LAUNCH(ctx, "conv3d_igemm");
+    return DAT_OK;
+}
+
+int cout_pad_of(const dat_conv_desc* d) {
+    const int bn = d->Cout <= 64 ? 64 : 128;
+    return (d->Cout + bn - 1) / bn * bn;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dat_conv3d_out_shape(const dat_conv_desc* d, int* Ho, int* Wo) {
+    if (!d || d->stride_h < 1 || d->stride_w < 1) return DAT_ERR_ARG;
+    *Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
+    *Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    return DAT_OK;
+}
+
+size_t dat_conv3d_packed_weight_bytes(const dat_conv_desc* d) {
+    return (size_t)d->KT * d->KH * d->KW * cout_pad_of(d) * d->Cin * dat_esize(d->dtype);
+}
+
+double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
+    int Ho, Wo;
+    dat_conv3d_out_shape(d, &Ho, &Wo);
+    return 2.0 * Cout_real * Cin_real * d->KT * d->KH * d->KW * (double)d->frames * Ho * Wo;
+}
+
+int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w, int Cout_real,
+                            int Cin_real, void* packed) {
+    DAT_ENFORCE(ctx, d && w && packed, "conv3d_pack_weights: null argument");
+    DAT_ENFORCE(ctx, Cout_real <= d->Cout && Cin_real <= d->Cin, "conv3d_pack_weights: real dims exceed descriptor");
+    const int ntap = d->KT * d->KH * d->KW;
+    const int cp = cout_pad_of(d);
+    const size_t total = (size_t)ntap * cp * d->Cin;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    if (d->dtype == DAT_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
+                           Cout_real, Cin_real, ntap, cp, d->Cin);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
+                           Cout_real, Cin_real, ntap, cp, d->Cin);
+    DAT_CHECK_LAUNCH(ctx, "pack_weights");
+    return DAT_OK;
+}
+
+int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                   const float* scale, const float* bias, const void* residual, void* y) {
+    DAT_ENFORCE(ctx, d && x && w_packed && y, "conv3d_fwd: null argument");
+    DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_fwd: bad dtype %d", d->dtype);
+    DAT_ENFORCE(ctx, d->Cin % 64 == 0, "conv3d_fwd: Cin (channel stride) %d must be a multiple of 64", d->Cin);
+    DAT_ENFORCE(ctx, d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_cstride >= d->Cout,
+                "conv3d_fwd: Cout %d / out_cstride %d must be multiples of 4", d->Cout, d->out_cstride);
+    DAT_ENFORCE(ctx, d->frames % d->T == 0, "conv3d_fwd: frames %d not a multiple of T %d", d->frames, d->T);
+    DAT_ENFORCE(ctx, d->res_mode == 0 || residual, "conv3d_fwd: res_mode %d needs a residual pointer", d->res_mode);
+    DAT_ENFORCE(ctx, d->pad_t * 2 + 1 == d->KT, "conv3d_fwd: temporal pad %d must be (KT-1)/2 for KT %d (output T == input T)",
+                d->pad_t, d->KT);
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
+    p.res = (const char*)residual; p.y = (char*)y;
+    p.frames = d->frames; p.T = d->T; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    dat_conv3d_out_shape(d, &p.Ho, &p.Wo);
+    DAT_ENFORCE(ctx, p.Ho > 0 && p.Wo > 0, "conv3d_fwd: empty output %dx%d", p.Ho, p.Wo);
+    DAT_ENFORCE(ctx, d->res_mode != 2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0), "conv3d_fwd: res_mode 2 needs even output dims");
+    p.Cout = d->Cout; p.out_cs = d->out_cstride; p.Cout_pad = cout_pad_of(d);
+    p.KT = d->KT; p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;
+    p.pt = d->pad_t; p.ph = d->pad_h; p.pw = d->pad_w; p.relu = d->relu; p.res_mode = d->res_mode;
+    hipStream_t st = (hipStream_t)s;
+
+    const bool small_n = d->Cout <= 64;
+    int tag = (small_n ? 64 : 128) * 1000 + 128 * 10 + d->dtype;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap) {
+        e0 = ctx->prof_ev[2 * ctx->prof_n];
+        e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
+        hipEventRecord(e0, st);
+    }
+    int rc;
+    if (d->dtype == DAT_BF16)
+        rc = small_n ? launch_conv<DAT_BF16, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_BF16, 128, 128, 2>(ctx, st, p, 7);
+    else
+        rc = small_n ? launch_conv<DAT_F32, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_F32, 128, 128, 2>(ctx, st, p, 7);
+    if (e1) {
+        hipEventRecord(e1, st);
+        ctx->prof_flops[ctx->prof_n] = 2.0 * d->Cout * d->Cin * d->KT * d->KH * d->KW * (double)d->frames * p.Ho * p.Wo;
+        ctx->prof_tag[ctx->prof_n] = tag;
+        ctx->prof_n++;
+    }
+    return rc;
+}
+
+int dat_stem_pack(dat_ctx* ctx, dat_stream s, const float* data, void* packed, int dtype, int N, int T, int H, int W) {
+    DAT_ENFORCE(ctx, data && packed, "stem_pack: null argument");
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const size_t total = (size_t)N * T * (Ho + 3) * Wo * 64;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    if (dtype == DAT_BF16)
+        hipLaunchKernelGGL(stem_pack_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, packed, N, T, H,
+                           W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_pack_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, packed, N, T, H, W,
+                           Ho, Wo);
+    DAT_CHECK_LAUNCH(ctx, "stem_pack");
+    return DAT_OK;
+}
+
+int dat_stem_weights(dat_ctx* ctx, dat_stream s, const float* conv1_w, int Cout, float* w_k4) {
+    DAT_ENFORCE(ctx, conv1_w && w_k4 && Cout > 0, "stem_weights: bad argument");
+    hipLaunchKernelGGL(stem_weights_kernel, dim3((Cout * 256 + 255) / 256), dim3(256), 0, (hipStream_t)s, conv1_w, w_k4,
+                       Cout);
+    DAT_CHECK_LAUNCH(ctx, "stem_weights");
+    return DAT_OK;
+}
+
+}  // extern "C"

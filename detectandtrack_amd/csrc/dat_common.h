@@ -1,0 +1,72 @@
+// Shared device/host helpers for libdat_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/dat_hip.h"
+
+struct dat_ctx {
+    int device;
+    std::string last_error;
+    // optional per-launch timing of the conv kernel (bench.py roofline leg)
+    int prof_enabled;
+    hipEvent_t* prof_ev;   // pairs
+    int prof_cap, prof_n;
+    double* prof_flops;    // algorithmic flops per recorded launch
+    int* prof_tag;         // kernel variant tag per recorded launch
+    // scratch owned by the ctx, grown on demand (proposal path)
+    void* ws;
+    size_t ws_bytes;
+};
+
+#define DAT_FAIL(ctx, code, ...)                                  \
+    do {                                                          \
+        char _b[512];                                             \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                    \
+        if (ctx) (ctx)->last_error = _b;                          \
+        return (code);                                            \
+    } while (0)
+
+#define DAT_CHECK_LAUNCH(ctx, what)                                                         \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess) DAT_FAIL(ctx, DAT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(_e)); \
+    } while (0)
+
+#define DAT_ENFORCE(ctx, cond, ...)                               \
+    do {                                                          \
+        if (!(cond)) DAT_FAIL(ctx, DAT_ERR_ARG, __VA_ARGS__);     \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+template <int DT> struct ElemOf;
+template <> struct ElemOf<DAT_F32> {
+    typedef float type;
+    static constexpr int size = 4;
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct ElemOf<DAT_BF16> {
+    typedef uint16_t type;
+    static constexpr int size = 2;
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
+};
+
+static inline int dat_esize(int dtype) { return dtype == DAT_BF16 ? 2 : 4; }
+static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }

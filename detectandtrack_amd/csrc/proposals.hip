@@ -1,0 +1,716 @@
+// On-device RPN proposal generation, FPN collect and NMS (gfx950).
+//
+// Replaces the reference's host round trip inside the net: GenerateProposalsOp
+// (lib/ops/generate_proposals.py:40-181), CollectAndDistributeFpnRpnProposalsOp.collect
+// (lib/ops/collect_and_distribute_fpn_rpn_proposals.py:44-62) and greedy NMS
+// (lib/utils/cython_nms.pyx:37-87 for boxes, lib/nms/py_cpu_nms_tubes.py:17-53 for tubes).
+//
+// Pipeline per RPN level (all levels batched in each launch):
+//   K0 keys+hist   : prob = sigmoid(logit) -> 32-bit monotonic key; 65536-bin histogram of key>>16
+//   K1 find bin    : the histogram bin holding the pre_nms-th largest key
+//   K2 compact     : keys above the bin -> selected list; keys in the bin -> boundary list
+//   K3 select/sort : exact radix-select inside the boundary list on the unique 64-bit composite
+//                    (key, ~index) [ties: lower (h,w,a) index first]; LDS bitonic sort (descending);
+//                    decode boxes (bbox_transform), clip, min-size filter; ordered compaction
+//   K4 nms mask    : 64x64 tiles, bit j of mask[i][cb] = overlap(i, j) suppresses (>= thr boxes, > thr tubes)
+//   K5 nms scan    : one wave per level; per 64-row chunk the intra-chunk dependency chain runs in registers
+//                    (readlane), later chunks get the OR of the kept rows; emits rois in score order
+// All floating-point box math is fp32 in the reference's operation order; this file is compiled with
+// -ffp-contract=off so no fma contraction changes a rounding (bit-exact NMS indices).
+#include "dat_common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int MAX_SORT = 4096;   // pre_nms cap per level (LDS bitonic sort capacity of K3)
+constexpr int MAX_T = 16;
+
+struct LevelState {
+    unsigned tb16;      // threshold histogram bin
+    unsigned n_gt;      // number of keys in bins above tb16
+    unsigned n_sel;     // atomic counter: selected list fill
+    unsigned n_bnd;     // atomic counter: boundary list fill
+    unsigned k_eff;     // min(pre_nms, N)
+    unsigned n_valid;   // boxes surviving the min-size filter (sorted)
+    unsigned n_keep;    // boxes surviving NMS
+    unsigned pad;
+};
+
+struct LevelDev {
+    const char* head;
+    const float* anchors;
+    int H, W, A, T;
+    float feat_stride;
+    int cstride, logit_off, delta_off, frame;
+    int N;                       // H*W*A
+    // workspace pointers
+    unsigned* keys;
+    unsigned* hist;
+    unsigned long long* sel;
+    unsigned long long* bnd;
+    float* boxes;                // [cap][4T] sorted, filtered
+    float* scores;               // [cap]
+    unsigned long long* mask;    // [cap][cap/64]
+    int* kept;                   // [cap] sorted positions kept by NMS
+    LevelState* state;
+};
+
+struct RpnParams {
+    LevelDev lv[MAX_LEVELS];
+    int n_levels;
+    int dtype;
+    int pre_nms, post_nms, cap;
+    float nms_thresh, min_size_scaled, im_h, im_w, batch_idx;
+    float* rois_out;
+    float* probs_out;
+    int* counts_out;
+};
+
+__device__ __forceinline__ float head_ld(const char* p, int dtype, size_t i) {
+    return dtype == DAT_BF16 ? bf2f(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+}
+
+__device__ __forceinline__ unsigned long long composite(unsigned key, unsigned idx) {
+    return ((unsigned long long)key << 32) | (unsigned long long)(~idx);
+}
+
+// ---- K0 ------------------------------------------------------------------------------------------
+__global__ void rpn_keys_hist_kernel(const RpnParams p) {
+    const LevelDev& L = p.lv[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.N; i += gridDim.x * blockDim.x) {
+        const int pos = i / L.A, a = i - pos * L.A;
+        const float logit = head_ld(L.head, p.dtype, ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.logit_off + a);
+        const float prob = 1.f / (1.f + expf(-logit));   // model_builder.py:583 Sigmoid
+        const unsigned key = __float_as_uint(prob);       // prob >= 0: bit pattern is monotonic
+        L.keys[i] = key;
+        atomicAdd(&L.hist[key >> 16], 1u);
+    }
+}
+
+// ---- K1 ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_find_bin_kernel(const RpnParams p) {
+    const LevelDev& L = p.lv[blockIdx.x];
+    __shared__ unsigned part[1024];
+    __shared__ unsigned found_bin, found_gt;
+    const int tid = threadIdx.x;
+    const unsigned k_eff = (unsigned)min(p.pre_nms, L.N);
+    // thread tid owns bins [64*tid, 64*tid+64); order of interest is from the TOP bin down
+    unsigned s = 0;
+    for (int b = 0; b < 64; ++b) s += L.hist[tid * 64 + b];
+    part[tid] = s;
+    if (tid == 0) { found_bin = 0; found_gt = 0; }
+    __syncthreads();
+    // suffix sums: above[tid] = sum of part[t] for t > tid  (1024 entries; simple log-step scan)
+    __shared__ unsigned suf[1024];
+    suf[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = (tid + off < 1024) ? suf[tid + off] : 0u;
+        __syncthreads();
+        suf[tid] += v;
+        __syncthreads();
+    }
+    const unsigned above = suf[tid] - s;     // keys in bins owned by higher threads
+    if (k_eff > 0 && above < k_eff && above + s >= k_eff) {
+        unsigned cum = above;
+        for (int b = 63; b >= 0; --b) {
+            const unsigned h = L.hist[tid * 64 + b];
+            if (cum + h >= k_eff) { found_bin = (unsigned)(tid * 64 + b); found_gt = cum; break; }
+            cum += h;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        L.state->tb16 = found_bin;
+        L.state->n_gt = found_gt;
+        L.state->k_eff = k_eff;
+    }
+}
+
+// ---- K2 ------------------------------------------------------------------------------------------
+__global__ void rpn_compact_kernel(const RpnParams p) {
+    const LevelDev& L = p.lv[blockIdx.y];
+    const unsigned tb = L.state->tb16;
+    if (L.state->k_eff == 0) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.N; i += gridDim.x * blockDim.x) {
+        const unsigned key = L.keys[i];
+        const unsigned b = key >> 16;
+        if (b > tb) {
+            const unsigned pos = atomicAdd(&L.state->n_sel, 1u);
+            L.sel[pos] = composite(key, (unsigned)i);
+        } else if (b == tb) {
+            const unsigned pos = atomicAdd(&L.state->n_bnd, 1u);
+            L.bnd[pos] = composite(key, (unsigned)i);
+        }
+    }
+}
+
+// block-wide descending bitonic sort of n (power of two) u64 in LDS
+__device__ void bitonic_desc(unsigned long long* buf, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = buf[i], b = buf[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// decode one sorted entry into a tube (4T floats); returns validity under the min-size filter.
+// Operation order follows utils/boxes.py:141-183 (weights 1), :243-253, generate_proposals.py:184-196.
+__device__ bool decode_tube(const RpnParams& p, const LevelDev& L, unsigned idx, float* out /*4T*/) {
+    const int pos = idx / L.A, a = idx - pos * L.A;
+    const int h = pos / L.W, w = pos - h * L.W;
+    const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
+    const float clip = 4.135166556742356f;  // float32(log(1000/16)), config.py:672
+    bool ok = true;
+    for (int t = 0; t < L.T; ++t) {
+        const float* an = L.anchors + (size_t)a * 4 * L.T + 4 * t;
+        const float ax1 = an[0] + sx, ay1 = an[1] + sy, ax2 = an[2] + sx, ay2 = an[3] + sy;
+        const size_t dbase = ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.delta_off + ((size_t)a * L.T + t) * 4;
+        const float dx = head_ld(L.head, p.dtype, dbase + 0), dy = head_ld(L.head, p.dtype, dbase + 1);
+        float dw = head_ld(L.head, p.dtype, dbase + 2), dh = head_ld(L.head, p.dtype, dbase + 3);
+        const float width = ax2 - ax1 + 1.0f, height = ay2 - ay1 + 1.0f;
+        const float cx = ax1 + 0.5f * width, cy = ay1 + 0.5f * height;
+        dw = fminf(dw, clip);
+        dh = fminf(dh, clip);
+        const float pcx = dx * width + cx, pcy = dy * height + cy;
+        // np.exp(float32): evaluate in double and round once (correctly rounded result)
+        const float pw = (float)exp((double)dw) * width, phh = (float)exp((double)dh) * height;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * phh, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * phh;
+        x1 = fmaxf(fminf(x1, p.im_w - 1.f), 0.f);
+        y1 = fmaxf(fminf(y1, p.im_h - 1.f), 0.f);
+        x2 = fmaxf(fminf(x2, p.im_w - 1.f), 0.f);
+        y2 = fmaxf(fminf(y2, p.im_h - 1.f), 0.f);
+        out[4 * t + 0] = x1; out[4 * t + 1] = y1; out[4 * t + 2] = x2; out[4 * t + 3] = y2;
+        const float ws = x2 - x1 + 1.f, hs = y2 - y1 + 1.f;
+        const float xc = x1 + ws / 2.f, yc = y1 + hs / 2.f;
+        ok = ok && (ws >= p.min_size_scaled) && (hs >= p.min_size_scaled) && (xc < p.im_w) && (yc < p.im_h);
+    }
+    return ok;
+}
+
+// ---- K3 ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnParams p) {
+    const LevelDev& L = p.lv[blockIdx.x];
+    __shared__ unsigned long long buf[MAX_SORT];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned cnt;
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_need;
+    __shared__ unsigned scan[1024];
+    const int tid = threadIdx.x;
+    const unsigned k_eff = L.state->k_eff;
+    if (k_eff == 0) {
+        if (tid == 0) L.state->n_valid = 0;
+        return;
+    }
+    const unsigned n_gt = L.state->n_sel;      // == state->n_gt
+    const unsigned n_bnd = L.state->n_bnd;
+    const unsigned need = k_eff - n_gt;        // how many boundary elements to take (1 <= need <= n_bnd)
+
+    // exact threshold inside the boundary list: radix-select on the low 48 bits (6 digits of 8 bits)
+    unsigned long long thr48 = 0;
+    if (need < n_bnd) {
+        if (tid == 0) { s_prefix = 0; s_need = need; }
+        __syncthreads();
+        for (int d = 5; d >= 0; --d) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const int shift = 8 * d;
+            // mask of the already-fixed higher digits within the 48-bit field
+            const unsigned long long himask = (d == 5) ? 0ull : ((~0ull << (shift + 8)) & 0xFFFFFFFFFFFFull);
+            for (unsigned i = tid; i < n_bnd; i += blockDim.x) {
+                const unsigned long long v = L.bnd[i] & 0xFFFFFFFFFFFFull;
+                if ((v & himask) == (prefix & himask)) atomicAdd(&hist[(unsigned)(v >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = s_need, cum = 0;
+                int dig = 255;
+                for (; dig >= 0; --dig) {
+                    if (cum + hist[dig] >= rem) break;
+                    cum += hist[dig];
+                }
+                s_need = rem - cum;
+                s_prefix = prefix | ((unsigned long long)dig << shift);
+            }
+            __syncthreads();
+        }
+        thr48 = s_prefix;
+    }
+    // gather the k_eff selected composites into LDS
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (unsigned i = tid; i < n_gt; i += blockDim.x) buf[atomicAdd(&cnt, 1u)] = L.sel[i];
+    for (unsigned i = tid; i < n_bnd; i += blockDim.x) {
+        const unsigned long long v = L.bnd[i];
+        if ((v & 0xFFFFFFFFFFFFull) >= thr48) {
+            const unsigned pos = atomicAdd(&cnt, 1u);
+            if (pos < MAX_SORT) buf[pos] = v;
+        }
+    }
+    __syncthreads();
+    int npad = 1;
+    while (npad < (int)k_eff) npad <<= 1;
+    for (int i = k_eff + tid; i < npad; i += blockDim.x) buf[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(buf, npad);
+
+    // decode + filter, ordered compaction: thread tid owns the contiguous entries [tid*per, tid*per+per)
+    const int per = (npad + 1023) / 1024;
+    float tube[4 * MAX_T];
+    unsigned local = 0, flags = 0;
+    for (int e = 0; e < per; ++e) {
+        const int j = tid * per + e;
+        if (j < (int)k_eff) {
+            const unsigned idx = ~(unsigned)(buf[j] & 0xFFFFFFFFull);
+            if (decode_tube(p, L, idx, tube)) { flags |= 1u << e; ++local; }
+        }
+    }
+    scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = (tid >= off) ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    unsigned outpos = scan[tid] - local;
+    for (int e = 0; e < per; ++e) {
+        if (flags & (1u << e)) {
+            const int j = tid * per + e;
+            const unsigned long long v = buf[j];
+            const unsigned idx = ~(unsigned)(v & 0xFFFFFFFFull);
+            decode_tube(p, L, idx, tube);
+            for (int c = 0; c < 4 * L.T; ++c) L.boxes[(size_t)outpos * 4 * L.T + c] = tube[c];
+            L.scores[outpos] = __uint_as_float((unsigned)(v >> 32));
+            ++outpos;
+        }
+    }
+    if (tid == 1023) L.state->n_valid = scan[1023];
+}
+
+// ---- K4: NMS suppression mask ---------------------------------------------------------------------------
+// overlap test in the reference's fp32 operation order.
+__device__ __forceinline__ bool suppresses(const float* bi, const float* bj, const float* ai, const float* aj, int T,
+                                           float thr) {
+    if (T == 1) {  // cython_nms.pyx:70-84, ovr >= thresh
+        const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+        const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+        const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+        const float inter = w * h;
+        const float ovr = inter / (ai[0] + aj[0] - inter);
+        return ovr >= thr;
+    }
+    float ovT = 0.f;  // py_cpu_nms_tubes.py:35-50, keep while mean <= thresh
+    for (int t = 0; t < T; ++t) {
+        const float xx1 = fmaxf(bi[4 * t + 0], bj[4 * t + 0]), yy1 = fmaxf(bi[4 * t + 1], bj[4 * t + 1]);
+        const float xx2 = fminf(bi[4 * t + 2], bj[4 * t + 2]), yy2 = fminf(bi[4 * t + 3], bj[4 * t + 3]);
+        const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+        const float inter = w * h;
+        ovT = ovT + inter / (ai[t] + aj[t] - inter);
+    }
+    ovT = ovT / (float)T;
+    return !(ovT <= thr);
+}
+
+struct NmsLevel {
+    const float* boxes;          // [n][4T] sorted by score desc
+    unsigned long long* mask;    // [n][nwords]
+    const unsigned* n_ptr;       // dev count
+    int* kept;                   // out: kept sorted positions
+    unsigned* n_keep_ptr;
+};
+struct NmsParams {
+    NmsLevel lv[MAX_LEVELS];
+    int T, cap;
+    float thr;
+};
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsParams p) {
+    const NmsLevel& L = p.lv[blockIdx.z];
+    const int n = (int)*L.n_ptr;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    const int nwords = (n + 63) / 64;
+    const int T = p.T;
+    __shared__ float cbox[64 * 4 * MAX_T];
+    __shared__ float carea[64 * MAX_T];
+    const int tid = threadIdx.x;
+    const int jg = cb * 64 + tid;
+    if (jg < n) {
+        for (int c = 0; c < 4 * T; ++c) cbox[tid * 4 * T + c] = L.boxes[(size_t)jg * 4 * T + c];
+        for (int t = 0; t < T; ++t) {
+            const float* b = L.boxes + (size_t)jg * 4 * T + 4 * t;
+            carea[tid * T + t] = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+        }
+    }
+    __syncthreads();
+    const int ig = rb * 64 + tid;
+    if (ig >= n) return;
+    float bi[4 * MAX_T], ai[MAX_T];
+    for (int c = 0; c < 4 * T; ++c) bi[c] = L.boxes[(size_t)ig * 4 * T + c];
+    for (int t = 0; t < T; ++t) ai[t] = (bi[4 * t + 2] - bi[4 * t + 0] + 1.f) * (bi[4 * t + 3] - bi[4 * t + 1] + 1.f);
+    unsigned long long bits = 0;
+    const int jend = min(64, n - cb * 64);
+    for (int j = 0; j < jend; ++j) {
+        if (cb * 64 + j <= ig) continue;
+        if (suppresses(bi, cbox + j * 4 * T, ai, carea + j * T, T, p.thr)) bits |= 1ull << j;
+    }
+    L.mask[(size_t)ig * nwords + cb] = bits;
+}
+
+// ---- K5: sequential resolution by one wave ---------------------------------------------------------------
+__global__ __launch_bounds__(64) void nms_scan_kernel(const NmsParams p) {
+    const NmsLevel& L = p.lv[blockIdx.x];
+    const int n = (int)*L.n_ptr;
+    const int lane = threadIdx.x;
+    const int nwords = (n + 63) / 64;  // <= 64
+    unsigned long long remv = 0;       // lane w holds removed-bits word w
+    int nkeep = 0;
+    for (int b = 0; b < nwords; ++b) {
+        const int row = b * 64 + lane;
+        const unsigned long long diag = (row < n) ? L.mask[(size_t)row * nwords + b] : 0ull;
+        unsigned long long cur = __shfl(remv, b, 64);
+        const int rows_here = min(64, n - b * 64);
+        unsigned long long kept = 0;
+        for (int i = 0; i < rows_here; ++i) {
+            if (!((cur >> i) & 1ull)) {
+                kept |= 1ull << i;
+                cur |= __shfl(diag, i, 64);
+            }
+        }
+        // emit kept rows of this chunk in order
+        if ((kept >> lane) & 1ull) {
+            const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+            L.kept[nkeep + rank] = row;
+        }
+        nkeep += __popcll(kept);
+        // propagate: later words get the OR of the kept rows' masks
+        if (lane > b && lane < nwords) {
+            unsigned long long acc = 0;
+            unsigned long long k = kept;
+            while (k) {
+                const int i = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= L.mask[(size_t)(b * 64 + i) * nwords + lane];
+            }
+            remv |= acc;
+        }
+    }
+    if (lane == 0) *L.n_keep_ptr = (unsigned)nkeep;
+}
+
+// ---- K6: emit rois of every level ---------------------------------------------------------------------------
+__global__ void rpn_emit_kernel(const RpnParams p) {
+    const LevelDev& L = p.lv[blockIdx.x];
+    const int nkeep = min((int)L.state->n_keep, p.post_nms);
+    const int cols = 4 * L.T + 1;
+    float* rois = p.rois_out + (size_t)blockIdx.x * p.post_nms * cols;
+    float* probs = p.probs_out + (size_t)blockIdx.x * p.post_nms;
+    for (int j = threadIdx.x; j < nkeep; j += blockDim.x) {
+        const int src = L.kept[j];
+        rois[(size_t)j * cols] = p.batch_idx;
+        for (int c = 0; c < 4 * L.T; ++c) rois[(size_t)j * cols + 1 + c] = L.boxes[(size_t)src * 4 * L.T + c];
+        probs[j] = L.scores[src];
+    }
+    if (threadIdx.x == 0) p.counts_out[blockIdx.x] = nkeep;
+}
+
+// ---- collect: global top post_nms over the concatenated levels -------------------------------------------------
+__global__ __launch_bounds__(1024) void collect_rois_kernel(const float* rois_lvls, const float* probs_lvls, const int* counts,
+                                                            int n_levels, int level_cap, int roi_cols, int post_nms,
+                                                            float* rois, int* n_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cbuf[];
+    __shared__ int offs[MAX_LEVELS + 1];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int o = 0;
+        for (int l = 0; l < n_levels; ++l) { offs[l] = o; o += counts[l]; }
+        offs[n_levels] = o;
+    }
+    __syncthreads();
+    const int total = offs[n_levels];
+    int npad = 1;
+    while (npad < total) npad <<= 1;
+    for (int l = 0; l < n_levels; ++l) {
+        const int c = counts[l];
+        for (int j = tid; j < c; j += blockDim.x) {
+            const unsigned key = __float_as_uint(probs_lvls[(size_t)l * level_cap + j]);
+            cbuf[offs[l] + j] = ((unsigned long long)key << 32) | (unsigned long long)(~(unsigned)(offs[l] + j));
+        }
+    }
+    for (int i = total + tid; i < npad; i += blockDim.x) cbuf[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(cbuf, npad);
+    const int nout = min(total, post_nms);
+    for (int j = tid; j < nout; j += blockDim.x) {
+        const unsigned cidx = ~(unsigned)(cbuf[j] & 0xFFFFFFFFull);
+        int l = 0;
+        while (l + 1 < n_levels && (int)cidx >= offs[l + 1]) ++l;
+        const float* src = rois_lvls + ((size_t)l * level_cap + (cidx - offs[l])) * roi_cols;
+        for (int c = 0; c < roi_cols; ++c) rois[(size_t)j * roi_cols + c] = src[c];
+    }
+    if (tid == 0) *n_out = nout;
+}
+
+// ---- generic NMS entry: sort any-order dets ---------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n, int T, float* boxes, int* orig,
+                                                             unsigned* n_dev) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sbuf[];
+    const int cols = 4 * T + 1;
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        unsigned long long v = 0ull;
+        if (i < n) {
+            // order by float value (scores may be negative): flip to a monotonic unsigned key
+            unsigned u = __float_as_uint(dets[(size_t)i * cols + 4 * T]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            v = ((unsigned long long)u << 32) | (unsigned long long)(~(unsigned)i);
+        }
+        sbuf[i] = v;
+    }
+    __syncthreads();
+    bitonic_desc(sbuf, npad);
+    // pads are 0 and every real composite is > 0 (low word ~i != 0 for i < 2^32-1), so reals come first
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const unsigned i = ~(unsigned)(sbuf[j] & 0xFFFFFFFFull);
+        orig[j] = (int)i;
+        for (int c = 0; c < 4 * T; ++c) boxes[(size_t)j * 4 * T + c] = dets[(size_t)i * cols + c];
+    }
+    if (threadIdx.x == 0) *n_dev = (unsigned)n;
+}
+
+// kept sorted positions -> reference output convention
+__global__ __launch_bounds__(1024) void nms_finish_kernel(const int* kept, const unsigned* n_keep_ptr, const int* orig, int n,
+                                                          int T, int* keep_out, int* num_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned fl[];
+    __shared__ unsigned scan[1024];
+    const int nk = (int)*n_keep_ptr;
+    const int tid = threadIdx.x;
+    if (T > 1) {  // tubes: score order (py_cpu_nms_tubes.py returns `keep` as visited)
+        for (int j = tid; j < nk; j += blockDim.x) keep_out[j] = orig[kept[j]];
+        if (tid == 0) *num_out = nk;
+        return;
+    }
+    // boxes: ascending original indices (np.where(suppressed == 0)[0], cython_nms.pyx:87)
+    for (int i = tid; i < n; i += blockDim.x) fl[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < nk; j += blockDim.x) fl[orig[kept[j]]] = 1;
+    __syncthreads();
+    const int per = (n + 1023) / 1024;
+    unsigned local = 0;
+    for (int e = 0; e < per; ++e) {
+        const int i = tid * per + e;
+        if (i < n) local += fl[i];
+    }
+    scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = (tid >= off) ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    unsigned pos = scan[tid] - local;
+    for (int e = 0; e < per; ++e) {
+        const int i = tid * per + e;
+        if (i < n && fl[i]) keep_out[pos++] = i;
+    }
+    if (tid == 0) *num_out = nk;
+}
+
+int ensure_ws(dat_ctx* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return DAT_OK;
+    if (ctx->ws) {
+        hipDeviceSynchronize();
+        hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = bytes + (bytes >> 2);
+    if (hipMalloc(&ctx->ws, want) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
+    ctx->ws_bytes = want;
+    return DAT_OK;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
+                      const float* const* anchors, int n_levels, const float* im_info, int pre_nms, int post_nms,
+                      float nms_thresh, float min_size, float batch_idx, float* rois_out, float* probs_out, int* counts_out) {
+    DAT_ENFORCE(ctx, heads && levels && anchors && im_info && rois_out && probs_out && counts_out, "rpn_proposals: null argument");
+    DAT_ENFORCE(ctx, n_levels >= 1 && n_levels <= MAX_LEVELS, "rpn_proposals: n_levels %d out of range", n_levels);
+    DAT_ENFORCE(ctx, pre_nms > 0 && pre_nms <= MAX_SORT, "rpn_proposals: RPN_PRE_NMS_TOP_N %d must be in 1..%d", pre_nms, MAX_SORT);
+    DAT_ENFORCE(ctx, post_nms > 0, "rpn_proposals: RPN_POST_NMS_TOP_N must be > 0");
+    DAT_ENFORCE(ctx, nms_thresh > 0.f, "rpn_proposals: RPN_NMS_THRESH must be > 0 (NMS is always applied)");
+    hipStream_t st = (hipStream_t)s;
+    RpnParams p;
+    memset(&p, 0, sizeof(p));
+    const int cap = pre_nms;
+    const int nwords_cap = (cap + 63) / 64;
+    int T = levels[0].T;
+    // workspace layout
+    size_t off = 0, state_off = 0, hist_off = 0;
+    state_off = off; off += align_up(sizeof(LevelState) * MAX_LEVELS);
+    hist_off = off; off += align_up((size_t)n_levels * 65536 * 4);
+    const size_t zero_bytes = off;  // states + histograms are zeroed every call
+    size_t per_level_off[MAX_LEVELS][7];
+    for (int l = 0; l < n_levels; ++l) {
+        DAT_ENFORCE(ctx, levels[l].T == T && T >= 1 && T <= MAX_T, "rpn_proposals: tube length %d unsupported", levels[l].T);
+        const size_t N = (size_t)levels[l].H * levels[l].W * levels[l].A;
+        DAT_ENFORCE(ctx, N > 0 && N < (1u << 31), "rpn_proposals: level %d has %zu anchors", l, N);
+        per_level_off[l][0] = off; off += align_up(N * 4);                       // keys
+        per_level_off[l][1] = off; off += align_up((size_t)cap * 8);             // sel
+        per_level_off[l][2] = off; off += align_up(N * 8);                       // bnd
+        per_level_off[l][3] = off; off += align_up((size_t)cap * 4 * T * 4);     // boxes
+        per_level_off[l][4] = off; off += align_up((size_t)cap * 4);             // scores
+        per_level_off[l][5] = off; off += align_up((size_t)cap * nwords_cap * 8);// mask
+        per_level_off[l][6] = off; off += align_up((size_t)cap * 4);             // kept
+    }
+    int rc = ensure_ws(ctx, off);
+    if (rc != DAT_OK) return rc;
+    char* ws = (char*)ctx->ws;
+    hipMemsetAsync(ws, 0, zero_bytes, st);
+    NmsParams np;
+    memset(&np, 0, sizeof(np));
+    int maxN = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        LevelDev& L = p.lv[l];
+        L.head = (const char*)heads[l];
+        L.anchors = anchors[l];
+        L.H = levels[l].H; L.W = levels[l].W; L.A = levels[l].A; L.T = T;
+        L.feat_stride = levels[l].feat_stride;
+        L.cstride = levels[l].cstride; L.logit_off = levels[l].logit_off; L.delta_off = levels[l].delta_off;
+        L.frame = levels[l].frame;
+        L.N = L.H * L.W * L.A;
+        maxN = L.N > maxN ? L.N : maxN;
+        L.keys = (unsigned*)(ws + per_level_off[l][0]);
+        L.hist = (unsigned*)(ws + hist_off) + (size_t)l * 65536;
+        L.sel = (unsigned long long*)(ws + per_level_off[l][1]);
+        L.bnd = (unsigned long long*)(ws + per_level_off[l][2]);
+        L.boxes = (float*)(ws + per_level_off[l][3]);
+        L.scores = (float*)(ws + per_level_off[l][4]);
+        L.mask = (unsigned long long*)(ws + per_level_off[l][5]);
+        L.kept = (int*)(ws + per_level_off[l][6]);
+        L.state = (LevelState*)(ws + state_off) + l;
+        np.lv[l].boxes = L.boxes; np.lv[l].mask = L.mask; np.lv[l].n_ptr = &L.state->n_valid;
+        np.lv[l].kept = L.kept; np.lv[l].n_keep_ptr = &L.state->n_keep;
+    }
+    p.n_levels = n_levels; p.dtype = dtype; p.pre_nms = pre_nms; p.post_nms = post_nms; p.cap = cap;
+    p.nms_thresh = nms_thresh;
+    p.min_size_scaled = (float)((double)min_size * (double)im_info[2]);
+    p.im_h = im_info[0]; p.im_w = im_info[1]; p.batch_idx = batch_idx;
+    p.rois_out = rois_out; p.probs_out = probs_out; p.counts_out = counts_out;
+    np.T = T; np.cap = cap; np.thr = nms_thresh;
+
+    int bx = (maxN + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(rpn_keys_hist_kernel, dim3(bx, n_levels), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(rpn_find_bin_kernel, dim3(n_levels), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(rpn_compact_kernel, dim3(bx, n_levels), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(rpn_select_sort_decode_kernel, dim3(n_levels), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords_cap, nwords_cap, n_levels), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_levels), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(rpn_emit_kernel, dim3(n_levels), dim3(256), 0, st, p);
+    DAT_CHECK_LAUNCH(ctx, "rpn_proposals");
+    return DAT_OK;
+}
+
+int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
+                     int n_levels, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out) {
+    DAT_ENFORCE(ctx, rois_lvls && probs_lvls && counts && rois && n_out, "collect_rois: null argument");
+    DAT_ENFORCE(ctx, n_levels >= 1 && n_levels <= MAX_LEVELS, "collect_rois: n_levels %d out of range", n_levels);
+    int npad = 1;
+    while (npad < n_levels * level_cap) npad <<= 1;
+    DAT_ENFORCE(ctx, (size_t)npad * 8 <= 128 * 1024, "collect_rois: %d candidate rois exceed the 16384-entry LDS sort", n_levels * level_cap);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)collect_rois_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(collect_rois_kernel, dim3(1), dim3(1024), (size_t)npad * 8, (hipStream_t)s, rois_lvls, probs_lvls, counts,
+                       n_levels, level_cap, roi_cols, post_nms, rois, n_out);
+    DAT_CHECK_LAUNCH(ctx, "collect_rois");
+    return DAT_OK;
+}
+
+int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float thresh, int* keep, int* num_keep) {
+    DAT_ENFORCE(ctx, keep && num_keep, "nms: null output");
+    DAT_ENFORCE(ctx, T >= 1 && T <= MAX_T, "nms: tube length %d unsupported", T);
+    hipStream_t st = (hipStream_t)s;
+    if (n == 0) {
+        hipMemsetAsync(num_keep, 0, sizeof(int), st);
+        return DAT_OK;
+    }
+    DAT_ENFORCE(ctx, dets, "nms: null dets");
+    DAT_ENFORCE(ctx, n > 0 && n <= MAX_SORT, "nms: %d boxes exceed the supported maximum %d", n, MAX_SORT);
+    const int nwords = (n + 63) / 64;
+    size_t off = 0;
+    const size_t o_state = off; off += align_up(16);
+    const size_t o_boxes = off; off += align_up((size_t)n * 4 * T * 4);
+    const size_t o_orig = off; off += align_up((size_t)n * 4);
+    const size_t o_mask = off; off += align_up((size_t)n * nwords * 8);
+    const size_t o_kept = off; off += align_up((size_t)n * 4);
+    int rc = ensure_ws(ctx, off);
+    if (rc != DAT_OK) return rc;
+    char* ws = (char*)ctx->ws;
+    unsigned* st_n = (unsigned*)(ws + o_state);
+    unsigned* st_keep = st_n + 1;
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), (size_t)npad * 8, st, dets, n, T, (float*)(ws + o_boxes),
+                       (int*)(ws + o_orig), st_n);
+    NmsParams np;
+    memset(&np, 0, sizeof(np));
+    np.lv[0].boxes = (const float*)(ws + o_boxes);
+    np.lv[0].mask = (unsigned long long*)(ws + o_mask);
+    np.lv[0].n_ptr = st_n;
+    np.lv[0].kept = (int*)(ws + o_kept);
+    np.lv[0].n_keep_ptr = st_keep;
+    np.T = T; np.cap = n; np.thr = thresh;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, 1), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(1), dim3(1024), (size_t)n * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
+                       (const int*)(ws + o_orig), n, T, keep, num_keep);
+    DAT_CHECK_LAUNCH(ctx, "nms");
+    return DAT_OK;
+}
+
+int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                 float nms_overlap_thresh) {
+    DAT_ENFORCE(ctx, keep_out && num_out, "_nms: null output");
+    DAT_ENFORCE(ctx, boxes_dim >= 5 && (boxes_dim - 1) % 4 == 0, "_nms: boxes_dim %d must be 4T+1", boxes_dim);
+    if (boxes_num == 0) { *num_out = 0; return DAT_OK; }
+    const int T = (boxes_dim - 1) / 4;
+    float* d_dets = nullptr;
+    int* d_keep = nullptr;
+    const size_t bytes = (size_t)boxes_num * boxes_dim * 4;
+    if (hipMalloc(&d_dets, bytes) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed");
+    if (hipMalloc(&d_keep, (size_t)(boxes_num + 1) * 4) != hipSuccess) { hipFree(d_dets); DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed"); }
+    hipMemcpy(d_dets, boxes_host, bytes, hipMemcpyHostToDevice);
+    int rc = dat_nms(ctx, nullptr, d_dets, boxes_num, T, nms_overlap_thresh, d_keep, d_keep + boxes_num);
+    if (rc == DAT_OK) {
+        hipDeviceSynchronize();
+        hipMemcpy(num_out, d_keep + boxes_num, 4, hipMemcpyDeviceToHost);
+        hipMemcpy(keep_out, d_keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_dets);
+    hipFree(d_keep);
+    return rc;
+}
+
+}  // extern "C"

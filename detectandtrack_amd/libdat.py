@@ -1,0 +1,115 @@
+"""ctypes binding of libdat_hip.so (C ABI in include/dat_hip.h).
+
+This is the ONLY way the Python host side reaches the kernels: plain pointers and sizes,
+no torch types in the signatures.  torch is used by callers purely as a device-memory /
+stream provider (`tensor.data_ptr()`, `torch.cuda.current_stream().cuda_stream`).
+
+There is deliberately NO fallback: if the shared library is missing, importing this
+module raises (build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C detectandtrack_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdat_hip.so')
+
+DAT_F32, DAT_BF16 = 0, 1
+DAT_OK = 0
+
+
+class DatError(RuntimeError):
+    """Raised for a non-zero C-ABI return code; message = dat_last_error() (the CAFFE_ENFORCE analogue)."""
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        'dtype', 'frames', 'T', 'H', 'W', 'Cin', 'Cout', 'out_cstride', 'KT', 'KH', 'KW',
+        'stride_h', 'stride_w', 'pad_t', 'pad_h', 'pad_w', 'relu', 'res_mode')]
+
+
+class RoiLevel(C.Structure):
+    _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
+
+
+class RpnLevel(C.Structure):
+    _fields_ = [('H', C.c_int), ('W', C.c_int), ('A', C.c_int), ('T', C.c_int), ('feat_stride', C.c_float),
+                ('cstride', C.c_int), ('logit_off', C.c_int), ('delta_off', C.c_int), ('frame', C.c_int)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('libdat_hip.so not built at %s — run __graft_entry__.build()' % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+_p, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
+_PROTOS = {
+    'dat_version': (_i, []),
+    'dat_ctx_create': (_i, [C.POINTER(_p), _i]),
+    'dat_ctx_destroy': (None, [_p]),
+    'dat_last_error': (C.c_char_p, [_p]),
+    'dat_prof_enable': (_i, [_p, _i]),
+    'dat_prof_read': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_f)]),
+    'dat_zero_even_fwd': (_i, [_p, _p, _p, _ll]),
+    'dat_affine_channel_nd_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _ll]),
+    'dat_affine_channel_nd_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _ll]),
+    'dat_ncdhw_to_ndhwc': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    'dat_ndhwc_to_ncdhw': (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    'dat_conv3d_out_shape': (_i, [C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i)]),
+    'dat_conv3d_packed_weight_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'dat_conv3d_pack_weights': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p]),
+    'dat_conv3d_fwd': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
+    'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),
+    'dat_stem_pack': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),
+    'dat_stem_weights': (_i, [_p, _p, _p, _i, _p]),
+    'dat_maxpool_hw': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
+    'dat_time_avg': (_i, [_p, _p, _i, _p, _p, _i, _i, _ll]),
+    'dat_roi_align': (_i, [_p, _p, _i, C.POINTER(RoiLevel), _i, _i, _f, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
+    'dat_spatial_mean': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i]),
+    'dat_softmax_rows': (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
+    'dat_rpn_proposals': (_i, [_p, _p, _i, C.POINTER(_p), C.POINTER(RpnLevel), C.POINTER(_p), _i, C.POINTER(_f),
+                               _i, _i, _f, _f, _f, _p, _p, _p]),
+    'dat_collect_rois': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'dat_nms': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
+    'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
+    'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
+    'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+}
+EXPORTS = sorted(_PROTOS)
+for _name, (_res, _args) in _PROTOS.items():
+    _fn = getattr(_lib, _name)  # AttributeError here == header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class Ctx(object):
+    """One context per GPU process (reference: one process per GPU at inference, lib/utils/subprocess.py:38-63)."""
+
+    def __init__(self, device=0):
+        h = _p()
+        rc = _lib.dat_ctx_create(C.byref(h), int(device))
+        if rc != DAT_OK:
+            raise DatError('dat_ctx_create(device=%d) failed with %d (no visible MI355X?)' % (device, rc))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, 'h', None):
+            _lib.dat_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != DAT_OK:
+            raise DatError('%s (code %d)' % (_lib.dat_last_error(self.h).decode(), rc))
+
+    def call(self, name, *args):
+        self.check(getattr(_lib, name)(self.h, *args))
+
+
+def lib():
+    return _lib

@@ -1,0 +1,322 @@
+"""Thin Python wrappers over the C ABI (include/dat_hip.h) working on torch CUDA tensors.
+
+torch is plumbing only: it owns HBM allocations and the HIP stream; every computation
+below is a libdat_hip kernel.  No CPU fallbacks exist — a missing library or a missing
+GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import libdat as L
+
+F32, BF16 = L.DAT_F32, L.DAT_BF16
+
+
+def tdtype(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+_CTX = {}
+
+
+def ctx(device=None):
+    """Per-device context (created lazily)."""
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _CTX:
+        _CTX[device] = L.Ctx(device)
+    return _CTX[device]
+
+
+# ---- toy + AffineChannelNd (the reference's own native ops) ---------------------------------------
+def zero_even(x):
+    """In-place ZeroEven on a 1-D fp32 tensor (lib/ops/zero_even_op.cc:17-30 semantics)."""
+    if x.dim() != 1:
+        raise L.DatError('ZeroEven: X.ndim() == 1 required, got %d dims' % x.dim())
+    ctx().call('dat_zero_even_fwd', _stream(), _ptr(x), C.c_longlong(x.numel()))
+    return x
+
+
+def affine_channel_nd(x, scale, bias, out=None):
+    """y = x*scale[c] + bias[c] on NC(...) fp32; out may alias x (in-place)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = x.new_empty(x.shape) if out is None else out
+    n, c = x.shape[0], x.shape[1]
+    inner = int(np.prod(x.shape[2:])) if x.dim() > 2 else 1
+    ctx().call('dat_affine_channel_nd_fwd', _stream(), _ptr(x), _ptr(scale), _ptr(bias), _ptr(out), n, c,
+               C.c_longlong(inner))
+    return out
+
+
+def affine_channel_nd_grad(dy, scale):
+    dx = dy.new_empty(dy.shape)
+    n, c = dy.shape[0], dy.shape[1]
+    inner = int(np.prod(dy.shape[2:])) if dy.dim() > 2 else 1
+    ctx().call('dat_affine_channel_nd_bwd', _stream(), _ptr(dy), _ptr(scale), _ptr(dx), n, c, C.c_longlong(inner))
+    return dx
+
+
+# ---- boundary layout moves ---------------------------------------------------------------------------
+def to_ndhwc(x, dtype, cs=None):
+    """x fp32 NC(T)HW (4-D or 5-D) -> [N*T, H, W, cs] in dtype."""
+    if x.dim() == 4:
+        x = x[:, :, None]
+    x = x.contiguous()
+    n, c, t, h, w = x.shape
+    cs = cs or round_up(c, 64)
+    out = torch.empty((n * t, h, w, cs), dtype=tdtype(dtype), device=x.device)
+    ctx().call('dat_ncdhw_to_ndhwc', _stream(), _ptr(x), _ptr(out), dtype, n, c, t, h, w, cs)
+    return out
+
+
+def to_ncdhw(x, dtype, n, c, t):
+    """x [N*T, H, W, cs] -> fp32 [N, C, T, H, W]."""
+    f, h, w, cs = x.shape
+    assert f == n * t
+    out = torch.empty((n, c, t, h, w), dtype=torch.float32, device=x.device)
+    ctx().call('dat_ndhwc_to_ncdhw', _stream(), _ptr(x), dtype, _ptr(out), n, c, t, h, w, cs)
+    return out
+
+
+# ---- fused conv ------------------------------------------------------------------------------------------
+class ConvLayer(object):
+    """A conv with packed weights + fused epilogue parameters, ready to launch.
+
+    w: fp32 [Cout, Cin, KT, KH, KW] (reference blob layout, CUDA tensor)
+    scale/bias: fp32 [Cout] or None (AffineChannelNd / conv bias); padded to the stored Cout.
+    """
+
+    def __init__(self, w, scale=None, bias=None, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=BF16,
+                 cin_stride=None):
+        w = w.contiguous().float()
+        self.cout_real, self.cin_real, self.kt, self.kh, self.kw = [int(v) for v in w.shape]
+        self.dtype = dtype
+        self.cin = cin_stride or round_up(self.cin_real, 64)
+        self.cout = round_up(self.cout_real, 4)
+        self.cstride = round_up(self.cout_real, 64)  # outputs feed later convs: keep C % 64 == 0
+        self.stride = tuple(stride)
+        self.pads = tuple(pads)
+        self.relu = bool(relu)
+        dev = w.device
+        self.scale = None
+        self.bias = None
+        if scale is not None:
+            self.scale = torch.ones(self.cout, dtype=torch.float32, device=dev)
+            self.scale[:self.cout_real] = scale.float()
+        if bias is not None:
+            self.bias = torch.zeros(self.cout, dtype=torch.float32, device=dev)
+            self.bias[:self.cout_real] = bias.float()
+        d = self.desc(1, 1, 8, 8)
+        nbytes = L.lib().dat_conv3d_packed_weight_bytes(C.byref(d))
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(w), self.cout_real, self.cin_real,
+                   _ptr(self.packed))
+
+    def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None):
+        d = L.ConvDesc()
+        d.dtype = self.dtype
+        d.frames, d.T, d.H, d.W, d.Cin = frames, T, H, W, self.cin
+        d.Cout = self.cout
+        d.out_cstride = cstride or self.cstride
+        d.KT, d.KH, d.KW = self.kt, self.kh, self.kw
+        d.stride_h, d.stride_w = self.stride
+        d.pad_t, d.pad_h, d.pad_w = self.pads
+        d.relu = int(self.relu if relu is None else relu)
+        d.res_mode = res_mode
+        return d
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pads[1] - self.kh) // self.stride[0] + 1,
+                (W + 2 * self.pads[2] - self.kw) // self.stride[1] + 1)
+
+    def flops(self, frames, H, W):
+        ho, wo = self.out_hw(H, W)
+        return 2.0 * self.cout_real * self.cin_real * self.kt * self.kh * self.kw * frames * ho * wo
+
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None):
+        frames, H, W, cin = x.shape
+        assert cin == self.cin, 'channel stride %d != layer Cin %d' % (cin, self.cin)
+        assert x.dtype == tdtype(self.dtype) and x.is_contiguous()
+        if res_mode is None:
+            res_mode = 1 if residual is not None else 0
+        d = self.desc(frames, T, H, W, res_mode)
+        ho, wo = self.out_hw(H, W)
+        if out is None:
+            alloc = torch.zeros if self.cstride != self.cout else torch.empty
+            out = alloc((frames, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
+        ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
+                   _ptr(self.bias), _ptr(residual), _ptr(out))
+        return out
+
+
+def stem_pack(data, dtype):
+    """data fp32 [N,3,T,H,W] -> packed [N*T, Ho+3, Wo, 64] (see dat_hip.h)."""
+    data = data.contiguous()
+    n, c, t, h, w = data.shape
+    assert c == 3
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    out = torch.empty((n * t, ho + 3, wo, 64), dtype=tdtype(dtype), device=data.device)
+    ctx().call('dat_stem_pack', _stream(), _ptr(data), _ptr(out), dtype, n, t, h, w)
+    return out
+
+
+def stem_layer(conv1_w, scale, bias, dtype):
+    """conv1 [Cout,3,1,7,7] -> ConvLayer over the packed stem input (KH=4, KW=1, pad 0)."""
+    cout = conv1_w.shape[0]
+    w4 = torch.empty((cout, 64, 1, 4, 1), dtype=torch.float32, device=conv1_w.device)
+    ctx().call('dat_stem_weights', _stream(), _ptr(conv1_w.contiguous().float()), cout, _ptr(w4))
+    return ConvLayer(w4, scale, bias, stride=(1, 1), pads=(0, 0, 0), relu=True, dtype=dtype, cin_stride=64)
+
+
+def maxpool_hw(x, dtype, k, stride, pad):
+    f, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((f, ho, wo, c), dtype=x.dtype, device=x.device)
+    ctx().call('dat_maxpool_hw', _stream(), dtype, _ptr(x), _ptr(out), f, h, w, c, k, stride, pad)
+    return out
+
+
+def time_avg(x, dtype, n, t):
+    f, h, w, c = x.shape
+    assert f == n * t
+    out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    ctx().call('dat_time_avg', _stream(), dtype, _ptr(x), _ptr(out), n, t, C.c_longlong(h * w * c))
+    return out
+
+
+def roi_align(feats, scales, dtype, rois, T, Tr, t0, pooled, sampling, k_min=2, canon_scale=224., canon_level=4):
+    """feats: list of [N*T,H,W,C] (finest level FIRST, i.e. level k_min first); rois fp32 [R, 4Tr+1] (CUDA)."""
+    nl = len(feats)
+    lv = (L.RoiLevel * nl)()
+    for i, (f, s) in enumerate(zip(feats, scales)):
+        lv[i].feat = f.data_ptr()
+        lv[i].H, lv[i].W = f.shape[1], f.shape[2]
+        lv[i].spatial_scale = s
+    c = feats[0].shape[3]
+    r = rois.shape[0]
+    out = torch.empty((r * Tr, pooled, pooled, c), dtype=feats[0].dtype, device=feats[0].device)
+    ctx().call('dat_roi_align', _stream(), dtype, lv, nl, k_min, C.c_float(canon_scale), canon_level, T, c,
+               _ptr(rois), r, Tr, t0, pooled, sampling, _ptr(out))
+    return out
+
+
+def spatial_mean(x, dtype, c):
+    f, h, w, cs = x.shape
+    out = torch.empty((f, c), dtype=torch.float32, device=x.device)
+    ctx().call('dat_spatial_mean', _stream(), dtype, _ptr(x), _ptr(out), f, h * w, c, cs)
+    return out
+
+
+def softmax_rows(x, k):
+    rows, ld = x.shape
+    out = torch.empty((rows, k), dtype=torch.float32, device=x.device)
+    ctx().call('dat_softmax_rows', _stream(), _ptr(x), _ptr(out), rows, k, ld, k)
+    return out
+
+
+class RpnLevelSpec(object):
+    def __init__(self, head, H, W, A, T, feat_stride, cstride, logit_off, delta_off, frame, anchors):
+        self.head, self.H, self.W, self.A, self.T = head, H, W, A, T
+        self.feat_stride, self.cstride = feat_stride, cstride
+        self.logit_off, self.delta_off, self.frame = logit_off, delta_off, frame
+        self.anchors = anchors  # fp32 CUDA [A, 4T]
+
+
+def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_size, batch_idx=0.):
+    """Returns (rois [nl, post_nms, 4T+1], probs [nl, post_nms], counts int32 [nl]) CUDA tensors."""
+    nl = len(levels)
+    T = levels[0].T
+    dev = levels[0].head.device
+    heads = (C.c_void_p * nl)(*[l.head.data_ptr() for l in levels])
+    anchors = (C.c_void_p * nl)(*[l.anchors.data_ptr() for l in levels])
+    lv = (L.RpnLevel * nl)()
+    for i, l in enumerate(levels):
+        lv[i].H, lv[i].W, lv[i].A, lv[i].T = l.H, l.W, l.A, l.T
+        lv[i].feat_stride = l.feat_stride
+        lv[i].cstride, lv[i].logit_off, lv[i].delta_off, lv[i].frame = l.cstride, l.logit_off, l.delta_off, l.frame
+    info = (C.c_float * 3)(*[float(v) for v in im_info])
+    rois = torch.zeros((nl, post_nms, 4 * T + 1), dtype=torch.float32, device=dev)
+    probs = torch.zeros((nl, post_nms), dtype=torch.float32, device=dev)
+    counts = torch.zeros((nl,), dtype=torch.int32, device=dev)
+    ctx().call('dat_rpn_proposals', _stream(), dtype, heads, lv, anchors, nl, info, pre_nms, post_nms,
+               C.c_float(nms_thresh), C.c_float(min_size), C.c_float(batch_idx), _ptr(rois), _ptr(probs), _ptr(counts))
+    return rois, probs, counts
+
+
+def collect_rois(rois, probs, counts, post_nms):
+    nl, cap, cols = rois.shape
+    out = torch.zeros((post_nms, cols), dtype=torch.float32, device=rois.device)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=rois.device)
+    ctx().call('dat_collect_rois', _stream(), _ptr(rois), _ptr(probs), _ptr(counts), nl, cap, cols, post_nms,
+               _ptr(out), _ptr(n_out))
+    return out, n_out
+
+
+def nms(dets, thresh):
+    """dets CUDA fp32 [n, 4T+1]; returns CUDA int32 keep (reference ordering conventions)."""
+    n, cols = dets.shape
+    T = (cols - 1) // 4
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dets.device)
+    nk = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    ctx().call('dat_nms', _stream(), _ptr(dets.contiguous()), n, T, C.c_float(thresh), _ptr(keep), _ptr(nk))
+    return keep[:int(nk.item())]
+
+
+def nms_host(dets_np, thresh):
+    """numpy in / numpy out, `_nms` convention of lib/nms/gpu_nms.hpp:3-9 (dets pre-sorted by score)."""
+    dets_np = np.ascontiguousarray(dets_np, dtype=np.float32)
+    n, dim = dets_np.shape
+    keep = np.zeros((max(n, 1),), dtype=np.int32)
+    num = C.c_int(0)
+    ctx().call('dat_nms_host', keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num),
+               dets_np.ctypes.data_as(C.POINTER(C.c_float)), n, dim, C.c_float(thresh))
+    return keep[:num.value]
+
+
+def deconv_k4s2_as_conv3x3(w):
+    """ConvTranspose weight fp32 [Cin, K, 4, 4] -> conv weight fp32 [4K, Cin, 1, 3, 3]."""
+    cin, k = int(w.shape[0]), int(w.shape[1])
+    out = torch.empty((4 * k, cin, 1, 3, 3), dtype=torch.float32, device=w.device)
+    ctx().call('dat_deconv_k4s2_weights', _stream(), _ptr(w.contiguous().float()), cin, k, _ptr(out))
+    return out
+
+
+def kps_finalize(sub, dtype, R, Tr, K, up):
+    f, s, s2, cs = sub.shape
+    assert f == R * Tr and s == s2
+    m = 2 * s * up
+    out = torch.empty((R, Tr * K, m, m), dtype=torch.float32, device=sub.device)
+    ctx().call('dat_kps_finalize', _stream(), dtype, _ptr(sub), R, Tr, s, cs, K, up, _ptr(out))
+    return out
+
+
+class ConvProfiler(object):
+    """HIP-event timing of every conv launch (bench.py roofline leg)."""
+
+    def __init__(self, capacity=4096):
+        self.capacity = capacity
+
+    def start(self):
+        L.lib().dat_prof_enable(ctx().h, self.capacity)
+
+    def stop(self):
+        tags = (C.c_int * self.capacity)()
+        flops = (C.c_double * self.capacity)()
+        ms = (C.c_float * self.capacity)()
+        n = L.lib().dat_prof_read(ctx().h, self.capacity, tags, flops, ms)
+        L.lib().dat_prof_enable(ctx().h, 0)
+        return [(tags[i], flops[i], ms[i]) for i in range(n)]

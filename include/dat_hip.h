@@ -1,0 +1,189 @@
+/* libdat_hip.so — C ABI of the MI355X-native DetectAndTrack hot path.
+ *
+ * Plain C: opaque context, device pointers, sizes, POD descriptors. No C++ or torch
+ * types cross this boundary; errors are return codes + dat_last_error() text (the
+ * replacement for Caffe2's CAFFE_ENFORCE message, cf. reference
+ * tests/test_zero_even_op.py:43).  Unless a function says "host", every pointer is a
+ * DEVICE pointer owned by the caller; nothing here synchronises the stream.
+ *
+ * What each entry point replaces in the reference (facebookresearch/DetectAndTrack):
+ *   - the Caffe2 operator-plugin boundary of lib/ops (REGISTER_CUDA_OPERATOR,
+ *     lib/ops/affine_channel_nd_op.cu:95-98; loaded via lib/utils/c2.py:53-56), and
+ *   - the one real C ABI in the tree, lib/nms/gpu_nms.hpp:3-9 (`_nms`), and
+ *   - the external Caffe2/cuDNN ops called by name from the lib/modeling builders
+ *     (ConvNd, MaxPool, RoIAlign, ConvTranspose, FC, ...; census in SURVEY.md §3.5).
+ *
+ * Internal activation layout: NDHWC ("frames x H x W x C", C contiguous, C % 64 == 0),
+ * fp32 (parity mode) or bf16 (performance mode).  The reference's NC[T]HW fp32 blobs
+ * appear only at the boundary (dat_ncdhw_to_ndhwc / dat_ndhwc_to_ncdhw, dat_stem_pack,
+ * dat_kps_finalize).
+ */
+#ifndef DAT_HIP_H_
+#define DAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dat_ctx dat_ctx;
+typedef void* dat_stream; /* hipStream_t */
+
+enum { DAT_F32 = 0, DAT_BF16 = 1 };
+enum { DAT_OK = 0, DAT_ERR_ARG = -1, DAT_ERR_LAUNCH = -2, DAT_ERR_ALLOC = -3, DAT_ERR_UNSUPPORTED = -4 };
+
+/* ---- context ------------------------------------------------------------------------- */
+int dat_version(void);
+int dat_ctx_create(dat_ctx** out, int device);
+void dat_ctx_destroy(dat_ctx* ctx);
+const char* dat_last_error(dat_ctx* ctx);
+
+/* Per-launch HIP-event timing of the conv kernel (used by bench.py's roofline leg).
+ * enable: start recording (capacity launches); read: sync the events and return
+ * n records {tag, flops, milliseconds}; tag = BN*1000 + BP*10 + dtype. */
+int dat_prof_enable(dat_ctx* ctx, int capacity);
+int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float* ms);
+
+/* ---- toy op: ZeroEven  (lib/ops/zero_even_op.cu:25-56) --------------------------------- */
+int dat_zero_even_fwd(dat_ctx* ctx, dat_stream s, float* x, long long n);
+
+/* ---- AffineChannelNd  (lib/ops/affine_channel_nd_op.cu:20-92) -------------------------- */
+/* NC(spatial...) fp32, y = x*scale[c] + bias[c]; in-place allowed (.cc:23-24). */
+int dat_affine_channel_nd_fwd(dat_ctx* ctx, dat_stream s, const float* x, const float* scale, const float* bias,
+                              float* y, int N, int C, long long inner);
+/* gradient: dX = dY*scale[c]; no dscale/dbias (affine_channel_nd_op.cc:29-37). */
+int dat_affine_channel_nd_bwd(dat_ctx* ctx, dat_stream s, const float* dy, const float* scale, float* dx, int N,
+                              int C, long long inner);
+
+/* ---- boundary layout moves --------------------------------------------------------------- */
+/* src NC(T)HW fp32 [N,C,T,H,W] -> dst [N*T,H,W,Cs] (channels >= C zero-filled). */
+int dat_ncdhw_to_ndhwc(dat_ctx* ctx, dat_stream s, const float* src, void* dst, int dtype, int N, int C, int T,
+                       int H, int W, int Cs);
+/* src [N*T,H,W,Cs] -> dst NC(T)HW fp32 [N,C,T,H,W] (first C channels). */
+int dat_ndhwc_to_ncdhw(dat_ctx* ctx, dat_stream s, const void* src, int dtype, float* dst, int N, int C, int T,
+                       int H, int W, int Cs);
+
+/* ---- fused 3D convolution: ConvNd/Conv/FC + bias|AffineChannelNd + Sum + Relu ------------ */
+/* Replaces ConvNd (lib/modeling/ResNet3D.py:258, detector.py:421-433), AffineChannelNd
+ * (a3), Relu, Sum (ResNet3D.py:146-154), UpsampleNearest+Sum (FPN3D.py:207-222), Conv
+ * (FPN.py:222-262), FC (head_builder.py:34-37), ConvTranspose-as-subpixel-conv. */
+typedef struct {
+    int dtype;               /* DAT_F32 | DAT_BF16 (activations and packed weights) */
+    int frames, T;           /* frames = N*T input frames; temporal taps never cross a multiple of T */
+    int H, W, Cin;           /* input NDHWC dims; Cin = channel stride, multiple of 64 */
+    int Cout;                /* outputs written per position (multiple of 4) */
+    int out_cstride;         /* channel stride of y (>= Cout) */
+    int KT, KH, KW;          /* kernel */
+    int stride_h, stride_w;  /* temporal stride is 1 (VIDEO.TIME_STRIDE_ON unsupported: FPN3D.py:199-203) */
+    int pad_t, pad_h, pad_w; /* symmetric explicit pads, Caffe2 `pads=2*[..]` */
+    int relu;                /* fused Relu */
+    int res_mode;            /* 0 none | 1 residual same shape | 2 residual at (h/2, w/2) (nearest 2x) */
+} dat_conv_desc;
+
+int dat_conv3d_out_shape(const dat_conv_desc* d, int* Ho, int* Wo);
+/* bytes of the packed weight buffer [KT*KH*KW][Cout_pad][Cin] in d->dtype */
+size_t dat_conv3d_packed_weight_bytes(const dat_conv_desc* d);
+/* w: fp32 [Cout_real, Cin_real, KT, KH, KW] (reference blob layout); rows/cols beyond are zero. */
+int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w, int Cout_real,
+                            int Cin_real, void* packed);
+/* y = act( conv(x, w)*scale[c] + bias[c] + residual ); scale may be NULL (=1), bias may be NULL (=0).
+ * scale/bias: fp32 [Cout].  residual: same dtype/stride as y. */
+int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                   const float* scale, const float* bias, const void* residual, void* y);
+/* algorithmic FLOPs of one launch: 2*Cout*Cin*KT*KH*KW*frames*Ho*Wo */
+double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real);
+
+/* ---- stem: conv1 [1,7,7]/s[1,2,2] input packing (ResNet3D.py:258-262) ---------------------- */
+/* data NC(T)HW fp32 [N,3,T,H,W] -> packed [N*T, Ho+3, Wo, 64]:
+ *   packed[f, r, ow, dkh*32 + kw*3 + c] = data[n, c, t, 2r-3+dkh, 2ow-3+kw] (0 outside), so that
+ *   conv1 == a (KH=4, KW=1, stride 1, pad 0) conv over r with 64 channels. */
+int dat_stem_pack(dat_ctx* ctx, dat_stream s, const float* data, void* packed, int dtype, int N, int T, int H,
+                  int W);
+/* conv1_w fp32 [64,3,1,7,7] -> fp32 [64,64,1,4,1] in the packed-channel order above (then dat_conv3d_pack_weights) */
+int dat_stem_weights(dat_ctx* ctx, dat_stream s, const float* conv1_w, int Cout, float* w_k4);
+
+/* ---- MaxPool [1,k,k]/s[1,st,st] (ResNet3D.py:263-265; FPN3D.py:158-163 with k=1) ------------- */
+int dat_maxpool_hw(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int frames, int H, int W, int C,
+                   int k, int stride, int pad);
+
+/* ---- time pooling (detector.py:559-576): avg over T -> frames/T frames ----------------------- */
+int dat_time_avg(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int N, int T, long long hwc);
+
+/* ---- RoIAlign, tube- and FPN-level-aware (detector.py:216-310 + ops/roi_blob_transforms.py:25-36) ---- */
+typedef struct {
+    const void* feat;    /* [N*T, H, W, C] */
+    int H, W;
+    float spatial_scale;
+} dat_roi_level;
+/* rois fp32 [R, 4*Tr+1] (col0 = batch idx n).  Tube slot t reads frame n*T + t (Tr == T) or n*T + t0 (Tr == 1:
+ * 2D heads on a key frame, detector.py:571-576).  With n_levels > 1 each RoI picks level
+ * clip(floor(canon_level + log2(sqrt(mean_t area)/canon_scale + 1e-6)), k_min, k_min+n_levels-1)
+ * (lib/modeling/FPN.py:349-360) and levels[lvl - k_min]; output rows stay in RoI order, which is what the
+ * reference obtains with Concat + BatchPermutation(rois_idx_restore) (detector.py:283-296).
+ * out [R*Tr, P, P, C].  Legacy Detectron RoIAlign: no half-pixel shift, roi size clamped to >= 1,
+ * sampling_ratio^2 samples per bin (ceil(roi/P) when sampling_ratio <= 0). */
+int dat_roi_align(dat_ctx* ctx, dat_stream s, int dtype, const dat_roi_level* levels, int n_levels, int k_min,
+                  float canon_scale, int canon_level, int T, int C, const float* rois, int R, int Tr, int t0,
+                  int pooled, int sampling_ratio, void* out);
+
+/* ---- small head maths ------------------------------------------------------------------------- */
+/* mean over H,W of [frames,H,W,C] -> [frames,C] fp32 (ReduceBackMean x2, ResNet3D.py:318-319) */
+int dat_spatial_mean(dat_ctx* ctx, dat_stream s, int dtype, const void* x, float* y, int frames, int HW, int C,
+                     int Cs);
+/* softmax over the first K of each row of stride ld (model_builder.py:452) */
+int dat_softmax_rows(dat_ctx* ctx, dat_stream s, const float* x, float* y, int rows, int K, int ld_in, int ld_out);
+
+/* ---- RPN proposals: GenerateProposalsOp on device (lib/ops/generate_proposals.py:40-181) -------- */
+typedef struct {
+    int H, W, A, T;          /* grid, anchors per cell, frames per tube */
+    float feat_stride;
+    int cstride;             /* channel stride of the head tensor */
+    int logit_off, delta_off;/* channel offsets: logits [A], deltas [A*T*4] (anchor, frame, xywh) */
+    int frame;               /* which frame of the head tensor holds this image's map */
+} dat_rpn_level;
+
+/* head: conv output [frames,H,W,cstride] (fp32 or bf16) holding RAW logits (sigmoid applied here,
+ * model_builder.py:583) and deltas.  anchors: fp32 [A, 4T] cell anchors (generate_anchors.py).
+ * Per level l writes (score order): rois_out + l*post_nms*(4T+1), probs_out + l*post_nms, count[l].
+ * Semantics: top pre_nms by score (ties: lower (h,w,a) index first) -> bbox_transform, weights 1
+ * (boxes.py:141-183) -> clip (boxes.py:243-253) -> min_size*im_scale filter AND-ed over frames
+ * (generate_proposals.py:184-196) -> NMS (>= thresh boxes / > thresh tubes) -> first post_nms. */
+int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
+                      const float* const* anchors, int n_levels, const float* im_info /* HOST [3]: H, W, scale */,
+                      int pre_nms, int post_nms, float nms_thresh, float min_size, float batch_idx,
+                      float* rois_out, float* probs_out, int* counts_out);
+
+/* CollectAndDistributeFpnRpnProposalsOp.collect (lib/ops/collect_and_distribute_fpn_rpn_proposals.py:44-62).
+ * In: per-level rois/probs/counts as written by dat_rpn_proposals (level stride = level_cap rows of roi_cols).
+ * Out: rois [n_out, roi_cols] = global top post_nms by score (ties: lower concat index), n_out (dev int32[1]).
+ * The per-level split (`distribute`, :65-87) is not materialised on device: dat_roi_align assigns levels in-kernel. */
+int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
+                     int n_levels, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out);
+
+/* ---- NMS (lib/utils/cython_nms.pyx:37-87, lib/nms/py_cpu_nms_tubes.py:17-53) ---------------------- */
+/* dets: dev fp32 [n, 4T+1], ANY order.  keep: dev int32[n]; boxes (T==1): ascending original indices
+ * (cython_nms semantics, suppress at IoU >= thresh); tubes (T>1): score order, suppress at mean IoU > thresh.
+ * num_keep: dev int32[1]. */
+int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float thresh, int* keep, int* num_keep);
+/* Host-pointer convenience wrapper with the reference's `_nms` convention (lib/nms/gpu_nms.hpp:3-9):
+ * boxes_host [boxes_num, boxes_dim] PRE-SORTED by score, keep_out has room for boxes_num ints.
+ * Synchronous; returns 0 or a DAT_ERR code (the reference only printed errors). */
+int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                 float nms_overlap_thresh);
+
+/* ---- keypoint head tail: ConvTranspose k4s2p1 (as 3x3 sub-pixel conv) + bilinear up (detector.py:348-380) -- */
+/* Expand kps_score_lowres_w fp32 [Cin, K, 4, 4] (Caffe2 ConvTranspose layout) into an equivalent 3x3 conv
+ * weight fp32 [4*K, Cin, 1, 3, 3] whose output channel (a*2+b)*K + k is sub-pixel (a,b) of keypoint k. */
+int dat_deconv_k4s2_weights(dat_ctx* ctx, dat_stream s, const float* w, int Cin, int K, float* w3x3);
+/* sub [R*Tr, S, S, cs] (4K sub-pixel channels, bias already added) -> kps_score fp32 NCHW
+ * [R, Tr*K, 2*up*S, 2*up*S]: pixel-shuffle to 2S then the fixed bilinear ConvTranspose (k=2*up, s=up,
+ * p=up/2; model_builder.py:858-868 incl. time->channel ordering t*K+k). */
+int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int R, int Tr, int S, int cs, int K,
+                     int up, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAT_HIP_H_ */

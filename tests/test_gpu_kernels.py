@@ -1,0 +1,401 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from detectandtrack_amd.ops import hip_ops
+    return hip_ops
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_zero_even(ops):
+    # reference tests/test_zero_even_op.py:24-113: empty, odd/even lengths, shape error text
+    for n in (0, 1, 2, 5, 6, 1001):
+        x = torch.arange(1, n + 1, dtype=torch.float32).cuda()
+        y = ops.zero_even(x.clone()).cpu().numpy()
+        exp = np.arange(1, n + 1, dtype=np.float32)
+        exp[0::2] = 0
+        np.testing.assert_array_equal(y, exp)
+    from detectandtrack_amd.libdat import DatError
+    with pytest.raises(DatError, match=r'X\.ndim\(\) == 1'):
+        ops.zero_even(torch.zeros(2, 2).cuda())
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 7), (1, 64, 3, 8, 12), (3, 16, 4, 4), (1, 3, 2, 5, 5)])
+def test_affine_channel_nd(ops, shape):
+    rs = np.random.RandomState(0)
+    x = rs.randn(*shape).astype(np.float32)
+    s = rs.uniform(0.5, 1.5, shape[1]).astype(np.float32)
+    b = rs.randn(shape[1]).astype(np.float32)
+    bs = [1, -1] + [1] * (len(shape) - 2)
+    exp = x * s.reshape(bs) + b.reshape(bs)
+    xd = _dev(x)
+    y = ops.affine_channel_nd(xd, _dev(s), _dev(b))
+    np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=0, atol=1e-6)
+    ops.affine_channel_nd(xd, _dev(s), _dev(b), out=xd)  # in-place (affine_channel_nd_op.cc:23-24)
+    np.testing.assert_allclose(xd.cpu().numpy(), exp, rtol=0, atol=1e-6)
+    g = ops.affine_channel_nd_grad(_dev(x), _dev(s))
+    np.testing.assert_allclose(g.cpu().numpy(), x * s.reshape(bs), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_layout_roundtrip(ops, dtype):
+    rs = np.random.RandomState(1)
+    x = rs.randn(2, 5, 3, 9, 11).astype(np.float32)
+    nd = ops.to_ndhwc(_dev(x), dtype, 64)
+    assert nd.shape == (6, 9, 11, 64)
+    ref = np.transpose(x, (0, 2, 3, 4, 1)).reshape(6, 9, 11, 5)
+    got = nd.float().cpu().numpy()
+    tol = 0 if dtype == 0 else 2e-2
+    np.testing.assert_allclose(got[..., :5], ref, rtol=tol, atol=tol)
+    assert np.all(got[..., 5:] == 0)
+    back = ops.to_ncdhw(nd, dtype, 2, 5, 3).cpu().numpy()
+    np.testing.assert_allclose(back, x, rtol=tol, atol=tol)
+
+
+# ------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name, N, T, H, W, Cin, Cout, (kt,kh,kw), (sh,sw), relu, res_mode, affine
+    ('1x1', 1, 2, 12, 20, 64, 128, (1, 1, 1), (1, 1), False, 0, True),
+    ('3x3_2d', 1, 1, 17, 23, 64, 64, (1, 3, 3), (1, 1), True, 0, True),
+    ('3x3x3', 1, 4, 14, 18, 64, 128, (3, 3, 3), (1, 1), True, 1, True),
+    ('3x3x3_c256', 1, 3, 9, 21, 128, 256, (3, 3, 3), (1, 1), False, 0, False),
+    ('3x3_s2', 1, 2, 20, 28, 64, 128, (3, 3, 3), (2, 2), True, 0, True),
+    ('1x1_s2', 1, 2, 20, 28, 128, 256, (1, 1, 1), (2, 2), False, 0, True),
+    ('1x1_up2', 1, 2, 8, 12, 128, 256, (1, 1, 1), (1, 1), False, 2, False),
+    ('3x3_batch', 3, 1, 14, 14, 64, 64, (1, 3, 3), (1, 1), True, 0, False),
+    ('cout12', 1, 1, 10, 14, 64, 12, (1, 1, 1), (1, 1), False, 0, False),
+    ('fc_like', 1, 1, 1, 37, 448, 96, (1, 1, 1), (1, 1), True, 0, False),
+    ('wide', 1, 1, 6, 150, 64, 64, (1, 3, 3), (1, 1), False, 0, True),
+]
+
+
+def _conv_ref(x, w, scale, bias, res, stride, pads, relu):
+    y = F.conv3d(torch.from_numpy(x), torch.from_numpy(w), None, stride=(1,) + stride, padding=pads)
+    if scale is not None:
+        y = y * torch.from_numpy(scale).view(1, -1, 1, 1, 1)
+    if bias is not None:
+        y = y + torch.from_numpy(bias).view(1, -1, 1, 1, 1)
+    if res is not None:
+        y = y + torch.from_numpy(res)
+    return (F.relu(y) if relu else y).numpy()
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d(ops, case, dtype):
+    name, N, T, H, W, Cin, Cout, k, s, relu, res_mode, affine = case
+    rs = np.random.RandomState(abs(hash(name)) % 1000)
+    x = rs.randn(N, Cin, T, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, *k) * np.sqrt(2.0 / (Cin * k[0] * k[1] * k[2]))).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32) if affine else None
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    pads = (k[0] // 2, k[1] // 2, k[2] // 2)
+    Ho = (H + 2 * pads[1] - k[1]) // s[0] + 1
+    Wo = (W + 2 * pads[2] - k[2]) // s[1] + 1
+    res = None
+    res_small = None
+    if res_mode == 1:
+        res = rs.randn(N, Cout, T, Ho, Wo).astype(np.float32)
+    elif res_mode == 2:
+        res_small = rs.randn(N, Cout, T, Ho // 2, Wo // 2).astype(np.float32)
+        res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    if dtype == 1:  # bf16: quantise the operands the kernel will see, so only accumulation order differs
+        q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+        x, w = q(x), q(w)
+        if res is not None:
+            res = q(res)
+            res_small = q(res_small) if res_small is not None else None
+    ref = _conv_ref(x, w, scale, bias, res, s, pads, relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=s, pads=pads,
+                          relu=relu, dtype=dtype)
+    xd = ops.to_ndhwc(_dev(x), dtype)
+    rd = None
+    if res_mode == 1:
+        rd = ops.to_ndhwc(_dev(res), dtype, layer.cstride)
+    elif res_mode == 2:
+        rd = ops.to_ndhwc(_dev(res_small), dtype, layer.cstride)
+    y = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    got = ops.to_ncdhw(y, dtype, N, Cout, T).cpu().numpy()
+    err = np.abs(got - ref).max()
+    tol = 2e-4 if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    print('conv %s dtype=%d max-abs err %.3e (ref max %.2f)' % (name, dtype, err, np.abs(ref).max()))
+    assert err < tol
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_stem_conv1(ops, dtype):
+    rs = np.random.RandomState(5)
+    N, T, H, W = 1, 2, 38, 50
+    x = (rs.uniform(0, 255, (N, 3, T, H, W)) - 110).astype(np.float32)
+    w = (rs.randn(64, 3, 1, 7, 7) * 0.05).astype(np.float32)
+    s = rs.uniform(0.5, 1.5, 64).astype(np.float32)
+    b = (rs.randn(64) * 0.1).astype(np.float32)
+    if dtype == 1:
+        q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+        x, w = q(x), q(w)
+    ref = _conv_ref(x, w, s, b, None, (2, 2), (0, 3, 3), True)
+    layer = ops.stem_layer(_dev(w), _dev(s), _dev(b), dtype)
+    packed = ops.stem_pack(_dev(x), dtype)
+    y = layer(packed, T=T)
+    got = ops.to_ncdhw(y, dtype, N, 64, T).cpu().numpy()
+    err = np.abs(got - ref).max()
+    print('stem dtype=%d err %.3e ref max %.1f' % (dtype, err, np.abs(ref).max()))
+    assert got.shape == ref.shape
+    assert err < (2e-3 if dtype == 0 else 0.02 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_maxpool(ops, dtype):
+    rs = np.random.RandomState(6)
+    x = rs.randn(1, 64, 2, 13, 18).astype(np.float32)
+    if dtype == 1:
+        x = torch.from_numpy(x).bfloat16().float().numpy()
+    ref = F.max_pool3d(torch.from_numpy(x), (1, 3, 3), (1, 2, 2), (0, 1, 1)).numpy()
+    y = ops.maxpool_hw(ops.to_ndhwc(_dev(x), dtype), dtype, 3, 2, 1)
+    np.testing.assert_array_equal(ops.to_ncdhw(y, dtype, 1, 64, 2).cpu().numpy(), ref)
+    # P6 = MaxPool k1 s2 (FPN3D.py:158-163)
+    ref6 = x[:, :, :, ::2, ::2]
+    y6 = ops.maxpool_hw(ops.to_ndhwc(_dev(x), dtype), dtype, 1, 2, 0)
+    np.testing.assert_array_equal(ops.to_ncdhw(y6, dtype, 1, 64, 2).cpu().numpy(), ref6)
+
+
+def test_time_avg(ops):
+    rs = np.random.RandomState(7)
+    x = rs.randn(2, 64, 3, 5, 6).astype(np.float32)
+    y = ops.time_avg(ops.to_ndhwc(_dev(x), 0), 0, 2, 3)
+    got = ops.to_ncdhw(y, 0, 2, 64, 1).cpu().numpy()[:, :, 0]
+    np.testing.assert_allclose(got, x.mean(axis=2), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _rand_rois(rs, n, W, H, T=1, batch=1):
+    r = np.zeros((n, 4 * T + 1), dtype=np.float32)
+    r[:, 0] = rs.randint(0, batch, n)
+    x1 = rs.uniform(-10, W - 20, n)
+    y1 = rs.uniform(-10, H - 20, n)
+    w = rs.uniform(2, W * 0.8, n)
+    h = rs.uniform(2, H * 0.8, n)
+    for t in range(T):
+        j = rs.uniform(-4, 4, (4, n))
+        r[:, 1 + 4 * t] = x1 + j[0]
+        r[:, 2 + 4 * t] = y1 + j[1]
+        r[:, 3 + 4 * t] = x1 + w + j[2]
+        r[:, 4 + 4 * t] = y1 + h + j[3]
+    return r
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_roi_align_single_level(ops, dtype):
+    from oracle.roi_align import roi_align_2d
+    rs = np.random.RandomState(8)
+    feat = rs.randn(2, 64, 1, 20, 30).astype(np.float32)
+    if dtype == 1:
+        feat = torch.from_numpy(feat).bfloat16().float().numpy()
+    rois = _rand_rois(rs, 23, 30 * 16, 20 * 16, batch=2)
+    ref = roi_align_2d(feat[:, :, 0], rois, 7, 1. / 16., 2)
+    fd = ops.to_ndhwc(_dev(feat), dtype)
+    out = ops.roi_align([fd], [1. / 16.], dtype, _dev(rois), T=1, Tr=1, t0=0, pooled=7, sampling=2)
+    got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
+    err = np.abs(got - ref).max()
+    print('roi_align dtype=%d err %.3e' % (dtype, err))
+    assert err < (1e-4 if dtype == 0 else 3e-2)
+
+
+def test_roi_align_tube_and_keyframe(ops):
+    from oracle.roi_align import roi_align_tube, roi_align_2d
+    rs = np.random.RandomState(9)
+    T = 3
+    feat = rs.randn(1, 64, T, 16, 20).astype(np.float32)
+    rois = _rand_rois(rs, 9, 20 * 16, 16 * 16, T=T)
+    ref = roi_align_tube(feat, rois, 14, 1. / 16., 2)  # (R, C, T, P, P)
+    fd = ops.to_ndhwc(_dev(feat), 0)
+    out = ops.roi_align([fd], [1. / 16.], 0, _dev(rois), T=T, Tr=T, t0=0, pooled=14, sampling=2)
+    got = out.cpu().numpy().reshape(9, T, 14, 14, 64).transpose(0, 4, 1, 2, 3)
+    assert np.abs(got - ref).max() < 1e-4
+    # 2D rois on the key frame of a T-frame feature (slice-center link)
+    rois2 = _rand_rois(rs, 7, 20 * 16, 16 * 16)
+    ref2 = roi_align_2d(feat[:, :, 1], rois2, 7, 1. / 16., 2)
+    out2 = ops.roi_align([fd], [1. / 16.], 0, _dev(rois2), T=T, Tr=1, t0=1, pooled=7, sampling=2)
+    assert np.abs(out2.cpu().numpy().transpose(0, 3, 1, 2) - ref2).max() < 1e-4
+
+
+def test_roi_align_fpn_levels(ops):
+    from oracle import proposals as op
+    from oracle.roi_align import roi_align_2d
+    rs = np.random.RandomState(10)
+    feats = [rs.randn(1, 64, 1, 64 // 2 ** i, 96 // 2 ** i).astype(np.float32) for i in range(4)]  # P2..P5
+    rois = _rand_rois(rs, 60, 96 * 4, 64 * 4)
+    rois[:10, 3] = rois[:10, 1] + rs.uniform(200, 380, 10)
+    rois[:10, 4] = rois[:10, 2] + rs.uniform(150, 250, 10)
+    lvls = op.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+    assert len(np.unique(lvls)) >= 3
+    ref = np.zeros((60, 64, 7, 7), np.float32)
+    for i in range(60):
+        l = int(lvls[i])
+        ref[i] = roi_align_2d(feats[l - 2][:, :, 0], rois[i:i + 1], 7, 1. / 2 ** l, 2)[0]
+    fds = [ops.to_ndhwc(_dev(f), 0) for f in feats]
+    out = ops.roi_align(fds, [1. / 2 ** l for l in range(2, 6)], 0, _dev(rois), T=1, Tr=1, t0=0, pooled=7, sampling=2)
+    assert np.abs(out.cpu().numpy().transpose(0, 3, 1, 2) - ref).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('key', ['nms_n300_t3', 'nms_n300_t5', 'nms_n1000_t7', 'nms_n1_t5', 'nms_n2_t5'])
+def test_nms_boxes_bit_exact_vs_reference(ops, golden, key):
+    dets = golden[key + '_dets']
+    keep = ops.nms(_dev(dets), float(key.split('_t')[1]) / 10.).cpu().numpy()
+    np.testing.assert_array_equal(keep, golden[key + '_keep'])
+
+
+@pytest.mark.parametrize('key,thr', [('tnms_n200_T3_t5', 0.5), ('tnms_n120_T8_t7', 0.7), ('tnms_n1_T3_t5', 0.5)])
+def test_nms_tubes_bit_exact_vs_reference(ops, golden, key, thr):
+    keep = ops.nms(_dev(golden[key + '_dets']), thr).cpu().numpy()
+    np.testing.assert_array_equal(keep, golden[key + '_keep'])
+
+
+def test_nms_fuzz_and_host_wrapper(ops):
+    from oracle import nms as onms
+    rs = np.random.RandomState(12)
+    for n in (3, 64, 65, 129, 777, 2500, 4096):
+        b = rs.uniform(0, 300, (n, 4)).astype(np.float32)
+        b[:, 2:] = b[:, :2] + rs.uniform(1, 80, (n, 2)).astype(np.float32)
+        d = np.hstack((b, rs.uniform(0, 1, (n, 1)).astype(np.float32)))
+        for thr in (0.3, 0.7):
+            np.testing.assert_array_equal(ops.nms(_dev(d), thr).cpu().numpy(), onms.nms_boxes(d, thr))
+    # empty
+    assert ops.nms(torch.zeros((0, 5)).cuda(), 0.5).numel() == 0
+    # `_nms` convention (lib/nms/gpu_nms.hpp:3-9): pre-sorted host boxes, keep = positions
+    d = d[np.argsort(-d[:, 4], kind='stable')]
+    keep = ops.nms_host(d, 0.5)
+    np.testing.assert_array_equal(keep, onms.nms_boxes(d, 0.5))
+    # heavy-overlap adversarial: identical boxes, only the best survives
+    same = np.tile(np.array([[10, 10, 50, 50]], np.float32), (500, 1))
+    dd = np.hstack((same, rs.uniform(0, 1, (500, 1)).astype(np.float32)))
+    k = ops.nms(_dev(dd), 0.5).cpu().numpy()
+    assert k.tolist() == [int(np.argmax(dd[:, 4]))]
+
+
+def _head_tensor(ops, scores, deltas, dtype):
+    """scores (1,A,H,W) probabilities, deltas (1,4AT,H,W) -> head [1,H,W,cs] holding LOGITS + deltas."""
+    A = scores.shape[1]
+    p = np.clip(scores.astype(np.float64), 1e-7, 1 - 1e-7)
+    logits = np.log(p / (1 - p)).astype(np.float32)
+    cat = np.concatenate([logits, deltas], axis=1)
+    return ops.to_ndhwc(_dev(cat), dtype, 64), A
+
+
+@pytest.mark.parametrize('name', ['gp_fpn3', 'gp_fpn2_min', 'gp_c4_T3'])
+def test_rpn_proposals_vs_reference_golden(ops, golden, name):
+    """Device GenerateProposals vs the REAL reference op's output (tests/golden/make_golden.py).
+
+    The device recomputes sigmoid(logit(p)), so a probability can move by an ulp; scores in the golden
+    inputs are well separated, hence order and NMS decisions are unaffected and boxes must agree to 1e-3 px."""
+    stride, pre, post, thr, min_size = golden[name + '_cfg']
+    scores, deltas = golden[name + '_scores'], golden[name + '_deltas']
+    anchors = golden[name + '_anchors']
+    A, T = anchors.shape[0], anchors.shape[1] // 4
+    head, _ = _head_tensor(ops, scores, deltas, 0)
+    H, W = scores.shape[2:]
+    lvl = ops.RpnLevelSpec(head, H, W, A, T, float(stride), 64, 0, A, 0, _dev(anchors.astype(np.float32)))
+    rois, probs, counts = ops.rpn_proposals([lvl], 0, golden[name + '_im_info'][0], int(pre), int(post), float(thr),
+                                            float(min_size))
+    n = int(counts[0].item())
+    ref_rois, ref_probs = golden[name + '_rois'], golden[name + '_probs']
+    assert n == ref_rois.shape[0]
+    np.testing.assert_allclose(rois[0, :n].cpu().numpy(), ref_rois, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(probs[0, :n].cpu().numpy(), ref_probs[:, 0], rtol=0, atol=1e-6)
+
+
+def test_rpn_proposals_multilevel_and_collect(ops):
+    from oracle import proposals as op
+    from oracle.anchors import generate_anchors
+    rs = np.random.RandomState(13)
+    shapes = {2: (48, 64), 3: (24, 32), 4: (12, 16), 5: (6, 8), 6: (3, 4)}
+    im_info = np.array([[192., 256., 1.0]], np.float32)
+    specs, ref_r, ref_p = [], [], []
+    for lvl in range(2, 7):
+        H, W = shapes[lvl]
+        anchors = generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2))
+        scores = rs.uniform(0.01, 0.99, (1, 3, H, W)).astype(np.float32)
+        deltas = (rs.randn(1, 12, H, W) * 0.3).astype(np.float32)
+        head, _ = _head_tensor(ops, scores, deltas, 0)
+        # the oracle must see exactly the probabilities the device will compute from the logits
+        lg = ops.to_ncdhw(head, 0, 1, 3, 1).cpu().numpy()[:, :, 0]
+        probs_dev = (1.0 / (1.0 + np.exp(-lg.astype(np.float32)))).astype(np.float32)
+        r, p = op.generate_proposals(probs_dev, deltas, im_info, anchors, 1. / 2 ** lvl, 1000, 300, 0.7, 0)
+        ref_r.append(r)
+        ref_p.append(p)
+        specs.append(ops.RpnLevelSpec(head, H, W, 3, 1, float(2 ** lvl), 64, 0, 3, 0, _dev(anchors.astype(np.float32))))
+    rois, probs, counts = ops.rpn_proposals(specs, 0, im_info[0], 1000, 300, 0.7, 0.)
+    cnt = counts.cpu().numpy()
+    for i in range(5):
+        assert cnt[i] == ref_r[i].shape[0], (i, cnt[i], ref_r[i].shape)
+        np.testing.assert_allclose(rois[i, :cnt[i]].cpu().numpy(), ref_r[i], atol=2e-3)
+    out, n_out = ops.collect_rois(rois, probs, counts, 300)
+    exp = op.collect([r for r in ref_r], [p for p in ref_p], 300)
+    assert int(n_out.item()) == exp.shape[0]
+    np.testing.assert_allclose(out[:exp.shape[0]].cpu().numpy(), exp, atol=2e-3)
+
+
+def test_rpn_proposals_ties_and_small_levels(ops):
+    """All-equal scores (zero-initialised RPN): ties resolve to the lowest (h, w, a) index; N < pre_nms."""
+    from oracle import proposals as op
+    from oracle.anchors import generate_anchors
+    anchors = generate_anchors(16., (64,), (0.5, 1, 2))
+    H, W = 40, 50   # N = 6000 > pre_nms
+    scores = np.full((1, 3, H, W), 0.5, np.float32)
+    deltas = (np.random.RandomState(14).randn(1, 12, H, W) * 0.2).astype(np.float32)
+    im_info = np.array([[640., 800., 1.0]], np.float32)
+    head, _ = _head_tensor(ops, scores, deltas, 0)
+    spec = ops.RpnLevelSpec(head, H, W, 3, 1, 16., 64, 0, 3, 0, _dev(anchors.astype(np.float32)))
+    rois, probs, counts = ops.rpn_proposals([spec], 0, im_info[0], 700, 200, 0.7, 0.)
+    r, p = op.generate_proposals(scores, deltas, im_info, anchors, 1. / 16, 700, 200, 0.7, 0)
+    n = int(counts[0].item())
+    assert n == r.shape[0]
+    np.testing.assert_allclose(rois[0, :n].cpu().numpy(), r, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_kps_tail(ops, dtype):
+    """ConvTranspose k4s2p1 (as sub-pixel 3x3 conv) + bilinear ConvTranspose == oracle.net3d.kps_outputs_2d."""
+    from oracle.net3d import Net, opts_for
+    rs = np.random.RandomState(15)
+    R, Cin, K, S = 3, 64, 17, 14
+    x = np.maximum(rs.randn(R, Cin, S, S), 0).astype(np.float32)
+    w = (rs.randn(Cin, K, 4, 4) * 0.05).astype(np.float32)
+    b = (rs.randn(K) * 0.1).astype(np.float32)
+    if dtype == 1:
+        q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+        x, w = q(x), q(w)
+    net = Net({'kps_score_lowres_w': w, 'kps_score_lowres_b': b}, opts_for('R18'))
+    ref = net.kps_outputs_2d(torch.from_numpy(x)).numpy()
+    w3 = ops.deconv_k4s2_as_conv3x3(_dev(w))
+    layer = ops.ConvLayer(w3, None, _dev(np.tile(b, 4)), stride=(1, 1), pads=(0, 1, 1), relu=False, dtype=dtype)
+    sub = layer(ops.to_ndhwc(_dev(x), dtype), T=1)
+    out = ops.kps_finalize(sub, dtype, R, 1, K, 2).cpu().numpy()
+    assert out.shape == ref.shape == (R, K, 56, 56)
+    err = np.abs(out - ref).max()
+    print('kps tail dtype=%d err %.3e' % (dtype, err))
+    assert err < (1e-4 if dtype == 0 else 3e-2)
+
+
+def test_spatial_mean_softmax(ops):
+    rs = np.random.RandomState(16)
+    x = rs.randn(4, 64, 1, 7, 7).astype(np.float32)
+    m = ops.spatial_mean(ops.to_ndhwc(_dev(x), 0), 0, 64).cpu().numpy()
+    np.testing.assert_allclose(m, x.mean(axis=(2, 3, 4)), atol=1e-5)
+    z = rs.randn(11, 12).astype(np.float32)
+    sm = ops.softmax_rows(_dev(z), 2).cpu().numpy()
+    np.testing.assert_allclose(sm, torch.softmax(torch.from_numpy(z[:, :2]), 1).numpy(), atol=1e-6)
