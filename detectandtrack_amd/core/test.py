@@ -1,0 +1,177 @@
+"""Inference driver — mirror of reference lib/core/test.py (single-scale path; TTA variants are
+COMPETITION_MODE-only and out of the hot-path scope).
+
+Call order and blob names are the reference's (:158-252 im_detect_bbox, :584-627 im_detect_keypoints, :750-806
+box_results_with_nms_and_limit, :865-894 keypoint_results, :897-957 im_detect_all): feed `data`/`im_info`, run
+`model.net`, fetch `rois`/`cls_prob`/`bbox_pred`; per-class NMS + top-100 on the host glue (NMS itself on the
+device through core.nms_wrapper); feed `keypoint_rois`, run `model.keypoint_net`, fetch `kps_score`.
+"""
+from collections import defaultdict
+
+import numpy as np
+
+from detectandtrack_amd.core.config import cfg
+from detectandtrack_amd.core.nms_wrapper import nms
+from detectandtrack_amd.utils.timer import Timer
+from detectandtrack_amd import workspace
+import detectandtrack_amd.utils.blob as blob_utils
+import detectandtrack_amd.utils.boxes as box_utils
+import detectandtrack_amd.utils.keypoints as keypoint_utils
+
+
+def _get_image_blob(im):
+    """im: list of BGR frames (len 1 for images) -> (data blob, scale factors) (:43-75)."""
+    per_frame, scales = [], []
+    for frame in im:
+        ims, sc = blob_utils.prep_im_for_blob(frame, cfg.PIXEL_MEANS, cfg.TEST.SCALES, cfg.TEST.MAX_SIZE)
+        per_frame.append(ims)
+        scales.append(sc)
+    for s in scales:
+        assert scales[0] == s
+    processed = [frames[i] for i in range(len(per_frame[0])) for frames in per_frame]
+    return blob_utils.im_list_to_blob(processed), np.array(scales[0])
+
+
+def _project_im_rois(im_rois, scales):
+    """(:95-123) single scale: every roi at pyramid level 0."""
+    im_rois = im_rois.astype(np.float64, copy=False)
+    if len(scales) > 1:
+        w = im_rois[:, 2] - im_rois[:, 0] + 1
+        h = im_rois[:, 3] - im_rois[:, 1] + 1
+        areas = (w * h)[:, np.newaxis] * (scales[np.newaxis, :] ** 2)
+        levels = np.abs(areas - 224 * 224).argmin(axis=1)[:, np.newaxis]
+    else:
+        levels = np.zeros((im_rois.shape[0], 1), dtype=np.int64)
+    return im_rois * scales[levels], levels
+
+
+def _get_rois_blob(im_rois, im_scale_factors):
+    """R x (4T) boxes in image coordinates -> R x (4T+1) [level, boxes * scale] fp32 (:78-92)."""
+    rois, levels = _project_im_rois(im_rois, im_scale_factors)
+    return np.hstack((levels, rois)).astype(np.float32, copy=False)
+
+
+def _get_blobs(im, rois):
+    """(:146-157)"""
+    blobs = {}
+    blobs['data'], im_scale_factors = _get_image_blob(im)
+    if cfg.MODEL.FASTER_RCNN and rois is None:
+        blobs['im_info'] = np.array([[blobs['data'].shape[-2], blobs['data'].shape[-1], im_scale_factors[0]]],
+                                    dtype=np.float32)
+    if rois is not None:
+        blobs['rois'] = _get_rois_blob(rois, im_scale_factors)
+    return blobs, im_scale_factors
+
+
+def im_detect_bbox(model, im, boxes=None):
+    """(:158-252) returns scores (R x K), pred_boxes (R x 4TK), im_scales."""
+    inputs, im_scales = _get_blobs(im, boxes)
+    for k, v in inputs.items():
+        workspace.FeedBlob(k, v)
+    workspace.RunNet(model.net.Proto().name)
+    return _read_bbox_outputs(im, im_scales)
+
+
+def _read_bbox_outputs(im, im_scales):
+    assert cfg.MODEL.FASTER_RCNN and len(im_scales) == 1, 'Only single-image / single-scale batch implemented'
+    rois = workspace.FetchBlob('rois')
+    boxes = rois[:, 1:] / im_scales[0]
+    scores = workspace.FetchBlob('cls_prob')
+    scores = scores.reshape([-1, scores.shape[-1]])
+    time_dim = boxes.shape[-1] // 4
+    if cfg.TEST.BBOX_REG:
+        box_deltas = workspace.FetchBlob('bbox_pred')
+        box_deltas = box_deltas.reshape([-1, box_deltas.shape[-1]])
+        if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG:
+            box_deltas = box_deltas[:, -4 * time_dim:]
+        pred_boxes = box_utils.bbox_transform(boxes, box_deltas, cfg.MODEL.BBOX_REG_WEIGHTS)
+        pred_boxes = box_utils.clip_tiled_boxes(pred_boxes, im[0].shape)
+        if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG:
+            pred_boxes = np.tile(pred_boxes, (1, scores.shape[1]))
+    else:
+        pred_boxes = np.tile(boxes, (1, scores.shape[1]))
+    return scores, pred_boxes, im_scales
+
+
+def box_results_with_nms_and_limit(scores, boxes):
+    """Score threshold, per-class NMS, keep the DETECTIONS_PER_IM best over all classes (:750-806)."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    time_dim = boxes.shape[-1] // (num_classes * 4)
+    cls_boxes = [[] for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0]
+        dets_j = np.hstack((boxes[inds, j * 4 * time_dim:(j + 1) * 4 * time_dim],
+                            scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
+        if cfg.TEST.SOFT_NMS.ENABLED or cfg.TEST.BBOX_VOTE.ENABLED:
+            raise NotImplementedError('Soft-NMS / box voting are disabled in every shipped config')
+        keep = nms(dets_j, cfg.TEST.NMS)
+        cls_boxes[j] = dets_j[keep, :]
+    if cfg.TEST.DETECTIONS_PER_IM > 0:
+        image_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
+        if len(image_scores) > cfg.TEST.DETECTIONS_PER_IM:
+            thresh = np.sort(image_scores)[-cfg.TEST.DETECTIONS_PER_IM]
+            for j in range(1, num_classes):
+                cls_boxes[j] = cls_boxes[j][np.where(cls_boxes[j][:, -1] >= thresh)[0], :]
+    im_results = np.vstack([cls_boxes[j] for j in range(1, num_classes)])
+    return im_results[:, -1], im_results[:, :-1], cls_boxes
+
+
+def im_detect_keypoints(model, im_scales, boxes):
+    """(:584-627) returns R x (17 T) x M x M heatmap logits."""
+    assert len(im_scales) == 1, 'Only single-image / single-scale batch implemented'
+    time_dim = boxes.shape[-1] // 4
+    M = cfg.KRCNN.HEATMAP_SIZE
+    if boxes.shape[0] == 0:
+        return np.zeros((0, time_dim * cfg.KRCNN.NUM_KEYPOINTS, M, M), np.float32)
+    workspace.FeedBlob('keypoint_rois', _get_rois_blob(boxes, im_scales))
+    workspace.RunNet(model.keypoint_net.Proto().name)
+    heat = workspace.FetchBlob('kps_score')
+    if heat.ndim == 3:
+        heat = np.expand_dims(heat, axis=0)
+    return heat
+
+
+def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes):
+    """(:865-894) per-frame heatmap decoding, concatenated along the keypoint axis for tubes."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    K = cfg.KRCNN.NUM_KEYPOINTS
+    cls_keyps = [[] for _ in range(num_classes)]
+    person = keypoint_utils.get_person_class_index()
+    assert pred_heatmaps.shape[1] % K == 0, 'Heatmaps must be 17xT'
+    time_dim = pred_heatmaps.shape[1] // K
+    assert time_dim == ref_boxes.shape[-1] // 4, 'Same T for boxes and keypoints'
+    per_t = [keypoint_utils.heatmaps_to_keypoints(pred_heatmaps[:, t * K:(t + 1) * K], ref_boxes[:, t * 4:(t + 1) * 4])
+             for t in range(time_dim)]
+    xy = np.concatenate(per_t, axis=-1)
+    if cfg.KRCNN.NMS_OKS:
+        raise NotImplementedError('Handle tubes')
+    cls_keyps[person] = [xy[i] for i in range(xy.shape[0])]
+    return cls_keyps
+
+
+def im_detect_all(model, im, box_proposals, timers=None):
+    """(:897-957)"""
+    if timers is None:
+        timers = defaultdict(Timer)
+    if cfg.TEST.COMPETITION_MODE:
+        raise NotImplementedError('test-time augmentation (COMPETITION_MODE) is out of the hot-path scope; the '
+                                  'shipped configs set TEST.COMPETITION_MODE False')
+    timers['im_detect_bbox'].tic()
+    scores, boxes, im_scales = im_detect_bbox(model, im, box_proposals)
+    timers['im_detect_bbox'].toc()
+    timers['misc_bbox'].tic()
+    scores, boxes, cls_boxes = box_results_with_nms_and_limit(scores, boxes)
+    timers['misc_bbox'].toc()
+    if cfg.MODEL.MASK_ON and boxes.shape[0] > 0:
+        raise NotImplementedError('Handle tubes..')
+    cls_segms = None
+    if cfg.MODEL.KEYPOINTS_ON and boxes.shape[0] > 0:
+        timers['im_detect_keypoints'].tic()
+        heatmaps = im_detect_keypoints(model, im_scales, boxes)
+        timers['im_detect_keypoints'].toc()
+        timers['misc_keypoints'].tic()
+        cls_keyps = keypoint_results(cls_boxes, heatmaps, boxes)
+        timers['misc_keypoints'].toc()
+    else:
+        cls_keyps = None
+    return cls_boxes, cls_segms, cls_keyps

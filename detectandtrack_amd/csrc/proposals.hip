@@ -41,7 +41,7 @@ struct LevelDev {
     const float* anchors;
     int H, W, A, T;
     float feat_stride;
-    int cstride, logit_off, delta_off, frame;
+    int cstride, logit_off, delta_off, frame, apply_sigmoid;
     int N;                       // H*W*A
     // workspace pointers
     unsigned* keys;
@@ -80,7 +80,7 @@ __global__ void rpn_keys_hist_kernel(const RpnParams p) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.N; i += gridDim.x * blockDim.x) {
         const int pos = i / L.A, a = i - pos * L.A;
         const float logit = head_ld(L.head, p.dtype, ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.logit_off + a);
-        const float prob = 1.f / (1.f + expf(-logit));   // model_builder.py:583 Sigmoid
+        const float prob = L.apply_sigmoid ? 1.f / (1.f + expf(-logit)) : logit;   // model_builder.py:583 Sigmoid
         const unsigned key = __float_as_uint(prob);       // prob >= 0: bit pattern is monotonic
         L.keys[i] = key;
         atomicAdd(&L.hist[key >> 16], 1u);
@@ -596,6 +596,7 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
         L.feat_stride = levels[l].feat_stride;
         L.cstride = levels[l].cstride; L.logit_off = levels[l].logit_off; L.delta_off = levels[l].delta_off;
         L.frame = levels[l].frame;
+        L.apply_sigmoid = levels[l].apply_sigmoid;
         L.N = L.H * L.W * L.A;
         maxN = L.N > maxN ? L.N : maxN;
         L.keys = (unsigned*)(ws + per_level_off[l][0]);

@@ -1,0 +1,40 @@
+"""Network-input preparation — mirror of reference lib/utils/blob.py:40-90."""
+import numpy as np
+
+from detectandtrack_amd.core.config import cfg
+import detectandtrack_amd.utils.image as image_utils
+
+
+def im_list_to_blob(ims):
+    """List of HxWx3 (BGR, mean-subtracted) images -> NCHW blob, zero-padded to a common size (a multiple of
+    FPN.COARSEST_STRIDE when FPN is on, :47-50); video models get (B, C, T, H, W) (:59-61)."""
+    if not isinstance(ims, list):
+        ims = [ims]
+    max_shape = np.array([im.shape for im in ims]).max(axis=0)
+    if cfg.FPN.FPN_ON:
+        stride = float(cfg.FPN.COARSEST_STRIDE)
+        max_shape[0] = int(np.ceil(max_shape[0] / stride) * stride)
+        max_shape[1] = int(np.ceil(max_shape[1] / stride) * stride)
+    blob = np.zeros((len(ims), max_shape[0], max_shape[1], 3), dtype=np.float32)
+    for i, im in enumerate(ims):
+        blob[i, 0:im.shape[0], 0:im.shape[1], :] = im
+    blob = blob.transpose((0, 3, 1, 2))
+    if cfg.MODEL.VIDEO_ON:
+        blob = image_utils.move_batch_to_time(blob, cfg.VIDEO.NUM_FRAMES)
+    return blob
+
+
+def prep_im_for_blob(im, pixel_means, target_sizes, max_size):
+    """Mean-subtract and scale so the short side is target_size, capped so the long side <= max_size (:71-90)."""
+    im = im.astype(np.float32, copy=False)
+    im = im - pixel_means
+    short, long_ = np.min(im.shape[0:2]), np.max(im.shape[0:2])
+    ims, scales = [], []
+    for target in target_sizes:
+        scale = float(target) / float(short)
+        if np.round(scale * long_) > max_size:
+            scale = float(max_size) / float(long_)
+        out_w, out_h = int(np.round(im.shape[1] * scale)), int(np.round(im.shape[0] * scale))
+        ims.append(image_utils.resize_bilinear(im, out_w, out_h))
+        scales.append(scale)
+    return ims, scales

@@ -1,0 +1,430 @@
+"""Workspace + executor: the `caffe2.python.workspace` surface the reference engines use
+(`FeedBlob` / `RunNet` / `FetchBlob` / `CreateNet`, lib/core/test.py:190-232,611-621), running the recorded op
+lists of `modeling.detector` as HIP kernel launches through the C ABI (detectandtrack_amd.ops.hip_ops).
+
+Blobs live on the MI355X as NDHWC tensors (fp32 parity mode / bf16 performance mode, cfg.HIP.DTYPE); `FetchBlob`
+converts back to the reference's NC[T]HW fp32 layout, so engine code written against the reference reads the
+same arrays.  One process drives one GPU (reference inference model: one subprocess per GPU,
+lib/utils/subprocess.py:38-63).  There is no CPU execution path.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from detectandtrack_amd.core.config import cfg
+from detectandtrack_amd.ops import hip_ops as ops
+
+logger = logging.getLogger(__name__)
+
+
+class Blob(object):
+    """A device blob.  kind: 'fmap' [N*T,H,W,Cs] | 'rows' [1,1,R,Cs] (FC activations) | 'mat' fp32 tensor |
+    'rois' fp32 [cap, cols] + device count."""
+    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host')
+
+    def __init__(self, t, kind, N=1, T=1, C=0, dt=0, five_d=False, count=None):
+        self.t, self.kind, self.N, self.T, self.C, self.dt = t, kind, N, T, C, dt
+        self.five_d = five_d
+        self.count = count
+        self.sigmoid_of = None
+        self.host = None
+
+
+class Workspace(object):
+    def __init__(self, device=0):
+        self.device = torch.device('cuda', device)
+        self.blobs = {}
+        self.params = {}        # name -> np.ndarray (host master copy, reference blob layout)
+        self.nets = {}
+        self._layers = {}       # (net name, op index) -> prepared ConvLayer etc.
+        self._dev_params = {}
+        self.conv_log = None    # when a list: (name, algorithmic flops) per conv launch (bench roofline leg)
+
+    # ---- reference workspace API -------------------------------------------------------------------------------
+    def FeedBlob(self, name, arr):
+        name = _unscoped(name)
+        if isinstance(arr, torch.Tensor):
+            t = arr.to(self.device)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        b = Blob(t, 'mat')
+        b.host = None if isinstance(arr, torch.Tensor) else np.asarray(arr)
+        self.blobs[name] = b
+
+    def FetchBlob(self, name):
+        name = _unscoped(name)
+        if name in self.params and name not in self.blobs:
+            return self.params[name]
+        b = self.blobs[name]
+        if b.kind == 'fmap':
+            out = ops.to_ncdhw(b.t, b.dt, b.N, b.C, b.T).cpu().numpy()
+            return out if b.five_d else out[:, :, 0]
+        if b.kind == 'rows':
+            r = b.t.shape[2]
+            m = ops.to_ncdhw(b.t.view(r, 1, 1, b.t.shape[3]), b.dt, r, b.C, 1).cpu().numpy().reshape(r, b.C)
+            return m[:_count(b)] if b.count is not None else m
+        if b.kind == 'rois':
+            return b.t[:_count(b)].cpu().numpy()
+        arr = b.t.cpu().numpy()
+        if b.sigmoid_of is not None:
+            arr = 1.0 / (1.0 + np.exp(-arr))
+        return arr[:_count(b)] if b.count is not None else arr
+
+    def HasBlob(self, name):
+        return _unscoped(name) in self.blobs or _unscoped(name) in self.params
+
+    def Blobs(self):
+        return list(self.blobs.keys())
+
+    def CreateNet(self, net):
+        self.nets[net.name] = net
+        return net
+
+    def RunNet(self, name):
+        name = getattr(name, 'name', name)
+        net = self.nets[name]
+        Executor(self, net).run()
+
+    def ResetWorkspace(self):
+        self.blobs.clear()
+        self._layers.clear()
+        self._dev_params.clear()
+
+    # ---- parameters -----------------------------------------------------------------------------------------------
+    def dev_param(self, name):
+        if name not in self._dev_params:
+            self._dev_params[name] = torch.from_numpy(np.ascontiguousarray(self.params[name], dtype=np.float32)).to(self.device)
+        return self._dev_params[name]
+
+    def set_param(self, name, arr):
+        self.params[name] = np.asarray(arr, dtype=np.float32)
+        self._dev_params.pop(name, None)
+        self._layers.clear()
+
+
+def _unscoped(name):
+    name = str(name)
+    return name[name.rfind('/') + 1:]  # 'gpu_0/rois' -> 'rois' (core.ScopedName, lib/utils/c2.py)
+
+
+def _count(b):
+    return int(b.count.item()) if isinstance(b.count, torch.Tensor) else int(b.count)
+
+
+def _dt():
+    return ops.BF16 if cfg.HIP.DTYPE == 'bf16' else ops.F32
+
+
+def _w5(w):
+    w = np.asarray(w, dtype=np.float32)
+    return w if w.ndim == 5 else w[:, :, None]  # 2D conv weight [o,i,k,k] -> [o,i,1,k,k]
+
+
+class Executor(object):
+    """Interprets one recorded net.  Prepared layers (packed weights) are cached in the workspace."""
+
+    def __init__(self, ws, net):
+        self.ws, self.net = ws, net
+        self.pending_rpn = []
+        self.has_collect = any(op.type == 'CollectAndDistributeFpnRpnProposals' for op in net.ops)
+
+    def run(self):
+        self._plan_rpn_siblings()
+        for i, op in enumerate(self.net.ops):
+            if i in self._skip:
+                continue
+            getattr(self, 'op_' + op.type)(i, op)
+
+    # ---- RPN head sibling fusion: logits + deltas 1x1 convs on the same input run as ONE conv ------------------------
+    def _plan_rpn_siblings(self):
+        self._skip, self._fused = set(), {}
+        ops_ = self.net.ops
+        prod = {}
+        for i, op in enumerate(ops_):
+            for o in op.outputs:
+                prod[o] = i
+        for gi, gp in enumerate(ops_):
+            if gp.type != 'GenerateProposals':
+                continue
+            probs, deltas = gp.inputs[0], gp.inputs[1]
+            si = prod.get(probs)
+            if si is None or ops_[si].type != 'Sigmoid':
+                continue
+            li, di = prod.get(ops_[si].inputs[0]), prod.get(deltas)
+            if li is None or di is None:
+                continue
+            lo, do = ops_[li], ops_[di]
+            if lo.type == 'Conv' and do.type == 'Conv' and lo.inputs[0] == do.inputs[0] and \
+                    lo.args['kernels'] == [1, 1, 1] == do.args['kernels'] and lo.args['residual'] is None and \
+                    do.args['residual'] is None:
+                first = min(li, di)
+                self._skip.update({li, di, si})
+                self._skip.discard(first)
+                self._fused[first] = (lo, do, gi)
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------------
+    def _layer(self, key, build):
+        k = (self.net.name, key)
+        if k not in self.ws._layers:
+            self.ws._layers[k] = build()
+        return self.ws._layers[k]
+
+    def _log_conv(self, name, layer, frames, H, W):
+        if self.ws.conv_log is not None:
+            self.ws.conv_log.append((name, layer.flops(frames, H, W)))
+
+    # ---- ops ---------------------------------------------------------------------------------------------------------------
+    def op_Conv(self, i, op):
+        ws, a = self.ws, op.args
+        if i in self._fused:
+            return self._rpn_head_conv(i)
+        xin = ws.blobs[op.inputs[0]]
+        dt = _dt()
+        if op.inputs[0] == 'data':
+            return self._stem(i, op, xin)
+        assert xin.kind == 'fmap', (op, xin.kind)
+
+        def build():
+            w = ops.torch.from_numpy(_w5(ws.params[a['w']])).to(ws.device)
+            scale = ws.dev_param(a['scale']) if a['scale'] else None
+            bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
+            return ops.ConvLayer(w, scale, bias, stride=a['strides'], pads=a['pads'], relu=a['relu'], dtype=dt,
+                                 cin_stride=xin.t.shape[3])
+        layer = self._layer(i, build)
+        res = ws.blobs[a['residual']].t if a['residual'] else None
+        self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
+        y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'])
+        ws.blobs[op.outputs[0]] = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
+
+    def _stem(self, i, op, xin):
+        ws, a, dt = self.ws, op.args, _dt()
+        assert a['kernels'] == [1, 7, 7] and a['strides'] == [2, 2] and a['pads'] == [0, 3, 3] and a['dim_in'] == 3, \
+            'the network input must feed the [1,7,7]/[1,2,2] stem conv (ResNet3D.py:258)'
+        data = xin.t
+        five_d = data.dim() == 5
+        if not five_d:
+            data = data[:, :, None]
+        n, _, t, h, w = data.shape
+
+        def build():
+            scale = ws.dev_param(a['scale']) if a['scale'] else None
+            bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
+            lay = ops.stem_layer(ops.torch.from_numpy(_w5(ws.params[a['w']])).to(ws.device), scale, bias, dt)
+            lay.relu = a['relu']
+            return lay
+        layer = self._layer(i, build)
+        packed = ops.stem_pack(data.float(), dt)
+        if ws.conv_log is not None:
+            ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_out'] * 3 * 49 * n * t * ho * wo))
+        y = layer(packed, T=t)
+        ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
+
+    def _rpn_head_conv(self, i):
+        ws, dt = self.ws, _dt()
+        lo, do, gi = self._fused[i]
+        xin = ws.blobs[lo.inputs[0]]
+        A = lo.args['dim_out']
+
+        def build():
+            w = np.concatenate([_w5(ws.params[lo.args['w']]), _w5(ws.params[do.args['w']])], axis=0)
+            b = np.concatenate([ws.params[lo.args['b']], ws.params[do.args['b']]], axis=0)
+            return ops.ConvLayer(ops.torch.from_numpy(w).to(ws.device), None, ops.torch.from_numpy(b).to(ws.device),
+                                 stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt, cin_stride=xin.t.shape[3])
+        layer = self._layer(('rpnhead', i), build)
+        self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
+        y = layer(xin.t, T=xin.T)
+        head = Blob(y, 'fmap', xin.N, xin.T, A + do.args['dim_out'], dt, xin.five_d)
+        ws.blobs[lo.outputs[0] + '+' + do.outputs[0]] = head
+        ws.blobs['_rpnhead_for_%d' % gi] = head
+
+    def op_MaxPool(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        y = ops.maxpool_hw(x.t, x.dt, op.args['k'], op.args['stride'], op.args['pad'])
+        self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, x.T, x.C, x.dt, x.five_d)
+
+    def op_SliceKeyFrame(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        k = op.args['keyframe']
+        f, h, w, c = x.t.shape
+        y = x.t.view(x.N, x.T, h, w, c)[:, k].contiguous() if x.N > 1 else x.t[k:k + 1]
+        self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, 1, x.C, x.dt, False)
+
+    def op_TimePoolAvg(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        y = ops.time_avg(x.t, x.dt, x.N, x.T)
+        self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, 1, x.C, x.dt, False)
+
+    def op_TimeToBatch(self, i, op):
+        self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
+
+    def op_Alias(self, i, op):
+        self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
+
+    def op_Sigmoid(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        b = Blob(x.t, x.kind, x.N, x.T, x.C, x.dt, x.five_d)
+        b.sigmoid_of = op.inputs[0]
+        self.ws.blobs[op.outputs[0]] = b
+
+    def op_GenerateProposals(self, i, op):
+        ws = self.ws
+        head = ws.blobs.get('_rpnhead_for_%d' % i)
+        assert head is not None, 'GenerateProposals expects the fused logits+deltas head conv (op %d)' % i
+        anchors = op.args['anchors']
+        A, T = anchors.shape[0], anchors.shape[1] // 4
+        f, h, w, cs = head.t.shape
+        key = ('anchors', i)
+        an = self._layer(key, lambda: ops.torch.from_numpy(anchors.astype(np.float32)).to(ws.device))
+        spec = ops.RpnLevelSpec(head.t, h, w, A, T, 1. / op.args['spatial_scale'], cs, 0, A, 0, an, apply_sigmoid=True)
+        self.pending_rpn.append((spec, op))
+        if not self.has_collect:
+            self._run_rpn(single=True)
+
+    def _run_rpn(self, single=False):
+        ws = self.ws
+        key = 'TRAIN' if self.net._helper is not None and self.net._helper.train else 'TEST'
+        im_info = ws.blobs['im_info']
+        info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
+        assert info.shape[0] == 1, 'one clip per forward (reference inference is batch 1, core/test.py:212-214)'
+        specs = [s for s, _ in self.pending_rpn]
+        rois, probs, counts = ops.rpn_proposals(specs, _dt(), info[0], cfg[key].RPN_PRE_NMS_TOP_N,
+                                                cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
+                                                cfg[key].RPN_MIN_SIZE)
+        for li, (_, op) in enumerate(self.pending_rpn):
+            ws.blobs[op.outputs[0]] = Blob(rois[li], 'rois', count=counts[li:li + 1])
+            if len(op.outputs) > 1:
+                ws.blobs[op.outputs[1]] = Blob(probs[li].view(-1, 1), 'mat', count=counts[li:li + 1])
+        self._rpn_out = (rois, probs, counts)
+        self.pending_rpn = []
+
+    def op_CollectAndDistributeFpnRpnProposals(self, i, op):
+        ws = self.ws
+        self._run_rpn()
+        rois, probs, counts = self._rpn_out
+        key = 'TRAIN' if self.net._helper is not None and self.net._helper.train else 'TEST'
+        out, n_out = ops.collect_rois(rois, probs, counts, cfg[key].RPN_POST_NMS_TOP_N)
+        ws.blobs['rois'] = Blob(out, 'rois', count=n_out)
+        # rois_fpn<l> / rois_idx_restore_int32 are derived lazily on the host if somebody fetches them; the device
+        # RoIAlign assigns levels in-kernel (no Concat + BatchPermutation, detector.py:283-296)
+        for name in op.outputs[1:]:
+            ws.blobs.pop(name, None)
+
+    def op_RoIFeatureTransform(self, i, op):
+        ws, a = self.ws, op.args
+        feats = [ws.blobs[n] for n in op.inputs[:a['n_feat']]]
+        rois = ws.blobs[op.inputs[-1]]
+        rt = rois.t
+        if rt.dim() != 2:
+            rt = rt.view(-1, rt.shape[-1])
+        R, cols = rt.shape
+        Tr = (cols - 1) // 4
+        f0 = feats[0]
+        assert Tr == 1 or Tr == f0.T, 'tube rois of %d frames on features with T=%d' % (Tr, f0.T)
+        y = ops.roi_align([f.t for f in feats], a['scales'], f0.dt, rt.float().contiguous(), T=f0.T, Tr=Tr, t0=0,
+                          pooled=a['resolution'], sampling=a['sampling_ratio'], k_min=cfg.FPN.ROI_MIN_LEVEL,
+                          canon_scale=float(cfg.FPN.ROI_CANONICAL_SCALE), canon_level=cfg.FPN.ROI_CANONICAL_LEVEL)
+        b = Blob(y, 'fmap', R, Tr, f0.C, f0.dt, Tr > 1)
+        b.count = rois.count
+        ws.blobs[op.outputs[0]] = b
+
+    def op_FC(self, i, op):
+        ws, a, dt = self.ws, op.args, _dt()
+        x = ws.blobs[op.inputs[0]]
+        if x.kind == 'fmap':
+            f, p, p2, cs = x.t.shape
+            assert cs == x.C, 'FC over a channel-padded RoI feature is not supported'
+            xin = x.t.view(1, 1, f, p * p2 * cs)
+            perm = (x.C, p, p2)
+        else:
+            xin, perm = x.t, None
+
+        def build():
+            w = np.asarray(ws.params[a['w']], dtype=np.float32)
+            if perm is not None:  # reference flattens NCHW (c, h, w); our RoI features are (h, w, c)
+                c, hh, ww = perm
+                w = w.reshape(w.shape[0], c, hh, ww).transpose(0, 2, 3, 1).reshape(w.shape[0], -1)
+            return ops.ConvLayer(ops.torch.from_numpy(np.ascontiguousarray(w[:, :, None, None, None])).to(ws.device), None,
+                                 ws.dev_param(a['b']), stride=(1, 1), pads=(0, 0, 0), relu=a['relu'], dtype=dt,
+                                 cin_stride=xin.shape[3])
+        layer = self._layer(i, build)
+        self._log_conv(op.outputs[0], layer, 1, 1, xin.shape[2])
+        y = layer(xin, T=1)
+        b = Blob(y, 'rows', 1, 1, a['dim_out'], dt)
+        b.count = x.count
+        ws.blobs[op.outputs[0]] = b
+
+    def _rows_to_mat(self, b):
+        r, cs = b.t.shape[2], b.t.shape[3]
+        return ops.to_ncdhw(b.t.view(r, 1, 1, cs), b.dt, r, b.C, 1).view(r, b.C)
+
+    def op_Softmax(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        m = self._rows_to_mat(x)
+        b = Blob(ops.softmax_rows(m, x.C), 'mat')
+        b.count = x.count
+        self.ws.blobs[op.outputs[0]] = b
+
+    def op_ConvTranspose(self, i, op):
+        ws, a, dt = self.ws, op.args, _dt()
+        x = ws.blobs[op.inputs[0]]
+
+        def build():
+            w3 = ops.deconv_k4s2_as_conv3x3(ws.dev_param(a['w']))
+            bias = ws.dev_param(a['b']).repeat(4)
+            return ops.ConvLayer(w3, None, bias, stride=(1, 1), pads=(0, 1, 1), relu=False, dtype=dt,
+                                 cin_stride=x.t.shape[3])
+        layer = self._layer(i, build)
+        if ws.conv_log is not None:   # algorithmic flops of the deconv itself: 16 taps / 4 outputs per input position
+            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] * 16 * x.t.shape[0] * x.t.shape[1] * x.t.shape[2]))
+        y = layer(x.t, T=1)
+        b = Blob(y, 'fmap', x.N, x.T, 4 * a['dim_out'], dt, x.five_d)
+        ws.blobs[op.outputs[0]] = b
+
+    def op_BilinearInterpolation(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        K = op.args['dim']
+        out = ops.kps_finalize(x.t, x.dt, x.N, x.T, K, op.args['up_scale'])
+        self.ws.blobs[op.outputs[0]] = Blob(out, 'mat')
+
+    def __getattr__(self, name):
+        if name.startswith('op_'):
+            raise NotImplementedError('executor has no handler for recorded op type %s' % name[3:])
+        raise AttributeError(name)
+
+
+# ---- module-level API (drop-in for `from caffe2.python import workspace`) --------------------------------------------------
+_GLOBAL = None
+
+
+def GlobalWorkspace():
+    global _GLOBAL
+    if _GLOBAL is None:
+        _GLOBAL = Workspace(torch.cuda.current_device())
+    return _GLOBAL
+
+
+def ResetWorkspace():
+    global _GLOBAL
+    _GLOBAL = None
+
+
+def FeedBlob(name, arr):
+    GlobalWorkspace().FeedBlob(name, arr)
+
+
+def FetchBlob(name):
+    return GlobalWorkspace().FetchBlob(name)
+
+
+def HasBlob(name):
+    return GlobalWorkspace().HasBlob(name)
+
+
+def CreateNet(net):
+    return GlobalWorkspace().CreateNet(net)
+
+
+def RunNet(name):
+    GlobalWorkspace().RunNet(name)

@@ -142,6 +142,7 @@ typedef struct {
     int cstride;             /* channel stride of the head tensor */
     int logit_off, delta_off;/* channel offsets: logits [A], deltas [A*T*4] (anchor, frame, xywh) */
     int frame;               /* which frame of the head tensor holds this image's map */
+    int apply_sigmoid;       /* 1: head holds raw logits (model_builder.py:583 Sigmoid fused here); 0: probabilities */
 } dat_rpn_level;
 
 /* head: conv output [frames,H,W,cstride] (fp32 or bf16) holding RAW logits (sigmoid applied here,

@@ -1,0 +1,59 @@
+"""Shared helpers for the end-to-end model tests / smoke(): build the product model + the oracle on the same
+synthetic weights and inputs."""
+import numpy as np
+
+
+def fpn3d_kps_cfg(arch='18', T=4, kt=3, link='slice-center', pre=300, post=100, dtype='fp32'):
+    return {
+        'MODEL': {'TYPE': 'keypoint_rcnn', 'CONV_BODY': 'FPN3D.add_fpn_ResNet%s_conv5_body' % arch,
+                  'ROI_HEAD': 'head_builder.add_roi_2mlp_head', 'NUM_CLASSES': 2, 'FASTER_RCNN': True,
+                  'KEYPOINTS_ON': True, 'VIDEO_ON': True},
+        'FPN': {'FPN_ON': True, 'MULTILEVEL_ROIS': True, 'MULTILEVEL_RPN': True},
+        'FAST_RCNN': {'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 7, 'ROI_XFORM_SAMPLING_RATIO': 2},
+        'KRCNN': {'ROI_KEYPOINTS_HEAD': 'keypoint_rcnn_heads.add_roi_pose_head_v1convX', 'NUM_STACKED_CONVS': 8,
+                  'NUM_KEYPOINTS': 17, 'USE_DECONV_OUTPUT': True, 'CONV_INIT': 'MSRAFill', 'CONV_HEAD_DIM': 512,
+                  'UP_SCALE': 2, 'HEATMAP_SIZE': 56, 'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 14,
+                  'ROI_XFORM_SAMPLING_RATIO': 2},
+        'VIDEO': {'NUM_FRAMES': T, 'TIME_KERNEL_DIM': kt, 'BODY_HEAD_LINK': link, 'WEIGHTS_INFLATE_MODE': 'center-only'},
+        'TEST': {'RPN_PRE_NMS_TOP_N': pre, 'RPN_POST_NMS_TOP_N': post, 'COMPETITION_MODE': False, 'NMS': 0.5},
+        'HIP': {'DTYPE': dtype},
+    }
+
+
+def build_product(cfg_dict, seed=3):
+    """Returns (model, workspace, weights dict).  Needs the GPU."""
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    reset_cfg()
+    cfg_from_cfg(cfg_dict)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=False)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    weights = net_utils.synthetic_params(model, seed)
+    for k, v in weights.items():
+        ws.set_param(k, v)
+    ws.CreateNet(model.net)
+    ws.CreateNet(model.conv_body_net)
+    if model.keypoint_net is not None:
+        ws.CreateNet(model.keypoint_net)
+    return model, ws, weights
+
+
+def synthetic_clip(T, H, W, seed=3):
+    """uint8-like BGR frames minus PIXEL_MEANS, NC(T)HW fp32."""
+    rs = np.random.RandomState(seed)
+    means = np.array([102.9801, 115.9465, 122.7717], dtype=np.float32).reshape(1, 3, 1, 1, 1)
+    # smooth-ish content so activations are not pure noise
+    base = rs.uniform(0, 255, (1, 3, T, H // 8 + 1, W // 8 + 1)).astype(np.float32)
+    data = np.repeat(np.repeat(base, 8, axis=3), 8, axis=4)[:, :, :, :H, :W]
+    data = data + rs.uniform(-20, 20, data.shape).astype(np.float32)
+    return np.clip(data, 0, 255) - means
+
+
+def oracle_opts(arch, T, kt, link, pre, post):
+    from oracle.net3d import opts_for
+    return opts_for('R' + arch, kt_body=kt, body_head_link=link, num_frames_mid=T, pre_nms_topn=pre,
+                    post_nms_topn=post)

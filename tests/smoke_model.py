@@ -1,22 +1,35 @@
-"""smoke(): one tiny hot-path invocation on cuda:0 checked against the oracle (used by __graft_entry__)."""
+"""smoke(): ONE tiny forward of the detector hot path on cuda:0 (body + FPN3D + RPN/proposals + box head +
+keypoint head, fp32 parity mode) checked against the CPU oracle.  Used by __graft_entry__.smoke()."""
 import numpy as np
 import torch
 
+from tests.model_util import fpn3d_kps_cfg, build_product, synthetic_clip, oracle_opts
 
-def run_smoke():
-    from detectandtrack_amd.ops import hip_ops as ops
-    from oracle.net3d import Net, opts_for
-    rs = np.random.RandomState(3)
-    x = rs.randn(1, 64, 2, 12, 16).astype(np.float32)
-    w = (rs.randn(64, 64, 3, 3, 3) * 0.05).astype(np.float32)
-    s = rs.uniform(0.5, 1.5, 64).astype(np.float32)
-    b = (rs.randn(64) * 0.1).astype(np.float32)
-    net = Net({'c_w': w, 'c_bn_s': s, 'c_bn_b': b}, opts_for('R18'))
-    ref = torch.relu(net.conv_affine_nd(torch.from_numpy(x), 'c', [3, 3, 3], [1, 1, 1], [1, 1, 1])).numpy()
-    dev = lambda a: torch.from_numpy(a).cuda()
-    layer = ops.ConvLayer(dev(w), dev(s), dev(b), stride=(1, 1), pads=(1, 1, 1), relu=True, dtype=ops.F32)
-    y = layer(ops.to_ndhwc(dev(x), ops.F32), T=2)
-    got = ops.to_ncdhw(y, ops.F32, 1, 64, 2).cpu().numpy()
-    err = float(np.abs(got - ref).max())
-    assert err < 1e-3, err
+
+def run_smoke(T=2, H=64, W=96):
+    from oracle.net3d import Net
+    model, ws, weights = build_product(fpn3d_kps_cfg('18', T=T, pre=200, post=50, dtype='fp32'))
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    rois = ws.FetchBlob('rois')
+    assert rois.shape[0] > 0 and rois.shape[1] == 5
+    kp_rois = rois[:6].copy()
+    ws.FeedBlob('keypoint_rois', kp_rois)
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    torch.cuda.synchronize()
+    # oracle on the same weights / inputs / rois
+    net = Net(weights, oracle_opts('18', T, 3, 'slice-center', 200, 50))
+    net.body(torch.from_numpy(data))
+    p2d = net.time_link(net.fpn())
+    from oracle import proposals as op
+    _, per_level, restore = op.distribute(kp_rois, 2, 5)
+    feat = net.roi_feat_fpn(p2d[1:], per_level, restore, 14, 2)
+    ref = net.kps_head_2d(feat).numpy()
+    err = float(np.abs(kps - ref).max())
+    assert kps.shape == ref.shape == (kp_rois.shape[0], 17, 56, 56)
+    assert err < 1e-3, 'kps_score max-abs error %.3e exceeds the 1e-3 fp32 parity bar' % err
     return err

@@ -286,28 +286,32 @@ def test_nms_fuzz_and_host_wrapper(ops):
     assert k.tolist() == [int(np.argmax(dd[:, 4]))]
 
 
-def _head_tensor(ops, scores, deltas, dtype):
-    """scores (1,A,H,W) probabilities, deltas (1,4AT,H,W) -> head [1,H,W,cs] holding LOGITS + deltas."""
+def _head_tensor(ops, scores, deltas, dtype, logits=True):
+    """scores (1,A,H,W) probabilities, deltas (1,4AT,H,W) -> head [1,H,W,cs] holding LOGITS (or probs) + deltas."""
     A = scores.shape[1]
-    p = np.clip(scores.astype(np.float64), 1e-7, 1 - 1e-7)
-    logits = np.log(p / (1 - p)).astype(np.float32)
-    cat = np.concatenate([logits, deltas], axis=1)
-    return ops.to_ndhwc(_dev(cat), dtype, 64), A
+    first = scores
+    if logits:
+        p = np.clip(scores.astype(np.float64), 1e-7, 1 - 1e-7)
+        first = np.log(p / (1 - p)).astype(np.float32)
+    cat = np.concatenate([first, deltas], axis=1)
+    cs = (cat.shape[1] + 63) // 64 * 64
+    return ops.to_ndhwc(_dev(cat), dtype, cs), cs
 
 
 @pytest.mark.parametrize('name', ['gp_fpn3', 'gp_fpn2_min', 'gp_c4_T3'])
 def test_rpn_proposals_vs_reference_golden(ops, golden, name):
     """Device GenerateProposals vs the REAL reference op's output (tests/golden/make_golden.py).
 
-    The device recomputes sigmoid(logit(p)), so a probability can move by an ulp; scores in the golden
-    inputs are well separated, hence order and NMS decisions are unaffected and boxes must agree to 1e-3 px."""
+    Probabilities are fed as-is (apply_sigmoid=0 == the reference op boundary, which takes rpn_cls_probs), so
+    the sort order is identical; boxes agree to 2e-3 px (device exp is correctly rounded, numpy's is ~1 ulp)."""
     stride, pre, post, thr, min_size = golden[name + '_cfg']
     scores, deltas = golden[name + '_scores'], golden[name + '_deltas']
     anchors = golden[name + '_anchors']
     A, T = anchors.shape[0], anchors.shape[1] // 4
-    head, _ = _head_tensor(ops, scores, deltas, 0)
+    head, cs = _head_tensor(ops, scores, deltas, 0, logits=False)
     H, W = scores.shape[2:]
-    lvl = ops.RpnLevelSpec(head, H, W, A, T, float(stride), 64, 0, A, 0, _dev(anchors.astype(np.float32)))
+    lvl = ops.RpnLevelSpec(head, H, W, A, T, float(stride), cs, 0, A, 0, _dev(anchors.astype(np.float32)),
+                           apply_sigmoid=False)
     rois, probs, counts = ops.rpn_proposals([lvl], 0, golden[name + '_im_info'][0], int(pre), int(post), float(thr),
                                             float(min_size))
     n = int(counts[0].item())

@@ -1,0 +1,109 @@
+"""End-to-end GPU parity: the recorded graph executed through the C ABI vs the oracle graph (fp32 parity mode,
+north-star bar: kps_score within 1e-3 max-abs) plus the bf16 performance mode with its own (looser) bound."""
+import numpy as np
+import pytest
+import torch
+
+from tests.model_util import fpn3d_kps_cfg, build_product, synthetic_clip, oracle_opts
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pyramid(weights, arch, data, T, kt=3, link='slice-center', pre=300, post=100):
+    from oracle.net3d import Net
+    net = Net(weights, oracle_opts(arch, T, kt, link, pre, post))
+    net.body(torch.from_numpy(data))
+    pyr = net.fpn()
+    return net, pyr
+
+
+@pytest.mark.parametrize('arch,T,H,W', [('18', 4, 96, 128), ('50', 2, 64, 96)])
+def test_fp32_forward_matches_oracle(arch, T, H, W):
+    from oracle import proposals as op
+    model, ws, weights = build_product(fpn3d_kps_cfg(arch, T=T, dtype='fp32'))
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    net, pyr = _oracle_pyramid(weights, arch, data, T)
+    last = {'18': 'res%d_1_sum', '50': None}
+    # body + FPN blobs (NC(T)HW fp32 at the boundary)
+    names = ['pool1'] + [b for b in ws.Blobs() if b.endswith('_sum') and b.startswith('res')] + \
+            [b for b in ws.Blobs() if b.startswith('fpn_res') and b.endswith('_sum')]
+    for n in names:
+        got = ws.FetchBlob(n)
+        ref = net.blobs[n].numpy()
+        assert got.shape == ref.shape, (n, got.shape, ref.shape)
+        err = np.abs(got - ref).max()
+        print('%-24s max-abs %.3e (ref max %.2f)' % (n, err, np.abs(ref).max()))
+        assert err < 1e-3 * max(1.0, np.abs(ref).max()), n
+    # RPN head outputs, per level
+    p2d = net.time_link(pyr)
+    ref_rois, _, _ = net.fpn_rpn(p2d, im_info)
+    for lvl in range(2, 7):
+        head = ws.FetchBlob('rpn_cls_logits_fpn%d+rpn_bbox_pred_fpn%d' % (lvl, lvl))
+        probs = 1.0 / (1.0 + np.exp(-head[:, :3]))
+        np.testing.assert_allclose(probs, net.blobs['rpn_cls_probs_fpn%d' % lvl].numpy(), atol=1e-4)
+        np.testing.assert_allclose(head[:, 3:15], net.blobs['rpn_bbox_pred_fpn%d' % lvl].numpy(), atol=1e-3)
+    # proposals: same set up to fp32 re-ordering of near-equal scores
+    rois = ws.FetchBlob('rois')
+    assert rois.shape[1] == 5 and rois.shape[0] == ref_rois.shape[0]
+    d = np.abs(rois[:, None, 1:] - ref_rois[None, :, 1:]).max(axis=2).min(axis=1)
+    assert (d < 0.05).mean() > 0.95, 'only %.1f%% of device rois found in the oracle set' % (100 * (d < 0.05).mean())
+    # box head on the DEVICE rois (oracle features, oracle head)
+    _, per_level, restore = op.distribute(rois, 2, 5)
+    feat = net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2)
+    cls_prob, bbox_pred = net.box_head_2mlp(feat)
+    np.testing.assert_allclose(ws.FetchBlob('cls_prob'), cls_prob, atol=1e-4)
+    np.testing.assert_allclose(ws.FetchBlob('bbox_pred'), bbox_pred, atol=1e-3)
+    # keypoint net on a few boxes
+    kp_rois = rois[:7].copy()
+    ws.FeedBlob('keypoint_rois', kp_rois)
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    _, per_level, restore = op.distribute(kp_rois, 2, 5)
+    ref = net.kps_head_2d(net.roi_feat_fpn(p2d[1:], per_level, restore, 14, 2)).numpy()
+    err = np.abs(kps - ref).max()
+    print('kps_score max-abs %.3e (ref max %.2f)' % (err, np.abs(ref).max()))
+    assert kps.shape == ref.shape
+    assert err < 1e-3
+
+
+def test_bf16_forward_close_to_oracle():
+    """Performance mode: bf16 activations/weights with fp32 accumulation; reported, looser bound."""
+    T, H, W = 4, 96, 128
+    model, ws, weights = build_product(fpn3d_kps_cfg('18', T=T, dtype='bf16'))
+    data = synthetic_clip(T, H, W)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', np.array([[H, W, 1.0]], dtype=np.float32))
+    ws.RunNet(model.net.name)
+    net, pyr = _oracle_pyramid(weights, '18', data, T)
+    for n in ('res2_1_sum', 'res5_1_sum', 'fpn_res2_1_sum'):
+        got, ref = ws.FetchBlob(n), net.blobs[n].numpy()
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        print('bf16 %-16s max-abs/max %.3e' % (n, rel))
+        assert rel < 0.06, n
+    rois = ws.FetchBlob('rois')
+    assert rois.shape[0] > 0
+    ws.FeedBlob('keypoint_rois', rois[:5].copy())
+    ws.RunNet(model.keypoint_net.name)
+    assert np.isfinite(ws.FetchBlob('kps_score')).all()
+
+
+def test_im_detect_all_surface():
+    """The reference engine surface (core/test.py:897) runs end to end on synthetic frames."""
+    from detectandtrack_amd.core import test as test_engine
+    from detectandtrack_amd.core.config import cfg
+    T = 2
+    model, ws, _ = build_product(fpn3d_kps_cfg('18', T=T, dtype='fp32'))
+    cfg.TEST.SCALES = (64,)
+    cfg.TEST.MAX_SIZE = 128
+    cfg.TEST.SCORE_THRESH = 0.0
+    rs = np.random.RandomState(0)
+    frames = [rs.randint(0, 255, (60, 90, 3)).astype(np.uint8) for _ in range(T)]
+    cls_boxes, cls_segms, cls_keyps = test_engine.im_detect_all(model, frames, None)
+    assert cls_segms is None
+    assert cls_boxes[1].shape[1] == 5 and cls_boxes[1].shape[0] <= cfg.TEST.DETECTIONS_PER_IM
+    if cls_boxes[1].shape[0] > 0:
+        assert len(cls_keyps[1]) == cls_boxes[1].shape[0] and cls_keyps[1][0].shape == (4, 17)
