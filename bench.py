@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — clips/sec of the 3D Mask R-CNN keypoint detector hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic clip that is ALREADY RESIDENT IN HBM:
+`model.net` (ResNet3D body + FPN3D + FPN RPN + on-device proposals/NMS + RoIAlign + 2-MLP box head), the
+reference's host glue between the nets (core/test.py:750-806: score threshold, per-class NMS on the device,
+top-100) and `model.keypoint_net` (RoIAlign + 8 convs + deconv + bilinear up) up to the `kps_score` blob.
+Image decoding/resizing and the host heatmap->keypoint decoding ("next") are outside the step.
+
+Multi-GPU: clips are independent units — every rank processes its own clip stream, no
+data-path collective; the only collectives are the barrier + MAX-reduce of the timing. scaling = weak.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def model_cfg(arch, T, dtype):
+    return {
+        'MODEL': {'TYPE': 'keypoint_rcnn', 'CONV_BODY': 'FPN3D.add_fpn_ResNet%s_conv5_body' % arch,
+                  'ROI_HEAD': 'head_builder.add_roi_2mlp_head', 'NUM_CLASSES': 2, 'FASTER_RCNN': True,
+                  'KEYPOINTS_ON': True, 'VIDEO_ON': True},
+        'FPN': {'FPN_ON': True, 'MULTILEVEL_ROIS': True, 'MULTILEVEL_RPN': True},
+        'FAST_RCNN': {'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 7, 'ROI_XFORM_SAMPLING_RATIO': 2},
+        'KRCNN': {'ROI_KEYPOINTS_HEAD': 'keypoint_rcnn_heads.add_roi_pose_head_v1convX', 'NUM_STACKED_CONVS': 8,
+                  'NUM_KEYPOINTS': 17, 'USE_DECONV_OUTPUT': True, 'CONV_INIT': 'MSRAFill', 'CONV_HEAD_DIM': 512,
+                  'UP_SCALE': 2, 'HEATMAP_SIZE': 56, 'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 14,
+                  'ROI_XFORM_SAMPLING_RATIO': 2},
+        'VIDEO': {'NUM_FRAMES': T, 'TIME_KERNEL_DIM': 3, 'BODY_HEAD_LINK': 'slice-center',
+                  'WEIGHTS_INFLATE_MODE': 'center-only'},
+        'TEST': {'RPN_PRE_NMS_TOP_N': 1000, 'RPN_POST_NMS_TOP_N': 1000, 'COMPETITION_MODE': False, 'NMS': 0.5,
+                 'SCALES': (800,), 'MAX_SIZE': 1333},
+        'HIP': {'DTYPE': dtype},
+    }
+
+
+def synthetic_clip(T, H, W, seed):
+    """Seeded uint8-like BGR frames minus PIXEL_MEANS, NC(T)HW fp32."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand((1, 3, T, H // 8, W // 8), generator=g) * 255.0
+    data = torch.nn.functional.interpolate(base.view(1, 3 * T, H // 8, W // 8), size=(H, W), mode='nearest').view(1, 3, T, H, W)
+    data = (data + (torch.rand(data.shape, generator=g) - 0.5) * 40.0).clamp_(0, 255)
+    means = torch.tensor([102.9801, 115.9465, 122.7717]).view(1, 3, 1, 1, 1)
+    return (data - means).contiguous()
+
+
+def build(arch, T, dtype):
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    reset_cfg()
+    cfg_from_cfg(model_cfg(arch, T, dtype))
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=False)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    for k, v in net_utils.synthetic_params(model, cfg.RNG_SEED).items():   # no checkpoints offline: random init
+        ws.set_param(k, v)
+    ws.CreateNet(model.net)
+    ws.CreateNet(model.keypoint_net)
+    return model, ws
+
+
+def one_step(model, ws, data_dev, im_info, im_shape):
+    """core/test.py:im_detect_all without image prep and without host heatmap decoding."""
+    from detectandtrack_amd.core import test as engine
+    ws.FeedBlob('data', data_dev)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    scores, boxes, _ = engine._read_bbox_outputs([np.zeros(im_shape, np.uint8)], np.array([im_info[0, 2]]))
+    scores, boxes, cls_boxes = engine.box_results_with_nms_and_limit(scores, boxes)
+    n_det = boxes.shape[0]
+    if n_det > 0:
+        ws.FeedBlob('keypoint_rois', engine._get_rois_blob(boxes, np.array([im_info[0, 2]])))
+        ws.RunNet(model.keypoint_net.name)
+    return n_det
+
+
+def cpu_baseline(arch, T, seconds_budget=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference graph) timed on the host cores on a bounded sample:
+    the same model on a reduced 8x256x320 clip (full clips take minutes on CPU)."""
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from oracle.net3d import Net, opts_for
+    from oracle import proposals as op
+    H, W = 256, 320
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = model_builder.create(cfg.MODEL.TYPE, train=False)
+    weights = net_utils.synthetic_params(model, cfg.RNG_SEED)
+    data = synthetic_clip(T, H, W, 3)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    opts = opts_for('R' + arch, kt_body=3, body_head_link='slice-center', num_frames_mid=T, pre_nms_topn=1000,
+                    post_nms_topn=200)
+    n, t0 = 0, time.time()
+    while True:
+        net = Net(weights, opts)
+        net.body(data)
+        p2d = net.time_link(net.fpn())
+        rois, per_level, restore = net.fpn_rpn(p2d, im_info)
+        feat = net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2)
+        net.box_head_2mlp(feat)
+        kp = rois[:8]
+        _, pl, rs = op.distribute(kp, 2, 5)
+        net.kps_head_2d(net.roi_feat_fpn(p2d[1:], pl, rs, 14, 2))
+        n += 1
+        el = time.time() - t0
+        if el > seconds_budget or n >= 8:
+            break
+    return {'value': n / el, 'unit': 'clips/s (reduced %dx%dx%d clips)' % (T, H, W), 'cores': cores, 'kind': 'port',
+            'sample': '%d forward passes of oracle.net3d (torch-CPU fp32, %d threads) on a %dx%dx%d clip, '
+                      '200 rois, 8 keypoint rois; %.1f s' % (n, cores, T, H, W, el)}
+
+
+def cpu_tracker_baseline():
+    """Host Hungarian tracker (stays on the host by design, tools/compute_tracks.py) on the synthetic detection
+    set of BASELINE.md §4: 50 videos x 100 frames x ~8 persons, single core as the reference runs it."""
+    try:
+        from detectandtrack_amd.core import tracking_engine as te
+    except Exception as e:  # tracker not built yet
+        return {'error': repr(e)}
+    return te.benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--arch', default='18', choices=['18', '50', '101'])
+    ap.add_argument('--frames', type=int, default=8)
+    ap.add_argument('--height', type=int, default=768)
+    ap.add_argument('--width', type=int, default=1344)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == a.gpus or world == 1, 'launch with --nproc-per-node == --gpus'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+
+    from detectandtrack_amd.ops import hip_ops as ops
+    model, ws = build(a.arch, a.frames, a.dtype)
+    T, H, W = a.frames, a.height, a.width
+    # every rank gets its own clips (weak scaling): seed by rank
+    clips = [synthetic_clip(T, H, W, 1000 * rank + i).cuda() for i in range(2)]
+    im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
+    im_shape = (int(round(H / im_info[0, 2])), int(round(W / im_info[0, 2])), 3)
+
+    n_det = 0
+    for i in range(a.warmup):
+        n_det = one_step(model, ws, clips[i % 2], im_info, im_shape)
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY `steps` steps, barrier + synchronize on both sides ----
+    prof = ops.ConvProfiler(capacity=256 * max(a.steps, 1))
+    ws.conv_log = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof.start()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        n_det = one_step(model, ws, clips[i % 2], im_info, im_shape)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    records = prof.stop()
+    conv_log, ws.conv_log = ws.conv_log, None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (conv3d_igemm, the BN=128 instantiation) from per-launch HIP events ----
+    assert len(records) == len(conv_log), (len(records), len(conv_log))
+    dom_tag = 128 * 1000 + 128 * 10 + (1 if a.dtype == 'bf16' else 0)
+    dom_fl = sum(fl for (tag, _, ms), (_, fl) in zip(records, conv_log) if tag == dom_tag)
+    dom_ms = sum(ms for (tag, _, ms) in records if tag == dom_tag)
+    dom_n = sum(1 for (tag, _, ms) in records if tag == dom_tag)
+    all_fl = sum(fl for _, fl in conv_log)
+    all_ms = sum(ms for _, _, ms in records)
+    peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    roofline = {
+        'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel<%s,128,128,2>' % a.dtype,
+        'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+        'traffic': None,
+        'launches_per_step': dom_n // max(a.steps, 1),
+        'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
+        'algorithmic_tflop_per_step': round(dom_fl / max(a.steps, 1) / 1e12, 4),
+        'all_conv_kernels': {'tflop_per_step': round(all_fl / max(a.steps, 1) / 1e12, 4),
+                             'ms_per_step': round(all_ms / max(a.steps, 1), 3),
+                             'tflops': round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
+    }
+    out = {
+        'metric': 'clips/sec (8-frame 800px)', 'value': round(a.gpus * a.steps / elapsed, 4), 'unit': 'clips/s',
+        'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': '3D R-%s FPN3D keypoint R-CNN inference, 1x3x%dx%dx%d clip per step per GPU '
+                               '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score)'
+                               % (a.arch, T, H, W, n_det),
+                   'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
+                   'parallelism': 'clip-sharded x%d (no data-path collective)' % a.gpus},
+        'roofline': roofline,
+    }
+    if not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a.arch, T)
+        out['cpu_tracker'] = cpu_tracker_baseline()
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

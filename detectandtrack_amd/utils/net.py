@@ -53,9 +53,15 @@ def initialize_params(model, ws, seed=None):
 
 
 def synthetic_params(model, seed=3):
-    """Deterministic non-degenerate weights for parity tests / benchmarks: convs MSRA-normal,
-    affine scale U(0.5, 1.5) and bias N(0, 0.1), conv/FC biases N(0, 0.05); fixed bilinear kernel as specified."""
+    """Deterministic, well-conditioned weights for parity tests / benchmarks (no checkpoints are available offline):
+    ReLU-followed convs N(0, 2/fan_in), linear convs/FCs N(0, 1/fan_in), conv1 additionally /64 (inputs are
+    mean-subtracted pixels), affine scale U(0.5, 1) — U(0.2, 0.4) on the last affine of a residual branch so that
+    activations stay O(1..10) through the stack —, affine bias N(0, 0.1), conv/FC biases N(0, 0.05); the bilinear
+    up-sampling kernel is the fixed one of detector.py:356-372."""
     rs = np.random.RandomState(seed)
+    trans = cfg.RESNETS.TRANS_FUNC
+    last_bn = '_branch2c_bn_s' if trans == 'bottleneck_transformation' else '_branch2b_bn_s'
+    linear = ('fpn_', 'rpn_cls', 'rpn_bbox', 'cls_score', 'bbox_pred', 'kps_score')
     out = {}
     for name in model.params:
         spec = model.param_specs[name]
@@ -63,14 +69,22 @@ def synthetic_params(model, seed=3):
         if spec['init'][0] == 'BilinearFill':
             out[name] = _fill('BilinearFill', spec['init'][1], shape, rs)
         elif spec.get('affine'):
-            out[name] = (rs.uniform(0.5, 1.5, shape) if name.endswith('_s') else rs.randn(*shape) * 0.1).astype(np.float32)
+            if name.endswith('_s'):
+                lo, hi = (0.2, 0.4) if name.endswith(last_bn) else (0.5, 1.0)
+                out[name] = rs.uniform(lo, hi, shape).astype(np.float32)
+            else:
+                out[name] = (rs.randn(*shape) * 0.1).astype(np.float32)
         elif len(shape) == 1:
             out[name] = (rs.randn(*shape) * 0.05).astype(np.float32)
         else:
             fan_in = int(np.prod(shape)) / shape[0]
             if name.startswith('kps_score_lowres'):   # ConvTranspose [in, out, k, k]: 4 taps reach each output
                 fan_in = shape[0] * 4
-            out[name] = (rs.randn(*shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+            gain = 1.0 if name.startswith(linear) else 2.0
+            w = rs.randn(*shape) * np.sqrt(gain / fan_in)
+            if name == 'conv1_w':
+                w = w / 64.0
+            out[name] = w.astype(np.float32)
     return out
 
 
