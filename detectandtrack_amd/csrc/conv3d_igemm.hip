@@ -146,92 +146,115 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams
     const size_t w_tap_stride = (size_t)p.Cout_pad * p.Cin * ES;  // bytes between taps
     const int npatch_items = p.PH * p.PW * 8;
 
-    // weight tile prefetch registers
-    uint4 wreg[W_ITEMS];
-    auto w_prefetch = [&](int kt, int cc, int tap) {
-        const char* base = p.w + (size_t)(kt * ntap + tap) * w_tap_stride + (size_t)cc * CK * ES;
+    // weight tile prefetch registers (macros, not lambdas: a by-reference lambda capture of the register array
+    // made hipcc keep it in scratch memory, which serialised every step behind its global loads)
+    static_assert(W_ITEMS == 2 || W_ITEMS == 4, "weight tile = 2 or 4 16-byte items per thread");
+    uint4 w0, w1, w2 = make_uint4(0, 0, 0, 0), w3 = make_uint4(0, 0, 0, 0);  // named registers, never an array (scratch!)
+    // item i of this thread: row (tid + i*256) >> 3 = (tid >> 3) + 32*i, slot tid & 7
+    const size_t w_thr_off = (size_t)(n0 + (tid >> 3)) * p.Cin * ES + (tid & 7) * 16;
+    const size_t w_item_stride = (size_t)32 * p.Cin * ES;
+    const int w_lds0 = swz(tid >> 3, tid & 7), w_lds1 = swz((tid >> 3) + 32, tid & 7);
+    const int w_lds2 = swz((tid >> 3) + 64, tid & 7), w_lds3 = swz((tid >> 3) + 96, tid & 7);
+#define W_PREFETCH(KT_, CC_, TAP_)                                                                              \
+    {                                                                                                           \
+        const char* wbase_ = p.w + (size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_thr_off; \
+        w0 = *(const uint4*)(wbase_);                                                                           \
+        w1 = *(const uint4*)(wbase_ + w_item_stride);                                                           \
+        if (W_ITEMS == 4) {                                                                                     \
+            w2 = *(const uint4*)(wbase_ + 2 * w_item_stride);                                                   \
+            w3 = *(const uint4*)(wbase_ + 3 * w_item_stride);                                                   \
+        }                                                                                                       \
+    }
+#define W_COMMIT(BUF_)                                                                                          \
+    {                                                                                                           \
+        char* wdst_ = wbuf + (BUF_) * BN * ROWB;                                                                \
+        *(uint4*)(wdst_ + w_lds0) = w0;                                                                         \
+        *(uint4*)(wdst_ + w_lds1) = w1;                                                                         \
+        if (W_ITEMS == 4) {                                                                                     \
+            *(uint4*)(wdst_ + w_lds2) = w2;                                                                     \
+            *(uint4*)(wdst_ + w_lds3) = w3;                                                                     \
+        }                                                                                                       \
+    }
+
+    // per-lane LDS byte offsets that do not change across taps: weight rows (per k-slice), patch swizzle keys
+    int a_off[MT];
 #pragma unroll
-        for (int i = 0; i < W_ITEMS; ++i) {
-            const int it = tid + i * NTHREADS;
-            const int row = it >> 3, slot = it & 7;
-            wreg[i] = *(const uint4*)(base + (size_t)(n0 + row) * p.Cin * ES + slot * 16);
-        }
-    };
-    auto w_commit = [&](int buf) {
-        char* dst = wbuf + buf * BN * ROWB;
-#pragma unroll
-        for (int i = 0; i < W_ITEMS; ++i) {
-            const int it = tid + i * NTHREADS;
-            const int row = it >> 3, slot = it & 7;
-            *(uint4*)(dst + swz(row, slot)) = wreg[i];
-        }
-    };
-    auto patch_load = [&](int kt, int cc) {
-        const int fin = f + kt - p.pt;
-        const char* base = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
-        for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * 4) {
-            uint4 v[4];
-            int rows[4], slots[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * NTHREADS;
-                const int row = it >> 3, slot = it & 7;
-                rows[u] = row;
-                slots[u] = slot;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (it < npatch_items) {
-                    const int prow = row / p.PW, pcol = row - prow * p.PW;
-                    const int ih = ih0 + prow * p.psh, iw = iw0 + pcol * p.psw;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                        v[u] = *(const uint4*)(base + ((size_t)ih * p.W + iw) * p.Cin * ES + slot * 16);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (it0 + u * NTHREADS < npatch_items) *(uint4*)(patch + swz(rows[u], slots[u])) = v[u];
-        }
-    };
+    for (int i = 0; i < MT; ++i) a_off[i] = wave_n * WN + i * 32 + (lane & 31);
 
     if (total > 0) {
         int kt = kt_lo, cc = 0, tap = 0;
-        w_prefetch(kt, cc, tap);
+        W_PREFETCH(kt, cc, tap);
         for (int step = 0; step < total; ++step) {
             if (tap == 0) {
                 __syncthreads();  // all waves finished reading the previous patch
-                patch_load(kt, cc);
+                // ---- stage the input patch (tile + halo) of (kt, cc) ----
+                const int fin = f + kt - p.pt;
+                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+                for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * 4) {
+                    uint4 v[4];
+                    int offs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int it = it0 + u * NTHREADS;
+                        const int row = it >> 3, slot = it & 7;
+                        offs[u] = swz(row, slot);
+                        v[u] = make_uint4(0, 0, 0, 0);
+                        if (it < npatch_items) {
+                            const int prow = row / p.PW, pcol = row - prow * p.PW;
+                            const int ih = ih0 + prow * p.psh, iw = iw0 + pcol * p.psw;
+                            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                                v[u] = *(const uint4*)(xbase + ((size_t)ih * p.W + iw) * p.Cin * ES + slot * 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (it0 + u * NTHREADS < npatch_items) *(uint4*)(patch + offs[u]) = v[u];
+                }
             }
-            w_commit(step & 1);
+            W_COMMIT(step & 1);
             __syncthreads();
-            // advance to the next (kt, cc, tap) and prefetch its weight tile
+            // advance to the next (kt, cc, tap) and prefetch its weight tile (lands during this step's MFMAs)
             int ntap_i = tap + 1, ncc = cc, nkt = kt;
             if (ntap_i == ntap) {
                 ntap_i = 0;
                 if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
             }
-            if (step + 1 < total) w_prefetch(nkt, ncc, ntap_i);
+            if (step + 1 < total) W_PREFETCH(nkt, ncc, ntap_i);
 
-            // ---- compute this tap: 4 k-slices of 16 B per row ----
+            // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             const int tapoff = (p.psh == 1 ? kh : 0) * p.PW + (p.psw == 1 ? kw : 0);
             const char* wb = wbuf + (step & 1) * BN * ROWB;
+            int brow[PT];
+#pragma unroll
+            for (int j = 0; j < PT; ++j) brow[j] = rowbase[j] + tapoff;
+            uint4 a[2][MT], b[2][PT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + swz(a_off[i], khalf));
+#pragma unroll
+            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + swz(brow[j], khalf));
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int slot = ks * 2 + khalf;
-                uint4 a[MT], b[PT];
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks < 3) {
+                    const int slot = (ks + 1) * 2 + khalf;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(wb + swz(wave_n * WN + i * 32 + (lane & 31), slot));
+                    for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + swz(a_off[i], slot));
 #pragma unroll
-                for (int j = 0; j < PT; ++j) b[j] = *(const uint4*)(patch + swz(rowbase[j] + tapoff, slot));
+                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + swz(brow[j], slot));
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < PT; ++j) Mma<DT>::step(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
             }
             tap = ntap_i;
             cc = ncc;
             kt = nkt;
         }
     }
+#undef W_PREFETCH
+#undef W_COMMIT
 
     // ---- epilogue: affine/bias + residual + relu, channel-contiguous stores ----
     // D[i = channel][j = position]: lane holds position lane&31; register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5).
