@@ -102,14 +102,14 @@ def cpu_baseline(arch, T, seconds_budget=25.0):
     from oracle.net3d import Net, opts_for
     from oracle import proposals as op
     H, W = 256, 320
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # torch-CPU conv3d stops scaling well before 256 threads
     torch.set_num_threads(cores)
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     weights = net_utils.synthetic_params(model, cfg.RNG_SEED)
     data = synthetic_clip(T, H, W, 3)
     im_info = np.array([[H, W, 1.0]], np.float32)
     opts = opts_for('R' + arch, kt_body=3, body_head_link='slice-center', num_frames_mid=T, pre_nms_topn=1000,
-                    post_nms_topn=200)
+                    post_nms_topn=50)
     n, t0 = 0, time.time()
     while True:
         net = Net(weights, opts)
@@ -118,7 +118,7 @@ def cpu_baseline(arch, T, seconds_budget=25.0):
         rois, per_level, restore = net.fpn_rpn(p2d, im_info)
         feat = net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2)
         net.box_head_2mlp(feat)
-        kp = rois[:8]
+        kp = rois[:4]
         _, pl, rs = op.distribute(kp, 2, 5)
         net.kps_head_2d(net.roi_feat_fpn(p2d[1:], pl, rs, 14, 2))
         n += 1
@@ -127,7 +127,7 @@ def cpu_baseline(arch, T, seconds_budget=25.0):
             break
     return {'value': n / el, 'unit': 'clips/s (reduced %dx%dx%d clips)' % (T, H, W), 'cores': cores, 'kind': 'port',
             'sample': '%d forward passes of oracle.net3d (torch-CPU fp32, %d threads) on a %dx%dx%d clip, '
-                      '200 rois, 8 keypoint rois; %.1f s' % (n, cores, T, H, W, el)}
+                      '50 rois, 4 keypoint rois; %.1f s' % (n, cores, T, H, W, el)}
 
 
 def cpu_tracker_baseline():

@@ -1,0 +1,121 @@
+"""Dataset-level inference engine — mirror of reference lib/core/test_engine.py (model init :50-74, the clip loop
+:124-204, per-GPU fan-out :278-308, detections.pkl layout :199-204).
+
+The clip list is an in-memory "roidb": a list of dicts with `image` (list of T frame paths or arrays) — the COCO-json /
+PoseTrack dataset layer (lib/datasets, needs pycocotools + the dataset files) is outside the hot-path scope, so the
+entry points accept either a pickled roidb or a synthetic one.
+"""
+import logging
+import os
+import pickle
+from collections import defaultdict
+
+import numpy as np
+
+from detectandtrack_amd.core.config import cfg, get_output_dir
+from detectandtrack_amd.core.test import im_detect_all
+from detectandtrack_amd.modeling import model_builder
+from detectandtrack_amd.utils.timer import Timer
+from detectandtrack_amd.utils import dist as dist_utils
+from detectandtrack_amd.utils import net as net_utils
+from detectandtrack_amd import workspace
+
+logger = logging.getLogger(__name__)
+
+
+def initialize_model_from_cfg():
+    """(:50-74) build the inference model, load TEST.WEIGHTS (or random-init when empty), create the nets."""
+    model = model_builder.create(cfg.MODEL.TYPE, train=False)
+    ws = workspace.GlobalWorkspace()
+    net_utils.initialize_params(model, ws)
+    if cfg.TEST.WEIGHTS:
+        net_utils.initialize_from_weights_file(model, ws, cfg.TEST.WEIGHTS)
+    ws.CreateNet(model.net)
+    ws.CreateNet(model.conv_body_net)
+    if cfg.MODEL.KEYPOINTS_ON:
+        ws.CreateNet(model.keypoint_net)
+    return model
+
+
+def empty_results(num_classes, num_images):
+    """(:258-275)"""
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    all_keyps = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    all_segms = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    return all_boxes, all_segms, all_keyps
+
+
+def extend_results(index, all_res, im_res):
+    for cls_idx in range(1, len(im_res)):
+        all_res[cls_idx][index] = im_res[cls_idx]
+
+
+def load_clip(entry):
+    """roidb entry -> list of T BGR frames (arrays are used as-is; paths need an image reader)."""
+    frames = entry['image'] if isinstance(entry['image'], (list, tuple)) else [entry['image']]
+    out = []
+    for f in frames:
+        if isinstance(f, np.ndarray):
+            out.append(f)
+        else:
+            raise NotImplementedError('image decoding is host I/O outside the hot-path scope (no OpenCV here): '
+                                      'provide frames as arrays (e.g. a pre-decoded roidb pickle)')
+    return out
+
+
+def test_net(roidb, ind_range=None, output_dir=None):
+    """Run the detector over roidb[start:end] (one clip per step) and dump detection_range_s_e.pkl (:124-204)."""
+    model = initialize_model_from_cfg()
+    start, end = (0, len(roidb)) if ind_range is None else ind_range
+    part = roidb[start:end]
+    num_classes = cfg.MODEL.NUM_CLASSES
+    all_boxes, all_segms, all_keyps = empty_results(num_classes, len(part))
+    timers = defaultdict(Timer)
+    for i, entry in enumerate(part):
+        cls_boxes_i, cls_segms_i, cls_keyps_i = im_detect_all(model, load_clip(entry), None, timers)
+        extend_results(i, all_boxes, cls_boxes_i)
+        if cls_keyps_i is not None:
+            extend_results(i, all_keyps, cls_keyps_i)
+        if i % 10 == 0:
+            logger.info('im_detect: range [%d, %d] of %d: %d/%d  bbox %.3fs misc_bbox %.3fs kps %.3fs misc_kps %.3fs',
+                        start + 1, end, len(roidb), i + 1, len(part), timers['im_detect_bbox'].average_time,
+                        timers['misc_bbox'].average_time, timers['im_detect_keypoints'].average_time,
+                        timers['misc_keypoints'].average_time)
+    res = dict(all_boxes=all_boxes, all_segms=all_segms, all_keyps=all_keyps)
+    if output_dir is not None:
+        name = 'detection_range_%s_%s.pkl' % (start, end) if ind_range is not None else 'detections.pkl'
+        with open(os.path.join(output_dir, name), 'wb') as f:
+            pickle.dump(res, f, pickle.HIGHEST_PROTOCOL)
+    return res
+
+
+def merge_range_results(parts):
+    """Concatenate per-range results in range order (:286-297)."""
+    merged = None
+    for p in parts:
+        if merged is None:
+            merged = {k: [list(c) for c in v] for k, v in p.items()}
+            continue
+        for k in merged:
+            for cls in range(len(merged[k])):
+                merged[k][cls] += p[k][cls]
+    return merged
+
+
+def test_net_on_dataset(roidb, multi_gpu=False, output_dir=None):
+    """(:311-333) under torch.distributed each rank takes its contiguous clip range; rank 0 merges and writes
+    detections.pkl.  Without a launcher it is the single-GPU path."""
+    output_dir = output_dir or get_output_dir(training=False)
+    dist = dist_utils.init_process_group() if multi_gpu else None
+    if dist is None:
+        return test_net(roidb, None, output_dir)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = dist_utils.shard_range(len(roidb), world, rank)
+    local = test_net(roidb, rng, output_dir)
+    parts = dist_utils.gather_in_range_order([local], dist)
+    if rank != 0:
+        return None
+    merged = merge_range_results(parts)
+    with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
+        pickle.dump(merged, f, pickle.HIGHEST_PROTOCOL)
+    return merged

@@ -1,0 +1,322 @@
+"""CPU tests of the host side: C-ABI exports, product/oracle separation, config, builders, tracker, sharding."""
+import ast
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI -------------------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    """libdat_hip.so loads (no GPU needed) and exports every function include/dat_hip.h declares."""
+    import ctypes
+    hdr = open(os.path.join(REPO, 'include', 'dat_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(dat_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(os.path.join(REPO, 'detectandtrack_amd', 'libdat_hip.so'))
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.dat_version() >= 1
+    from detectandtrack_amd import libdat
+    assert sorted(libdat.EXPORTS) == declared, set(declared) ^ set(libdat.EXPORTS)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no module of the product package, tools/ or bench's hot path imports it
+    (bench.py may use it ONLY inside cpu_baseline)."""
+    offenders = []
+    for path in glob.glob(os.path.join(REPO, 'detectandtrack_amd', '**', '*.py'), recursive=True) + \
+            glob.glob(os.path.join(REPO, 'tools', '*.py')):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                names = [node.module]
+            if any(n == 'oracle' or n.startswith('oracle.') for n in names):
+                offenders.append(path)
+    assert not offenders, offenders
+    src = open(os.path.join(REPO, 'bench.py')).read()
+    tree = ast.parse(src)
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and n.module and n.module.startswith('oracle') for n in ast.walk(fn))
+        assert (not uses) or fn.name == 'cpu_baseline', fn.name
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from detectandtrack_amd import libdat
+    with pytest.raises(libdat.DatError):
+        libdat.Ctx(0)
+
+
+# ---- config ----------------------------------------------------------------------------------------------------------------
+def test_cfg_defaults_and_merge(tmp_path):
+    from detectandtrack_amd.core.config import cfg, cfg_from_file, cfg_from_list, assert_and_infer_cfg, reset_cfg
+    reset_cfg()
+    assert cfg.TEST.NMS == 0.3 and cfg.RPN.SIZES == (64, 128, 256, 512) and cfg.RNG_SEED == 3
+    assert abs(cfg.BBOX_XFORM_CLIP - np.log(1000. / 16.)) < 1e-12
+    y = tmp_path / 'c.yaml'
+    y.write_text('MODEL:\n  TYPE: keypoint_rcnn\n  FASTER_RCNN: True\nVIDEO:\n  NUM_FRAMES: 3\n  TIME_KERNEL_DIM: 3\n'
+                 'TEST:\n  SCALES: (256,)\n  NMS: 0.5\n')
+    cfg_from_file(str(y))
+    cfg_from_list(['TEST.MAX_SIZE', '333', 'NUM_GPUS', '1'])
+    assert_and_infer_cfg()
+    assert cfg.VIDEO.TIME_KERNEL_DIM.BODY == 3 and cfg.VIDEO.TIME_KERNEL_DIM.HEAD_KPS == 3   # config.py:839-850
+    assert cfg.VIDEO.NUM_FRAMES_MID == 3 and cfg.RPN.ON and cfg.TEST.SCALES == (256,) and cfg.TEST.MAX_SIZE == 333
+    with pytest.raises(KeyError):
+        from detectandtrack_amd.core.config import cfg_from_cfg
+        cfg_from_cfg({'NOT_A_KEY': 1})
+    with pytest.raises(ValueError):
+        from detectandtrack_amd.core.config import cfg_from_cfg
+        cfg_from_cfg({'TEST': {'NMS': 'high'}})
+    reset_cfg()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference configs not mounted')
+def test_every_shipped_reference_yaml_loads():
+    from detectandtrack_amd.core.config import cfg, cfg_from_file, assert_and_infer_cfg, reset_cfg
+    files = sorted(glob.glob('/root/reference/configs/video/*/*.yaml'))
+    assert len(files) == 12
+    for f in files:
+        reset_cfg()
+        cfg_from_file(f)
+        assert_and_infer_cfg()
+        assert cfg.MODEL.TYPE == 'keypoint_rcnn'
+    reset_cfg()
+
+
+# ---- builders ----------------------------------------------------------------------------------------------------------------
+def _build(cfg_dict):
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    reset_cfg()
+    cfg_from_cfg(cfg_dict)
+    assert_and_infer_cfg()
+    return model_builder.create(cfg.MODEL.TYPE, train=False)
+
+
+def test_builder_r18_fpn3d_graph_and_params():
+    from tests.model_util import fpn3d_kps_cfg
+    m = _build(fpn3d_kps_cfg('18', T=8))
+    convs = [op for op in m.net.ops if op.type == 'Conv']
+    body_fpn = [op for op in m.conv_body_net.ops if op.type == 'Conv']
+    assert len(body_fpn) == 28          # 1 stem + 16 block convs + 3 shortcuts + 4 laterals + 4 post-hoc
+    # every AffineChannelNd / Relu / Sum is folded into a conv epilogue
+    assert not [op for op in m.net.ops if op.type in ('AffineChannel', 'Relu', 'Sum', 'UpsampleNearest2x')]
+    lat = [op for op in body_fpn if op.outputs[0] == 'fpn_inner_res4_1_sum'][0]
+    assert lat.args['res_mode'] == 2 and lat.args['residual'] == 'fpn_inner_res5_1_sum'
+    blk = [op for op in body_fpn if op.outputs[0] == 'res3_1_sum'][0]
+    assert blk.args['relu'] and blk.args['res_mode'] == 1 and blk.args['kernels'] == [3, 3, 3]
+    # reference parameter names / shapes
+    ps = m.param_specs
+    assert ps['conv1_w']['shape'] == (64, 3, 1, 7, 7) and ps['res_conv1_bn_s']['shape'] == (64,)
+    assert ps['res2_0_branch2a_w']['shape'] == (64, 64, 1, 3, 3)          # kT = 1 in res2 (ResNet3D.py:270-272)
+    assert ps['res3_0_branch2a_w']['shape'] == (128, 64, 3, 3, 3)
+    assert ps['res3_0_branch1_w']['shape'] == (128, 64, 1, 1, 1)
+    assert ps['fpn_inner_res4_1_sum_lateral_w']['shape'] == (256, 256, 1, 1, 1)
+    assert ps['fpn_res2_1_sum_w']['shape'] == (256, 256, 3, 3, 3)
+    assert ps['conv_rpn_fpn2_w']['shape'] == (256, 256, 3, 3) and 'conv_rpn_fpn3_w' not in ps   # shared (FPN.py:246)
+    assert ps['fc6_w']['shape'] == (1024, 256 * 49) and ps['kps_score_lowres_w']['shape'] == (512, 17, 4, 4)
+    assert [op.type for op in m.keypoint_net.ops] == ['RoIFeatureTransform'] + ['Conv'] * 8 + ['ConvTranspose', 'BilinearInterpolation']
+    # frozen: affine params and the bilinear kernel never train (detector.py:57-65, 378-379)
+    tr = m.TrainableParams()
+    assert 'res2_0_branch2a_bn_s' not in tr and 'kps_score_w' not in tr and 'conv1_w' in tr
+    from detectandtrack_amd.core.config import reset_cfg
+    reset_cfg()
+
+
+def test_builder_r50_and_c4_tube_graphs():
+    from tests.model_util import fpn3d_kps_cfg
+    m = _build(fpn3d_kps_cfg('50', T=4))
+    ps = m.param_specs
+    assert ps['res2_0_branch2a_w']['shape'] == (64, 64, 1, 1, 1) and ps['res3_0_branch2b_w']['shape'] == (128, 128, 3, 3, 3)
+    assert ps['res5_2_branch2c_w']['shape'] == (2048, 512, 1, 1, 1)
+    assert len([op for op in m.conv_body_net.ops if op.type == 'Conv']) == 1 + 16 * 3 + 4 + 4 + 4
+    # shipped 3D config: C4 body + res5 tube head + 3D keypoint head (configs/video/3d/04_*.yaml)
+    c4 = {'MODEL': {'TYPE': 'keypoint_rcnn', 'CONV_BODY': 'ResNet3D.add_ResNet18_conv4_body',
+                    'ROI_HEAD': 'ResNet3D.add_ResNet18_roi_conv5_head', 'NUM_CLASSES': 2, 'FASTER_RCNN': True,
+                    'KEYPOINTS_ON': True, 'VIDEO_ON': True},
+          'FAST_RCNN': {'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 7, 'ROI_XFORM_SAMPLING_RATIO': 2},
+          'KRCNN': {'ROI_KEYPOINTS_HEAD': 'keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d', 'NUM_STACKED_CONVS': 8,
+                    'NUM_KEYPOINTS': 17, 'USE_DECONV_OUTPUT': True, 'CONV_INIT': 'MSRAFill', 'CONV_HEAD_DIM': 512,
+                    'UP_SCALE': 2, 'HEATMAP_SIZE': 56, 'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 14,
+                    'ROI_XFORM_SAMPLING_RATIO': 2, 'NO_3D_DECONV_TIME_TO_CH': True},
+          'VIDEO': {'NUM_FRAMES': 3, 'TIME_KERNEL_DIM': 3, 'BODY_HEAD_LINK': '', 'WEIGHTS_INFLATE_MODE': 'center-only'}}
+    m = _build(c4)
+    ps = m.param_specs
+    assert ps['conv_rpn_w']['shape'] == (256, 256, 3, 3, 3) and ps['rpn_cls_logits_1_w']['shape'] == (12, 256, 1, 1, 1)
+    assert ps['res5_0_branch2a_w']['shape'] == (512, 256, 1, 3, 3)      # res5 head is kT = 1 (ResNet3D.py:314-316)
+    assert ps['conv_fcn1_w']['shape'] == (512, 256, 3, 3, 3)
+    gp = [op for op in m.net.ops if op.type == 'GenerateProposals'][0]
+    assert gp.args['anchors'].shape == (12, 12)                          # A = 12 tube anchors x 4*T
+    from detectandtrack_amd.core.config import reset_cfg
+    reset_cfg()
+
+
+def test_product_anchors_boxes_match_reference_golden(golden):
+    from detectandtrack_amd.core.config import reset_cfg
+    from detectandtrack_amd.modeling.generate_anchors import generate_anchors
+    import detectandtrack_amd.utils.boxes as bu
+    reset_cfg()
+    np.testing.assert_array_equal(generate_anchors(16., (64, 128, 256, 512), (0.5, 1, 2), time_dim=3), golden['anchors_c4_T3'])
+    for lvl in range(2, 7):
+        np.testing.assert_array_equal(generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2)), golden['anchors_fpn%d' % lvl])
+    np.testing.assert_array_equal(bu.bbox_transform(golden['bt_boxes'].astype(np.float64), golden['bt_deltas'], (10., 10., 5., 5.)),
+                                  golden['bt_out_w10'])
+    tt = bu.bbox_transform(golden['tt_boxes'].astype(np.float64), golden['tt_deltas'], (10., 10., 5., 5.))
+    np.testing.assert_array_equal(tt, golden['tt_out'])
+    np.testing.assert_array_equal(bu.clip_tiled_boxes(tt.copy(), (256, 320)), golden['clip_out'])
+    np.testing.assert_array_equal(bu.bbox_transform_inv(golden['bt_boxes'], golden['inv_gt'], (10., 10., 5., 5.)), golden['inv_out'])
+    np.testing.assert_array_equal(bu.bbox_overlaps(golden['iou_a'], golden['iou_b']), golden['iou_out'])
+    np.testing.assert_array_equal(bu.bbox_overlaps(golden['iou_ta'], golden['iou_tb']), golden['iou_tube_out'])
+    import detectandtrack_amd.modeling.FPN as fpn
+    np.testing.assert_array_equal(fpn.map_rois_to_fpn_levels(golden['lvl_rois'][:, 1:], 2, 5), golden['lvl_out'])
+
+
+def test_weight_inflation_matches_reference(golden):
+    from detectandtrack_amd.utils.net import inflate_weights
+    src = golden['inflate_src']
+    tgt = np.zeros((8, 4, 3, 3, 3), np.float32)
+    for mode in ('mean-repeat', 'repeat', 'center-only'):
+        np.testing.assert_array_equal(inflate_weights(src, tgt, 'x_w', mode), golden['inflate_' + mode.replace('-', '_')])
+
+
+def test_weights_file_roundtrip(tmp_path):
+    from tests.model_util import fpn3d_kps_cfg
+    from detectandtrack_amd.utils import net as nu
+    m = _build(fpn3d_kps_cfg('18', T=2))
+
+    class WS(object):
+        def __init__(self):
+            self.params = {}
+
+        def set_param(self, k, v):
+            self.params[k] = np.asarray(v, np.float32)
+    ws = WS()
+    nu.initialize_params(m, ws, seed=1)
+    assert set(ws.params) == set(m.params)
+    assert ws.params['res2_0_branch2a_bn_s'].min() == 1.0 and abs(ws.params['rpn_cls_logits_fpn2_w'].std() - 0.01) < 2e-3
+    f = str(tmp_path / 'w.pkl')
+    nu.save_model_to_weights_file(f, m, ws)
+    ws2 = WS()
+    nu.initialize_params(m, ws2, seed=2)
+    nu.initialize_from_weights_file(m, ws2, f)
+    for k in m.params:
+        np.testing.assert_array_equal(ws.params[k], ws2.params[k])
+    # 2D checkpoint -> 3D model: conv weights inflate centre-only (VIDEO.WEIGHTS_INFLATE_MODE)
+    import pickle
+    blobs = {k: (v[:, :, 1] if v.ndim == 5 and v.shape[2] == 3 else v) for k, v in ws.params.items()}
+    with open(f, 'wb') as fh:
+        pickle.dump({'blobs': blobs}, fh, protocol=2)
+    ws3 = WS()
+    nu.initialize_params(m, ws3, seed=2)
+    nu.initialize_from_weights_file(m, ws3, f)
+    w = ws3.params['res3_0_branch2a_w']
+    assert w.shape[2] == 3 and np.all(w[:, :, 0] == 0) and np.all(w[:, :, 2] == 0)
+    np.testing.assert_array_equal(w[:, :, 1], ws.params['res3_0_branch2a_w'][:, :, 1])
+    from detectandtrack_amd.core.config import reset_cfg
+    reset_cfg()
+
+
+# ---- host utils ----------------------------------------------------------------------------------------------------------------
+def test_image_resize_and_blob_prep():
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import image as iu, blob as bu
+    reset_cfg()
+    im = np.arange(12, dtype=np.float32).reshape(3, 4)
+    np.testing.assert_allclose(iu.resize_bilinear(im, 4, 3), im)
+    np.testing.assert_allclose(iu.resize_bicubic(im, 4, 3), im, atol=1e-6)
+    up = iu.resize_bilinear(im, 8, 6)
+    assert up.shape == (6, 8) and abs(up.mean() - im.mean()) < 1e-4
+    const = iu.resize_bicubic(np.full((5, 7, 2), 3.0, np.float32), 11, 9)
+    np.testing.assert_allclose(const, 3.0, atol=1e-5)
+    # S-B of SURVEY.md §8: 720x1280 @ scale 800 / max 1333 -> 750x1333 -> pad32 -> 768x1344
+    cfg.FPN.FPN_ON = True
+    cfg.MODEL.VIDEO_ON = True
+    cfg.VIDEO.NUM_FRAMES = 2
+    ims, sc = bu.prep_im_for_blob(np.zeros((720, 1280, 3), np.uint8), cfg.PIXEL_MEANS, (800,), 1333)
+    assert ims[0].shape == (750, 1333, 3) and abs(sc[0] - 1333. / 1280.) < 1e-9
+    blob = bu.im_list_to_blob([ims[0], ims[0]])
+    assert blob.shape == (1, 3, 2, 768, 1344)
+    reset_cfg()
+
+
+def test_tracker_hungarian_greedy_and_ids():
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.core import tracking_engine as te
+    reset_cfg()
+    C = np.array([[0.1, 0.9, 0.8], [0.2, 0.15, 0.7]])
+    m = te._compute_matches(None, None, None, None, 'hungarian', C=C)
+    assert m.tolist() == [0, 1, -1]
+    m = te._compute_matches(None, None, None, None, 'greedy', C=C)
+    assert m.tolist() == [0, 1, -1]
+    # two people crossing: identities follow overlap
+    b0 = np.array([[0, 0, 50, 100, 0.99], [200, 0, 250, 100, 0.98]], np.float32)
+    b1 = np.array([[205, 0, 255, 100, 0.97], [5, 0, 55, 100, 0.99], [400, 0, 450, 100, 0.96]], np.float32)
+    json_data = [{'image': 'v/a/%d.jpg' % i, 'height': 200, 'width': 500} for i in range(2)]
+    dets = {'all_boxes': [[], [b0, b1]], 'all_keyps': [[], [[np.zeros((4, 17))] * 2, [np.zeros((4, 17))] * 3]]}
+    cfg.TRACKING.DISTANCE_METRIC_WTS = (1.0, 0.0, 0.0)
+    out = te.compute_matches_tracks(json_data, dets)
+    assert out['all_tracks'][1] == [[0, 1], [1, 0, 2]]
+    # centre-frame selection + pruning (tracking_engine.py:731-755)
+    tube = np.array([[0, 0, 10, 10, 20, 20, 60, 60, 40, 40, 50, 50, 0.99], [0, 0, 1, 1, 0, 0, 2, 2, 0, 0, 1, 1, 0.99]], np.float32)
+    d = {'all_boxes': [[], [tube]], 'all_keyps': [[], [[np.zeros((4, 51)), np.zeros((4, 51))]]]}
+    cfg.KRCNN.NUM_KEYPOINTS = 17
+    te._center_detections(d)
+    assert d['all_boxes'][1][0].tolist()[0] == [20, 20, 60, 60, np.float32(0.99)] and d['all_keyps'][1][0][0].shape == (4, 17)
+    te._prune_bad_detections(d, [{'height': 100, 'width': 100}], 0.95)
+    assert d['all_boxes'][1][0].shape == (1, 5)
+    reset_cfg()
+
+
+def test_shard_range_matches_array_split():
+    from detectandtrack_amd.utils.dist import shard_range
+    for n in (0, 1, 7, 50, 101):
+        for w in (1, 2, 3, 8):
+            parts = np.array_split(np.arange(n), w)
+            for r in range(w):
+                s, e = shard_range(n, w, r)
+                assert list(range(s, e)) == parts[r].tolist()
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from detectandtrack_amd.utils import dist as du
+    from detectandtrack_amd.core.test_engine import merge_range_results
+    dist = du.init_process_group('gloo')
+    s, e = du.shard_range(11, world, rank)
+    local = {'all_boxes': [[], [np.full((1, 5), i, np.float32) for i in range(s, e)]], 'all_keyps': [[], [[] for _ in range(s, e)]]}
+    parts = du.gather_in_range_order([local], dist)
+    t = du.max_over_ranks(1.0 + rank, dist)
+    dist.barrier()
+    if rank == 0:
+        merged = merge_range_results(parts)
+        q.put(([int(b[0, 0]) for b in merged['all_boxes'][1]], t))
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_sharding_protocol_gloo_world2():
+    """N>1 path on CPU (gloo, world_size 2): contiguous clip ranges, range-order merge on rank 0, MAX timing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    order, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert order == list(range(11)) and tmax == 2.0

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Tracking entry point — mirror of reference tools/compute_tracks.py:43-56: loads <output_dir>/detections.pkl (or
+TRACKING.DETECTIONS_FILE), runs the host Hungarian tracker, writes detections_withTracks.pkl."""
+import argparse
+import logging
+import pickle
+
+import _path  # noqa
+from detectandtrack_amd.core.config import cfg, cfg_from_file, cfg_from_list, assert_and_infer_cfg, get_output_dir
+from detectandtrack_amd.core.tracking_engine import run_posetrack_tracking
+
+
+def main():
+    logging.basicConfig(level=logging.INFO)
+    p = argparse.ArgumentParser()
+    p.add_argument('--cfg', dest='cfg_file', required=True)
+    p.add_argument('--roidb', required=True, help='pickled clip list (needs image/height/width per entry)')
+    p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
+    args = p.parse_args()
+    cfg_from_file(args.cfg_file)
+    if args.opts:
+        cfg_from_list(args.opts)
+    assert_and_infer_cfg()
+    with open(args.roidb, 'rb') as f:
+        roidb = pickle.load(f)
+    json_data = [{'image': e.get('name', 'images/vid0000/%06d.jpg' % i), 'height': e['height'], 'width': e['width']}
+                 for i, e in enumerate(roidb)]
+    run_posetrack_tracking(get_output_dir(training=False), json_data)
+
+
+if __name__ == '__main__':
+    main()

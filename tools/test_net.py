@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Inference entry point — mirror of reference tools/test_net.py:66-143.
+
+    python tools/test_net.py --cfg configs/x.yaml [--range s e] [--multi-gpu-testing] [--roidb clips.pkl] [KEY VAL ...]
+
+Differences forced by the offline environment: the clip list comes from `--roidb` (a pickled list of
+{'image': [T frame arrays], 'height', 'width'}) or `--synthetic N` instead of the PoseTrack JSON (needs pycocotools
+and the dataset).  `--multi-gpu-testing` shards clips over the ranks of a torch.distributed launch
+(`python -m torch.distributed.run --nproc-per-node N tools/test_net.py ...`), the reference's one-process-per-GPU
+`--range` protocol (lib/utils/subprocess.py:38-63) also works unchanged.
+"""
+import argparse
+import logging
+import os
+import pickle
+import sys
+
+import numpy as np
+
+import _path  # noqa
+from detectandtrack_amd.core.config import cfg, cfg_from_file, cfg_from_list, assert_and_infer_cfg, get_output_dir
+from detectandtrack_amd.core import test_engine
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='Test a detection network on the MI355X')
+    p.add_argument('--cfg', dest='cfg_file', required=True)
+    p.add_argument('--range', dest='range', type=int, nargs=2, default=None)
+    p.add_argument('--multi-gpu-testing', dest='multi_gpu_testing', action='store_true')
+    p.add_argument('--roidb', default='', help='pickled clip list')
+    p.add_argument('--synthetic', type=int, default=0, help='use N synthetic clips')
+    p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
+    return p.parse_args()
+
+
+def synthetic_roidb(n, T, h=720, w=1280, seed=3):
+    rs = np.random.RandomState(seed)
+    return [{'image': [rs.randint(0, 255, (h, w, 3)).astype(np.uint8) for _ in range(T)], 'height': h, 'width': w,
+             'name': 'images/vid%04d/%06d.jpg' % (i // 100, i % 100)} for i in range(n)]
+
+
+def main():
+    logging.basicConfig(level=logging.INFO)
+    args = parse_args()
+    cfg_from_file(args.cfg_file)
+    if args.opts:
+        cfg_from_list(args.opts)
+    assert_and_infer_cfg()
+    if args.roidb:
+        with open(args.roidb, 'rb') as f:
+            roidb = pickle.load(f)
+    else:
+        roidb = synthetic_roidb(max(args.synthetic, 1), max(cfg.VIDEO.NUM_FRAMES, 1))
+    out = get_output_dir(training=False)
+    if args.range is not None:
+        test_engine.test_net(roidb, tuple(args.range), out)
+    else:
+        test_engine.test_net_on_dataset(roidb, multi_gpu=args.multi_gpu_testing, output_dir=out)
+
+
+if __name__ == '__main__':
+    main()
