@@ -24,11 +24,14 @@
 //     channel-contiguous NDHWC stores in the epilogue;
 //   * blockIdx -> tile mapping is XCD-aware: output-channel blocks of one spatial tile and neighbouring
 //     tiles land on the same XCD (shared L2 for patch + weights).
+#include <stdlib.h>
+
 #include "dat_common.h"
 
 namespace {
 
-constexpr int ROWB = 128;   // bytes per LDS row (one 128-B line of channels)
+constexpr int ROWB = 128;   // bytes per weight LDS row (one 128-B line of channels), XOR-swizzled
+constexpr int PPITCH = 144; // patch row pitch: 128 B + 16 B pad -> consecutive rows rotate through all 16 slots, linear addressing
 constexpr int NTHREADS = 256;
 
 struct ConvParams {
@@ -48,6 +51,7 @@ struct ConvParams {
     int psh, psw;             // patch sampling step in the input (stride for 1x1 kernels, else 1)
     int ash, asw;             // patch-row step per output position (stride for KxK kernels, else 1)
     int n_cchunks;            // Cin / CK
+    int ablate;               // DEBUG (DAT_CONV_ABLATE): 1 skip patch reloads, 2 skip weight streaming
     int nblk_n;               // Cout_pad / BN
     unsigned nblocks;
 };
@@ -74,7 +78,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + ((
 
 // BN = output channels per block, BP = output positions per block, WAVES_N x WAVES_P = 4 waves.
 template <int DT, int BN, int BP, int WAVES_N>
-__global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
     constexpr int CK = Mma<DT>::CK;
     constexpr int WAVES_P = 4 / WAVES_N;
@@ -151,18 +155,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams
     static_assert(W_ITEMS == 2 || W_ITEMS == 4, "weight tile = 2 or 4 16-byte items per thread");
     uint4 w0, w1, w2 = make_uint4(0, 0, 0, 0), w3 = make_uint4(0, 0, 0, 0);  // named registers, never an array (scratch!)
     // item i of this thread: row (tid + i*256) >> 3 = (tid >> 3) + 32*i, slot tid & 7
-    const size_t w_thr_off = (size_t)(n0 + (tid >> 3)) * p.Cin * ES + (tid & 7) * 16;
-    const size_t w_item_stride = (size_t)32 * p.Cin * ES;
+    const unsigned w_thr_off = (unsigned)(tid >> 3) * (unsigned)(p.Cin * ES) + (tid & 7) * 16;   // lane part (32-bit)
+    const unsigned w_item_stride = 32u * (unsigned)(p.Cin * ES);
+    const size_t w_blk_off = (size_t)n0 * p.Cin * ES;                                             // uniform part
     const int w_lds0 = swz(tid >> 3, tid & 7), w_lds1 = swz((tid >> 3) + 32, tid & 7);
     const int w_lds2 = swz((tid >> 3) + 64, tid & 7), w_lds3 = swz((tid >> 3) + 96, tid & 7);
 #define W_PREFETCH(KT_, CC_, TAP_)                                                                              \
     {                                                                                                           \
-        const char* wbase_ = p.w + (size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_thr_off; \
-        w0 = *(const uint4*)(wbase_);                                                                           \
-        w1 = *(const uint4*)(wbase_ + w_item_stride);                                                           \
+        const char* wbase_ = p.w + ((size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_blk_off); \
+        w0 = *(const uint4*)(wbase_ + w_thr_off);                                                               \
+        w1 = *(const uint4*)(wbase_ + (w_thr_off + w_item_stride));                                             \
         if (W_ITEMS == 4) {                                                                                     \
-            w2 = *(const uint4*)(wbase_ + 2 * w_item_stride);                                                   \
-            w3 = *(const uint4*)(wbase_ + 3 * w_item_stride);                                                   \
+            w2 = *(const uint4*)(wbase_ + (w_thr_off + 2 * w_item_stride));                                     \
+            w3 = *(const uint4*)(wbase_ + (w_thr_off + 3 * w_item_stride));                                     \
         }                                                                                                       \
     }
 #define W_COMMIT(BUF_)                                                                                          \
@@ -176,16 +181,22 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams
         }                                                                                                       \
     }
 
-    // per-lane LDS byte offsets that do not change across taps: weight rows (per k-slice), patch swizzle keys
-    int a_off[MT];
+    // per-lane LDS byte offsets of the weight fragments (lane-constant): row -> 4 k-slices, XOR-swizzled
+    int a_off[MT][4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_off[i] = wave_n * WN + i * 32 + (lane & 31);
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a_off[i][ks] = swz(wave_n * WN + i * 32 + (lane & 31), ks * 2 + khalf);
+    // patch rows are padded (PPITCH) and NOT swizzled: a fragment address is base(row) + ks*32 as an immediate
+    int b_base[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) b_base[j] = rowbase[j] * PPITCH + khalf * 16;
 
     if (total > 0) {
-        int kt = kt_lo, cc = 0, tap = 0;
+        int kt = kt_lo, cc = 0, tap = 0, kh = 0, kw = 0;
         W_PREFETCH(kt, cc, tap);
         for (int step = 0; step < total; ++step) {
-            if (tap == 0) {
+            if (tap == 0 && !((p.ablate & 1) && step > 0)) {
                 __syncthreads();  // all waves finished reading the previous patch
                 // ---- stage the input patch (tile + halo) of (kt, cc) ----
                 const int fin = f + kt - p.pt;
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams
                     for (int u = 0; u < 4; ++u) {
                         const int it = it0 + u * NTHREADS;
                         const int row = it >> 3, slot = it & 7;
-                        offs[u] = swz(row, slot);
+                        offs[u] = row * PPITCH + slot * 16;
                         v[u] = make_uint4(0, 0, 0, 0);
                         if (it < npatch_items) {
                             const int prow = row / p.PW, pcol = row - prow * p.PW;
@@ -211,46 +222,43 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_igemm_kernel(const ConvParams
                         if (it0 + u * NTHREADS < npatch_items) *(uint4*)(patch + offs[u]) = v[u];
                 }
             }
-            W_COMMIT(step & 1);
+            if (!((p.ablate & 2) && step > 1)) W_COMMIT(step & 1);
             __syncthreads();
             // advance to the next (kt, cc, tap) and prefetch its weight tile (lands during this step's MFMAs)
-            int ntap_i = tap + 1, ncc = cc, nkt = kt;
+            const int tapoff = ((p.psh == 1 ? kh : 0) * p.PW + (p.psw == 1 ? kw : 0)) * PPITCH;
+            int ntap_i = tap + 1, ncc = cc, nkt = kt, nkh = kh, nkw = kw + 1;
+            if (nkw == p.KW) { nkw = 0; ++nkh; }
             if (ntap_i == ntap) {
-                ntap_i = 0;
+                ntap_i = 0; nkh = 0; nkw = 0;
                 if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
             }
-            if (step + 1 < total) W_PREFETCH(nkt, ncc, ntap_i);
+            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, ntap_i);
 
             // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const int tapoff = (p.psh == 1 ? kh : 0) * p.PW + (p.psw == 1 ? kw : 0);
             const char* wb = wbuf + (step & 1) * BN * ROWB;
-            int brow[PT];
+            const char* bp[PT];
 #pragma unroll
-            for (int j = 0; j < PT; ++j) brow[j] = rowbase[j] + tapoff;
+            for (int j = 0; j < PT; ++j) bp[j] = patch + (b_base[j] + tapoff);
             uint4 a[2][MT], b[2][PT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + swz(a_off[i], khalf));
+            for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
 #pragma unroll
-            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + swz(brow[j], khalf));
+            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j]);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks < 3) {
-                    const int slot = (ks + 1) * 2 + khalf;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + swz(a_off[i], slot));
+                    for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
 #pragma unroll
-                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + swz(brow[j], slot));
+                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (ks + 1) * 32);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
             }
-            tap = ntap_i;
-            cc = ncc;
-            kt = nkt;
+            tap = ntap_i; cc = ncc; kt = nkt; kh = nkh; kw = nkw;
         }
     }
 #undef W_PREFETCH
@@ -375,6 +383,12 @@ struct TileChoice {
 
 // pick the 2^a x 2^b tile (a+b = log2(BP)) that wastes the fewest output positions, tie -> squarer patch
 TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int KW) {
+    static int force_tw = -2;
+    if (force_tw == -2) {
+        const char* e = getenv("DAT_CONV_TW_LOG2");
+        force_tw = e ? atoi(e) : -1;
+    }
+    if (force_tw >= 0 && force_tw <= bp_log2) return TileChoice{bp_log2 - force_tw, force_tw};
     TileChoice best{0, bp_log2};
     double best_cost = 1e30;
     for (int a = 0; a <= bp_log2; ++a) {
@@ -385,7 +399,10 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
         const long long PH = (KH == 1) ? th : (th - 1) * sh + KH;
         const long long PW = (KW == 1) ? tw : (tw - 1) * sw + KW;
         const double halo = (double)(PH * PW) / (double)(th * tw);
-        const double cost = waste * (1.0 + 0.15 * (halo - 1.0));
+        // a 32-lane MFMA column block spans 32/tw tile rows; with tw < 32 and a halo the LDS rows it reads are not
+        // consecutive, which costs ~2-way bank conflicts on part of every ds_read_b128 (measured)
+        const double conflict = (tw < 32 && KW > 1) ? 1.06 : 1.0;
+        const double cost = waste * (1.0 + 0.15 * (halo - 1.0)) * conflict;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = TileChoice{a, b};
@@ -409,11 +426,16 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
     p.PH = (p.KH == 1) ? th : (th - 1) * p.sh + p.KH;
     p.PW = (p.KW == 1) ? tw : (tw - 1) * p.sw + p.KW;
     p.n_cchunks = p.Cin / Mma<DT>::CK;
+    {
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("DAT_CONV_ABLATE"); abl = e ? atoi(e) : 0; }
+        p.ablate = abl;
+    }
     p.nblk_n = p.Cout_pad / BN;
     const long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
     p.nblocks = (unsigned)nblocks;
-    const size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * ROWB;
+    const size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * PPITCH;
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N>;
@@ -496,7 +518,20 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     hipStream_t st = (hipStream_t)s;
 
     const bool small_n = d->Cout <= 64;
-    int tag = (small_n ? 64 : 128) * 1000 + 128 * 10 + d->dtype;
+    // tile variant: BP = 256 positions per block (each wave 64 channels x 128 positions) halves the barriers and the
+    // weight-tile traffic per MFMA; used when the layer has enough tiles to fill the chip.  DAT_CONV_BP overrides.
+    static int force_bp = -1;
+    if (force_bp < 0) {
+        const char* e = getenv("DAT_CONV_BP");
+        force_bp = e ? atoi(e) : 0;
+    }
+    const long long pos = (long long)d->frames * p.Ho * p.Wo;
+    const long long nb = (p.Cout_pad / (small_n ? 64 : 128));
+    bool big = !small_n && (d->KH * d->KW > 1) && d->stride_h == 1 && d->stride_w == 1 && (pos / 256) * nb >= 2 * 256;
+    if (force_bp == 128) big = false;
+    if (force_bp == 256) big = (d->stride_h == 1 && d->stride_w == 1);
+    const int bp = big ? 256 : 128;
+    int tag = (small_n ? 64 : 128) * 1000 + bp * 10 + d->dtype;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
@@ -504,10 +539,17 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         hipEventRecord(e0, st);
     }
     int rc;
-    if (d->dtype == DAT_BF16)
-        rc = small_n ? launch_conv<DAT_BF16, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_BF16, 128, 128, 2>(ctx, st, p, 7);
-    else
-        rc = small_n ? launch_conv<DAT_F32, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_F32, 128, 128, 2>(ctx, st, p, 7);
+    if (d->dtype == DAT_BF16) {
+        if (big)
+            rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8);
+        else
+            rc = small_n ? launch_conv<DAT_BF16, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_BF16, 128, 128, 2>(ctx, st, p, 7);
+    } else {
+        if (big)
+            rc = small_n ? launch_conv<DAT_F32, 64, 256, 1>(ctx, st, p, 8) : launch_conv<DAT_F32, 128, 256, 2>(ctx, st, p, 8);
+        else
+            rc = small_n ? launch_conv<DAT_F32, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_F32, 128, 128, 2>(ctx, st, p, 7);
+    }
     if (e1) {
         hipEventRecord(e1, st);
         ctx->prof_flops[ctx->prof_n] = 2.0 * d->Cout * d->Cin * d->KT * d->KH * d->KW * (double)d->frames * p.Ho * p.Wo;
