@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -205,16 +206,30 @@ def main():
 
     # ---- roofline of the dominant kernel (conv3d_igemm, the BN=128 instantiation) from per-launch HIP events ----
     assert len(records) == len(conv_log), (len(records), len(conv_log))
-    dom_tag = 128 * 1000 + 128 * 10 + (1 if a.dtype == 'bf16' else 0)
-    dom_fl = sum(fl for (tag, _, ms), (_, fl) in zip(records, conv_log) if tag == dom_tag)
-    dom_ms = sum(ms for (tag, _, ms) in records if tag == dom_tag)
-    dom_n = sum(1 for (tag, _, ms) in records if tag == dom_tag)
+    # dominant kernel = the conv3d_igemm instantiation with the largest total time in the timed region
+    by_tag = {}
+    for (tag, _, ms), (_, fl) in zip(records, conv_log):
+        t = by_tag.setdefault(tag, [0.0, 0.0, 0])
+        t[0] += fl
+        t[1] += ms
+        t[2] += 1
+    dom_tag = max(by_tag, key=lambda k: by_tag[k][1])
+    dom_fl, dom_ms, dom_n = by_tag[dom_tag]
+    if a.dump_convs:
+        agg = {}
+        for (tag, _, ms), (name, fl) in zip(records, conv_log):
+            e = agg.setdefault(name, [0.0, 0.0, tag])
+            e[0] += fl
+            e[1] += ms
+        for name, (fl, ms, tag) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s' % (name, tag, ms / a.steps, fl / ms / 1e9 if ms > 0 else 0),
+                  file=sys.stderr)
     all_fl = sum(fl for _, fl in conv_log)
     all_ms = sum(ms for _, _, ms in records)
     peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     roofline = {
-        'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel<%s,128,128,2>' % a.dtype,
+        'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 1000, (dom_tag % 1000) // 10),
         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
         'traffic': None,
         'launches_per_step': dom_n // max(a.steps, 1),

@@ -1,6 +1,20 @@
 // Context, error text and per-launch profiling of libdat_hip (see include/dat_hip.h).
 #include "dat_common.h"
 
+int dat_ensure_ws(dat_ctx* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return DAT_OK;
+    if (ctx->ws) {
+        hipDeviceSynchronize();
+        hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = bytes + (bytes >> 2);
+    if (hipMalloc(&ctx->ws, want) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
+    ctx->ws_bytes = want;
+    return DAT_OK;
+}
+
 extern "C" {
 
 int dat_version(void) { return 1; }

@@ -48,9 +48,17 @@ struct ConvParams {
     int th_log2, tw_log2;     // output tile = 2^th x 2^tw positions
     int tiles_h, tiles_w;
     int PH, PW;               // patch rows/cols (LDS rows = PH*PW)
-    int psh, psw;             // patch sampling step in the input (stride for 1x1 kernels, else 1)
-    int ash, asw;             // patch-row step per output position (stride for KxK kernels, else 1)
+    int psh, psw;             // patch sampling step in the input (= conv stride)
+    // spatial tap schedule of one (kt, channel chunk): taps grouped by stride-parity plane, so that every plane is a
+    // dense (tile + halo/stride) patch whose rows are read consecutively (stride-2 convs: 4 small patches)
+    int tab_n;
+    int tab_tap[32];          // kh*KW + kw (weight tap index)
+    int tab_rowoff[32];       // LDS row offset of this tap inside the plane patch
+    short tab_dy[32], tab_dx[32];  // input offset of the plane's patch cell (0,0) relative to (ih0, iw0)
+    unsigned tab_new;         // bit i: entry i starts a new plane (patch reload)
     int n_cchunks;            // Cin / CK
+    int ksplit;               // split-K over the (kt, channel-chunk) sequence; > 1 => fp32 partials to `part`
+    float* part;              // [ksplit][frames*Ho*Wo][Cout] fp32 (split-K only)
     int ablate;               // DEBUG (DAT_CONV_ABLATE): 1 skip patch reloads, 2 skip weight streaming
     int nblk_n;               // Cout_pad / BN
     unsigned nblocks;
@@ -106,6 +114,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
         const unsigned xcd = bid % nx, k = bid / nx;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
     const int nb = bid % p.nblk_n;
     unsigned tile = bid / p.nblk_n;
     const int tw_i = tile % p.tiles_w;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     for (int j = 0; j < PT; ++j) {
         const int pos = wave_p * WP + j * 32 + (lane & 31);
         const int ohl = pos >> p.tw_log2, owl = pos & (TW - 1);
-        rowbase[j] = ohl * p.ash * p.PW + owl * p.asw;
+        rowbase[j] = ohl * p.PW + owl;
     }
     const int khalf = lane >> 5;
 
@@ -144,8 +154,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     while (kt_lo < p.KT && (t + kt_lo - p.pt) < 0) ++kt_lo;
     while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.T) --kt_hi;
     const int n_kt = kt_hi - kt_lo + 1;
-    const int ntap = p.KH * p.KW;
-    const int total = n_kt * p.n_cchunks * ntap;
+    const int ntap = p.KH * p.KW;      // weight taps per kt
+    const int ntab = p.tab_n;          // == ntap, in plane order
+    const int npatch = n_kt * p.n_cchunks;                 // (kt, channel chunk) patches of this output frame
+    const int pi_lo = (npatch * split) / p.ksplit, pi_hi = (npatch * (split + 1)) / p.ksplit;
+    const int total = (pi_hi - pi_lo) * ntab;
 
     const size_t w_tap_stride = (size_t)p.Cout_pad * p.Cin * ES;  // bytes between taps
     const int npatch_items = p.PH * p.PW * 8;
@@ -193,14 +206,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     for (int j = 0; j < PT; ++j) b_base[j] = rowbase[j] * PPITCH + khalf * 16;
 
     if (total > 0) {
-        int kt = kt_lo, cc = 0, tap = 0, kh = 0, kw = 0;
-        W_PREFETCH(kt, cc, tap);
+        int kt = kt_lo + pi_lo / p.n_cchunks, cc = pi_lo % p.n_cchunks, ti = 0;
+        W_PREFETCH(kt, cc, p.tab_tap[0]);
         for (int step = 0; step < total; ++step) {
-            if (tap == 0 && !((p.ablate & 1) && step > 0)) {
+            if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0)) {
                 __syncthreads();  // all waves finished reading the previous patch
-                // ---- stage the input patch (tile + halo) of (kt, cc) ----
+                // ---- stage the input patch (tile + halo) of (kt, cc, plane) ----
                 const int fin = f + kt - p.pt;
                 const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+                const int py0 = ih0 + p.tab_dy[ti], px0 = iw0 + p.tab_dx[ti];
                 for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * 4) {
                     uint4 v[4];
                     int offs[4];
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                         v[u] = make_uint4(0, 0, 0, 0);
                         if (it < npatch_items) {
                             const int prow = row / p.PW, pcol = row - prow * p.PW;
-                            const int ih = ih0 + prow * p.psh, iw = iw0 + pcol * p.psw;
+                            const int ih = py0 + prow * p.psh, iw = px0 + pcol * p.psw;
                             if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
                                 v[u] = *(const uint4*)(xbase + ((size_t)ih * p.W + iw) * p.Cin * ES + slot * 16);
                         }
@@ -224,15 +238,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             }
             if (!((p.ablate & 2) && step > 1)) W_COMMIT(step & 1);
             __syncthreads();
-            // advance to the next (kt, cc, tap) and prefetch its weight tile (lands during this step's MFMAs)
-            const int tapoff = ((p.psh == 1 ? kh : 0) * p.PW + (p.psw == 1 ? kw : 0)) * PPITCH;
-            int ntap_i = tap + 1, ncc = cc, nkt = kt, nkh = kh, nkw = kw + 1;
-            if (nkw == p.KW) { nkw = 0; ++nkh; }
-            if (ntap_i == ntap) {
-                ntap_i = 0; nkh = 0; nkw = 0;
+            // advance to the next (kt, cc, table entry) and prefetch its weight tile (lands during this step's MFMAs)
+            const int tapoff = p.tab_rowoff[ti] * PPITCH;
+            int nti = ti + 1, ncc = cc, nkt = kt;
+            if (nti == ntab) {
+                nti = 0;
                 if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
             }
-            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, ntap_i);
+            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti]);
 
             // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
             const char* wb = wbuf + (step & 1) * BN * ROWB;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
                     for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
             }
-            tap = ntap_i; cc = ncc; kt = nkt; kh = nkh; kw = nkw;
+            ti = nti; cc = ncc; kt = nkt;
         }
     }
 #undef W_PREFETCH
@@ -283,6 +296,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+                if (p.ksplit > 1) {   // raw fp32 partial sums; splitk_finish_kernel applies the epilogue
+                    const size_t npos = (size_t)p.frames * p.Ho * p.Wo;
+                    *(float4*)(p.part + ((size_t)split * npos + opos) * p.Cout + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 if (p.scale) {
                     const float4 s = *(const float4*)(p.scale + c);
                     v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
@@ -318,6 +336,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     }
 }
 
+// split-K finish: y = act(sum_s part[s] * scale + bias + residual), 4 channels per thread
+template <int DT>
+__global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit, size_t npos, int Cout, int out_cs,
+                                     const float* __restrict__ scale, const float* __restrict__ bias,
+                                     const char* __restrict__ res, int res_mode, int frames, int Ho, int Wo, int relu,
+                                     char* __restrict__ y) {
+    const int c4 = Cout >> 2;
+    const size_t total = npos * c4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        const size_t opos = i / c4;
+        float4 a = *(const float4*)(part + opos * Cout + c);
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 b = *(const float4*)(part + ((size_t)s * npos + opos) * Cout + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (scale) { const float4 s4 = *(const float4*)(scale + c); v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w; }
+        if (bias) { const float4 b4 = *(const float4*)(bias + c); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+        if (res_mode) {
+            size_t rpos = opos;
+            if (res_mode == 2) {
+                const int ow = opos % Wo;
+                const size_t q = opos / Wo;
+                const int oh = q % Ho;
+                const size_t f = q / Ho;
+                rpos = (f * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1);
+            }
+            if (DT == DAT_BF16) {
+                const uint2 r = *(const uint2*)(res + (rpos * out_cs + c) * 2);
+                v[0] += bf2f((uint16_t)(r.x & 0xffff)); v[1] += bf2f((uint16_t)(r.x >> 16));
+                v[2] += bf2f((uint16_t)(r.y & 0xffff)); v[3] += bf2f((uint16_t)(r.y >> 16));
+            } else {
+                const float4 r = *(const float4*)(res + (rpos * out_cs + c) * 4);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
+        }
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (DT == DAT_BF16) {
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *(uint2*)(y + (opos * out_cs + c) * 2) = o;
+        } else {
+            *(float4*)(y + (opos * out_cs + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: fp32 [Cout_real, Cin_real, KT, KH, KW] -> [tap][Cout_pad][Cin] in dtype, zero padded
 template <int DT>
@@ -334,28 +401,42 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
     }
 }
 
-// stem packing (see dat_hip.h: dat_stem_pack)
+// stem packing (see dat_hip.h: dat_stem_pack): one thread = one 16-byte group of output channels
 template <int DT>
 __global__ void stem_pack_kernel(const float* __restrict__ data, void* __restrict__ out, int N, int T, int H, int W,
                                  int Ho, int Wo) {
+    constexpr int V = 16 / ElemOf<DT>::size;   // channels per thread
+    constexpr int G = 64 / V;                  // groups per position
     const int R = Ho + 3;
-    const size_t total = (size_t)N * T * R * Wo * 64;
+    const size_t total = (size_t)N * T * R * Wo * G;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = i & 63;
-        size_t q = i >> 6;
+        const int g = i % G;
+        size_t q = i / G;
         const int ow = q % Wo; q /= Wo;
         const int r = q % R; q /= R;
         const int t = q % T;
         const int n = q / T;
-        const int dkh = ch >> 5, rem = ch & 31;
-        float v = 0.f;
-        if (rem < 21) {
-            const int kw = rem / 3, c = rem - kw * 3;
-            const int ih = 2 * r - 3 + dkh, iw = 2 * ow - 3 + kw;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                v = data[((((size_t)n * 3 + c) * T + t) * H + ih) * W + iw];
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = g * V + e;
+            const int dkh = ch >> 5, rem = ch & 31;
+            float x = 0.f;
+            if (rem < 21) {
+                const int kw = rem / 3, c = rem - kw * 3;
+                const int ih = 2 * r - 3 + dkh, iw = 2 * ow - 3 + kw;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) x = data[((((size_t)n * 3 + c) * T + t) * H + ih) * W + iw];
+            }
+            v[e] = x;
         }
-        ElemOf<DT>::st(out, i, v);
+        uint4 o;
+        if (DT == DAT_BF16) {
+            o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            o.z = f2bf(v[4 % V]) | ((uint32_t)f2bf(v[5 % V]) << 16); o.w = f2bf(v[6 % V]) | ((uint32_t)f2bf(v[7 % V]) << 16);
+        } else {
+            o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+        }
+        *(uint4*)((char*)out + i * 16) = o;
     }
 }
 
@@ -396,8 +477,8 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
         const long long th = 1 << a, tw = 1 << b;
         const long long tiles = cdiv_ll(Ho, th) * cdiv_ll(Wo, tw);
         const double waste = (double)(tiles * th * tw) / ((double)Ho * Wo);
-        const long long PH = (KH == 1) ? th : (th - 1) * sh + KH;
-        const long long PW = (KW == 1) ? tw : (tw - 1) * sw + KW;
+        const long long PH = th + (KH - 1) / sh;
+        const long long PW = tw + (KW - 1) / sw;
         const double halo = (double)(PH * PW) / (double)(th * tw);
         // a 32-lane MFMA column block spans 32/tw tile rows; with tw < 32 and a halo the LDS rows it reads are not
         // consecutive, which costs ~2-way bank conflicts on part of every ds_read_b128 (measured)
@@ -419,12 +500,30 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
     const int th = 1 << tc.th_log2, tw = 1 << tc.tw_log2;
     p.tiles_h = (p.Ho + th - 1) / th;
     p.tiles_w = (p.Wo + tw - 1) / tw;
-    p.psh = (p.KH == 1) ? p.sh : 1;
-    p.psw = (p.KW == 1) ? p.sw : 1;
-    p.ash = (p.KH == 1) ? 1 : p.sh;
-    p.asw = (p.KW == 1) ? 1 : p.sw;
-    p.PH = (p.KH == 1) ? th : (th - 1) * p.sh + p.KH;
-    p.PW = (p.KW == 1) ? tw : (tw - 1) * p.sw + p.KW;
+    p.psh = p.sh;
+    p.psw = p.sw;
+    p.PH = th + (p.KH - 1) / p.sh;
+    p.PW = tw + (p.KW - 1) / p.sw;
+    {   // tap table in stride-parity plane order
+        int n = 0;
+        p.tab_new = 0;
+        DAT_ENFORCE(ctx, p.KH * p.KW <= 32, "conv3d: %dx%d spatial kernel exceeds the 32-entry tap table", p.KH, p.KW);
+        for (int py = 0; py < p.sh && py < p.KH; ++py)
+            for (int px = 0; px < p.sw && px < p.KW; ++px) {
+                bool first = true;
+                for (int kh = py; kh < p.KH; kh += p.sh)
+                    for (int kw = px; kw < p.KW; kw += p.sw) {
+                        p.tab_tap[n] = kh * p.KW + kw;
+                        p.tab_rowoff[n] = (kh / p.sh) * p.PW + (kw / p.sw);
+                        p.tab_dy[n] = (short)py;
+                        p.tab_dx[n] = (short)px;
+                        if (first) p.tab_new |= 1u << n;
+                        first = false;
+                        ++n;
+                    }
+            }
+        p.tab_n = n;
+    }
     p.n_cchunks = p.Cin / Mma<DT>::CK;
     {
         static int abl = -1;
@@ -432,7 +531,34 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
         p.ablate = abl;
     }
     p.nblk_n = p.Cout_pad / BN;
-    const long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
+    long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
+    // split-K: small feature maps give fewer blocks than the chip holds (2 per CU); splitting the (kt, chunk)
+    // sequence restores occupancy at the price of an fp32 partial round trip (a few % of the layer's time)
+    {
+        static int force_ks = -1;
+        if (force_ks < 0) { const char* e = getenv("DAT_CONV_KSPLIT"); force_ks = e ? atoi(e) : 0; }
+        const int npatch_min = (p.KT > 1 ? p.KT - 1 : 1) * p.n_cchunks;
+        int ks = 1;
+        const long long slots = 2 * 256;
+        const bool deep_1x1 = (p.KH * p.KW == 1 && p.n_cchunks >= 16);   // FC-like: K = thousands of channels
+        if (nblocks < slots + slots / 2 && (p.KH * p.KW > 1 || deep_1x1)) {
+            ks = (int)((2 * slots + nblocks - 1) / nblocks);
+            const int ks_max = deep_1x1 ? 8 : 4;
+            if (ks > ks_max) ks = ks_max;
+            if (ks > npatch_min) ks = npatch_min;
+            if (ks < 1) ks = 1;
+        }
+        if (force_ks > 0) ks = force_ks > npatch_min ? npatch_min : force_ks;
+        p.ksplit = ks;
+        p.part = nullptr;
+        if (ks > 1) {
+            const size_t bytes = (size_t)ks * p.frames * p.Ho * p.Wo * p.Cout * sizeof(float);
+            int rc = dat_ensure_ws(ctx, bytes);
+            if (rc != DAT_OK) return rc;
+            p.part = (float*)ctx->ws;
+        }
+        nblocks *= ks;
+    }
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
     p.nblocks = (unsigned)nblocks;
     const size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * PPITCH;
@@ -445,6 +571,13 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NTHREADS), lds, st, p);
+    if (p.ksplit > 1) {
+        const size_t npos = (size_t)p.frames * p.Ho * p.Wo;
+        const size_t tot = npos * (p.Cout >> 2);
+        const int blocks = (int)std::min<size_t>((tot + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(splitk_finish_kernel<DT>, dim3(blocks), dim3(256), 0, st, (const float*)p.part, p.ksplit, npos, p.Cout,
+                           p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y);
+    }
     DAT_CHECK_LAUNCH(ctx, "conv3d_igemm");
     return DAT_OK;
 }
@@ -527,9 +660,9 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     }
     const long long pos = (long long)d->frames * p.Ho * p.Wo;
     const long long nb = (p.Cout_pad / (small_n ? 64 : 128));
-    bool big = !small_n && (d->KH * d->KW > 1) && d->stride_h == 1 && d->stride_w == 1 && (pos / 256) * nb >= 2 * 256;
+    bool big = !small_n && (d->KH * d->KW > 1) && (pos / 256) * nb >= 2 * 256;
     if (force_bp == 128) big = false;
-    if (force_bp == 256) big = (d->stride_h == 1 && d->stride_w == 1);
+    if (force_bp == 256) big = true;
     const int bp = big ? 256 : 128;
     int tag = (small_n ? 64 : 128) * 1000 + bp * 10 + d->dtype;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -562,8 +695,8 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
 int dat_stem_pack(dat_ctx* ctx, dat_stream s, const float* data, void* packed, int dtype, int N, int T, int H, int W) {
     DAT_ENFORCE(ctx, data && packed, "stem_pack: null argument");
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    const size_t total = (size_t)N * T * (Ho + 3) * Wo * 64;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    const size_t total = (size_t)N * T * (Ho + 3) * Wo * (64 / (16 / dat_esize(dtype)));
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 64);
     if (dtype == DAT_BF16)
         hipLaunchKernelGGL(stem_pack_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, packed, N, T, H,
                            W, Ho, Wo);

@@ -68,5 +68,8 @@ template <> struct ElemOf<DAT_BF16> {
     __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
 };
 
+// grow the ctx-owned scratch (synchronises + reallocates only when it must grow); defined in c_api.hip
+int dat_ensure_ws(dat_ctx* ctx, size_t bytes);
+
 static inline int dat_esize(int dtype) { return dtype == DAT_BF16 ? 2 : 4; }
 static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }

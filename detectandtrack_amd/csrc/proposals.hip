@@ -379,13 +379,18 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsParams p) {
     for (int b = 0; b < nwords; ++b) {
         const int row = b * 64 + lane;
         const unsigned long long diag = (row < n) ? L.mask[(size_t)row * nwords + b] : 0ull;
-        unsigned long long cur = __shfl(remv, b, 64);
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        const unsigned rlo = (unsigned)remv, rhi = (unsigned)(remv >> 32);
+        // v_readlane (scalar path) instead of ds_bpermute shuffles: the 64-step dependency chain runs on the SALU
+        unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rhi, b) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)rlo, b);
         const int rows_here = min(64, n - b * 64);
         unsigned long long kept = 0;
         for (int i = 0; i < rows_here; ++i) {
             if (!((cur >> i) & 1ull)) {
                 kept |= 1ull << i;
-                cur |= __shfl(diag, i, 64);
+                cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
             }
         }
         // emit kept rows of this chunk in order
@@ -529,19 +534,7 @@ __global__ __launch_bounds__(1024) void nms_finish_kernel(const int* kept, const
     if (tid == 0) *num_out = nk;
 }
 
-int ensure_ws(dat_ctx* ctx, size_t bytes) {
-    if (ctx->ws_bytes >= bytes) return DAT_OK;
-    if (ctx->ws) {
-        hipDeviceSynchronize();
-        hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
-    }
-    const size_t want = bytes + (bytes >> 2);
-    if (hipMalloc(&ctx->ws, want) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
-    ctx->ws_bytes = want;
-    return DAT_OK;
-}
+int ensure_ws(dat_ctx* ctx, size_t bytes) { return dat_ensure_ws(ctx, bytes); }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
