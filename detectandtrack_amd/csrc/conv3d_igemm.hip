@@ -24,6 +24,7 @@
 //     channel-contiguous NDHWC stores in the epilogue;
 //   * blockIdx -> tile mapping is XCD-aware: output-channel blocks of one spatial tile and neighbouring
 //     tiles land on the same XCD (shared L2 for patch + weights).
+#include <math.h>
 #include <stdlib.h>
 
 #include "dat_common.h"
@@ -493,7 +494,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
 }
 
 template <int DT, int BN, int BP, int WAVES_N>
-int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
+int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
     const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW);
     p.th_log2 = tc.th_log2;
     p.tw_log2 = tc.tw_log2;
@@ -532,23 +533,10 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2) {
     }
     p.nblk_n = p.Cout_pad / BN;
     long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
-    // split-K: small feature maps give fewer blocks than the chip holds (2 per CU); splitting the (kt, chunk)
-    // sequence restores occupancy at the price of an fp32 partial round trip (a few % of the layer's time)
+    // split-K (chosen by plan_conv): fp32 partial sums in the ctx workspace, finished by splitk_finish_kernel
     {
-        static int force_ks = -1;
-        if (force_ks < 0) { const char* e = getenv("DAT_CONV_KSPLIT"); force_ks = e ? atoi(e) : 0; }
         const int npatch_min = (p.KT > 1 ? p.KT - 1 : 1) * p.n_cchunks;
-        int ks = 1;
-        const long long slots = 2 * 256;
-        const bool deep_1x1 = (p.KH * p.KW == 1 && p.n_cchunks >= 16);   // FC-like: K = thousands of channels
-        if (nblocks < slots + slots / 2 && (p.KH * p.KW > 1 || deep_1x1)) {
-            ks = (int)((2 * slots + nblocks - 1) / nblocks);
-            const int ks_max = deep_1x1 ? 8 : 4;
-            if (ks > ks_max) ks = ks_max;
-            if (ks > npatch_min) ks = npatch_min;
-            if (ks < 1) ks = 1;
-        }
-        if (force_ks > 0) ks = force_ks > npatch_min ? npatch_min : force_ks;
+        int ks = ksplit < 1 ? 1 : (ksplit > npatch_min ? npatch_min : ksplit);
         p.ksplit = ks;
         p.part = nullptr;
         if (ks > 1) {
@@ -651,19 +639,49 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     hipStream_t st = (hipStream_t)s;
 
     const bool small_n = d->Cout <= 64;
-    // tile variant: BP = 256 positions per block (each wave 64 channels x 128 positions) halves the barriers and the
-    // weight-tile traffic per MFMA; used when the layer has enough tiles to fill the chip.  DAT_CONV_BP overrides.
-    static int force_bp = -1;
+    // ---- plan: positions per block (128 | 256) and split-K factor from a small makespan model ----------------
+    // A block runs steps = ceil(npatch/ks) * taps tap-steps; 2 blocks share a CU (512 slots).  Measured on MI355X:
+    // a BP=128 step costs ~1.35 us, a BP=256 step ~2.15 us (2x the work).  The grid runs in "rounds" of 512 blocks;
+    // with few rounds the last partial round costs a full one.  Split-K adds an fp32 partial round trip.
+    static int force_bp = -1, force_ks = -1;
     if (force_bp < 0) {
         const char* e = getenv("DAT_CONV_BP");
         force_bp = e ? atoi(e) : 0;
+        const char* k = getenv("DAT_CONV_KSPLIT");
+        force_ks = k ? atoi(k) : 0;
     }
-    const long long pos = (long long)d->frames * p.Ho * p.Wo;
-    const long long nb = (p.Cout_pad / (small_n ? 64 : 128));
-    bool big = !small_n && (d->KH * d->KW > 1) && (pos / 256) * nb >= 2 * 256;
-    if (force_bp == 128) big = false;
-    if (force_bp == 256) big = true;
-    const int bp = big ? 256 : 128;
+    const int ck = d->dtype == DAT_BF16 ? 64 : 32;
+    const int ncc = d->Cin / ck;
+    const int npatch = d->KT * ncc, npatch_min = (d->KT > 1 ? d->KT - 1 : 1) * ncc;
+    const int ntaps = d->KH * d->KW;
+    const long long nbn = p.Cout_pad / (small_n ? 64 : 128);
+    int bp = 128, ksplit = 1;
+    {
+        double best = 1e30;
+        const bool deep_1x1 = (ntaps == 1 && ncc >= 16);
+        for (int cand_bp = 128; cand_bp <= 256; cand_bp += 128) {
+            if (cand_bp == 256 && (small_n || ntaps == 1)) continue;   // the 64-channel and 1x1 variants do not profit
+            if (force_bp && cand_bp != force_bp && !(force_bp == 256 && (small_n || ntaps == 1))) continue;
+            const int lg = cand_bp == 256 ? 8 : 7;
+            const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW);
+            const long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * d->frames;
+            const int ks_max = (ntaps > 1 || deep_1x1) ? (deep_1x1 ? 8 : 4) : 1;
+            for (int ks = 1; ks <= ks_max && ks <= npatch_min; ++ks) {
+                if (force_ks && ks != std::min(force_ks, npatch_min)) continue;
+                const double nblk = (double)tiles * nbn * ks;
+                const double slots = 512.0;
+                double rounds = nblk / slots;
+                if (rounds <= 3.0) rounds = ceil(rounds); else rounds += 0.5;
+                const double steps = ceil((double)npatch / ks) * ntaps;
+                const double step_us = cand_bp == 256 ? 2.15 : 1.35;
+                const double fixed_us = 2.0 + 0.6 * ceil((double)npatch / ks);      // epilogue + exposed patch loads
+                double t = rounds * (steps * step_us + fixed_us);
+                if (ks > 1) t += 4.0 + 2.0 * ks * (double)d->frames * p.Ho * p.Wo * d->Cout * 4.0 / 3.0e6;  // us @3 TB/s
+                if (t < best) { best = t; bp = cand_bp; ksplit = ks; }
+            }
+        }
+    }
+    const bool big = bp == 256;
     int tag = (small_n ? 64 : 128) * 1000 + bp * 10 + d->dtype;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap) {
@@ -674,14 +692,14 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     int rc;
     if (d->dtype == DAT_BF16) {
         if (big)
-            rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8);
+            rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8, ksplit);
         else
-            rc = small_n ? launch_conv<DAT_BF16, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_BF16, 128, 128, 2>(ctx, st, p, 7);
+            rc = small_n ? launch_conv<DAT_BF16, 64, 128, 1>(ctx, st, p, 7, ksplit) : launch_conv<DAT_BF16, 128, 128, 2>(ctx, st, p, 7, ksplit);
     } else {
         if (big)
-            rc = small_n ? launch_conv<DAT_F32, 64, 256, 1>(ctx, st, p, 8) : launch_conv<DAT_F32, 128, 256, 2>(ctx, st, p, 8);
+            rc = small_n ? launch_conv<DAT_F32, 64, 256, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_F32, 128, 256, 2>(ctx, st, p, 8, ksplit);
         else
-            rc = small_n ? launch_conv<DAT_F32, 64, 128, 1>(ctx, st, p, 7) : launch_conv<DAT_F32, 128, 128, 2>(ctx, st, p, 7);
+            rc = small_n ? launch_conv<DAT_F32, 64, 128, 1>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 128, 128, 2>(ctx, st, p, 7, ksplit);
     }
     if (e1) {
         hipEventRecord(e1, st);

@@ -399,14 +399,15 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsParams p) {
             L.kept[nkeep + rank] = row;
         }
         nkeep += __popcll(kept);
-        // propagate: later words get the OR of the kept rows' masks
+        // propagate: later words get the OR of the kept rows' masks.  Loads are unconditional with a fixed trip count
+        // so that they pipeline (a data-dependent `while (kept)` loop serialised one L2 round trip per kept row).
         if (lane > b && lane < nwords) {
             unsigned long long acc = 0;
-            unsigned long long k = kept;
-            while (k) {
-                const int i = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= L.mask[(size_t)(b * 64 + i) * nwords + lane];
+            const unsigned long long* mrow = L.mask + (size_t)(b * 64) * nwords + lane;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) {
+                const unsigned long long m = (i < rows_here) ? mrow[(size_t)i * nwords] : 0ull;
+                acc |= ((kept >> i) & 1ull) ? m : 0ull;
             }
             remv |= acc;
         }
