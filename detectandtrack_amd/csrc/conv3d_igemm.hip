@@ -682,7 +682,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         }
     }
     const bool big = bp == 256;
-    int tag = (small_n ? 64 : 128) * 1000 + bp * 10 + d->dtype;
+    int tag = (small_n ? 64 : 128) * 10000 + bp * 10 + d->dtype;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];

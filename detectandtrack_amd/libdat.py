@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdat_hip.so')
+LIB_PATH = os.environ.get('DAT_LIB', os.path.join(_HERE, 'libdat_hip.so'))
 
 DAT_F32, DAT_BF16 = 0, 1
 DAT_OK = 0

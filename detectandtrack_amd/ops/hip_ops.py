@@ -34,12 +34,14 @@ _CTX = {}
 
 
 def ctx(device=None):
-    """Per-device context (created lazily)."""
+    """Context of the current (device, HIP stream) pair, created lazily.  The C-ABI context owns scratch memory that
+    kernels of ONE stream may use at a time, so concurrent streams (clip pipelining) get their own context."""
     if device is None:
         device = torch.cuda.current_device()
-    if device not in _CTX:
-        _CTX[device] = L.Ctx(device)
-    return _CTX[device]
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    if key not in _CTX:
+        _CTX[key] = L.Ctx(device)
+    return _CTX[key]
 
 
 # ---- toy + AffineChannelNd (the reference's own native ops) ---------------------------------------

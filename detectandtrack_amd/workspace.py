@@ -91,6 +91,16 @@ class Workspace(object):
         self._layers.clear()
         self._dev_params.clear()
 
+    def fork(self):
+        """A second blob namespace over the SAME parameters / packed layers / nets: lets two clips be in flight on
+        two HIP streams (host post-processing of clip i overlaps the device forward of clip i+1)."""
+        w = Workspace.__new__(Workspace)
+        w.device = self.device
+        w.blobs = {}
+        w.params, w.nets, w._layers, w._dev_params = self.params, self.nets, self._layers, self._dev_params
+        w.conv_log = None
+        return w
+
     # ---- parameters -----------------------------------------------------------------------------------------------
     def dev_param(self, name):
         if name not in self._dev_params:

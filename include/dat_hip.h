@@ -42,7 +42,7 @@ const char* dat_last_error(dat_ctx* ctx);
 
 /* Per-launch HIP-event timing of the conv kernel (used by bench.py's roofline leg).
  * enable: start recording (capacity launches); read: sync the events and return
- * n records {tag, flops, milliseconds}; tag = BN*1000 + BP*10 + dtype. */
+ * n records {tag, flops, milliseconds}; tag = BN*10000 + BP*10 + dtype. */
 int dat_prof_enable(dat_ctx* ctx, int capacity);
 int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float* ms);
 
