@@ -57,6 +57,7 @@ struct ConvParams {
     int tab_rowoff[32];       // LDS row offset of this tap inside the plane patch
     short tab_dy[32], tab_dx[32];  // input offset of the plane's patch cell (0,0) relative to (ih0, iw0)
     unsigned tab_new;         // bit i: entry i starts a new plane (patch reload)
+    unsigned pw_magic;        // ceil(2^32 / PW): row / PW == umulhi(row, pw_magic) for row, PW < 2^16
     int n_cchunks;            // Cin / CK
     int ksplit;               // split-K over the (kt, channel-chunk) sequence; > 1 => fp32 partials to `part`
     float* part;              // [ksplit][frames*Ho*Wo][Cout] fp32 (split-K only)
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
     for (int j = 0; j < PT; ++j) b_base[j] = rowbase[j] * PPITCH + khalf * 16;
 
+    constexpr int NPI = 4;   // patch items (16 B) per thread per batch of loads (each extra item costs ~12 VGPRs at the register peak)
     if (total > 0) {
         int kt = kt_lo + pi_lo / p.n_cchunks, cc = pi_lo % p.n_cchunks, ti = 0;
         W_PREFETCH(kt, cc, p.tab_tap[0]);
@@ -216,25 +218,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 const int fin = f + kt - p.pt;
                 const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
                 const int py0 = ih0 + p.tab_dy[ti], px0 = iw0 + p.tab_dx[ti];
-                for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * 4) {
-                    uint4 v[4];
-                    int offs[4];
+#pragma unroll 1
+                for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * NPI) {
+                    uint4 v[NPI];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NPI; ++u) {
                         const int it = it0 + u * NTHREADS;
                         const int row = it >> 3, slot = it & 7;
-                        offs[u] = row * PPITCH + slot * 16;
                         v[u] = make_uint4(0, 0, 0, 0);
                         if (it < npatch_items) {
-                            const int prow = row / p.PW, pcol = row - prow * p.PW;
+                            const int prow = (int)__umulhi((unsigned)row, p.pw_magic), pcol = row - prow * p.PW;
                             const int ih = py0 + prow * p.psh, iw = px0 + pcol * p.psw;
                             if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                                v[u] = *(const uint4*)(xbase + ((size_t)ih * p.W + iw) * p.Cin * ES + slot * 16);
+                                v[u] = *(const uint4*)(xbase + ((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16)));
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (it0 + u * NTHREADS < npatch_items) *(uint4*)(patch + offs[u]) = v[u];
+                    for (int u = 0; u < NPI; ++u) {
+                        const int it = it0 + u * NTHREADS;
+                        if (it < npatch_items) *(uint4*)(patch + (it >> 3) * PPITCH + (it & 7) * 16) = v[u];
+                    }
                 }
             }
             if (!((p.ablate & 2) && step > 1)) W_COMMIT(step & 1);
@@ -525,6 +528,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
             }
         p.tab_n = n;
     }
+    p.pw_magic = (unsigned)((0x100000000ull + (unsigned)p.PW - 1) / (unsigned)p.PW);
     p.n_cchunks = p.Cin / Mma<DT>::CK;
     {
         static int abl = -1;
@@ -549,7 +553,12 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     }
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
     p.nblocks = (unsigned)nblocks;
-    const size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * PPITCH;
+    size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * PPITCH;
+    {
+        static int pad = -1;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
+        if (pad < 0) { const char* e = getenv("DAT_CONV_LDS_PAD"); pad = e ? atoi(e) : 0; }
+        lds += pad;
+    }
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N>;
