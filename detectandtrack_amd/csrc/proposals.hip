@@ -41,7 +41,7 @@ struct LevelDev {
     const float* anchors;
     int H, W, A, T;
     float feat_stride;
-    int cstride, logit_off, delta_off, frame, apply_sigmoid;
+    int cstride, logit_off, delta_off, frame, apply_sigmoid, per_frame;
     int N;                       // H*W*A
     // workspace pointers
     unsigned* keys;
@@ -79,7 +79,12 @@ __global__ void rpn_keys_hist_kernel(const RpnParams p) {
     const LevelDev& L = p.lv[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.N; i += gridDim.x * blockDim.x) {
         const int pos = i / L.A, a = i - pos * L.A;
-        const float logit = head_ld(L.head, p.dtype, ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.logit_off + a);
+        float logit = head_ld(L.head, p.dtype, ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.logit_off + a);
+        if (L.per_frame) {   // tube RPN: objectness logits averaged over the T frames (TimePool 'avg', model_builder.py:532)
+            for (int t = 1; t < L.T; ++t)
+                logit += head_ld(L.head, p.dtype, ((size_t)(L.frame + t) * L.H * L.W + pos) * L.cstride + L.logit_off + a);
+            logit = logit / (float)L.T;
+        }
         const float prob = L.apply_sigmoid ? 1.f / (1.f + expf(-logit)) : logit;   // model_builder.py:583 Sigmoid
         const unsigned key = __float_as_uint(prob);       // prob >= 0: bit pattern is monotonic
         L.keys[i] = key;
@@ -173,7 +178,11 @@ __device__ bool decode_tube(const RpnParams& p, const LevelDev& L, unsigned idx,
     for (int t = 0; t < L.T; ++t) {
         const float* an = L.anchors + (size_t)a * 4 * L.T + 4 * t;
         const float ax1 = an[0] + sx, ay1 = an[1] + sy, ax2 = an[2] + sx, ay2 = an[3] + sy;
-        const size_t dbase = ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.delta_off + ((size_t)a * L.T + t) * 4;
+        // deltas of frame t: channel (a, t, xywh) of one position (2D heads / reference layout, model_builder.py:552-563)
+        // or, when the head tensor keeps its T frames (per_frame), channel (a, xywh) of frame `frame + t`
+        const size_t dbase = L.per_frame
+            ? ((size_t)(L.frame + t) * L.H * L.W + pos) * L.cstride + L.delta_off + (size_t)a * 4
+            : ((size_t)L.frame * L.H * L.W + pos) * L.cstride + L.delta_off + ((size_t)a * L.T + t) * 4;
         const float dx = head_ld(L.head, p.dtype, dbase + 0), dy = head_ld(L.head, p.dtype, dbase + 1);
         float dw = head_ld(L.head, p.dtype, dbase + 2), dh = head_ld(L.head, p.dtype, dbase + 3);
         const float width = ax2 - ax1 + 1.0f, height = ay2 - ay1 + 1.0f;
@@ -591,6 +600,7 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
         L.cstride = levels[l].cstride; L.logit_off = levels[l].logit_off; L.delta_off = levels[l].delta_off;
         L.frame = levels[l].frame;
         L.apply_sigmoid = levels[l].apply_sigmoid;
+        L.per_frame = levels[l].per_frame;
         L.N = L.H * L.W * L.A;
         maxN = L.N > maxN ? L.N : maxN;
         L.keys = (unsigned*)(ws + per_level_off[l][0]);

@@ -35,7 +35,7 @@ class RoiLevel(C.Structure):
 class RpnLevel(C.Structure):
     _fields_ = [('H', C.c_int), ('W', C.c_int), ('A', C.c_int), ('T', C.c_int), ('feat_stride', C.c_float),
                 ('cstride', C.c_int), ('logit_off', C.c_int), ('delta_off', C.c_int), ('frame', C.c_int),
-                ('apply_sigmoid', C.c_int)]
+                ('apply_sigmoid', C.c_int), ('per_frame', C.c_int)]
 
 
 if not os.path.exists(LIB_PATH):

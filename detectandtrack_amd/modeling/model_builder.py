@@ -172,8 +172,9 @@ def add_rpn_outputs(model, blob_in, dim_in, spatial_scale, nd=False, time_dim=1)
                           weight_init=g, bias_init=z)
         model.TimeMean(lg, 'rpn_cls_logits')                       # TimePool 'avg' (:532)
         # deltas: 4A channels per frame; GenerateProposals reads them as (anchor, frame, xywh) (:545-563)
-        model.ConvNd('conv_rpn', 'rpn_bbox_pred', dim_in, 4 * A, [1, 1, 1], pads=2 * [0, 0, 0], strides=[1, 1, 1],
-                     weight_init=g, bias_init=z)
+        d = model.ConvNd('conv_rpn', 'rpn_bbox_pred_1', dim_in, 4 * A, [1, 1, 1], pads=2 * [0, 0, 0],
+                         strides=[1, 1, 1], weight_init=g, bias_init=z)
+        model.net.add(_op('RpnDeltasPerFrame', [d], ['rpn_bbox_pred']))
     else:
         model.Conv(blob_in, 'conv_rpn', dim_in, dim_in, 3, pad=1, stride=1, weight_init=g, bias_init=z)
         model.Relu('conv_rpn', 'conv_rpn')

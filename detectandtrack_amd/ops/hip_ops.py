@@ -232,12 +232,13 @@ def softmax_rows(x, k):
 
 class RpnLevelSpec(object):
     def __init__(self, head, H, W, A, T, feat_stride, cstride, logit_off, delta_off, frame, anchors,
-                 apply_sigmoid=True):
+                 apply_sigmoid=True, per_frame=False):
         self.head, self.H, self.W, self.A, self.T = head, H, W, A, T
         self.feat_stride, self.cstride = feat_stride, cstride
         self.logit_off, self.delta_off, self.frame = logit_off, delta_off, frame
         self.anchors = anchors  # fp32 CUDA [A, 4T]
         self.apply_sigmoid = apply_sigmoid
+        self.per_frame = per_frame
 
 
 def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_size, batch_idx=0.):
@@ -253,6 +254,7 @@ def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_siz
         lv[i].feat_stride = l.feat_stride
         lv[i].cstride, lv[i].logit_off, lv[i].delta_off, lv[i].frame = l.cstride, l.logit_off, l.delta_off, l.frame
         lv[i].apply_sigmoid = int(l.apply_sigmoid)
+        lv[i].per_frame = int(l.per_frame)
     info = (C.c_float * 3)(*[float(v) for v in im_info])
     rois = torch.zeros((nl, post_nms, 4 * T + 1), dtype=torch.float32, device=dev)
     probs = torch.zeros((nl, post_nms), dtype=torch.float32, device=dev)

@@ -148,7 +148,7 @@ class Executor(object):
 
     # ---- RPN head sibling fusion: logits + deltas 1x1 convs on the same input run as ONE conv ------------------------
     def _plan_rpn_siblings(self):
-        self._skip, self._fused = set(), {}
+        self._skip, self._fused, self._per_frame = set(), {}, set()
         ops_ = self.net.ops
         prod = {}
         for i, op in enumerate(ops_):
@@ -164,12 +164,26 @@ class Executor(object):
             li, di = prod.get(ops_[si].inputs[0]), prod.get(deltas)
             if li is None or di is None:
                 continue
+            ti = ri = None
+            if ops_[li].type == 'TimeMean':   # tube RPN: logits averaged over T inside the proposal kernel
+                ti, li = li, prod.get(ops_[li].inputs[0])
+                if li is None:
+                    continue
+            if ops_[di].type == 'RpnDeltasPerFrame':   # (a, xywh) x T frames read in place as (a, t, xywh)
+                if ti is None:
+                    continue
+                ri, di = di, prod.get(ops_[di].inputs[0])
+                if di is None:
+                    continue
             lo, do = ops_[li], ops_[di]
             if lo.type == 'Conv' and do.type == 'Conv' and lo.inputs[0] == do.inputs[0] and \
                     lo.args['kernels'] == [1, 1, 1] == do.args['kernels'] and lo.args['residual'] is None and \
                     do.args['residual'] is None:
                 first = min(li, di)
                 self._skip.update({li, di, si})
+                if ti is not None:
+                    self._skip.update({ti, ri})
+                    self._per_frame.add(gi)
                 self._skip.discard(first)
                 self._fused[first] = (lo, do, gi)
 
@@ -205,7 +219,9 @@ class Executor(object):
         res = ws.blobs[a['residual']].t if a['residual'] else None
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
         y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'])
-        ws.blobs[op.outputs[0]] = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
+        b = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
+        b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
+        ws.blobs[op.outputs[0]] = b
 
     def _stem(self, i, op, xin):
         ws, a, dt = self.ws, op.args, _dt()
@@ -269,6 +285,41 @@ class Executor(object):
     def op_TimeToBatch(self, i, op):
         self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
 
+    def op_SpatialMean(self, i, op):
+        # [R*T,H,W,Cs] -> [R*T,1,1,Cs]; stays a feature map so the 1x1x1 output convs run on it (ResNet3D.py:318-325)
+        x = self.ws.blobs[op.inputs[0]]
+        f, cs = x.t.shape[0], x.t.shape[3]
+        m = ops.spatial_mean(x.t, x.dt, cs)                       # fp32 [R*T, Cs]
+        y = m if x.dt == ops.F32 else m.to(ops.tdtype(x.dt))
+        b = Blob(y.view(f, 1, 1, cs), 'fmap', x.N, x.T, x.C, x.dt, x.five_d)
+        b.count = x.count
+        self.ws.blobs[op.outputs[0]] = b
+
+    def _head_rows(self, x):
+        """[R*T,1,1,Cs] head output -> fp32 [R, T, C]."""
+        f, h, w, cs = x.t.shape
+        assert h == 1 and w == 1, 'tube head outputs are 1x1 spatial (model_builder.py:427-473)'
+        return x.t.view(x.N, x.T, cs)[:, :, :x.C].float()
+
+    def op_TimeMean(self, i, op):
+        # class scores of the T frames averaged (ReduceBackMean over T, model_builder.py:436-441)
+        x = self.ws.blobs[op.inputs[0]]
+        m = self._head_rows(x)
+        y = ops.time_avg(m.contiguous().view(x.N * x.T, 1, 1, x.C), ops.F32, x.N, x.T).view(1, 1, x.N, x.C)
+        b = Blob(y, 'rows', 1, 1, x.C, ops.F32)
+        b.count = x.count
+        self.ws.blobs[op.outputs[0]] = b
+
+    def op_TubeDeltasToRows(self, i, op):
+        # R,(K,4),T,1,1 -> R,(K,T,4) (model_builder.py:446-473: ExpandDims/Reshape/Transpose/ReduceBackMean x2)
+        x = self.ws.blobs[op.inputs[0]]
+        m = self._head_rows(x)                                    # [R, T, K*4]
+        R, T, K4 = m.shape
+        y = m.view(R, T, K4 // 4, 4).permute(0, 2, 1, 3).reshape(R, K4 * T).contiguous()
+        b = Blob(y, 'mat')
+        b.count = x.count
+        self.ws.blobs[op.outputs[0]] = b
+
     def op_Alias(self, i, op):
         self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
 
@@ -287,7 +338,11 @@ class Executor(object):
         f, h, w, cs = head.t.shape
         key = ('anchors', i)
         an = self._layer(key, lambda: ops.torch.from_numpy(anchors.astype(np.float32)).to(ws.device))
-        spec = ops.RpnLevelSpec(head.t, h, w, A, T, 1. / op.args['spatial_scale'], cs, 0, A, 0, an, apply_sigmoid=True)
+        per_frame = i in self._per_frame
+        assert per_frame == (head.T > 1) and (not per_frame or head.T == T), \
+            'tube RPN head with %d frames for %d-frame anchors' % (head.T, T)
+        spec = ops.RpnLevelSpec(head.t, h, w, A, T, 1. / op.args['spatial_scale'], cs, 0, A, 0, an, apply_sigmoid=True,
+                                per_frame=per_frame)
         self.pending_rpn.append((spec, op))
         if not self.has_collect:
             self._run_rpn(single=True)

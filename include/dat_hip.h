@@ -143,6 +143,9 @@ typedef struct {
     int logit_off, delta_off;/* channel offsets: logits [A], deltas [A*T*4] (anchor, frame, xywh) */
     int frame;               /* which frame of the head tensor holds this image's map */
     int apply_sigmoid;       /* 1: head holds raw logits (model_builder.py:583 Sigmoid fused here); 0: probabilities */
+    int per_frame;           /* tube RPN on a head tensor that keeps its T frames: logits = mean over frames frame..frame+T-1
+                                (TimePool avg, model_builder.py:532), deltas of tube slot t read from frame+t at channel
+                                delta_off + a*4 (model_builder.py:545-563 regroups exactly this into (a, t, xywh)) */
 } dat_rpn_level;
 
 /* head: conv output [frames,H,W,cstride] (fp32 or bf16) holding RAW logits (sigmoid applied here,
