@@ -31,7 +31,7 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-def model_cfg(arch, T, dtype):
+def model_cfg(arch, T, dtype, keyframe_dce=False):
     return {
         'MODEL': {'TYPE': 'keypoint_rcnn', 'CONV_BODY': 'FPN3D.add_fpn_ResNet%s_conv5_body' % arch,
                   'ROI_HEAD': 'head_builder.add_roi_2mlp_head', 'NUM_CLASSES': 2, 'FASTER_RCNN': True,
@@ -46,7 +46,7 @@ def model_cfg(arch, T, dtype):
                   'WEIGHTS_INFLATE_MODE': 'center-only'},
         'TEST': {'RPN_PRE_NMS_TOP_N': 1000, 'RPN_POST_NMS_TOP_N': 1000, 'COMPETITION_MODE': False, 'NMS': 0.5,
                  'SCALES': (800,), 'MAX_SIZE': 1333},
-        'HIP': {'DTYPE': dtype},
+        'HIP': {'DTYPE': dtype, 'KEYFRAME_DCE': bool(keyframe_dce)},
     }
 
 
@@ -60,13 +60,13 @@ def synthetic_clip(T, H, W, seed):
     return (data - means).contiguous()
 
 
-def build(arch, T, dtype):
+def build(arch, T, dtype, keyframe_dce=False):
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
     from detectandtrack_amd.utils import net as net_utils
     from detectandtrack_amd import workspace
     reset_cfg()
-    cfg_from_cfg(model_cfg(arch, T, dtype))
+    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce))
     assert_and_infer_cfg()
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     workspace.ResetWorkspace()
@@ -194,6 +194,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
     ap.add_argument('--pipeline', type=int, default=2, help='clips in flight per GPU (1 = strictly sequential)')
+    ap.add_argument('--keyframe-dce', action='store_true',
+                    help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '
+                         '(identical detections; NOT the default, the default materialises every frame like the reference)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -208,7 +211,7 @@ def main():
         dist.init_process_group('nccl')
 
     from detectandtrack_amd.ops import hip_ops as ops
-    model, ws = build(a.arch, a.frames, a.dtype)
+    model, ws = build(a.arch, a.frames, a.dtype, a.keyframe_dce)
     T, H, W = a.frames, a.height, a.width
     # every rank gets its own clips (weak scaling): seed by rank
     clips = [synthetic_clip(T, H, W, 1000 * rank + i).cuda() for i in range(2)]
@@ -309,6 +312,7 @@ def main():
                                '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score)'
                                % (a.arch, T, H, W, n_det),
                    'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
+                   'clips_in_flight': a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
                    'parallelism': 'clip-sharded x%d (no data-path collective)' % a.gpus},
         'roofline': roofline,
     }

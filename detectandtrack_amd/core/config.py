@@ -234,7 +234,10 @@ def _build_defaults():
     c.PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])     # config.py:677 (BGR)
     c.ROOT_DIR = os.getcwd()
     # extension (not in the reference): arithmetic mode of the HIP path, 'bf16' (performance) | 'fp32' (parity)
-    c.HIP = AttrDict({'DTYPE': 'bf16'})
+    # KEYFRAME_DCE (opt-in): with BODY_HEAD_LINK 'slice-center' the heads read only the centre frame of every FPN
+    # output; True computes just that frame of convs whose output is consumed solely by SliceKeyFrame (identical
+    # rois / scores / heatmaps, the unread frames of fpn_res*_sum are never materialised)
+    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False})
     return c
 
 

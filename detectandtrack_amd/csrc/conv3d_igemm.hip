@@ -42,7 +42,8 @@ struct ConvParams {
     const float* bias;
     const char* res;
     char* y;
-    int frames, T, H, W, Cin;
+    int frames, T, H, W, Cin;   // frames = OUTPUT frames (clips * otn)
+    int ot0, otn;               // output frames per clip: t in [ot0, ot0 + otn)
     int Ho, Wo, Cout, out_cs, Cout_pad;
     int KT, KH, KW, sh, sw, pt, ph, pw;
     int relu, res_mode;
@@ -123,8 +124,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     const int tw_i = tile % p.tiles_w;
     tile /= p.tiles_w;
     const int th_i = tile % p.tiles_h;
-    const int f = tile / p.tiles_h;          // output frame (n*T + t)
-    const int t = f % p.T;
+    const int f = tile / p.tiles_h;          // output frame (n*otn + t - ot0)
+    const int clip = f / p.otn;
+    const int t = p.ot0 + (f - clip * p.otn);
+    const int f_in = clip * p.T + t;         // input frame aligned with this output frame
     const int n0 = nb * BN;
     const int TW = 1 << p.tw_log2;
     const int oh0 = th_i << p.th_log2;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0)) {
                 __syncthreads();  // all waves finished reading the previous patch
                 // ---- stage the input patch (tile + halo) of (kt, cc, plane) ----
-                const int fin = f + kt - p.pt;
+                const int fin = f_in + kt - p.pt;
                 const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
                 const int py0 = ih0 + p.tab_dy[ti], px0 = iw0 + p.tab_dx[ti];
 #pragma unroll 1
@@ -602,7 +605,8 @@ size_t dat_conv3d_packed_weight_bytes(const dat_conv_desc* d) {
 double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
     int Ho, Wo;
     dat_conv3d_out_shape(d, &Ho, &Wo);
-    return 2.0 * Cout_real * Cin_real * d->KT * d->KH * d->KW * (double)d->frames * Ho * Wo;
+    const double oframes = d->out_tn > 0 && d->T > 0 ? (double)(d->frames / d->T) * d->out_tn : (double)d->frames;
+    return 2.0 * Cout_real * Cin_real * d->KT * d->KH * d->KW * oframes * Ho * Wo;
 }
 
 int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w, int Cout_real,
@@ -638,7 +642,11 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     memset(&p, 0, sizeof(p));
     p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
     p.res = (const char*)residual; p.y = (char*)y;
-    p.frames = d->frames; p.T = d->T; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    p.ot0 = d->out_tn > 0 ? d->out_t0 : 0;
+    p.otn = d->out_tn > 0 ? d->out_tn : d->T;
+    DAT_ENFORCE(ctx, p.ot0 >= 0 && p.ot0 + p.otn <= d->T, "conv3d_fwd: output frames [%d, %d) outside T %d", p.ot0,
+                p.ot0 + p.otn, d->T);
+    p.frames = d->frames / d->T * p.otn; p.T = d->T; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
     dat_conv3d_out_shape(d, &p.Ho, &p.Wo);
     DAT_ENFORCE(ctx, p.Ho > 0 && p.Wo > 0, "conv3d_fwd: empty output %dx%d", p.Ho, p.Wo);
     DAT_ENFORCE(ctx, d->res_mode != 2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0), "conv3d_fwd: res_mode 2 needs even output dims");
@@ -673,7 +681,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
             if (force_bp && cand_bp != force_bp && !(force_bp == 256 && (small_n || ntaps == 1))) continue;
             const int lg = cand_bp == 256 ? 8 : 7;
             const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW);
-            const long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * d->frames;
+            const long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * p.frames;
             const int ks_max = (ntaps > 1 || deep_1x1) ? (deep_1x1 ? 8 : 4) : 1;
             for (int ks = 1; ks <= ks_max && ks <= npatch_min; ++ks) {
                 if (force_ks && ks != std::min(force_ks, npatch_min)) continue;
@@ -685,7 +693,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
                 const double step_us = cand_bp == 256 ? 2.15 : 1.35;
                 const double fixed_us = 2.0 + 0.6 * ceil((double)npatch / ks);      // epilogue + exposed patch loads
                 double t = rounds * (steps * step_us + fixed_us);
-                if (ks > 1) t += 4.0 + 2.0 * ks * (double)d->frames * p.Ho * p.Wo * d->Cout * 4.0 / 3.0e6;  // us @3 TB/s
+                if (ks > 1) t += 4.0 + 2.0 * ks * (double)p.frames * p.Ho * p.Wo * d->Cout * 4.0 / 3.0e6;  // us @3 TB/s
                 if (t < best) { best = t; bp = cand_bp; ksplit = ks; }
             }
         }
@@ -712,7 +720,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     }
     if (e1) {
         hipEventRecord(e1, st);
-        ctx->prof_flops[ctx->prof_n] = 2.0 * d->Cout * d->Cin * d->KT * d->KH * d->KW * (double)d->frames * p.Ho * p.Wo;
+        ctx->prof_flops[ctx->prof_n] = 2.0 * d->Cout * d->Cin * d->KT * d->KH * d->KW * (double)p.frames * p.Ho * p.Wo;
         ctx->prof_tag[ctx->prof_n] = tag;
         ctx->prof_n++;
     }

@@ -128,7 +128,7 @@ class ConvLayer(object):
         ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(w), self.cout_real, self.cin_real,
                    _ptr(self.packed))
 
-    def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None):
+    def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None, out_t=None):
         d = L.ConvDesc()
         d.dtype = self.dtype
         d.frames, d.T, d.H, d.W, d.Cin = frames, T, H, W, self.cin
@@ -139,6 +139,7 @@ class ConvLayer(object):
         d.pad_t, d.pad_h, d.pad_w = self.pads
         d.relu = int(self.relu if relu is None else relu)
         d.res_mode = res_mode
+        d.out_t0, d.out_tn = out_t if out_t is not None else (0, 0)
         return d
 
     def out_hw(self, H, W):
@@ -149,17 +150,19 @@ class ConvLayer(object):
         ho, wo = self.out_hw(H, W)
         return 2.0 * self.cout_real * self.cin_real * self.kt * self.kh * self.kw * frames * ho * wo
 
-    def __call__(self, x, T=1, residual=None, res_mode=None, out=None):
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None):
+        """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored."""
         frames, H, W, cin = x.shape
         assert cin == self.cin, 'channel stride %d != layer Cin %d' % (cin, self.cin)
         assert x.dtype == tdtype(self.dtype) and x.is_contiguous()
         if res_mode is None:
             res_mode = 1 if residual is not None else 0
-        d = self.desc(frames, T, H, W, res_mode)
+        d = self.desc(frames, T, H, W, res_mode, out_t=out_t)
         ho, wo = self.out_hw(H, W)
+        oframes = frames if out_t is None else frames // T * out_t[1]
         if out is None:
             alloc = torch.zeros if self.cstride != self.cout else torch.empty
-            out = alloc((frames, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
+            out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
         ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
                    _ptr(self.bias), _ptr(residual), _ptr(out))
         return out

@@ -21,7 +21,7 @@ logger = logging.getLogger(__name__)
 class Blob(object):
     """A device blob.  kind: 'fmap' [N*T,H,W,Cs] | 'rows' [1,1,R,Cs] (FC activations) | 'mat' fp32 tensor |
     'rois' fp32 [cap, cols] + device count."""
-    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host')
+    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe')
 
     def __init__(self, t, kind, N=1, T=1, C=0, dt=0, five_d=False, count=None):
         self.t, self.kind, self.N, self.T, self.C, self.dt = t, kind, N, T, C, dt
@@ -29,6 +29,7 @@ class Blob(object):
         self.count = count
         self.sigmoid_of = None
         self.host = None
+        self.keyframe = None    # set when only this frame of a T-frame blob was computed (cfg.HIP.KEYFRAME_DCE)
 
 
 class Workspace(object):
@@ -141,6 +142,7 @@ class Executor(object):
 
     def run(self):
         self._plan_rpn_siblings()
+        self._plan_keyframe_dce()
         for i, op in enumerate(self.net.ops):
             if i in self._skip:
                 continue
@@ -187,6 +189,45 @@ class Executor(object):
                 self._skip.discard(first)
                 self._fused[first] = (lo, do, gi)
 
+    # ---- opt-in dead-frame elimination (cfg.HIP.KEYFRAME_DCE) -------------------------------------------------------
+    def _plan_keyframe_dce(self):
+        """self._keyframe[blob] = k when every reader of `blob` (in any net of this workspace) is a SliceKeyFrame at
+        frame k, directly or through frame-wise ops (MaxPool with time kernel 1, FPN3D.py:155-164)."""
+        self._keyframe = {}
+        if not cfg.HIP.KEYFRAME_DCE:
+            return
+        readers = {}
+        for net in self.ws.nets.values():
+            for op in net.ops:
+                for b in op.inputs:
+                    readers.setdefault(b, []).append(op)
+                res = op.args.get('residual') if isinstance(op.args, dict) else None
+                if res:
+                    readers.setdefault(res, []).append(op)
+
+        def need(blob, depth=0):
+            ks = set()
+            rs = readers.get(blob, [])
+            if not rs or depth > 4:
+                return None
+            for op in rs:
+                if op.type == 'SliceKeyFrame':
+                    ks.add(op.args['keyframe'])
+                elif op.type == 'MaxPool' and op.inputs[0] == blob:
+                    k = need(op.outputs[0], depth + 1)
+                    if k is None:
+                        return None
+                    ks.add(k)
+                else:
+                    return None
+            return ks.pop() if len(ks) == 1 else None
+
+        for op in self.net.ops:
+            if op.type in ('Conv', 'MaxPool'):
+                k = need(op.outputs[0])
+                if k is not None:
+                    self._keyframe[op.outputs[0]] = k
+
     # ---- helpers ---------------------------------------------------------------------------------------------------------
     def _layer(self, key, build):
         k = (self.net.name, key)
@@ -217,9 +258,20 @@ class Executor(object):
                                  cin_stride=xin.t.shape[3])
         layer = self._layer(i, build)
         res = ws.blobs[a['residual']].t if a['residual'] else None
+        k = self._keyframe.get(op.outputs[0])
+        if k is not None and xin.T > 1 and xin.keyframe is None and res is None:
+            if ws.conv_log is not None:
+                ws.conv_log.append((op.outputs[0], layer.flops(xin.N, xin.t.shape[1], xin.t.shape[2])))
+            y = layer(xin.t, T=xin.T, out_t=(k, 1))
+            b = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
+            b.keyframe = k
+            ws.blobs[op.outputs[0]] = b
+            return
+        assert xin.keyframe is None or a['kernels'][0] == 1, 'temporal conv on a key-frame-only blob'
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
         y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'])
         b = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
+        b.keyframe = xin.keyframe
         b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
         ws.blobs[op.outputs[0]] = b
 
@@ -268,11 +320,17 @@ class Executor(object):
     def op_MaxPool(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
         y = ops.maxpool_hw(x.t, x.dt, op.args['k'], op.args['stride'], op.args['pad'])
-        self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, x.T, x.C, x.dt, x.five_d)
+        b = Blob(y, 'fmap', x.N, x.T, x.C, x.dt, x.five_d)
+        b.keyframe = x.keyframe
+        self.ws.blobs[op.outputs[0]] = b
 
     def op_SliceKeyFrame(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
         k = op.args['keyframe']
+        if x.keyframe is not None:   # producer already computed only this frame (cfg.HIP.KEYFRAME_DCE)
+            assert x.keyframe == k
+            self.ws.blobs[op.outputs[0]] = Blob(x.t, 'fmap', x.N, 1, x.C, x.dt, False)
+            return
         f, h, w, c = x.t.shape
         y = x.t.view(x.N, x.T, h, w, c)[:, k].contiguous() if x.N > 1 else x.t[k:k + 1]
         self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, 1, x.C, x.dt, False)

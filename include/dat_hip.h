@@ -80,6 +80,10 @@ typedef struct {
     int pad_t, pad_h, pad_w; /* symmetric explicit pads, Caffe2 `pads=2*[..]` */
     int relu;                /* fused Relu */
     int res_mode;            /* 0 none | 1 residual same shape | 2 residual at (h/2, w/2) (nearest 2x) */
+    int out_t0, out_tn;      /* out_tn > 0: write only output frames t in [out_t0, out_t0+out_tn) of every clip, stored
+                                compactly as [N*out_tn, Ho, Wo, C] (the frames a following SliceKeyFrame keeps,
+                                FPN3D.py:170-183 'slice-center'); out_tn == 0: all T frames.  residual (if any) is
+                                indexed like the output */
 } dat_conv_desc;
 
 int dat_conv3d_out_shape(const dat_conv_desc* d, int* Ho, int* Wo);

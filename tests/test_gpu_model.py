@@ -159,3 +159,32 @@ def test_c4_tube_forward_matches_oracle():
     err = np.abs(kps - ref).max()
     print('tube kps_score max-abs %.3e (ref max %.2f)' % (err, np.abs(ref).max()))
     assert err < 1e-3
+
+
+def test_keyframe_dce_gives_identical_head_inputs():
+    """cfg.HIP.KEYFRAME_DCE (opt-in): computing only the centre frame of the FPN outputs that 'slice-center' keeps
+    must not change anything the heads read."""
+    T, H, W = 4, 96, 128
+    outs = []
+    for dce in (False, True):
+        c = fpn3d_kps_cfg('18', T=T, dtype='fp32')
+        c['HIP']['KEYFRAME_DCE'] = dce
+        model, ws, _ = build_product(c)
+        ws.FeedBlob('data', synthetic_clip(T, H, W))
+        ws.FeedBlob('im_info', np.array([[H, W, 1.0]], dtype=np.float32))
+        ws.RunNet(model.net.name)
+        rois = ws.FetchBlob('rois')
+        ws.FeedBlob('keypoint_rois', rois[:6].copy())
+        ws.RunNet(model.keypoint_net.name)
+        sliced = sorted(b for b in ws.Blobs() if b.endswith('_slicekey'))
+        assert len(sliced) == 5
+        outs.append((rois, ws.FetchBlob('cls_prob'), ws.FetchBlob('kps_score'), [ws.FetchBlob(b) for b in sliced],
+                     ws.FetchBlob('fpn_res2_1_sum').shape))
+    a, b = outs
+    assert len(a[4]) == 5 and a[4][2] == T      # faithful mode keeps all T frames of P2
+    assert len(b[4]) == 4                        # DCE mode: only the centre frame exists
+    for x, y in zip(a[3], b[3]):
+        np.testing.assert_allclose(x, y, atol=1e-5)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-3)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-5)
+    np.testing.assert_allclose(a[2], b[2], atol=1e-5)
