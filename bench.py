@@ -50,6 +50,24 @@ def model_cfg(arch, T, dtype, keyframe_dce=False):
     }
 
 
+def pmc_traffic(a, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools/prof_round.sh + tools/pmc_summary.py on this exact workload); None when the run's workload or
+    dominant kernel differs from the profiled one.  bench.py cannot read PMC counters itself."""
+    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    w = rec.get('workload', {})
+    same = (w.get('arch') == a.arch and w.get('frames') == a.frames and w.get('height') == a.height and
+            w.get('width') == a.width and w.get('dtype') == a.dtype and bool(w.get('keyframe_dce')) == bool(a.keyframe_dce))
+    k = rec.get('kernels', {}).get(kernel_name)
+    if not same or k is None:
+        return None
+    return k['hbm_bytes_per_launch']
+
+
 def synthetic_clip(T, H, W, seed):
     """Seeded uint8-like BGR frames minus PIXEL_MEANS, NC(T)HW fp32."""
     g = torch.Generator().manual_seed(seed)
@@ -273,30 +291,33 @@ def main():
     assert len(records) == len(conv_log), (len(records), len(conv_log))
     # dominant kernel = the conv3d_igemm instantiation with the largest total time in the timed region
     by_tag = {}
-    for (tag, _, ms), (_, fl) in zip(records, conv_log):
-        t = by_tag.setdefault(tag, [0.0, 0.0, 0])
+    for (tag, _, ms), (_, fl, nbytes) in zip(records, conv_log):
+        t = by_tag.setdefault(tag, [0.0, 0.0, 0, 0.0])
         t[0] += fl
         t[1] += ms
         t[2] += 1
+        t[3] += nbytes
     dom_tag = max(by_tag, key=lambda k: by_tag[k][1])
-    dom_fl, dom_ms, dom_n = by_tag[dom_tag]
+    dom_fl, dom_ms, dom_n, dom_bytes = by_tag[dom_tag]
     if a.dump_convs:
         agg = {}
-        for (tag, _, ms), (name, fl) in zip(records, conv_log):
+        for (tag, _, ms), (name, fl, _b) in zip(records, conv_log):
             e = agg.setdefault(name, [0.0, 0.0, tag])
             e[0] += fl
             e[1] += ms
         for name, (fl, ms, tag) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s' % (name, tag, ms / prof_steps, fl / ms / 1e9 if ms > 0 else 0),
                   file=sys.stderr)
-    all_fl = sum(fl for _, fl in conv_log)
+    all_fl = sum(c[1] for c in conv_log)
     all_ms = sum(ms for _, _, ms in records)
     peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    kernel_name = 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10)
     roofline = {
-        'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10),
+        'bound': 'mfma', 'kernel': kernel_name,
         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': None,
+        'traffic': pmc_traffic(a, kernel_name),
+        'algorithmic_bytes_per_launch': round(dom_bytes / max(dom_n, 1)),
         'launches_per_step': dom_n // max(prof_steps, 1),
         'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
         'algorithmic_tflop_per_step': round(dom_fl / max(prof_steps, 1) / 1e12, 4),

@@ -121,12 +121,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     bid /= p.ksplit;
     const int nb = bid % p.nblk_n;
     unsigned tile = bid / p.nblk_n;
+    // frame index fastest: the blocks that share an input frame through the temporal taps (outputs t-1, t, t+1 of one
+    // spatial tile) are neighbours in the XCD's queue, so the re-reads hit that XCD's L2 instead of HBM / MALL
+    const int fc = tile % p.otn;
+    tile /= p.otn;
     const int tw_i = tile % p.tiles_w;
     tile /= p.tiles_w;
     const int th_i = tile % p.tiles_h;
-    const int f = tile / p.tiles_h;          // output frame (n*otn + t - ot0)
-    const int clip = f / p.otn;
-    const int t = p.ot0 + (f - clip * p.otn);
+    const int clip = tile / p.tiles_h;
+    const int f = clip * p.otn + fc;         // output frame (n*otn + t - ot0)
+    const int t = p.ot0 + fc;
     const int f_in = clip * p.T + t;         // input frame aligned with this output frame
     const int n0 = nb * BN;
     const int TW = 1 << p.tw_log2;
@@ -168,36 +172,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     const size_t w_tap_stride = (size_t)p.Cout_pad * p.Cin * ES;  // bytes between taps
     const int npatch_items = p.PH * p.PW * 8;
 
-    // weight tile prefetch registers (macros, not lambdas: a by-reference lambda capture of the register array
-    // made hipcc keep it in scratch memory, which serialised every step behind its global loads)
+    // ---- weight tile: global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers, no ds_write pass ----
+    // One wave-instruction lands 64 x 16 B = 8 tile rows, lane-linear (dest = uniform base + lane*16).  The XOR swizzle
+    // the fragment reads use is therefore applied on the SOURCE side: lane (row, phys slot) fetches the row's logical
+    // slot phys ^ ((row >> 1) & 7) -- the same involution as swz() (cdna_hip_programming.md rule 21).
+    // Item i of this thread: row (tid >> 3) + 32*i, phys slot tid & 7; (row >> 1) & 7 == (tid >> 4) & 7 for every i.
     static_assert(W_ITEMS == 2 || W_ITEMS == 4, "weight tile = 2 or 4 16-byte items per thread");
-    uint4 w0, w1, w2 = make_uint4(0, 0, 0, 0), w3 = make_uint4(0, 0, 0, 0);  // named registers, never an array (scratch!)
-    // item i of this thread: row (tid + i*256) >> 3 = (tid >> 3) + 32*i, slot tid & 7
-    const unsigned w_thr_off = (unsigned)(tid >> 3) * (unsigned)(p.Cin * ES) + (tid & 7) * 16;   // lane part (32-bit)
+    const unsigned w_thr_off = (unsigned)(tid >> 3) * (unsigned)(p.Cin * ES) + (unsigned)(((tid & 7) ^ ((tid >> 4) & 7)) * 16);
     const unsigned w_item_stride = 32u * (unsigned)(p.Cin * ES);
     const size_t w_blk_off = (size_t)n0 * p.Cin * ES;                                             // uniform part
-    const int w_lds0 = swz(tid >> 3, tid & 7), w_lds1 = swz((tid >> 3) + 32, tid & 7);
-    const int w_lds2 = swz((tid >> 3) + 64, tid & 7), w_lds3 = swz((tid >> 3) + 96, tid & 7);
-#define W_PREFETCH(KT_, CC_, TAP_)                                                                              \
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define W_DMA(SRC_, DST_) __builtin_amdgcn_global_load_lds((gptr_t)(SRC_), (lptr_t)(DST_), 16, 0, 0)
+#define W_PREFETCH(KT_, CC_, TAP_, BUF_)                                                                        \
     {                                                                                                           \
         const char* wbase_ = p.w + ((size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_blk_off); \
-        w0 = *(const uint4*)(wbase_ + w_thr_off);                                                               \
-        w1 = *(const uint4*)(wbase_ + (w_thr_off + w_item_stride));                                             \
+        char* wdst_ = wbuf + (BUF_) * BN * ROWB + wave * (8 * ROWB);                                            \
+        W_DMA(wbase_ + w_thr_off, wdst_);                                                                       \
+        W_DMA(wbase_ + (w_thr_off + w_item_stride), wdst_ + 32 * ROWB);                                         \
         if (W_ITEMS == 4) {                                                                                     \
-            w2 = *(const uint4*)(wbase_ + (w_thr_off + 2 * w_item_stride));                                     \
-            w3 = *(const uint4*)(wbase_ + (w_thr_off + 3 * w_item_stride));                                     \
+            W_DMA(wbase_ + (w_thr_off + 2 * w_item_stride), wdst_ + 64 * ROWB);                                 \
+            W_DMA(wbase_ + (w_thr_off + 3 * w_item_stride), wdst_ + 96 * ROWB);                                 \
         }                                                                                                       \
     }
-#define W_COMMIT(BUF_)                                                                                          \
-    {                                                                                                           \
-        char* wdst_ = wbuf + (BUF_) * BN * ROWB;                                                                \
-        *(uint4*)(wdst_ + w_lds0) = w0;                                                                         \
-        *(uint4*)(wdst_ + w_lds1) = w1;                                                                         \
-        if (W_ITEMS == 4) {                                                                                     \
-            *(uint4*)(wdst_ + w_lds2) = w2;                                                                     \
-            *(uint4*)(wdst_ + w_lds3) = w3;                                                                     \
-        }                                                                                                       \
-    }
+    // the tile of this step was requested one step ago: retire this wave's DMAs; the barrier that follows publishes
+    // every wave's part (a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier)
+#define W_COMMIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
     // per-lane LDS byte offsets of the weight fragments (lane-constant): row -> 4 k-slices, XOR-swizzled
     int a_off[MT][4];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     constexpr int NPI = 4;   // patch items (16 B) per thread per batch of loads (each extra item costs ~12 VGPRs at the register peak)
     if (total > 0) {
         int kt = kt_lo + pi_lo / p.n_cchunks, cc = pi_lo % p.n_cchunks, ti = 0;
-        W_PREFETCH(kt, cc, p.tab_tap[0]);
+        W_PREFETCH(kt, cc, p.tab_tap[0], 0);
         for (int step = 0; step < total; ++step) {
             if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0)) {
                 __syncthreads();  // all waves finished reading the previous patch
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                     }
                 }
             }
-            if (!((p.ablate & 2) && step > 1)) W_COMMIT(step & 1);
+            W_COMMIT();
             __syncthreads();
             // advance to the next (kt, cc, table entry) and prefetch its weight tile (lands during this step's MFMAs)
             const int tapoff = p.tab_rowoff[ti] * PPITCH;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 nti = 0;
                 if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
             }
-            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti]);
+            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti], (step + 1) & 1);
 
             // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
             const char* wb = wbuf + (step & 1) * BN * ROWB;
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     }
 #undef W_PREFETCH
 #undef W_COMMIT
+#undef W_DMA
 
     // ---- epilogue: affine/bias + residual + relu, channel-contiguous stores ----
     // D[i = channel][j = position]: lane holds position lane&31; register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5).

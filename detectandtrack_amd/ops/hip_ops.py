@@ -150,6 +150,20 @@ class ConvLayer(object):
         ho, wo = self.out_hw(H, W)
         return 2.0 * self.cout_real * self.cin_real * self.kt * self.kh * self.kw * frames * ho * wo
 
+    def hbm_bytes(self, frames, H, W, oframes=None, res_mode=0):
+        """Algorithmic HBM bytes of one launch: input + packed weights + output (+ residual), each touched once."""
+        es = 2 if self.dtype == BF16 else 4
+        ho, wo = self.out_hw(H, W)
+        in_frames = frames if oframes is None else min(frames, oframes * self.kt)   # key-frame outputs read kt frames
+        oframes = frames if oframes is None else oframes
+        b = in_frames * H * W * self.cin * es + self.kt * self.kh * self.kw * self.cout * self.cin * es
+        b += oframes * ho * wo * self.cstride * es
+        if res_mode == 1:
+            b += oframes * ho * wo * self.cstride * es
+        elif res_mode == 2:
+            b += oframes * (ho // 2) * (wo // 2) * self.cstride * es
+        return float(b)
+
     def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None):
         """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored."""
         frames, H, W, cin = x.shape

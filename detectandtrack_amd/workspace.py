@@ -235,9 +235,11 @@ class Executor(object):
             self.ws._layers[k] = build()
         return self.ws._layers[k]
 
-    def _log_conv(self, name, layer, frames, H, W):
+    def _log_conv(self, name, layer, frames, H, W, oframes=None, res_mode=0):
+        """(name, algorithmic flops, algorithmic HBM bytes) of one conv launch, for bench.py's roofline leg."""
         if self.ws.conv_log is not None:
-            self.ws.conv_log.append((name, layer.flops(frames, H, W)))
+            of = frames if oframes is None else oframes
+            self.ws.conv_log.append((name, layer.flops(of, H, W), layer.hbm_bytes(frames, H, W, oframes, res_mode)))
 
     # ---- ops ---------------------------------------------------------------------------------------------------------------
     def op_Conv(self, i, op):
@@ -260,15 +262,15 @@ class Executor(object):
         res = ws.blobs[a['residual']].t if a['residual'] else None
         k = self._keyframe.get(op.outputs[0])
         if k is not None and xin.T > 1 and xin.keyframe is None and res is None:
-            if ws.conv_log is not None:
-                ws.conv_log.append((op.outputs[0], layer.flops(xin.N, xin.t.shape[1], xin.t.shape[2])))
+            self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
             y = layer(xin.t, T=xin.T, out_t=(k, 1))
             b = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
             b.keyframe = k
             ws.blobs[op.outputs[0]] = b
             return
         assert xin.keyframe is None or a['kernels'][0] == 1, 'temporal conv on a key-frame-only blob'
-        self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
+        self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
+                       res_mode=(a['res_mode'] or 1) if res is not None else 0)
         y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'])
         b = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
         b.keyframe = xin.keyframe
@@ -295,7 +297,8 @@ class Executor(object):
         packed = ops.stem_pack(data.float(), dt)
         if ws.conv_log is not None:
             ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_out'] * 3 * 49 * n * t * ho * wo))
+            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_out'] * 3 * 49 * n * t * ho * wo,
+                                layer.hbm_bytes(packed.shape[0], packed.shape[1], packed.shape[2])))
         y = layer(packed, T=t)
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
 
@@ -500,7 +503,8 @@ class Executor(object):
                                  cin_stride=x.t.shape[3])
         layer = self._layer(i, build)
         if ws.conv_log is not None:   # algorithmic flops of the deconv itself: 16 taps / 4 outputs per input position
-            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] * 16 * x.t.shape[0] * x.t.shape[1] * x.t.shape[2]))
+            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] * 16 * x.t.shape[0] * x.t.shape[1] * x.t.shape[2],
+                                layer.hbm_bytes(x.t.shape[0], x.t.shape[1], x.t.shape[2])))
         y = layer(x.t, T=1)
         b = Blob(y, 'fmap', x.N, x.T, 4 * a['dim_out'], dt, x.five_d)
         ws.blobs[op.outputs[0]] = b

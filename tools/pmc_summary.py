@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Summarise the rocprofv3 passes of tools/prof_round.sh into the files kept under profiles/.
+
+  python tools/pmc_summary.py gpurun_out/r01c profiles/r01c
+
+Reads  <in>/stats/r1_kernel_stats.csv, <in>/pmc_fetch/r1_counter_collection.csv, <in>/pmc_write/...
+Writes <out>/kernel_stats.csv (copy), <out>/pmc_hbm.csv (per kernel: launches, FETCH_SIZE, WRITE_SIZE, corrected bytes)
+and profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
+
+Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3's FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so reads are doubled.  WRITE_SIZE is
+uncalibrated and taken as reported.
+"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+
+def per_kernel(path):
+    agg = collections.OrderedDict()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            e = agg.setdefault(r['Kernel_Name'], [0, 0.0])
+            e[0] += 1
+            e[1] += float(r['Counter_Value'])
+    return agg
+
+
+def short(name):
+    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
+    if m:
+        return 'conv3d_igemm_kernel<%s,%s,%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3))
+    m = re.search(r'([A-Za-z_0-9]+)(<[^(]*>)?\(', name)
+    return m.group(1) if m else name
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
+    fetch = per_kernel(os.path.join(src, 'pmc_fetch', 'r1_counter_collection.csv'))
+    write = per_kernel(os.path.join(src, 'pmc_write', 'r1_counter_collection.csv'))
+    kernels = {}
+    rows = []
+    for name, (n, fk) in sorted(fetch.items(), key=lambda kv: -kv[1][1]):
+        wn, wk = write.get(name, (0, 0.0))
+        rd = 2.0 * fk * 1024.0 / n
+        wr = wk * 1024.0 / wn if wn else 0.0
+        rows.append((short(name), n, fk / n, wk / wn if wn else 0.0, rd, wr, rd + wr))
+        kernels[short(name)] = {'launches_profiled': n, 'fetch_kib_per_launch_raw': round(fk / n, 2),
+                                'write_kib_per_launch_raw': round(wk / wn, 2) if wn else None,
+                                'hbm_bytes_per_launch': round(rd + wr)}
+    with open(os.path.join(dst, 'pmc_hbm.csv'), 'w') as f:
+        f.write('kernel,launches,FETCH_SIZE_KiB_per_launch,WRITE_SIZE_KiB_per_launch,read_bytes_corrected_x2,'
+                'write_bytes,hbm_bytes_per_launch\n')
+        for r in rows:
+            f.write('%s,%d,%.2f,%.2f,%.0f,%.0f,%.0f\n' % r)
+    with open(os.path.join(src, 'bench.json')) as f:
+        bench = json.loads(f.read().strip().splitlines()[-1])
+    wl = bench['config']['workload']
+    m = re.search(r'R-(\d+) .* 1x3x(\d+)x(\d+)x(\d+)', wl)
+    rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python bench.py '
+                     '--steps 3 --warmup 1 --pipeline 1; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
+           'workload': {'arch': m.group(1), 'frames': int(m.group(2)), 'height': int(m.group(3)),
+                        'width': int(m.group(4)), 'dtype': bench['dtype'],
+                        'keyframe_dce': bench['config'].get('keyframe_dce', False)},
+           'kernels': kernels}
+    with open(os.path.join(os.path.dirname(dst.rstrip('/')), 'pmc_traffic.json'), 'w') as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    for r in rows[:8]:
+        print('%-40s n=%4d read %8.1f MB write %8.1f MB' % (r[0], r[1], r[4] / 1e6, r[5] / 1e6))
+
+
+if __name__ == '__main__':
+    main()
