@@ -33,6 +33,11 @@ int dat_ctx_create(dat_ctx** out, int device) {
     c->prof_tag = nullptr;
     c->ws = nullptr;
     c->ws_bytes = 0;
+    c->zeros = nullptr;
+    if (hipMalloc(&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+        delete c;
+        return DAT_ERR_ALLOC;
+    }
     *out = c;
     return DAT_OK;
 }
@@ -46,6 +51,7 @@ void dat_ctx_destroy(dat_ctx* ctx) {
         delete[] ctx->prof_tag;
     }
     if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->zeros) hipFree(ctx->zeros);
     delete ctx;
 }
 

@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int ROWB = 128;   // bytes per weight LDS row (one 128-B line of channels), XOR-swizzled
-constexpr int PPITCH = 144; // patch row pitch: 128 B + 16 B pad -> consecutive rows rotate through all 16 slots, linear addressing
+constexpr int PPITCH = 128; // patch row pitch: one 128-B line per pixel, lane-linear LDS-DMA image, XOR-swizzled like the weights
 constexpr int NTHREADS = 256;
 
 struct ConvParams {
@@ -42,6 +42,8 @@ struct ConvParams {
     const float* bias;
     const char* res;
     char* y;
+    unsigned long long* dbg;    // DAT_CONV_TRACE builds only: per-phase cycle sums
+    const char* zeros;          // >= 16 zero bytes (what a halo lane of the patch LDS-DMA fetches)
     int frames, T, H, W, Cin;   // frames = OUTPUT frames (clips * otn)
     int ot0, otn;               // output frames per clip: t in [ot0, ot0 + otn)
     int Ho, Wo, Cout, out_cs, Cout_pad;
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     constexpr int W_ITEMS = BN * 8 / NTHREADS;  // 16-B items of the weight tile per thread
     static_assert(MT >= 1 && PT >= 1 && W_ITEMS >= 1, "tile too small");
 
+#ifdef DAT_CONV_TRACE
+    const unsigned long long tr_k0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tr_k1 = tr_k0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wbuf = smem;                       // 2 x BN x 128 B
     char* patch = smem + 2 * BN * ROWB;      // PH*PW x 128 B
@@ -205,48 +211,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a_off[i][ks] = swz(wave_n * WN + i * 32 + (lane & 31), ks * 2 + khalf);
-    // patch rows are padded (PPITCH) and NOT swizzled: a fragment address is base(row) + ks*32 as an immediate
-    int b_base[PT];
-#pragma unroll
-    for (int j = 0; j < PT; ++j) b_base[j] = rowbase[j] * PPITCH + khalf * 16;
-
-    constexpr int NPI = 4;   // patch items (16 B) per thread per batch of loads (each extra item costs ~12 VGPRs at the register peak)
     if (total > 0) {
         int kt = kt_lo + pi_lo / p.n_cchunks, cc = pi_lo % p.n_cchunks, ti = 0;
         W_PREFETCH(kt, cc, p.tab_tap[0], 0);
+        const int nchunks = (npatch_items + 63) >> 6;    // 1-KiB LDS-DMA pieces (8 patch rows each)
+#ifdef DAT_CONV_TRACE
+        unsigned long long tr_reload = 0, tr_wait = 0, tr_bar = 0, tr_issue = 0, tr_mma = 0, tr_t;
+#define TR_NOW() __builtin_readcyclecounter()
+#define TR_ADD(ACC_) { const unsigned long long n_ = TR_NOW(); ACC_ += n_ - tr_t; tr_t = n_; }
+        tr_t = TR_NOW();
+        const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+#else
+#define TR_ADD(ACC_)
+#endif
         for (int step = 0; step < total; ++step) {
-            if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0)) {
+            if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0) && !(p.ablate & 8)) {
                 __syncthreads();  // all waves finished reading the previous patch
-                // ---- stage the input patch (tile + halo) of (kt, cc, plane) ----
+                // ---- stage the input patch (tile + halo) of (kt, cc, plane): global -> LDS by LDS-DMA, every piece of
+                // the patch in flight at once (no staging registers, no ds_write pass).  Lane (row, phys slot) fetches the
+                // pixel's logical 16-B slot phys ^ ((row >> 1) & 7); halo pixels outside the frame fetch zeros.
                 const int fin = f_in + kt - p.pt;
                 const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
                 const int py0 = ih0 + p.tab_dy[ti], px0 = iw0 + p.tab_dx[ti];
-#pragma unroll 1
-                for (int it0 = tid; it0 < npatch_items; it0 += NTHREADS * NPI) {
-                    uint4 v[NPI];
-#pragma unroll
-                    for (int u = 0; u < NPI; ++u) {
-                        const int it = it0 + u * NTHREADS;
-                        const int row = it >> 3, slot = it & 7;
-                        v[u] = make_uint4(0, 0, 0, 0);
-                        if (it < npatch_items) {
-                            const int prow = (int)__umulhi((unsigned)row, p.pw_magic), pcol = row - prow * p.PW;
-                            const int ih = py0 + prow * p.psh, iw = px0 + pcol * p.psw;
-                            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                                v[u] = *(const uint4*)(xbase + ((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16)));
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NPI; ++u) {
-                        const int it = it0 + u * NTHREADS;
-                        if (it < npatch_items) *(uint4*)(patch + (it >> 3) * PPITCH + (it & 7) * 16) = v[u];
+#pragma unroll 2
+                for (int c = wave; c < nchunks; c += 4) {
+                    const int it = c * 64 + lane;
+                    if (it < npatch_items) {
+                        const int row = it >> 3;
+                        const int slot = (it ^ (row >> 1)) & 7;
+                        const int prow = (int)__umulhi((unsigned)row, p.pw_magic), pcol = row - prow * p.PW;
+                        const int ih = py0 + prow * p.psh, iw = px0 + pcol * p.psw;
+                        const char* src = p.zeros;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                            src = xbase + ((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16));
+                        W_DMA(src, patch + c * 1024);
                     }
                 }
             }
+            TR_ADD(tr_reload);
             W_COMMIT();
+            TR_ADD(tr_wait);
             __syncthreads();
+            TR_ADD(tr_bar);
             // advance to the next (kt, cc, table entry) and prefetch its weight tile (lands during this step's MFMAs)
-            const int tapoff = p.tab_rowoff[ti] * PPITCH;
+            const int tapoff = p.tab_rowoff[ti];
             int nti = ti + 1, ncc = cc, nkt = kt;
             if (nti == ntab) {
                 nti = 0;
@@ -254,16 +262,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             }
             if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti], (step + 1) & 1);
 
+            TR_ADD(tr_issue);
             // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
             const char* wb = wbuf + (step & 1) * BN * ROWB;
+            // patch fragment of (row, k-slice ks, k-half): 16-B slot (2*ks + khalf) ^ ((row >> 1) & 7) of the row's line
             const char* bp[PT];
+            int bx[PT];
 #pragma unroll
-            for (int j = 0; j < PT; ++j) bp[j] = patch + (b_base[j] + tapoff);
+            for (int j = 0; j < PT; ++j) {
+                const int row = rowbase[j] + tapoff;
+                const int g = (row >> 1) & 7;
+                bp[j] = patch + (row * PPITCH + ((khalf ^ (g & 1)) << 4));
+                bx[j] = g >> 1;
+            }
             uint4 a[2][MT], b[2][PT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
 #pragma unroll
-            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j]);
+            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j] + (bx[j] << 5));
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
                     for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
 #pragma unroll
-                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (ks + 1) * 32);
+                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (((ks + 1) ^ bx[j]) << 5));
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -279,69 +295,128 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                     for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
             }
             ti = nti; cc = ncc; kt = nkt;
+            TR_ADD(tr_mma);
         }
+#ifdef DAT_CONV_TRACE
+        if (tid == 0 && p.dbg) {
+            atomicAdd(&p.dbg[0], tr_reload); atomicAdd(&p.dbg[1], tr_wait); atomicAdd(&p.dbg[2], tr_bar);
+            atomicAdd(&p.dbg[3], tr_issue); atomicAdd(&p.dbg[4], tr_mma); atomicAdd(&p.dbg[5], (unsigned long long)total);
+            atomicAdd(&p.dbg[6], __builtin_amdgcn_s_memtime() - tr_c0);
+            atomicAdd(&p.dbg[7], __builtin_amdgcn_s_memrealtime() - tr_r0);
+        }
+        tr_k1 = __builtin_amdgcn_s_memtime();
+#endif
     }
 #undef W_PREFETCH
 #undef W_COMMIT
 #undef W_DMA
 
-    // ---- epilogue: affine/bias + residual + relu, channel-contiguous stores ----
-    // D[i = channel][j = position]: lane holds position lane&31; register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // ---- epilogue: affine/bias + residual + relu, staged through LDS so that HBM sees whole 128-B+ runs ----
+    // The MFMA result layout gives a lane 4 channels of ONE position (register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5)),
+    // i.e. 8-byte pieces 512+ bytes apart: written directly, every store instruction touched 32-64 different lines and a
+    // 256x128 tile took ~47k cycles (1x1 convs spent 80 % of their time here).  Each wave now transposes 32 positions x
+    // WN channels at a time through its own LDS slice (fp32, pitch WN*4+16 B: conflict-free b128 writes) and reads it
+    // back position-major, 16 B of output per lane, so one store instruction covers 4-8 complete position rows.
+    static_assert(WN == 64, "epilogue staging assumes 64 channels per wave");
+    constexpr int EPITCH = WN * 4 + 16;
+    constexpr int CPL = 16 / ES;                 // channels per lane in the store phase (8 bf16 / 4 fp32)
+    constexpr int LPP = WN / CPL;                // lanes per position (8 / 16)
+    constexpr int PPI = 64 / LPP;                // positions per store instruction (8 / 4)
+    __syncthreads();                             // every wave is done with the weight / patch buffers
+    char* est = smem + wave * (32 * EPITCH);
+    const int sl_c = (lane % LPP) * CPL;         // this lane's first channel inside the wave's 64
+    const int sl_p = lane / LPP;
+    const int cbase = n0 + wave_n * WN;
+    const int c_st = cbase + sl_c;
+    const bool part_mode = p.ksplit > 1;
+    float sc[CPL], bi[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        const bool ok = (c_st + e) < p.Cout;
+        sc[e] = (!part_mode && p.scale && ok) ? p.scale[c_st + e] : 1.f;
+        bi[e] = (!part_mode && p.bias && ok) ? p.bias[c_st + e] : 0.f;
+    }
+    const size_t npos_all = (size_t)p.frames * p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-        const int pos = wave_p * WP + j * 32 + (lane & 31);
-        const int oh = oh0 + (pos >> p.tw_log2), ow = ow0 + (pos & (TW - 1));
-        if (oh >= p.Ho || ow >= p.Wo) continue;
-        const size_t opos = ((size_t)f * p.Ho + oh) * p.Wo + ow;
-        size_t rpos = opos;
-        if (p.res_mode == 2) rpos = ((size_t)f * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1);
+        // phase 1: accumulators -> LDS [position][channel] fp32
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = n0 + wave_n * WN + i * 32 + g * 8 + khalf * 4;
-                if (c >= p.Cout) continue;
-                float v[4];
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(est + (lane & 31) * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                    make_float4(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: position-major read back, fused epilogue, 16-byte stores
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-                if (p.ksplit > 1) {   // raw fp32 partial sums; splitk_finish_kernel applies the epilogue
-                    const size_t npos = (size_t)p.frames * p.Ho * p.Wo;
-                    *(float4*)(p.part + ((size_t)split * npos + opos) * p.Cout + c) = make_float4(v[0], v[1], v[2], v[3]);
-                    continue;
-                }
-                if (p.scale) {
-                    const float4 s = *(const float4*)(p.scale + c);
-                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-                }
-                if (p.bias) {
-                    const float4 b = *(const float4*)(p.bias + c);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (p.res_mode) {
-                    if (DT == DAT_BF16) {
-                        const uint2 r = *(const uint2*)(p.res + (rpos * p.out_cs + c) * 2);
-                        v[0] += bf2f((uint16_t)(r.x & 0xffff)); v[1] += bf2f((uint16_t)(r.x >> 16));
-                        v[2] += bf2f((uint16_t)(r.y & 0xffff)); v[3] += bf2f((uint16_t)(r.y >> 16));
-                    } else {
-                        const float4 r = *(const float4*)(p.res + (rpos * p.out_cs + c) * 4);
-                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                    }
-                }
-                if (p.relu) {
+        for (int q = 0; q < 32 / PPI; ++q) {
+            const int pl = q * PPI + sl_p;                       // position inside this 32-position group
+            float v[CPL];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+            for (int e4 = 0; e4 < CPL / 4; ++e4) {
+                const float4 t = *(const float4*)(est + pl * EPITCH + (sl_c + e4 * 4) * 4);
+                v[e4 * 4 + 0] = t.x; v[e4 * 4 + 1] = t.y; v[e4 * 4 + 2] = t.z; v[e4 * 4 + 3] = t.w;
+            }
+            const int pos = wave_p * WP + j * 32 + pl;
+            const int oh = oh0 + (pos >> p.tw_log2), ow = ow0 + (pos & (TW - 1));
+            if (oh >= p.Ho || ow >= p.Wo || c_st >= p.Cout || (p.ablate & 4)) continue;
+            const size_t opos = ((size_t)f * p.Ho + oh) * p.Wo + ow;
+            const int nch = min(CPL, p.Cout - c_st);             // multiple of 4
+            if (part_mode) {   // raw fp32 partial sums; splitk_finish_kernel applies the epilogue
+                float* dst = p.part + ((size_t)split * npos_all + opos) * p.Cout + c_st;
+#pragma unroll
+                for (int e4 = 0; e4 < CPL / 4; ++e4)
+                    if (e4 * 4 < nch) *(float4*)(dst + e4 * 4) = make_float4(v[e4 * 4], v[e4 * 4 + 1], v[e4 * 4 + 2], v[e4 * 4 + 3]);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + bi[e];
+            if (p.res_mode) {
+                size_t rpos = opos;
+                if (p.res_mode == 2) rpos = ((size_t)f * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1);
+                const char* rp = p.res + (rpos * p.out_cs + c_st) * ES;
                 if (DT == DAT_BF16) {
-                    uint2 o;
-                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                    *(uint2*)(p.y + (opos * p.out_cs + c) * 2) = o;
+#pragma unroll
+                    for (int e4 = 0; e4 < CPL / 4; ++e4)
+                        if (e4 * 4 < nch) {
+                            const uint2 r = *(const uint2*)(rp + e4 * 8);
+                            v[e4 * 4 + 0] += bf2f((uint16_t)(r.x & 0xffff)); v[e4 * 4 + 1] += bf2f((uint16_t)(r.x >> 16));
+                            v[e4 * 4 + 2] += bf2f((uint16_t)(r.y & 0xffff)); v[e4 * 4 + 3] += bf2f((uint16_t)(r.y >> 16));
+                        }
                 } else {
-                    *(float4*)(p.y + (opos * p.out_cs + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    const float4 r = *(const float4*)rp;
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
             }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            char* yp = p.y + (opos * p.out_cs + c_st) * ES;
+            if (DT == DAT_BF16) {
+                uint32_t o[CPL / 2];
+#pragma unroll
+                for (int e2 = 0; e2 < CPL / 2; ++e2) o[e2] = (uint32_t)f2bf(v[2 * e2]) | ((uint32_t)f2bf(v[2 * e2 + 1]) << 16);
+                if (nch == CPL && (p.out_cs & 7) == 0) {
+                    *(uint4*)yp = make_uint4(o[0], o[1], o[2], o[3]);
+                } else {
+                    *(uint2*)yp = make_uint2(o[0], o[1]);
+                    if (nch > 4) *(uint2*)(yp + 8) = make_uint2(o[2], o[3]);
+                }
+            } else {
+                *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
+#ifdef DAT_CONV_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && p.dbg) {
+        const unsigned long long e = __builtin_amdgcn_s_memtime();
+        atomicAdd(&p.dbg[8], e - tr_k0);
+        atomicAdd(&p.dbg[9], e - tr_k1);
+    }
+#endif
 }
 
 // split-K finish: y = act(sum_s part[s] * scale + bias + residual), 4 channels per thread
@@ -557,7 +632,8 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     }
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
     p.nblocks = (unsigned)nblocks;
-    size_t lds = (size_t)2 * BN * ROWB + (size_t)p.PH * p.PW * PPITCH;
+    size_t lds = (size_t)2 * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
+    if (lds < 4 * 32 * (64 * 4 + 16)) lds = 4 * 32 * (64 * 4 + 16);                                   // epilogue staging slices
     {
         static int pad = -1;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
         if (pad < 0) { const char* e = getenv("DAT_CONV_LDS_PAD"); pad = e ? atoi(e) : 0; }
@@ -571,7 +647,23 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+#ifdef DAT_CONV_TRACE
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) hipMalloc(&dbg, 128);
+    hipMemsetAsync(dbg, 0, 128, st);
+    p.dbg = dbg;
+#endif
     hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NTHREADS), lds, st, p);
+#ifdef DAT_CONV_TRACE
+    {
+        unsigned long long h[16];
+        hipStreamSynchronize(st);
+        hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
+        if (h[5]) fprintf(stderr, "TRACE BN=%d BP=%d blocks=%u steps/blk=%.1f | per step: reload %.0f wait %.0f barrier %.0f issue %.0f mma %.0f | shader clock %.0f MHz | per block: total %.0f epilogue %.0f cycles\n",
+                          BN, BP, p.nblocks, (double)h[5] / p.nblocks, (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5],
+                          (double)h[3] / h[5], (double)h[4] / h[5], 100.0 * (double)h[6] / (double)h[7], (double)h[8] / p.nblocks, (double)h[9] / p.nblocks);
+    }
+#endif
     if (p.ksplit > 1) {
         const size_t npos = (size_t)p.frames * p.Ho * p.Wo;
         const size_t tot = npos * (p.Cout >> 2);
@@ -643,6 +735,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     memset(&p, 0, sizeof(p));
     p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
     p.res = (const char*)residual; p.y = (char*)y;
+    p.zeros = (const char*)ctx->zeros;
     p.ot0 = d->out_tn > 0 ? d->out_t0 : 0;
     p.otn = d->out_tn > 0 ? d->out_tn : d->T;
     DAT_ENFORCE(ctx, p.ot0 >= 0 && p.ot0 + p.otn <= d->T, "conv3d_fwd: output frames [%d, %d) outside T %d", p.ot0,

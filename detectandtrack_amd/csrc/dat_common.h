@@ -21,6 +21,7 @@ struct dat_ctx {
     // scratch owned by the ctx, grown on demand (proposal path)
     void* ws;
     size_t ws_bytes;
+    void* zeros;           // 256 zero bytes in HBM (conv patch loader: source of out-of-frame halo lanes)
 };
 
 #define DAT_FAIL(ctx, code, ...)                                  \
