@@ -318,6 +318,11 @@ def main():
         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
         'traffic': pmc_traffic(a, kernel_name),
         'algorithmic_bytes_per_launch': round(dom_bytes / max(dom_n, 1)),
+        # the part runs its MFMA kernels far below the 2.4 GHz the 2.5 PFLOP/s peak assumes: clock measured inside the
+        # conv kernel (s_memtime / s_memrealtime) over the profiled launches, and the dense peak rescaled to it
+        'shader_clock_mhz': round(getattr(prof, 'shader_mhz', 0.0), 1),
+        'peak_at_measured_clock': round(peak * getattr(prof, 'shader_mhz', 0.0) / 2400.0, 1),
+        'frac_at_measured_clock': round(achieved / (peak * prof.shader_mhz / 2400.0), 4) if getattr(prof, 'shader_mhz', 0.0) > 0 else None,
         'launches_per_step': dom_n // max(prof_steps, 1),
         'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
         'algorithmic_tflop_per_step': round(dom_fl / max(prof_steps, 1) / 1e12, 4),

@@ -34,7 +34,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
     c->ws = nullptr;
     c->ws_bytes = 0;
     c->zeros = nullptr;
-    if (hipMalloc(&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+    if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemset(c->zeros, 0, 512) != hipSuccess) {
         delete c;
         return DAT_ERR_ALLOC;
     }
@@ -78,6 +78,16 @@ int dat_prof_enable(dat_ctx* ctx, int capacity) {
     }
     ctx->prof_n = 0;
     ctx->prof_enabled = 1;
+    if (hipMemset((char*)ctx->zeros + 256, 0, 16) != hipSuccess) return DAT_ERR_LAUNCH;   // clock counters
+    return DAT_OK;
+}
+
+int dat_prof_clock(dat_ctx* ctx, double* shader_mhz) {
+    if (!ctx || !shader_mhz) return DAT_ERR_ARG;
+    unsigned long long h[2] = {0, 0};
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(h, (char*)ctx->zeros + 256, 16, hipMemcpyDeviceToHost) != hipSuccess) return DAT_ERR_LAUNCH;
+    *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;   // s_memrealtime ticks at 100 MHz
     return DAT_OK;
 }
 

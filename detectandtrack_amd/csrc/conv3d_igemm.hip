@@ -34,6 +34,9 @@ namespace {
 constexpr int ROWB = 128;   // bytes per weight LDS row (one 128-B line of channels), XOR-swizzled
 constexpr int PPITCH = 128; // patch row pitch: one 128-B line per pixel, lane-linear LDS-DMA image, XOR-swizzled like the weights
 constexpr int NTHREADS = 256;
+#ifndef DAT_KT_ROTATE
+#define DAT_KT_ROTATE 1
+#endif
 
 struct ConvParams {
     const char* x;
@@ -43,6 +46,7 @@ struct ConvParams {
     const char* res;
     char* y;
     unsigned long long* dbg;    // DAT_CONV_TRACE builds only: per-phase cycle sums
+    unsigned long long* clk;    // profiling only (dat_prof_enable): [0] += shader cycles, [1] += 100-MHz ticks per block
     const char* zeros;          // >= 16 zero bytes (what a halo lane of the patch LDS-DMA fetches)
     int frames, T, H, W, Cin;   // frames = OUTPUT frames (clips * otn)
     int ot0, otn;               // output frames per clip: t in [ot0, ot0 + otn)
@@ -106,6 +110,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     const unsigned long long tr_k0 = __builtin_amdgcn_s_memtime();
     unsigned long long tr_k1 = tr_k0;
 #endif
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wbuf = smem;                       // 2 x BN x 128 B
     char* patch = smem + 2 * BN * ROWB;      // PH*PW x 128 B
@@ -212,7 +218,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a_off[i][ks] = swz(wave_n * WN + i * 32 + (lane & 31), ks * 2 + khalf);
     if (total > 0) {
-        int kt = kt_lo + pi_lo / p.n_cchunks, cc = pi_lo % p.n_cchunks, ti = 0;
+        // temporal taps are visited in order of the INPUT frame index mod KT, not of kt: the blocks of output frames
+        // t-1, t, t+1 (queue neighbours on one XCD) then stage the same input frame during the same third of their
+        // lifetime, so the temporal re-reads hit that XCD's L2 instead of going back to the fabric
+        const int kt_hi_x = kt_lo + n_kt;      // one past the last valid kt
+        int kshift = 0;
+        if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
+        int kt = kt_lo + pi_lo / p.n_cchunks + kshift, cc = pi_lo % p.n_cchunks, ti = 0;
+        if (kt >= kt_hi_x) kt -= n_kt;
         W_PREFETCH(kt, cc, p.tab_tap[0], 0);
         const int nchunks = (npatch_items + 63) >> 6;    // 1-KiB LDS-DMA pieces (8 patch rows each)
 #ifdef DAT_CONV_TRACE
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             int nti = ti + 1, ncc = cc, nkt = kt;
             if (nti == ntab) {
                 nti = 0;
-                if (++ncc == p.n_cchunks) { ncc = 0; ++nkt; }
+                if (++ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
             }
             // (issuing the pieces between the k-slices' MFMAs instead measured 7 % slower: a DMA issue stalls the MFMA stream)
             if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti], (step + 1) & 1);
@@ -412,6 +425,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (p.clk && threadIdx.x == 0) {   // shader clock under this kernel's own load = 100 MHz * clk[0] / clk[1]
+        atomicAdd(&p.clk[0], __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(&p.clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
     }
 #ifdef DAT_CONV_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,6 +757,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
     p.res = (const char*)residual; p.y = (char*)y;
     p.zeros = (const char*)ctx->zeros;
+    p.clk = ctx->prof_enabled ? (unsigned long long*)((char*)ctx->zeros + 256) : nullptr;
     p.ot0 = d->out_tn > 0 ? d->out_t0 : 0;
     p.otn = d->out_tn > 0 ? d->out_tn : d->T;
     DAT_ENFORCE(ctx, p.ot0 >= 0 && p.ot0 + p.otn <= d->T, "conv3d_fwd: output frames [%d, %d) outside T %d", p.ot0,

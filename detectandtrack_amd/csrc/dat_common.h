@@ -21,7 +21,8 @@ struct dat_ctx {
     // scratch owned by the ctx, grown on demand (proposal path)
     void* ws;
     size_t ws_bytes;
-    void* zeros;           // 256 zero bytes in HBM (conv patch loader: source of out-of-frame halo lanes)
+    void* zeros;           // 512 B in HBM: [0,256) zeros (conv patch loader: source of out-of-frame halo lanes),
+                           // [256,272) profiling clock counters of the conv kernel
 };
 
 #define DAT_FAIL(ctx, code, ...)                                  \

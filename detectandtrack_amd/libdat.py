@@ -50,6 +50,7 @@ _PROTOS = {
     'dat_last_error': (C.c_char_p, [_p]),
     'dat_prof_enable': (_i, [_p, _i]),
     'dat_prof_read': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_f)]),
+    'dat_prof_clock': (_i, [_p, C.POINTER(_d)]),
     'dat_zero_even_fwd': (_i, [_p, _p, _p, _ll]),
     'dat_affine_channel_nd_fwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _ll]),
     'dat_affine_channel_nd_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _ll]),

@@ -342,5 +342,8 @@ class ConvProfiler(object):
         flops = (C.c_double * self.capacity)()
         ms = (C.c_float * self.capacity)()
         n = L.lib().dat_prof_read(ctx().h, self.capacity, tags, flops, ms)
+        mhz = C.c_double(0.0)
+        L.lib().dat_prof_clock(ctx().h, C.byref(mhz))
+        self.shader_mhz = mhz.value      # average shader clock of the conv kernel over the profiled launches
         L.lib().dat_prof_enable(ctx().h, 0)
         return [(tags[i], flops[i], ms[i]) for i in range(n)]

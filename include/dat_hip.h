@@ -45,6 +45,9 @@ const char* dat_last_error(dat_ctx* ctx);
  * n records {tag, flops, milliseconds}; tag = BN*10000 + BP*10 + dtype. */
 int dat_prof_enable(dat_ctx* ctx, int capacity);
 int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float* ms);
+/* Average shader clock (MHz) the conv kernel ran at since dat_prof_enable: every block adds its s_memtime (shader
+ * cycles) and s_memrealtime (100 MHz) deltas; MI355X drops well below its 2.4 GHz peak clock under MFMA load. */
+int dat_prof_clock(dat_ctx* ctx, double* shader_mhz);
 
 /* ---- toy op: ZeroEven  (lib/ops/zero_even_op.cu:25-56) --------------------------------- */
 int dat_zero_even_fwd(dat_ctx* ctx, dat_stream s, float* x, long long n);
