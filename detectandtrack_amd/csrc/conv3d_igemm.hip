@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 
     // ---- XCD-aware block -> (channel block, tile) map (bijective for any grid size) ----
     unsigned bid = blockIdx.x;
-    {
+    if (!(p.ablate & 16)) {
         const unsigned nx = 8, q = p.nblocks / nx, r = p.nblocks % nx;
         const unsigned xcd = bid % nx, k = bid / nx;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -196,6 +196,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 #define W_DMA(SRC_, DST_) __builtin_amdgcn_global_load_lds((gptr_t)(SRC_), (lptr_t)(DST_), 16, 0, 0)
+#ifndef DAT_PATCH_AUX
+#define DAT_PATCH_AUX 0
+#endif
+#define P_DMA(SRC_, DST_) __builtin_amdgcn_global_load_lds((gptr_t)(SRC_), (lptr_t)(DST_), 16, 0, DAT_PATCH_AUX)
 #define W_PREFETCH(KT_, CC_, TAP_, BUF_)                                                                        \
     {                                                                                                           \
         const char* wbase_ = p.w + ((size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_blk_off); \
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                         const char* src = p.zeros;
                         if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
                             src = xbase + ((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16));
-                        W_DMA(src, patch + c * 1024);
+                        P_DMA(src, patch + c * 1024);
                     }
                 }
             }
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #undef W_PREFETCH
 #undef W_COMMIT
 #undef W_DMA
+#undef P_DMA
 
     // ---- epilogue: affine/bias + residual + relu, staged through LDS so that HBM sees whole 128-B+ runs ----
     // The MFMA result layout gives a lane 4 channels of ONE position (register r -> channel (r&3) + 8*(r>>2) + 4*(lane>>5)),
