@@ -755,7 +755,10 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
                 "conv3d_fwd: Cout %d / out_cstride %d must be multiples of 4", d->Cout, d->out_cstride);
     DAT_ENFORCE(ctx, d->frames % d->T == 0, "conv3d_fwd: frames %d not a multiple of T %d", d->frames, d->T);
     DAT_ENFORCE(ctx, d->res_mode == 0 || residual, "conv3d_fwd: res_mode %d needs a residual pointer", d->res_mode);
-    DAT_ENFORCE(ctx, d->pad_t * 2 + 1 == d->KT, "conv3d_fwd: temporal pad %d must be (KT-1)/2 for KT %d (output T == input T)",
+    // full-length outputs need "same" temporal padding; an explicit output-frame window may use any pad_t (taps that
+    // fall outside [0, T) read zeros) -- e.g. KT == T, pad_t == 0, window {0}: a 1x1 conv over time-moved-to-channels
+    DAT_ENFORCE(ctx, d->pad_t * 2 + 1 == d->KT || d->out_tn > 0,
+                "conv3d_fwd: temporal pad %d must be (KT-1)/2 for KT %d unless out_t0/out_tn select the output frames",
                 d->pad_t, d->KT);
     ConvParams p;
     memset(&p, 0, sizeof(p));

@@ -121,29 +121,31 @@ def add_topdown_lateral_module(model, fpn_top, fpn_lateral, fpn_bottom, dim_top,
 
 
 def add_fpn_rpn_outputs(model, blobs_in, dim_in, spatial_scales, time_dim):
-    """DECLARED EXTENSION — tube RPN on the 3D pyramid (reference raises at :225-228; design after its dead code
-    :232-330 and the working C4 tube RPN model_builder.py:500-609): per level a kT x 3 x 3 conv + ReLU, 1x1x1
-    objectness (A channels, mean over T) and 1x1x1 deltas (4A per frame, regrouped anchor-major/time/xywh);
-    weights shared across levels from level k_min; tube anchors = 2D level anchors tiled T times."""
+    """DECLARED EXTENSION — tube RPN on the 3D pyramid.  The reference raises before its own
+    body (:235 'Redo bbox_targets like in model_builder.py'); the design below IS that dead body (:232-330): per level
+    a kT x 3 x 3 conv + ReLU, time moved into channels (channel index t*C + c), then 2D 1x1 heads over dim*T inputs:
+    objectness (A channels) and tube deltas (4*T*A channels, anchor-major / frame / xywh, what GenerateProposals
+    reads with tube anchors).  Heads share weights across levels from level k_min.  The reference's unused
+    'rpn_vis_cls_logits' head (:266-272, 'TODO need to use this in future') is not built."""
     A = len(cfg.FPN.RPN_ASPECT_RATIOS)
     k_max, k_min = cfg.FPN.RPN_MAX_LEVEL, cfg.FPN.RPN_MIN_LEVEL
     assert len(blobs_in) == k_max - k_min + 1
     kt = cfg.VIDEO.TIME_KERNEL_DIM.HEAD_RPN
     g, z = ('GaussianFill', {'std': 0.01}), ('ConstantFill', {'value': 0.})
+    smin = str(k_min)
     for lvl in range(k_min, k_max + 1):
         bl_in, sc, s = blobs_in[k_max - lvl], spatial_scales[k_max - lvl], str(lvl)
-        share = {} if lvl == k_min else None
-        def name(n):
-            return n + str(k_min)
-        kw = lambda n: ({} if lvl == k_min else dict(weight=name(n) + '_w', bias=name(n) + '_b'))
+
+        def shared(n):
+            return {} if lvl == k_min else dict(weight=n + smin + '_w', bias=n + smin + '_b')
         h = model.ConvNd(bl_in, 'conv_rpn_fpn' + s, dim_in, dim_in, [kt, 3, 3], pads=2 * [kt // 2, 1, 1],
-                         strides=[1, 1, 1], weight_init=g, bias_init=z, **kw('conv_rpn_fpn'))
+                         strides=[1, 1, 1], weight_init=g, bias_init=z, **shared('conv_rpn_fpn'))
         model.Relu(h, h)
-        lg = model.ConvNd(h, 'rpn_cls_logits_fpn' + s + '_1', dim_in, A, [1, 1, 1], pads=2 * [0, 0, 0],
-                          strides=[1, 1, 1], weight_init=g, bias_init=z, **kw('rpn_cls_logits_fpn'))
-        lg = model.TimeMean(lg, 'rpn_cls_logits_fpn' + s)
-        bp = model.ConvNd(h, 'rpn_bbox_pred_fpn' + s, dim_in, 4 * A, [1, 1, 1], pads=2 * [0, 0, 0],
-                          strides=[1, 1, 1], weight_init=g, bias_init=z, **kw('rpn_bbox_pred_fpn'))
+        h2 = model.MoveTimeToChannelDim(h, 'conv_rpn_timepooled_fpn' + s)
+        lg = model.Conv(h2, 'rpn_cls_logits_fpn' + s, dim_in * time_dim, A, 1, pad=0, stride=1, weight_init=g,
+                        bias_init=z, **shared('rpn_cls_logits_fpn'))
+        bp = model.Conv(h2, 'rpn_bbox_pred_fpn' + s, dim_in * time_dim, 4 * time_dim * A, 1, pad=0, stride=1,
+                        weight_init=g, bias_init=z, **shared('rpn_bbox_pred_fpn'))
         anchors = generate_anchors(stride=2. ** lvl, sizes=(cfg.FPN.RPN_ANCHOR_START_SIZE * 2. ** (lvl - k_min),),
                                    aspect_ratios=cfg.FPN.RPN_ASPECT_RATIOS, time_dim=time_dim)
         probs = model.net.Sigmoid(lg, 'rpn_cls_probs_fpn' + s)

@@ -117,7 +117,7 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
         spatial_scale_conv = spatial_scale_conv[-n_roi_levels:]
 
     blob_frcn, dim_frcn, _ = add_roi_frcn_head_func(model, blob_conv, dim_conv, spatial_scale_conv)
-    add_fast_rcnn_outputs(model, blob_frcn, dim_frcn, is_head_3d=head_3d)
+    add_fast_rcnn_outputs(model, blob_frcn, dim_frcn, is_head_3d=head_3d, time_dim=out_time_dim)
 
     if cfg.MODEL.MASK_ON:
         raise NotImplementedError('mask branch out of scope (core/test.py:916-917 raises for tubes)')
@@ -134,9 +134,17 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
 
 
 # ---- Fast R-CNN outputs (:426-478) ----------------------------------------------------------------------------------
-def add_fast_rcnn_outputs(model, blob_in, dim, is_head_3d):
+def add_fast_rcnn_outputs(model, blob_in, dim, is_head_3d, time_dim=1):
     g01, g001, z = ('GaussianFill', {'std': 0.01}), ('GaussianFill', {'std': 0.001}), ('ConstantFill', {'value': 0.})
-    if is_head_3d:
+    if is_head_3d and getattr(model, 'frcn_head_is_fc', False):
+        # DECLARED EXTENSION: tube rois on the FPN 2-MLP head (fc6 over T*C*res*res inputs,
+        # head_builder.py:29-33).  The reference would feed the 2-D fc7 into ConvNd here (:427-441), which Caffe2
+        # rejects; the outputs are FCs with the tube layout of the 3D branch: K scores, K*T*4 deltas
+        # (class-major / frame / xywh, :446-473).
+        model.FC(blob_in, 'cls_score', dim, model.num_classes, weight_init=g01, bias_init=z)
+        model.Softmax('cls_score', 'cls_prob', engine='CUDNN')
+        model.FC(blob_in, 'bbox_pred', dim, model.num_classes * 4 * time_dim, weight_init=g001, bias_init=z)
+    elif is_head_3d:
         # 1x1x1 convs on the R x C x T x 1 x 1 head output; class scores averaged over T, box deltas regrouped to
         # class-major / frame / xyxy (:427-473)
         c = model.ConvNd(blob_in, 'cls_score_1', dim, model.num_classes, [1, 1, 1], pads=2 * [0, 0, 0],

@@ -21,7 +21,7 @@ logger = logging.getLogger(__name__)
 class Blob(object):
     """A device blob.  kind: 'fmap' [N*T,H,W,Cs] | 'rows' [1,1,R,Cs] (FC activations) | 'mat' fp32 tensor |
     'rois' fp32 [cap, cols] + device count."""
-    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe')
+    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe', 't2c')
 
     def __init__(self, t, kind, N=1, T=1, C=0, dt=0, five_d=False, count=None):
         self.t, self.kind, self.N, self.T, self.C, self.dt = t, kind, N, T, C, dt
@@ -29,6 +29,7 @@ class Blob(object):
         self.count = count
         self.sigmoid_of = None
         self.host = None
+        self.t2c = False        # time moved into channels (detector.py:480-491): still stored as T frames of C channels
         self.keyframe = None    # set when only this frame of a T-frame blob was computed (cfg.HIP.KEYFRAME_DCE)
 
 
@@ -60,6 +61,8 @@ class Workspace(object):
         b = self.blobs[name]
         if b.kind == 'fmap':
             out = ops.to_ncdhw(b.t, b.dt, b.N, b.C, b.T).cpu().numpy()
+            if b.t2c:   # (N, C, T, H, W) -> (N, T*C, H, W), channel = t*C + c
+                return np.ascontiguousarray(out.transpose(0, 2, 1, 3, 4)).reshape(b.N, b.T * b.C, out.shape[3], out.shape[4])
             return out if b.five_d else out[:, :, 0]
         if b.kind == 'rows':
             r = b.t.shape[2]
@@ -251,6 +254,8 @@ class Executor(object):
         if op.inputs[0] == 'data':
             return self._stem(i, op, xin)
         assert xin.kind == 'fmap', (op, xin.kind)
+        if xin.t2c:
+            return self._conv_over_time_channels(i, op, xin)
 
         def build():
             w = ops.torch.from_numpy(_w5(ws.params[a['w']])).to(ws.device)
@@ -276,6 +281,23 @@ class Executor(object):
         b.keyframe = xin.keyframe
         b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
         ws.blobs[op.outputs[0]] = b
+
+    def _conv_over_time_channels(self, i, op, xin):
+        """1x1 conv on a blob whose T frames were moved into channels (index t*C + c): run as a KT = T conv with no
+        temporal padding that writes output frame 0 only -- the transposed copy never exists."""
+        ws, a, dt = self.ws, op.args, _dt()
+        assert a['kernels'] == [1, 1, 1] and a['strides'] == [1, 1] and a['residual'] is None, op
+        T, C = xin.T, xin.C
+
+        def build():
+            w = np.asarray(ws.params[a['w']], dtype=np.float32).reshape(a['dim_out'], T, C, 1, 1).transpose(0, 2, 1, 3, 4)
+            bias = ws.dev_param(a['b']) if a['b'] else None
+            return ops.ConvLayer(ops.torch.from_numpy(np.ascontiguousarray(w)).to(ws.device), None, bias, stride=(1, 1),
+                                 pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.t.shape[3])
+        layer = self._layer(i, build)
+        self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
+        y = layer(xin.t, T=T, out_t=(0, 1))
+        ws.blobs[op.outputs[0]] = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
 
     def _stem(self, i, op, xin):
         ws, a, dt = self.ws, op.args, _dt()
@@ -310,13 +332,21 @@ class Executor(object):
 
         def build():
             w = np.concatenate([_w5(ws.params[lo.args['w']]), _w5(ws.params[do.args['w']])], axis=0)
+            if xin.t2c:   # [O, T*C, 1, 1, 1] over time-moved-to-channels -> [O, C, T, 1, 1]
+                w = np.ascontiguousarray(w.reshape(w.shape[0], xin.T, xin.C, 1, 1).transpose(0, 2, 1, 3, 4))
             b = np.concatenate([ws.params[lo.args['b']], ws.params[do.args['b']]], axis=0)
             return ops.ConvLayer(ops.torch.from_numpy(w).to(ws.device), None, ops.torch.from_numpy(b).to(ws.device),
                                  stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt, cin_stride=xin.t.shape[3])
         layer = self._layer(('rpnhead', i), build)
-        self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
-        y = layer(xin.t, T=xin.T)
-        head = Blob(y, 'fmap', xin.N, xin.T, A + do.args['dim_out'], dt, xin.five_d)
+        if xin.t2c:
+            self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
+                           oframes=xin.N)
+            y = layer(xin.t, T=xin.T, out_t=(0, 1))
+            head = Blob(y, 'fmap', xin.N, 1, A + do.args['dim_out'], dt, False)
+        else:
+            self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
+            y = layer(xin.t, T=xin.T)
+            head = Blob(y, 'fmap', xin.N, xin.T, A + do.args['dim_out'], dt, xin.five_d)
         ws.blobs[lo.outputs[0] + '+' + do.outputs[0]] = head
         ws.blobs['_rpnhead_for_%d' % gi] = head
 
@@ -345,6 +375,12 @@ class Executor(object):
 
     def op_TimeToBatch(self, i, op):
         self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
+
+    def op_TimeToChannel(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        b = Blob(x.t, 'fmap', x.N, x.T, x.C, x.dt, False)
+        b.t2c = True
+        self.ws.blobs[op.outputs[0]] = b
 
     def op_SpatialMean(self, i, op):
         # [R*T,H,W,Cs] -> [R*T,1,1,Cs]; stays a feature map so the 1x1x1 output convs run on it (ResNet3D.py:318-325)
@@ -400,8 +436,8 @@ class Executor(object):
         key = ('anchors', i)
         an = self._layer(key, lambda: ops.torch.from_numpy(anchors.astype(np.float32)).to(ws.device))
         per_frame = i in self._per_frame
-        assert per_frame == (head.T > 1) and (not per_frame or head.T == T), \
-            'tube RPN head with %d frames for %d-frame anchors' % (head.T, T)
+        assert (head.T == T) if per_frame else (head.T == 1), \
+            'tube RPN head with %d frames for %d-frame anchors (per_frame %s)' % (head.T, T, per_frame)
         spec = ops.RpnLevelSpec(head.t, h, w, A, T, 1. / op.args['spatial_scale'], cs, 0, A, 0, an, apply_sigmoid=True,
                                 per_frame=per_frame)
         self.pending_rpn.append((spec, op))
@@ -461,16 +497,17 @@ class Executor(object):
         if x.kind == 'fmap':
             f, p, p2, cs = x.t.shape
             assert cs == x.C, 'FC over a channel-padded RoI feature is not supported'
-            xin = x.t.view(1, 1, f, p * p2 * cs)
-            perm = (x.C, p, p2)
+            # a tube RoI's T frames are contiguous: one row of T*p*p*C inputs per RoI (head_builder.py:29-33)
+            xin = x.t.view(1, 1, f // x.T, x.T * p * p2 * cs)
+            perm = (x.C, x.T, p, p2)
         else:
             xin, perm = x.t, None
 
         def build():
             w = np.asarray(ws.params[a['w']], dtype=np.float32)
-            if perm is not None:  # reference flattens NCHW (c, h, w); our RoI features are (h, w, c)
-                c, hh, ww = perm
-                w = w.reshape(w.shape[0], c, hh, ww).transpose(0, 2, 3, 1).reshape(w.shape[0], -1)
+            if perm is not None:  # reference flattens NC[T]HW (c, t, h, w); our RoI features are (t, h, w, c)
+                c, tt, hh, ww = perm
+                w = w.reshape(w.shape[0], c, tt, hh, ww).transpose(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
             return ops.ConvLayer(ops.torch.from_numpy(np.ascontiguousarray(w[:, :, None, None, None])).to(ws.device), None,
                                  ws.dev_param(a['b']), stride=(1, 1), pads=(0, 0, 0), relu=a['relu'], dtype=dt,
                                  cin_stride=xin.shape[3])

@@ -272,6 +272,68 @@ class Net(object):
         return y.reshape(R, T, K, M, M).reshape(R, T * K, M, M)
 
 
+    # ---- FPN tube path (declared extension) -----------------------------------------------
+    def fpn_rpn_tube(self, pyr, im_info):
+        # the design of the reference's dead FPN3D.py:232-330: kT x 3 x 3 conv + ReLU per level, time -> channels
+        # (detector.py:480-491: channel t*C + c), 2D 1x1 heads over C*T inputs; weights shared from level 2
+        o = self.o
+        T, kt = o['num_frames_mid'], o['kt_rpn']
+        k_min, k_max = 2, 6
+        rois_l, probs_l = [], []
+        for lvl in range(k_min, k_max + 1):
+            x = pyr[k_max - lvl]
+            w, b = _t(self.w['conv_rpn_fpn2_w']), _t(self.w['conv_rpn_fpn2_b'])
+            h = F.relu(F.conv3d(x, w, b, stride=1, padding=(kt // 2, 1, 1)))
+            N, C, Tt, H, W = h.shape
+            h2 = h.permute(0, 2, 1, 3, 4).reshape(N, Tt * C, H, W)
+            logits = self.conv2d(h2, 'rpn_cls_logits_fpn2', 1)
+            deltas = self.conv2d(h2, 'rpn_bbox_pred_fpn2', 1)
+            probs = torch.sigmoid(logits)
+            self.blobs['rpn_cls_probs_fpn%d' % lvl] = probs
+            self.blobs['rpn_bbox_pred_fpn%d' % lvl] = deltas
+            anchors = generate_anchors(stride=2. ** lvl, sizes=(o['rpn_anchor_start'] * 2. ** (lvl - k_min),),
+                                       aspect_ratios=o['rpn_aspect_ratios'], time_dim=T)
+            r, p = prop.generate_proposals(probs.numpy(), deltas.numpy(), im_info, anchors, 1. / 2. ** lvl,
+                                           o['pre_nms_topn'], o['post_nms_topn'], o['rpn_nms_thresh'],
+                                           o['rpn_min_size'])
+            rois_l.append(r)
+            probs_l.append(p)
+        return prop.collect(rois_l, probs_l, o['post_nms_topn'])
+
+    def roi_feat_fpn_tube(self, pyr_p5_to_p2, rois, pooled, sampling):
+        # detector.py:256-310 on tube rois: level by mean area over the frames (FPN.py:349-360), RoIAlign per frame
+        lvls = prop.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+        out = None
+        for lvl in range(2, 6):
+            idx = np.where(lvls == lvl)[0]
+            if len(idx) == 0:
+                continue
+            f = roi_align_tube(pyr_p5_to_p2[5 - lvl].numpy(), rois[idx], pooled, 1. / 2. ** lvl, sampling)
+            if out is None:
+                out = np.zeros((rois.shape[0],) + f.shape[1:], dtype=np.float32)
+            out[idx] = f
+        return out  # (R, C, T, P, P)
+
+    def box_head_2mlp_tube(self, roi_feat):
+        # head_builder.py:17-38 with fc6 over T*C*res*res (c, t, h, w order); outputs: K scores, K*T*4 deltas
+        x = _t(roi_feat).reshape(roi_feat.shape[0], -1)
+        x = F.relu(self.fc(x, 'fc6'))
+        x = F.relu(self.fc(x, 'fc7'))
+        return F.softmax(self.fc(x, 'cls_score'), dim=1).numpy(), self.fc(x, 'bbox_pred').numpy()
+
+    def kps_head_tube_feat(self, roi_feat):
+        # keypoint_rcnn_heads.py:39-73 nd=True on (R, C, T, 14, 14) tube features; see kps_head_tube
+        o = self.o
+        kt = o['kt_kps']
+        x = _t(roi_feat)
+        for i in range(o['kps_num_convs']):
+            x = F.relu(self.conv_nd(x, 'conv_fcn%d' % (i + 1), [kt, 3, 3], [1, 1, 1], [kt // 2, 1, 1]))
+        R, C, T, H, W = x.shape
+        y = self.kps_outputs_2d(x.permute(0, 2, 1, 3, 4).reshape(R * T, C, H, W))
+        K, M = y.shape[1], y.shape[2]
+        return y.reshape(R, T * K, M, M)
+
+
 def bilinear_kernel(dim, up_scale):
     """detector.py:356-372 (diagonal bilinear deconv kernel, size 2*up)."""
     size = up_scale * 2

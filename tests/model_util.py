@@ -68,3 +68,12 @@ def c4_tube_kps_cfg(T=3, kt=3, pre=300, post=60, dtype='fp32'):
     d['KRCNN'].update(ROI_KEYPOINTS_HEAD='keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d',
                       NO_3D_DECONV_TIME_TO_CH=True)
     return d
+
+
+def fpn3d_tube_kps_cfg(T=2, kt=3, pre=200, post=50, dtype='fp32'):
+    """Declared extension: FPN3D body kept 3D (BODY_HEAD_LINK ''), tube RPN per level, tube rois
+    on the 2-MLP box head, 3D keypoint head."""
+    d = fpn3d_kps_cfg('18', T=T, kt=kt, link='', pre=pre, post=post, dtype=dtype)
+    d['KRCNN'].update(ROI_KEYPOINTS_HEAD='keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d',
+                      NO_3D_DECONV_TIME_TO_CH=True)
+    return d

@@ -188,3 +188,53 @@ def test_keyframe_dce_gives_identical_head_inputs():
     np.testing.assert_allclose(a[0], b[0], atol=1e-3)
     np.testing.assert_allclose(a[1], b[1], atol=1e-5)
     np.testing.assert_allclose(a[2], b[2], atol=1e-5)
+
+
+def test_fpn3d_tube_heads_match_oracle():
+    """Declared extension: tube RPN on every FPN3D level (the design of the reference's dead
+    FPN3D.py:232-330: time -> channels, 2D 1x1 heads over C*T inputs), tube rois through the 2-MLP box head
+    (fc6 over T*C*49) and the 3D keypoint head."""
+    from oracle.net3d import Net
+    from tests.model_util import fpn3d_tube_kps_cfg
+    T, H, W = 2, 96, 128
+    pre, post = 200, 50
+    model, ws, weights = build_product(fpn3d_tube_kps_cfg(T=T, pre=pre, post=post))
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    net = Net(weights, oracle_opts('18', T, 3, '', pre, post))
+    net.body(torch.from_numpy(data))
+    pyr = net.fpn()                                   # [P6, P5, P4, P3, P2], 5-D
+    ref_rois = net.fpn_rpn_tube(pyr, im_info)
+    A = 3
+    for lvl in range(2, 7):
+        head = ws.FetchBlob('rpn_cls_logits_fpn%d+rpn_bbox_pred_fpn%d' % (lvl, lvl))     # (1, A + 4*T*A, h, w)
+        assert head.shape[1] == A + 4 * T * A
+        probs = 1.0 / (1.0 + np.exp(-head[:, :A]))
+        np.testing.assert_allclose(probs, net.blobs['rpn_cls_probs_fpn%d' % lvl].numpy(), atol=1e-4)
+        np.testing.assert_allclose(head[:, A:], net.blobs['rpn_bbox_pred_fpn%d' % lvl].numpy(), atol=1e-3)
+    moved = ws.FetchBlob('conv_rpn_timepooled_fpn3')  # time moved into channels: (1, T*C, h, w)
+    assert moved.shape[1] == T * 256
+    rois = ws.FetchBlob('rois')
+    assert rois.shape[1] == 4 * T + 1 and rois.shape[0] == ref_rois.shape[0]
+    dd = np.abs(rois[:, None, 1:] - ref_rois[None, :, 1:]).max(axis=2).min(axis=1)
+    assert (dd < 0.05).mean() > 0.95, 'only %.1f%% of device tubes found in the oracle set' % (100 * (dd < 0.05).mean())
+    # box head on the DEVICE tubes
+    feat = net.roi_feat_fpn_tube(pyr[1:], rois, 7, 2)
+    cls_prob, bbox_pred = net.box_head_2mlp_tube(feat)
+    np.testing.assert_allclose(ws.FetchBlob('cls_prob'), cls_prob, atol=1e-4)
+    got_bp = ws.FetchBlob('bbox_pred')
+    assert got_bp.shape == bbox_pred.shape == (rois.shape[0], 2 * T * 4)
+    np.testing.assert_allclose(got_bp, bbox_pred, atol=1e-3)
+    # 3D keypoint head on multi-level tube features
+    kp_rois = rois[:5].copy()
+    ws.FeedBlob('keypoint_rois', kp_rois)
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    ref = net.kps_head_tube_feat(net.roi_feat_fpn_tube(pyr[1:], kp_rois, 14, 2)).numpy()
+    assert kps.shape == ref.shape == (5, T * 17, 56, 56)
+    err = np.abs(kps - ref).max()
+    print('FPN tube kps_score max-abs %.3e (ref max %.2f)' % (err, np.abs(ref).max()))
+    assert err < 1e-3
