@@ -104,7 +104,8 @@ def stage_net(model, ws, data_dev, im_info):
 
 
 def stage_heads(model, ws, im_info, im_shape):
-    """Stage B: the reference's host glue (core/test.py:215-252, 750-806; NMS on the device) + `keypoint_net`."""
+    """Stage B: the reference's host glue (core/test.py:215-252, 750-806; NMS on the device) + `keypoint_net` + the
+    heatmap decode (on the device): the step ends with the per-detection 4 x 17 keypoint rows on the host."""
     from detectandtrack_amd.core import test as engine
     from detectandtrack_amd import workspace as wsmod
     prev, wsmod._GLOBAL = wsmod._GLOBAL, ws          # the engine functions talk to the global workspace
@@ -112,9 +113,8 @@ def stage_heads(model, ws, im_info, im_shape):
         scores, boxes, _ = engine._read_bbox_outputs([np.zeros(im_shape, np.uint8)], np.array([im_info[0, 2]]))
         scores, boxes, cls_boxes = engine.box_results_with_nms_and_limit(scores, boxes)
         n_det = boxes.shape[0]
-        if n_det > 0:
-            ws.FeedBlob('keypoint_rois', engine._get_rois_blob(boxes, np.array([im_info[0, 2]])))
-            ws.RunNet(model.keypoint_net.name)
+        if n_det > 0:   # keypoint net on the detections + on-device heatmap decode (core/test.py:584-627, 865-894)
+            engine.keypoint_results_on_device(model, cls_boxes, boxes, np.array([im_info[0, 2]]))
     finally:
         wsmod._GLOBAL = prev
     return n_det
@@ -152,7 +152,7 @@ class ClipPipeline(object):
         torch.cuda.synchronize()
 
 
-def cpu_baseline(arch, T, seconds_budget=25.0):
+def cpu_baseline(arch, T, seconds_budget=15.0):
     """The oracle (torch-CPU fp32 restatement of the reference graph) timed on the host cores on a bounded sample:
     the same model on a reduced 8x256x320 clip (full clips take minutes on CPU)."""
     from detectandtrack_amd.core.config import cfg
@@ -182,7 +182,7 @@ def cpu_baseline(arch, T, seconds_budget=25.0):
         net.kps_head_2d(net.roi_feat_fpn(p2d[1:], pl, rs, 14, 2))
         n += 1
         el = time.time() - t0
-        if el > seconds_budget or n >= 8:
+        if el > seconds_budget or n >= 64:
             break
     return {'value': n / el, 'unit': 'clips/s (reduced %dx%dx%d clips)' % (T, H, W), 'cores': cores, 'kind': 'port',
             'sample': '%d forward passes of oracle.net3d (torch-CPU fp32, %d threads) on a %dx%dx%d clip, '
@@ -335,7 +335,7 @@ def main():
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': '3D R-%s FPN3D keypoint R-CNN inference, 1x3x%dx%dx%d clip per step per GPU '
-                               '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score)'
+                               '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
                                % (a.arch, T, H, W, n_det),
                    'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
                    'clips_in_flight': a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),

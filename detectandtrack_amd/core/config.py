@@ -237,7 +237,8 @@ def _build_defaults():
     # KEYFRAME_DCE (opt-in): with BODY_HEAD_LINK 'slice-center' the heads read only the centre frame of every FPN
     # output; True computes just that frame of convs whose output is consumed solely by SliceKeyFrame (identical
     # rois / scores / heatmaps, the unread frames of fpn_res*_sum are never materialised)
-    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False})
+    # DEVICE_KPS_DECODE: heatmaps_to_keypoints (utils/keypoints.py:94-149) runs on the GPU; False = the reference's host loop
+    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True})
     return c
 
 

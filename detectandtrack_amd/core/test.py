@@ -131,6 +131,31 @@ def im_detect_keypoints(model, im_scales, boxes):
     return heat
 
 
+def keypoint_results_on_device(model, cls_boxes, ref_boxes, im_scales):
+    """im_detect_keypoints (:584-627) + keypoint_results (:865-894) without the heatmaps ever leaving the GPU
+    (SURVEY.md §8 f-2): run the keypoint net on `ref_boxes`, decode `kps_score` with dat_heatmaps_to_keypoints and
+    fetch only the R x 4 x (17 T) rows.  Same return value as keypoint_results."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    import torch
+    num_classes = cfg.MODEL.NUM_CLASSES
+    K = cfg.KRCNN.NUM_KEYPOINTS
+    cls_keyps = [[] for _ in range(num_classes)]
+    person = keypoint_utils.get_person_class_index()
+    assert len(im_scales) == 1, 'Only single-image / single-scale batch implemented'
+    time_dim = ref_boxes.shape[-1] // 4
+    if cfg.KRCNN.NMS_OKS:
+        raise NotImplementedError('Handle tubes')
+    workspace.FeedBlob('keypoint_rois', _get_rois_blob(ref_boxes, im_scales))
+    workspace.RunNet(model.keypoint_net.Proto().name)
+    ws = workspace.GlobalWorkspace()
+    heat = ws.blobs['kps_score'].t                      # fp32 [R, 17 T, M, M] on the device
+    assert heat.shape[1] == K * time_dim, 'Heatmaps must be 17xT'
+    boxes = torch.from_numpy(np.ascontiguousarray(ref_boxes, dtype=np.float32)).to(heat.device)
+    xy = ops.heatmaps_to_keypoints(heat.contiguous(), boxes, time_dim, K, cfg.KRCNN.INFERENCE_MIN_SIZE).cpu().numpy()
+    cls_keyps[person] = [xy[i] for i in range(xy.shape[0])]
+    return cls_keyps
+
+
 def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes):
     """(:865-894) per-frame heatmap decoding, concatenated along the keypoint axis for tubes."""
     num_classes = cfg.MODEL.NUM_CLASSES
@@ -165,7 +190,11 @@ def im_detect_all(model, im, box_proposals, timers=None):
     if cfg.MODEL.MASK_ON and boxes.shape[0] > 0:
         raise NotImplementedError('Handle tubes..')
     cls_segms = None
-    if cfg.MODEL.KEYPOINTS_ON and boxes.shape[0] > 0:
+    if cfg.MODEL.KEYPOINTS_ON and boxes.shape[0] > 0 and cfg.HIP.DEVICE_KPS_DECODE:
+        timers['im_detect_keypoints'].tic()
+        cls_keyps = keypoint_results_on_device(model, cls_boxes, boxes, im_scales)
+        timers['im_detect_keypoints'].toc()
+    elif cfg.MODEL.KEYPOINTS_ON and boxes.shape[0] > 0:
         timers['im_detect_keypoints'].tic()
         heatmaps = im_detect_keypoints(model, im_scales, boxes)
         timers['im_detect_keypoints'].toc()

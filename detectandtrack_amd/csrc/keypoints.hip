@@ -1,0 +1,130 @@
+// On-device keypoint heatmap decoding (gfx950).
+//
+// Replaces the host loop of lib/utils/keypoints.py:94-149 (heatmaps_to_keypoints): per RoI, per frame, per keypoint the
+// M x M logit map is resized bicubically (OpenCV INTER_CUBIC: a = -0.75, pixel-centre mapping, replicated borders) to the
+// RoI's (ceil) size, the argmax cell centre is mapped back to image coordinates and the spatial-softmax probability of
+// that cell is reported (:210-216 scores_to_probs).  The reference copies 1.7 MB of heatmaps per RoI to the host and loops
+// over RoIs in Python with cv2.resize; here one block handles one (RoI, frame, keypoint) map held in LDS and only the
+// 4 x (T*K) result rows leave the device.
+//
+// Arithmetic follows the host restatement (detectandtrack_amd/utils/image.py resize_bicubic, itself the oracle's) in the
+// same fp32 operation order -- rows first (4 taps accumulated in order), then columns -- and this file is compiled with
+// -ffp-contract=off, so the resized values, hence the argmax, are bit-identical to the host path on the same logits.
+#include "dat_common.h"
+
+namespace {
+
+struct KpParams {
+    const float* maps;    // [R, T*K, M, M]
+    const float* boxes;   // [R, 4*T] image-space x1 y1 x2 y2 per frame
+    float* out;           // [R, 4, T*K] rows x, y, logit, prob
+    int R, T, K, M, min_size;
+};
+
+__device__ __forceinline__ void cubic(float t, float c[4]) {
+    const float a = -0.75f;
+    c[0] = ((a * (t + 1.f) - 5.f * a) * (t + 1.f) + 8.f * a) * (t + 1.f) - 4.f * a;
+    c[1] = ((a + 2.f) * t - (a + 3.f)) * t * t + 1.f;
+    c[2] = ((a + 2.f) * (1.f - t) - (a + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    c[3] = 1.0f - c[0] - c[1] - c[2];
+}
+
+__device__ __forceinline__ void resample(int src_len, int dst_len, int d, int& i0, float& frac) {
+    const double scale = (double)src_len / (double)dst_len;
+    const double s = ((double)d + 0.5) * scale - 0.5;
+    const double fl = floor(s);
+    i0 = (int)fl;
+    frac = (float)(s - fl);
+}
+
+__global__ __launch_bounds__(256) void kps_decode_kernel(const KpParams p) {
+    extern __shared__ float map[];          // M*M logits of this (roi, t, k)
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    __shared__ float red_m[256], red_s[256];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x % p.K;
+    const int t = (blockIdx.x / p.K) % p.T;
+    const int r = blockIdx.x / (p.K * p.T);
+    const int M = p.M;
+    const float* src = p.maps + ((size_t)r * p.T * p.K + (size_t)t * p.K + k) * M * M;
+    for (int i = tid; i < M * M; i += blockDim.x) map[i] = src[i];
+    __syncthreads();
+
+    const float* b = p.boxes + ((size_t)r * p.T + t) * 4;
+    const float off_x = b[0], off_y = b[1];
+    const float width = fmaxf(b[2] - b[0], 1.f), height = fmaxf(b[3] - b[1], 1.f);
+    int mw = (int)ceilf(width), mh = (int)ceilf(height);
+    if (p.min_size > 0) { mw = max(mw, p.min_size); mh = max(mh, p.min_size); }
+
+    // every thread scans output pixels tid, tid+256, ... (row-major index = y*mw + x)
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    float run_m = -INFINITY, run_s = 0.f;       // online spatial softmax: sum exp(v - run_m)
+    const int n = mw * mh;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int y = i / mw, x = i - y * mw;
+        int y0, x0;
+        float fy, fx, cy[4], cx[4];
+        resample(M, mh, y, y0, fy);
+        resample(M, mw, x, x0, fx);
+        cubic(fy, cy);
+        cubic(fx, cx);
+        float v = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int xx = min(max(x0 - 1 + kx, 0), M - 1);
+            float rowv = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int yy = min(max(y0 - 1 + ky, 0), M - 1);
+                rowv = rowv + map[yy * M + xx] * cy[ky];
+            }
+            v = v + rowv * cx[kx];
+        }
+        if (v > best) { best = v; best_i = i; }      // ascending i per thread: first maximum kept
+        if (v > run_m) { run_s = run_s * expf(run_m - v) + 1.f; run_m = v; }
+        else run_s += expf(v - run_m);
+    }
+    red_v[tid] = best; red_i[tid] = best_i; red_m[tid] = run_m; red_s[tid] = run_s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const float v2 = red_v[tid + off];
+            const int i2 = red_i[tid + off];
+            if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+            const float m1 = red_m[tid], m2 = red_m[tid + off];
+            const float mm = fmaxf(m1, m2);
+            float s = 0.f;
+            if (m1 > -INFINITY) s += red_s[tid] * expf(m1 - mm);
+            if (m2 > -INFINITY) s += red_s[tid + off] * expf(m2 - mm);
+            red_m[tid] = mm; red_s[tid] = s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int pos = red_i[0];
+        const int x_int = pos % mw, y_int = (pos - x_int) / mw;
+        const float w_corr = width / (float)mw, h_corr = height / (float)mh;     // float32 / int -> float32 (NumPy)
+        const int TK = p.T * p.K, col = t * p.K + k;
+        float* o = p.out + (size_t)r * 4 * TK;
+        o[0 * TK + col] = (float)(((double)x_int + 0.5) * (double)w_corr + (double)off_x);
+        o[1 * TK + col] = (float)(((double)y_int + 0.5) * (double)h_corr + (double)off_y);
+        o[2 * TK + col] = red_v[0];
+        o[3 * TK + col] = 1.f / red_s[0];            // exp(max - max) / sum exp(v - max)
+    }
+}
+
+}  // namespace
+
+extern "C" int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int R, int T,
+                                         int K, int M, int min_size, float* out) {
+    DAT_ENFORCE(ctx, maps && boxes && out, "heatmaps_to_keypoints: null argument");
+    DAT_ENFORCE(ctx, T >= 1 && K >= 1 && M >= 2 && (size_t)M * M * 4 <= 64 * 1024, "heatmaps_to_keypoints: T %d K %d M %d unsupported", T, K, M);
+    if (R == 0) return DAT_OK;
+    KpParams p;
+    p.maps = maps; p.boxes = boxes; p.out = out; p.R = R; p.T = T; p.K = K; p.M = M; p.min_size = min_size;
+    hipLaunchKernelGGL(kps_decode_kernel, dim3((unsigned)(R * T * K)), dim3(256), (size_t)M * M * 4, (hipStream_t)s, p);
+    DAT_CHECK_LAUNCH(ctx, "heatmaps_to_keypoints");
+    return DAT_OK;
+}

@@ -75,6 +75,7 @@ _PROTOS = {
     'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }
 EXPORTS = sorted(_PROTOS)
 for _name, (_res, _args) in _PROTOS.items():

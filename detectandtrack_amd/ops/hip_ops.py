@@ -328,6 +328,16 @@ def kps_finalize(sub, dtype, R, Tr, K, up):
     return out
 
 
+def heatmaps_to_keypoints(maps, boxes, T, K, min_size=0):
+    """maps fp32 CUDA [R, T*K, M, M], boxes fp32 CUDA [R, 4T] -> fp32 CUDA [R, 4, T*K] rows (x, y, logit, prob)."""
+    R, TK, M, M2 = maps.shape
+    assert TK == T * K and M == M2 and boxes.shape == (R, 4 * T)
+    assert maps.dtype == torch.float32 and boxes.dtype == torch.float32 and maps.is_contiguous() and boxes.is_contiguous()
+    out = torch.empty((R, 4, TK), dtype=torch.float32, device=maps.device)
+    ctx().call('dat_heatmaps_to_keypoints', _stream(), _ptr(maps), _ptr(boxes), R, T, K, M, int(min_size), _ptr(out))
+    return out
+
+
 class ConvProfiler(object):
     """HIP-event timing of every conv launch (bench.py roofline leg)."""
 

@@ -194,6 +194,14 @@ int dat_deconv_k4s2_weights(dat_ctx* ctx, dat_stream s, const float* w, int Cin,
 int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int R, int Tr, int S, int cs, int K,
                      int up, float* out);
 
+/* ---- keypoint heatmap decoding  (lib/utils/keypoints.py:94-149 heatmaps_to_keypoints, :210-216) ---- */
+/* maps fp32 [R, T*K, M, M] (kps_score), boxes fp32 [R, 4*T] image-space tubes -> out fp32 [R, 4, T*K], rows
+ * (x, y, logit, prob), column t*K + k (core/test.py:875-893 concatenates the frames along the keypoint axis):
+ * bicubic (OpenCV INTER_CUBIC) resize of every map to the RoI's ceil size (>= min_size when min_size > 0,
+ * KRCNN.INFERENCE_MIN_SIZE), argmax cell centre mapped to the image, spatial-softmax probability of that cell. */
+int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int R, int T, int K,
+                              int M, int min_size, float* out);
+
 #ifdef __cplusplus
 }
 #endif

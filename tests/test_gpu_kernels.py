@@ -403,3 +403,35 @@ def test_spatial_mean_softmax(ops):
     z = rs.randn(11, 12).astype(np.float32)
     sm = ops.softmax_rows(_dev(z), 2).cpu().numpy()
     np.testing.assert_allclose(sm, torch.softmax(torch.from_numpy(z[:, :2]), 1).numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize('T,min_size', [(1, 0), (3, 0), (1, 40)])
+def test_heatmaps_to_keypoints_matches_host_decode(ops, T, min_size):
+    """dat_heatmaps_to_keypoints vs the host restatement of utils/keypoints.py:94-149 (bicubic resize to the RoI size,
+    argmax, spatial softmax): identical cells (x, y and logit exact), probability to fp32 summation order."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import keypoints as kp
+    reset_cfg()
+    cfg.KRCNN.INFERENCE_MIN_SIZE = min_size
+    cfg.KRCNN.NUM_KEYPOINTS = 17
+    rs = np.random.RandomState(11)
+    R, K, M = 9, 17, 56
+    maps = rs.randn(R, T * K, M, M).astype(np.float32) * 2.0
+    # smooth blobs so the maximum is not a lone noise pixel
+    yy, xx = np.mgrid[0:M, 0:M]
+    for r in range(R):
+        for c in range(T * K):
+            cy, cx = rs.uniform(5, M - 5, 2)
+            maps[r, c] += 6.0 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 18.0).astype(np.float32)
+    boxes = np.zeros((R, 4 * T), dtype=np.float32)
+    for t in range(T):
+        x1, y1 = rs.uniform(0, 300, R), rs.uniform(0, 200, R)
+        w, h = rs.uniform(0.4, 260, R), rs.uniform(0.4, 330, R)      # includes boxes below 1 px
+        boxes[:, 4 * t:4 * t + 4] = np.stack([x1, y1, x1 + w, y1 + h], axis=1)
+    got = ops.heatmaps_to_keypoints(_dev(maps), _dev(boxes), T, K, min_size).cpu().numpy()
+    ref = np.concatenate([kp.heatmaps_to_keypoints(maps[:, t * K:(t + 1) * K], boxes[:, 4 * t:4 * t + 4])
+                          for t in range(T)], axis=-1)
+    assert got.shape == ref.shape == (R, 4, T * K)
+    np.testing.assert_array_equal(got[:, :3], ref[:, :3])
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-5, atol=1e-9)
+    reset_cfg()

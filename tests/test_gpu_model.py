@@ -105,8 +105,15 @@ def test_im_detect_all_surface():
     cls_boxes, cls_segms, cls_keyps = test_engine.im_detect_all(model, frames, None)
     assert cls_segms is None
     assert cls_boxes[1].shape[1] == 5 and cls_boxes[1].shape[0] <= cfg.TEST.DETECTIONS_PER_IM
-    if cls_boxes[1].shape[0] > 0:
-        assert len(cls_keyps[1]) == cls_boxes[1].shape[0] and cls_keyps[1][0].shape == (4, 17)
+    assert cls_boxes[1].shape[0] > 0
+    assert len(cls_keyps[1]) == cls_boxes[1].shape[0] and cls_keyps[1][0].shape == (4, 17)
+    # the default decodes the heatmaps on the device; the reference's host loop must give the same rows
+    cfg.HIP.DEVICE_KPS_DECODE = False
+    cls_boxes_h, _, cls_keyps_h = test_engine.im_detect_all(model, frames, None)
+    np.testing.assert_array_equal(cls_boxes[1], cls_boxes_h[1])
+    for a, b in zip(cls_keyps[1], cls_keyps_h[1]):
+        np.testing.assert_array_equal(a[:3], b[:3])
+        np.testing.assert_allclose(a[3], b[3], rtol=2e-5)
 
 
 def test_c4_tube_forward_matches_oracle():
