@@ -1,0 +1,453 @@
+// Training-side kernels (gfx950): weight gradient of the fused conv (reference ops: Caffe2 ConvGradient
+// reached through model.AddGradientOperators, lib/modeling/model_builder.py:908-952) and the small elementwise pieces
+// of the backward pass.
+//
+// Weight gradient as K-contiguous GEMMs.  In NDHWC both operands of
+//     G[co][ci][tap] = sum_p g[p][co] * x[p + tap][ci]
+// have the reduction index p (positions) as their SLOW axis, which MFMA fragments cannot read.  Both tensors are
+// therefore re-packed once per layer into channel-major rows over a common padded position grid q = (clip, t, y, x):
+//     gT[co][q]           = g at (t, y, x), zero outside the output extent
+//     xT[plane][ci][q]    = x at (t - pt, s*y + py - ph, s*x + px - pw), zero outside the frame
+// (one plane per stride parity (py, px); stride 1 has a single plane).  A tap (kt, kh, kw) is then a pure offset
+// off = (kt*Hq + kh/s)*Wq + kw/s into plane (kh%s, kw%s): G[:, :, tap] = gT @ xT[plane][:, off:]^T, a GEMM whose rows are
+// K-contiguous for BOTH operands -- the same fragment layout as the forward kernel (A = rows of output channels, B = rows
+// of input channels, 128-byte K slices, XOR-swizzled LDS tiles, v_mfma_f32_32x32x16_bf16 / 32x32x2_f32).  bf16 rows
+// need 4-byte alignment, so a second copy of every plane shifted by one element serves the odd offsets (Wq is even).
+// Split-K over q across blocks; fp32 partial tiles are accumulated into G with atomics (G is tiny: Cout*Cin*taps).
+#include "dat_common.h"
+
+namespace {
+
+constexpr int ROWB = 128;
+constexpr int NT = 256;
+
+__device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + (((slot ^ (row >> 1)) & 7) << 4); }
+
+template <int DT> struct MmaT;
+template <> struct MmaT<DAT_BF16> {
+    static constexpr int CK = 64;
+    __device__ static __forceinline__ void step(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaT<DAT_F32> {
+    static constexpr int CK = 32;
+    __device__ static __forceinline__ void step(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+// ---- channel-major re-pack: NDHWC [clips*T, Hs, Ws, cs] -> rows [C][Qa] over the grid (clip, tf < Tq, yy < Hq, xx < Wq) ----
+struct PackParams {
+    const char* src;
+    char* dst;            // [C][Qa]
+    int clips, T, Hs, Ws, cs, C;
+    int Tq, Hq, Wq;
+    int st;               // spatial stride of the sampling (1 | 2)
+    int ot, oy, ox;       // source coordinate = (tf - ot, st*yy + oy, st*xx + ox)
+    int shift;            // element shift of this copy (0 | 1): dst[c][q] = value(q + shift)
+    long long Qtot, Qa;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void cq_pack_kernel(const PackParams p) {
+    typedef typename ElemOf<DT>::type E;
+    __shared__ E tile[64][65];
+    const long long q0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    // load: 64 positions x 64 channels (channel-contiguous reads)
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int ql = i >> 6, cl = i & 63;
+        const long long q = q0 + ql + p.shift;
+        E v = 0;
+        if (q < p.Qtot && c0 + cl < p.C) {
+            long long r = q;
+            const int xx = (int)(r % p.Wq); r /= p.Wq;
+            const int yy = (int)(r % p.Hq); r /= p.Hq;
+            const int tf = (int)(r % p.Tq);
+            const int n = (int)(r / p.Tq);
+            const int t = tf - p.ot, y = p.st * yy + p.oy, x = p.st * xx + p.ox;
+            if (t >= 0 && t < p.T && y >= 0 && y < p.Hs && x >= 0 && x < p.Ws)
+                v = ((const E*)p.src)[(((size_t)(n * p.T + t) * p.Hs + y) * p.Ws + x) * p.cs + c0 + cl];
+        }
+        tile[ql][cl] = v;
+    }
+    __syncthreads();
+    // store: each channel row gets 64 consecutive q
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cl = i >> 6, ql = i & 63;
+        if (c0 + cl < p.C && q0 + ql < p.Qa) ((E*)p.dst)[(size_t)(c0 + cl) * p.Qa + q0 + ql] = tile[ql][cl];
+    }
+}
+
+// ---- the GEMM: G[co][ci][tap] += sum_{q in [kbeg, kend)} gT[co][q] * xT[ci][q + off] -------------------------------------
+struct WgradParams {
+    const char* gT;       // [Cout][Qa]
+    const char* xT;       // planes/copies laid out by the host: plane_stride bytes apart
+    float* G;             // [Cout][Cin][ntaps] fp32
+    int Cout, Cin, ntaps;
+    long long Qa;         // row length (elements)
+    long long K;          // number of q to reduce (multiple of CK)
+    int ksplit;
+    int n_ci_tiles, n_co_tiles;
+    long long tap_off[32];     // element offset into the B row (already reduced by the copy's shift)
+    long long tap_base[32];    // byte offset of the (plane, copy) this tap reads
+};
+
+template <int DT>
+__global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) {
+    constexpr int ES = ElemOf<DT>::size;
+    constexpr int CK = MmaT<DT>::CK;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 128 * ROWB];
+    char* at = smem;
+    char* bt = smem + 128 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    unsigned bid = blockIdx.x;
+    const int split = bid % p.ksplit; bid /= p.ksplit;
+    const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+    const int co_t = bid % p.n_co_tiles;
+    const int tap = bid / p.n_co_tiles;
+    const long long ksteps = p.K / CK;
+    const long long s_lo = ksteps * split / p.ksplit, s_hi = ksteps * (split + 1) / p.ksplit;
+
+    // this thread stages 4 x 16 B of each tile: rows (tid >> 3) + 32*i, slot tid & 7
+    const int r0 = tid >> 3, slot = tid & 7;
+    const char* arow[4];
+    const char* brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = min(co_t * 128 + r0 + 32 * i, p.Cout - 1);     // clamped rows are masked at the store
+        const int ci = min(ci_t * 128 + r0 + 32 * i, p.Cin - 1);
+        arow[i] = p.gT + ((size_t)co * p.Qa) * ES + slot * 16;
+        brow[i] = p.xT + p.tap_base[tap] + ((size_t)ci * p.Qa + p.tap_off[tap]) * ES + slot * 16;
+    }
+    int lds_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_w[i] = swz(r0 + 32 * i, slot);
+
+    const int khalf = lane >> 5;
+    int a_off[2][4], b_off[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_off[i][ks] = swz(wave_m * 64 + i * 32 + (lane & 31), ks * 2 + khalf);
+            b_off[i][ks] = swz(wave_n * 64 + i * 32 + (lane & 31), ks * 2 + khalf);
+        }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define LOAD_TILES(S_)                                                     \
+    {                                                                      \
+        const size_t ko_ = (size_t)(S_) * CK * ES;                         \
+        ra0 = *(const uint4*)(arow[0] + ko_); ra1 = *(const uint4*)(arow[1] + ko_); \
+        ra2 = *(const uint4*)(arow[2] + ko_); ra3 = *(const uint4*)(arow[3] + ko_); \
+        rb0 = *(const uint4*)(brow[0] + ko_); rb1 = *(const uint4*)(brow[1] + ko_); \
+        rb2 = *(const uint4*)(brow[2] + ko_); rb3 = *(const uint4*)(brow[3] + ko_); \
+    }
+    if (s_lo < s_hi) LOAD_TILES(s_lo);
+    for (long long s = s_lo; s < s_hi; ++s) {
+        __syncthreads();     // previous step's fragment reads are done
+        *(uint4*)(at + lds_w[0]) = ra0; *(uint4*)(at + lds_w[1]) = ra1; *(uint4*)(at + lds_w[2]) = ra2; *(uint4*)(at + lds_w[3]) = ra3;
+        *(uint4*)(bt + lds_w[0]) = rb0; *(uint4*)(bt + lds_w[1]) = rb1; *(uint4*)(bt + lds_w[2]) = rb2; *(uint4*)(bt + lds_w[3]) = rb3;
+        __syncthreads();
+        if (s + 1 < s_hi) LOAD_TILES(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = *(const uint4*)(at + a_off[i][ks]); b[i] = *(const uint4*)(bt + b_off[i][ks]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) MmaT<DT>::step(a[i], b[j], acc[i][j]);
+        }
+    }
+#undef LOAD_TILES
+    // D[i = co][j = ci]: lane holds column ci = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci_t * 128 + wave_n * 64 + j * 32 + (lane & 31);
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_t * 128 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.Cout) atomicAdd(p.G + ((size_t)co * p.Cin + ci) * p.ntaps + tap, acc[i][j][r]);
+            }
+        }
+}
+
+// ---- elementwise backward pieces -----------------------------------------------------------------------------------------------
+// g = dy * (y > 0) (Relu backward on the fused conv's OUTPUT, exact because y == 0 exactly where the ReLU clipped),
+// optionally + dy2 first (a blob read by two consumers); channel sums of g accumulate into dbias (AffineChannelNd / conv
+// bias gradient, affine_channel_nd_op.cu:74-92 computes the same reduction for its bias).
+template <int DT>
+__global__ void relu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ dy2, const void* __restrict__ y,
+                                void* __restrict__ g, float* __restrict__ dbias, long long npos, int C, int cs, int relu) {
+    // thread = one channel quad of a strip of positions; blockDim.x = cs/4 quads... generic: grid-stride over (pos, c4)
+    const int nq = cs / 4;
+    const long long total = npos * nq;
+    __shared__ float red[1024 * 4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // make every thread own ONE channel quad so that its partial sums are per-channel: requires stride % nq == 0
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long pos = i / nq;
+        const int c = (int)(i - pos * nq) * 4;
+        float v[4], o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = ElemOf<DT>::ld(dy, pos * cs + c + e);
+            if (dy2) v[e] += ElemOf<DT>::ld(dy2, pos * cs + c + e);
+            o[e] = relu ? ElemOf<DT>::ld(y, pos * cs + c + e) : 1.f;
+            if (relu && !(o[e] > 0.f)) v[e] = 0.f;
+            if (c + e >= C) v[e] = 0.f;
+            ElemOf<DT>::st(g, pos * cs + c + e, v[e]);
+            s[e] += v[e];
+        }
+    }
+    if (!dbias) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = s[e];
+    __syncthreads();
+    // threads with the same (threadIdx.x % nq) hold the same channel quad (blockDim.x % nq == 0 enforced by the host)
+    if ((int)threadIdx.x < nq) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = threadIdx.x; j < (int)blockDim.x; j += nq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += red[j * 4 + e];
+        const int c = threadIdx.x * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < C) atomicAdd(dbias + c + e, t[e]);
+    }
+}
+
+// dst[f, 2y, 2x, :] = src[f, y, x, :], zeros elsewhere (input of the stride-2 data gradient run as a stride-1 conv)
+template <int DT>
+__global__ void zero_insert2x_kernel(const void* __restrict__ src, void* __restrict__ dst, int frames, int Hs, int Ws, int Hd,
+                                     int Wd, int cs) {
+    const long long total = (long long)frames * Hd * Wd * (cs / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (cs / 4)) * 4;
+        long long r = i / (cs / 4);
+        const int x = (int)(r % Wd); r /= Wd;
+        const int y = (int)(r % Hd);
+        const int f = (int)(r / Hd);
+        const bool live = !(x & 1) && !(y & 1) && (y >> 1) < Hs && (x >> 1) < Ws;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
+            if (live) v = ElemOf<DT>::ld(src, (((size_t)f * Hs + (y >> 1)) * Ws + (x >> 1)) * cs + c + e);
+            ElemOf<DT>::st(dst, (((size_t)f * Hd + y) * Wd + x) * cs + c + e, v);
+        }
+    }
+}
+
+// FPN top-down backward (FPN3D.py:207-222: UpsampleNearest x2 + Sum): dtop[f, y, x, :] (+)= sum of the 2x2 block of g
+template <int DT>
+__global__ void upsample2x_bwd_kernel(const void* __restrict__ g, void* __restrict__ dtop, int frames, int Ht, int Wt, int cs,
+                                      int accumulate) {
+    const long long total = (long long)frames * Ht * Wt * cs;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cs);
+        long long r = i / cs;
+        const int x = (int)(r % Wt); r /= Wt;
+        const int y = (int)(r % Ht);
+        const int f = (int)(r / Ht);
+        const size_t W2 = 2 * (size_t)Wt;
+        const size_t b = (((size_t)f * 2 * Ht + 2 * y) * W2 + 2 * x) * cs + c;
+        float v = ElemOf<DT>::ld(g, b) + ElemOf<DT>::ld(g, b + cs) + ElemOf<DT>::ld(g, b + W2 * cs) + ElemOf<DT>::ld(g, b + W2 * cs + cs);
+        if (accumulate) v += ElemOf<DT>::ld(dtop, i);
+        ElemOf<DT>::st(dtop, i, v);
+    }
+}
+
+// MomentumSGDUpdate with the reference's pre-processing (model_builder.py:954-985): biases: grad *= 2, no decay;
+// weights: grad += wd * w;  v = mu*v + lr*grad;  w -= v.
+__global__ void sgd_momentum_kernel(float* __restrict__ w, float* __restrict__ v, const float* __restrict__ grad, long long n,
+                                    float lr, float mu, float wd, int is_bias) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float g = grad[i];
+        g = is_bias ? 2.f * g : g + wd * w[i];
+        const float nv = mu * v[i] + lr * g;
+        v[i] = nv;
+        w[i] -= nv;
+    }
+}
+
+static inline int grid_for(long long n, int block) {
+    long long b = (n + block - 1) / block;
+    return (int)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+// geometry shared by the workspace query and the launch
+static void wgrad_geom(const dat_conv_desc* d, int* Ho, int* Wo, int* Tq, int* Hq, int* Wq, long long* Qtot, long long* Qa,
+                       int* ncopies) {
+    dat_conv3d_out_shape(d, Ho, Wo);
+    const int s = d->stride_h;
+    *Tq = d->T + d->KT - 1;
+    *Hq = *Ho + (d->KH - 1) / s;
+    *Wq = *Wo + (d->KW - 1) / s;
+    if (*Wq & 1) ++*Wq;
+    const int clips = d->frames / d->T;
+    *Qtot = (long long)clips * *Tq * *Hq * *Wq;
+    const long long max_off = ((long long)(d->KT - 1) * *Hq + (d->KH - 1) / s) * *Wq + (d->KW - 1) / s;
+    const int ck = d->dtype == DAT_BF16 ? 64 : 32;
+    long long k = (*Qtot + ck - 1) / ck * ck;
+    *Qa = k + (max_off + 63) / 64 * 64 + 64;
+    *ncopies = (d->dtype == DAT_BF16 && (d->KW - 1) / s >= 1) ? 2 : 1;
+}
+
+size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, int Cout_real) {
+    int Ho, Wo, Tq, Hq, Wq, nc;
+    long long Qtot, Qa;
+    wgrad_geom(d, &Ho, &Wo, &Tq, &Hq, &Wq, &Qtot, &Qa, &nc);
+    const int s = d->stride_h;
+    const size_t es = dat_esize(d->dtype);
+    return ((size_t)Cout_real + (size_t)Cin_real * s * s * nc) * (size_t)Qa * es + 256;
+}
+
+int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                     int Cin_real, int Cout_real, void* workspace, float* dW) {
+    DAT_ENFORCE(ctx, d && x && g && workspace && dW, "conv3d_wgrad: null argument");
+    DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_wgrad: bad dtype %d", d->dtype);
+    DAT_ENFORCE(ctx, d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2), "conv3d_wgrad: stride %dx%d", d->stride_h, d->stride_w);
+    DAT_ENFORCE(ctx, d->frames % d->T == 0 && d->pad_t * 2 + 1 == d->KT, "conv3d_wgrad: needs same-T convs");
+    DAT_ENFORCE(ctx, d->KT * d->KH * d->KW <= 32, "conv3d_wgrad: %d taps exceed 32", d->KT * d->KH * d->KW);
+    DAT_ENFORCE(ctx, d->Cin % 4 == 0 && g_cstride % 4 == 0, "conv3d_wgrad: channel strides must be multiples of 4");
+    hipStream_t st = (hipStream_t)s_;
+    int Ho, Wo, Tq, Hq, Wq, nc;
+    long long Qtot, Qa;
+    wgrad_geom(d, &Ho, &Wo, &Tq, &Hq, &Wq, &Qtot, &Qa, &nc);
+    const int s = d->stride_h;
+    const size_t es = dat_esize(d->dtype);
+    const int clips = d->frames / d->T;
+    char* gT = (char*)workspace;
+    char* xT = gT + (((size_t)Cout_real * Qa * es + 255) & ~(size_t)255);
+    const size_t plane_bytes = (size_t)Cin_real * Qa * es;
+
+    PackParams pp;
+    pp.clips = clips; pp.Tq = Tq; pp.Hq = Hq; pp.Wq = Wq; pp.Qtot = Qtot; pp.Qa = Qa;
+    auto launch_pack = [&](const PackParams& q) {
+        dim3 grid((unsigned)((Qa + 63) / 64), (unsigned)((q.C + 63) / 64));
+        if (d->dtype == DAT_BF16) hipLaunchKernelGGL(cq_pack_kernel<DAT_BF16>, grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(cq_pack_kernel<DAT_F32>, grid, dim3(256), 0, st, q);
+    };
+    // gT: the output-gradient grid, no shift, zero beyond (T, Ho, Wo)
+    pp.src = (const char*)g; pp.dst = gT; pp.T = d->T; pp.Hs = Ho; pp.Ws = Wo; pp.cs = g_cstride; pp.C = Cout_real;
+    pp.st = 1; pp.ot = 0; pp.oy = 0; pp.ox = 0; pp.shift = 0;
+    launch_pack(pp);
+    // xT planes (stride parity) x copies (element shift)
+    pp.src = (const char*)x; pp.T = d->T; pp.Hs = d->H; pp.Ws = d->W; pp.cs = d->Cin; pp.C = Cin_real; pp.st = s;
+    pp.ot = d->pad_t;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px)
+            for (int c = 0; c < nc; ++c) {
+                pp.dst = xT + ((size_t)((py * s + px) * nc + c)) * plane_bytes;
+                pp.oy = py - d->pad_h; pp.ox = px - d->pad_w; pp.shift = c;
+                launch_pack(pp);
+            }
+    DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad pack");
+
+    WgradParams wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.gT = gT; wp.xT = xT; wp.G = dW; wp.Cout = Cout_real; wp.Cin = Cin_real;
+    wp.ntaps = d->KT * d->KH * d->KW; wp.Qa = Qa;
+    const int ck = d->dtype == DAT_BF16 ? 64 : 32;
+    wp.K = (Qtot + ck - 1) / ck * ck;
+    wp.n_co_tiles = (Cout_real + 127) / 128; wp.n_ci_tiles = (Cin_real + 127) / 128;
+    for (int kt = 0; kt < d->KT; ++kt)
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int kw = 0; kw < d->KW; ++kw) {
+                const int tap = (kt * d->KH + kh) * d->KW + kw;
+                long long off = ((long long)kt * Hq + kh / s) * Wq + kw / s;
+                int copy = 0;
+                if (nc == 2 && (off & 1)) { copy = 1; off -= 1; }
+                wp.tap_off[tap] = off;
+                wp.tap_base[tap] = (long long)(((kh % s) * s + (kw % s)) * nc + copy) * (long long)plane_bytes;
+            }
+    const long long tiles = (long long)wp.ntaps * wp.n_co_tiles * wp.n_ci_tiles;
+    const long long ksteps = wp.K / ck;
+    long long ks = (2048 + tiles - 1) / tiles;          // aim at ~4 blocks per CU slot
+    if (ks > ksteps / 8) ks = ksteps / 8;               // at least 8 K-steps per block
+    if (ks < 1) ks = 1;
+    wp.ksplit = (int)ks;
+    if (hipMemsetAsync(dW, 0, (size_t)Cout_real * Cin_real * wp.ntaps * sizeof(float), st) != hipSuccess)
+        DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
+    const unsigned nblocks = (unsigned)(tiles * ks);
+    if (d->dtype == DAT_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<DAT_BF16>, dim3(nblocks), dim3(NT), 0, st, wp);
+    else hipLaunchKernelGGL(wgrad_gemm_kernel<DAT_F32>, dim3(nblocks), dim3(NT), 0, st, wp);
+    DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad gemm");
+    return DAT_OK;
+}
+
+int dat_relu_bias_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* dy, const void* dy2, const void* y, void* g,
+                      float* dbias, long long npos, int C, int cstride, int relu) {
+    DAT_ENFORCE(ctx, dy && g && (y || !relu), "relu_bias_bwd: null argument");
+    const int nq = cstride / 4;
+    const int block = nq > 256 ? nq : 256;              // a thread keeps ONE channel quad: block % nq == 0
+    DAT_ENFORCE(ctx, cstride % 4 == 0 && block <= 1024 && block % nq == 0,
+                "relu_bias_bwd: channel stride %d must be 4 * (a divisor of 256, or 512 / 1024)", cstride);
+    if (npos == 0) return DAT_OK;
+    long long blocks = (npos * nq + block - 1) / block;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == DAT_BF16)
+        hipLaunchKernelGGL(relu_bwd_kernel<DAT_BF16>, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)s, dy, dy2, y, g, dbias, npos, C, cstride, relu);
+    else
+        hipLaunchKernelGGL(relu_bwd_kernel<DAT_F32>, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)s, dy, dy2, y, g, dbias, npos, C, cstride, relu);
+    DAT_CHECK_LAUNCH(ctx, "relu_bias_bwd");
+    return DAT_OK;
+}
+
+int dat_zero_insert2x(dat_ctx* ctx, dat_stream s, int dtype, const void* src, void* dst, int frames, int Hs, int Ws, int Hd,
+                      int Wd, int cstride) {
+    DAT_ENFORCE(ctx, src && dst && cstride % 4 == 0, "zero_insert2x: bad argument");
+    DAT_ENFORCE(ctx, Hd >= 2 * Hs - 1 && Wd >= 2 * Ws - 1, "zero_insert2x: %dx%d does not hold 2x of %dx%d", Hd, Wd, Hs, Ws);
+    const long long n = (long long)frames * Hd * Wd * (cstride / 4);
+    if (dtype == DAT_BF16)
+        hipLaunchKernelGGL(zero_insert2x_kernel<DAT_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, src, dst, frames, Hs, Ws, Hd, Wd, cstride);
+    else
+        hipLaunchKernelGGL(zero_insert2x_kernel<DAT_F32>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, src, dst, frames, Hs, Ws, Hd, Wd, cstride);
+    DAT_CHECK_LAUNCH(ctx, "zero_insert2x");
+    return DAT_OK;
+}
+
+int dat_upsample2x_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* g, void* dtop, int frames, int Ht, int Wt,
+                       int cstride, int accumulate) {
+    DAT_ENFORCE(ctx, g && dtop, "upsample2x_bwd: null argument");
+    const long long n = (long long)frames * Ht * Wt * cstride;
+    if (dtype == DAT_BF16)
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<DAT_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, g, dtop, frames, Ht, Wt, cstride, accumulate);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<DAT_F32>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, g, dtop, frames, Ht, Wt, cstride, accumulate);
+    DAT_CHECK_LAUNCH(ctx, "upsample2x_bwd");
+    return DAT_OK;
+}
+
+int dat_sgd_momentum(dat_ctx* ctx, dat_stream s, float* w, float* v, const float* grad, long long n, float lr, float momentum,
+                     float weight_decay, int is_bias) {
+    DAT_ENFORCE(ctx, w && v && grad, "sgd_momentum: null argument");
+    if (n == 0) return DAT_OK;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, w, v, grad, n, lr, momentum, weight_decay, is_bias);
+    DAT_CHECK_LAUNCH(ctx, "sgd_momentum");
+    return DAT_OK;
+}
+
+}  // extern "C"

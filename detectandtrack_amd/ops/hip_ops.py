@@ -182,6 +182,98 @@ class ConvLayer(object):
         return out
 
 
+class ConvGrad(object):
+    """Backward of a ConvLayer-shaped conv (Caffe2 ConvGradient via AddGradientOperators,
+    model_builder.py:908-952).  `w`: the forward weight fp32 [Cout, Cin, KT, KH, KW]; `scale`: the fused
+    AffineChannelNd scale (or None).  With z = conv(x, w), y = act(z*scale + bias + res) and g = dL/dy masked by the ReLU:
+      data(g)   -> dL/dx  = conv_stride1(zero_insert(g), flip(w)^T * scale)      (the forward MFMA kernel)
+      weight(x, g) -> G = dL/d(z) / scale-free weight gradient;  dL/dw = scale*G,  dL/dscale[c] = <w[c], G[c]>.
+    """
+
+    def __init__(self, w, scale, stride, pads, dtype, x_cstride, g_cstride):
+        self.w = w.contiguous().float()
+        self.cout, self.cin, self.kt, self.kh, self.kw = [int(v) for v in self.w.shape]
+        self.scale = None if scale is None else scale.float()
+        self.stride, self.pads, self.dtype = tuple(stride), tuple(pads), dtype
+        self.x_cstride, self.g_cstride = x_cstride, g_cstride
+        assert self.stride[0] == self.stride[1] and self.stride[0] in (1, 2)
+        self._data_layer = None
+
+    def _fwd_desc(self, frames, T, H, W):
+        d = L.ConvDesc()
+        d.dtype = self.dtype
+        d.frames, d.T, d.H, d.W, d.Cin = frames, T, H, W, self.x_cstride
+        d.Cout = round_up(self.cout, 4)
+        d.out_cstride = self.g_cstride
+        d.KT, d.KH, d.KW = self.kt, self.kh, self.kw
+        d.stride_h, d.stride_w = self.stride
+        d.pad_t, d.pad_h, d.pad_w = self.pads
+        d.relu, d.res_mode, d.out_t0, d.out_tn = 0, 0, 0, 0
+        return d
+
+    def weight(self, x, g, T):
+        """x [frames,H,W,x_cstride], g [frames,Ho,Wo,g_cstride] -> (dW fp32 [Cout,Cin,KT,KH,KW], dscale fp32 [Cout] | None)"""
+        frames, H, W, _ = x.shape
+        d = self._fwd_desc(frames, T, H, W)
+        nbytes = L.lib().dat_conv3d_wgrad_workspace_bytes(C.byref(d), self.cin, self.cout)
+        wsb = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        G = torch.empty(self.w.shape, dtype=torch.float32, device=x.device)
+        ctx().call('dat_conv3d_wgrad', _stream(), C.byref(d), _ptr(x), _ptr(g), self.g_cstride, self.cin, self.cout,
+                   _ptr(wsb), _ptr(G))
+        if self.scale is None:
+            return G, None
+        dscale = (G * self.w).sum(dim=(1, 2, 3, 4))
+        return G * self.scale.view(-1, 1, 1, 1, 1), dscale
+
+    def data(self, g, T, H, W, accumulate_into=None):
+        """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given)."""
+        if self._data_layer is None:
+            w = self.w if self.scale is None else self.w * self.scale.view(-1, 1, 1, 1, 1)
+            wt = torch.flip(w, dims=(2, 3, 4)).transpose(0, 1).contiguous()          # [Cin, Cout, KT, KH, KW]
+            pads = (self.kt - 1 - self.pads[0], self.kh - 1 - self.pads[1], self.kw - 1 - self.pads[2])
+            self._data_layer = ConvLayer(wt, None, None, stride=(1, 1), pads=pads, relu=False, dtype=self.dtype,
+                                         cin_stride=self.g_cstride)
+        frames, Ho, Wo, cs = g.shape
+        Hz, Wz = H - self.kh + 1 + 2 * self.pads[1], W - self.kw + 1 + 2 * self.pads[2]
+        if self.stride[0] == 2 or (Hz, Wz) != (Ho, Wo):
+            gz = torch.empty((frames, Hz, Wz, cs), dtype=g.dtype, device=g.device)
+            if self.stride[0] == 2:
+                ctx().call('dat_zero_insert2x', _stream(), self.dtype, _ptr(g), _ptr(gz), frames, Ho, Wo, Hz, Wz, cs)
+            else:
+                raise AssertionError('stride-1 conv whose output extent differs from H - K + 1 + 2p')
+        else:
+            gz = g
+        lay = self._data_layer
+        if accumulate_into is not None:
+            return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into)
+        return lay(gz, T=T)
+
+
+def relu_bias_bwd(dy, y, dtype, C_real, relu=True, dy2=None, dbias=None):
+    """g = (dy [+ dy2]) * (y > 0); dbias[c] += sum over positions.  NDHWC tensors [.., cs]."""
+    cs = dy.shape[-1]
+    npos = dy.numel() // cs
+    g = torch.empty_like(dy)
+    ctx().call('dat_relu_bias_bwd', _stream(), dtype, _ptr(dy), _ptr(dy2), _ptr(y), _ptr(g), _ptr(dbias),
+               C.c_longlong(npos), C_real, cs, int(relu))
+    return g
+
+
+def upsample2x_bwd(g, dtype, dtop=None):
+    frames, H2, W2, cs = g.shape
+    acc = dtop is not None
+    if dtop is None:
+        dtop = torch.empty((frames, H2 // 2, W2 // 2, cs), dtype=g.dtype, device=g.device)
+    ctx().call('dat_upsample2x_bwd', _stream(), dtype, _ptr(g), _ptr(dtop), frames, H2 // 2, W2 // 2, cs, int(acc))
+    return dtop
+
+
+def sgd_momentum(w, v, grad, lr, momentum, weight_decay, is_bias):
+    assert w.dtype == v.dtype == grad.dtype == torch.float32 and w.numel() == v.numel() == grad.numel()
+    ctx().call('dat_sgd_momentum', _stream(), _ptr(w), _ptr(v), _ptr(grad), C.c_longlong(w.numel()), C.c_float(lr),
+               C.c_float(momentum), C.c_float(weight_decay), int(is_bias))
+
+
 def stem_pack(data, dtype):
     """data fp32 [N,3,T,H,W] -> packed [N*T, Ho+3, Wo, 64] (see dat_hip.h)."""
     data = data.contiguous()

@@ -202,6 +202,31 @@ int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int
 int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int R, int T, int K,
                               int M, int min_size, float* out);
 
+/* ---- training: backward of the fused conv and the update ------------------------------ */
+/* Weight gradient of a conv described like dat_conv3d_fwd (same-T, stride 1 or 2):
+ *   dW[co][ci][kt][kh][kw] = sum_p g[p][co] * x[p (+) tap][ci]      (fp32, reference blob layout, overwritten)
+ * x: the conv input NDHWC (channel stride d->Cin), g: gradient w.r.t. the conv output NDHWC (channel stride
+ * g_cstride).  Replaces Caffe2's ConvGradient filter path reached through AddGradientOperators
+ * (model_builder.py:908-952).  workspace: dat_conv3d_wgrad_workspace_bytes() bytes of device memory. */
+size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, int Cout_real);
+int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                     int Cin_real, int Cout_real, void* workspace, float* dW);
+/* g = (dy [+ dy2]) * (y > 0 if relu) over [npos][cstride] (channels >= C zeroed); dbias[c] += sum_p g (may be NULL).
+ * Relu backward on the fused conv's output + the bias / AffineChannelNd-bias reduction
+ * (affine_channel_nd_op.cu:74-92). */
+int dat_relu_bias_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* dy, const void* dy2, const void* y, void* g,
+                      float* dbias, long long npos, int C, int cstride, int relu);
+/* dst[f, 2y, 2x, :] = src[f, y, x, :], zero elsewhere: input of a stride-2 conv's data gradient run as a stride-1 conv */
+int dat_zero_insert2x(dat_ctx* ctx, dat_stream s, int dtype, const void* src, void* dst, int frames, int Hs, int Ws, int Hd,
+                      int Wd, int cstride);
+/* FPN top-down backward (FPN3D.py:207-222): dtop[f,y,x,:] (+)= sum of the 2x2 block of g [frames, 2Ht, 2Wt, cstride] */
+int dat_upsample2x_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* g, void* dtop, int frames, int Ht, int Wt,
+                       int cstride, int accumulate);
+/* MomentumSGDUpdate + the reference's gradient pre-processing (model_builder.py:954-985): biases: grad *= 2, no decay;
+ * weights: grad += weight_decay * w;  v = momentum*v + lr*grad;  w -= v.  All fp32. */
+int dat_sgd_momentum(dat_ctx* ctx, dat_stream s, float* w, float* v, const float* grad, long long n, float lr, float momentum,
+                     float weight_decay, int is_bias);
+
 #ifdef __cplusplus
 }
 #endif
