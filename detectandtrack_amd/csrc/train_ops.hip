@@ -288,6 +288,121 @@ __global__ void sgd_momentum_kernel(float* __restrict__ w, float* __restrict__ v
     }
 }
 
+// ---- RoIAlign backward: scatter the cell gradient over the bilinear taps of its samples (fp32 atomics) -------------------------
+// Mirrors roi_align.hip (legacy Detectron RoIAlign, FPN level picked per RoI in-kernel) sample for sample.
+struct RoiBwdParams {
+    float* dfeat[4];      // fp32 [frames, H, W, C] per level, accumulated into
+    int H[4], W[4];
+    float scale[4];
+    int n_levels, k_min, canon_level;
+    float canon_scale;
+    int T, C;
+    const float* rois;
+    int R, Tr, t0, pooled, sampling;
+    const char* dout;     // [R*Tr, P, P, C] in DT
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiBwdParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = p.pooled;
+    const long long ncell = (long long)p.R * p.Tr * P * P;
+    const int roi_cols = 4 * p.Tr + 1;
+    for (long long cell = (long long)blockIdx.x * 4 + wave; cell < ncell; cell += (long long)gridDim.x * 4) {
+        const int pw = cell % P;
+        long long q = cell / P;
+        const int ph = q % P; q /= P;
+        const int t = q % p.Tr;
+        const int r = q / p.Tr;
+        const float* roi = p.rois + (size_t)r * roi_cols;
+        const int n = (int)roi[0];
+        const float bx1 = roi[1 + 4 * t], by1 = roi[2 + 4 * t], bx2 = roi[3 + 4 * t], by2 = roi[4 + 4 * t];
+        int lvl = 0;
+        if (p.n_levels > 1) {
+            float asum = 0.f;
+            for (int tt = 0; tt < p.Tr; ++tt) {
+                const float w = roi[3 + 4 * tt] - roi[1 + 4 * tt] + 1.f;
+                const float h = roi[4 + 4 * tt] - roi[2 + 4 * tt] + 1.f;
+                asum += w * h;
+            }
+            const float sarea = sqrtf(asum / (float)p.Tr);
+            float l = floorf((float)p.canon_level + log2f(sarea / p.canon_scale + 1e-6f));
+            l = fminf(fmaxf(l, (float)p.k_min), (float)(p.k_min + p.n_levels - 1));
+            lvl = (int)l - p.k_min;
+        }
+        const int H = p.H[lvl], W = p.W[lvl];
+        const float sc = p.scale[lvl];
+        const int frame = n * p.T + (p.Tr == 1 ? p.t0 : t);
+        float* fbase = p.dfeat[lvl] + (size_t)frame * H * W * p.C;
+        const float x1 = bx1 * sc, y1 = by1 * sc, x2 = bx2 * sc, y2 = by2 * sc;
+        const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+        const float bw = rw / (float)P, bh = rh / (float)P;
+        const int gh = p.sampling > 0 ? p.sampling : (int)ceilf(rh / (float)P);
+        const int gw = p.sampling > 0 ? p.sampling : (int)ceilf(rw / (float)P);
+        const float inv = 1.f / (float)(gh * gw);
+        const size_t obase = ((((size_t)r * p.Tr + t) * P + ph) * P + pw) * p.C;
+        for (int c = lane; c < p.C; c += 64) {
+            const float g = ElemOf<DT>::ld(p.dout, obase + c) * inv;
+            if (g == 0.f) continue;
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = y1 + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = x1 + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
+                    float yy = y;
+                    if (yy < -1.f || yy > (float)H || x < -1.f || x > (float)W) continue;
+                    if (yy <= 0.f) yy = 0.f;
+                    if (x <= 0.f) x = 0.f;
+                    int yl = (int)yy, xl = (int)x, yh, xh;
+                    if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                    const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                    atomicAdd(fbase + ((size_t)yl * W + xl) * p.C + c, g * hy * hx);
+                    atomicAdd(fbase + ((size_t)yl * W + xh) * p.C + c, g * hy * lx);
+                    atomicAdd(fbase + ((size_t)yh * W + xl) * p.C + c, g * ly * hx);
+                    atomicAdd(fbase + ((size_t)yh * W + xh) * p.C + c, g * ly * lx);
+                }
+            }
+        }
+    }
+}
+
+// ---- backward of dat_kps_finalize: dsub[fr, y', x', (a*2+b)*K + k] = sum_{oy,ox} dout[r, t*K+k, oy, ox] f(oy) f(ox) ---------------
+template <int DT>
+__global__ void kps_finalize_bwd_kernel(const float* __restrict__ dout, int R, int Tr, int S, int cs, int K, int up,
+                                        void* __restrict__ dsub) {
+    const int L = 2 * S, M = L * up;
+    const int ksz = 2 * up, pad = up / 2;
+    const float factor = (float)((ksz + 1) / 2);
+    const float center = (ksz % 2 == 1) ? factor - 1.f : factor - 0.5f;
+    const size_t total = (size_t)R * Tr * S * S * cs;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = i % cs;
+        size_t q = i / cs;
+        const int xs = q % S; q /= S;
+        const int ys = q % S;
+        const size_t fr = q / S;
+        float acc = 0.f;
+        if (ch < 4 * K) {
+            const int k = ch % K, ab = ch / K;
+            const int y = 2 * ys + (ab >> 1), x = 2 * xs + (ab & 1);
+            const size_t r = fr / Tr, t = fr % Tr;
+            const float* src = dout + ((r * Tr + t) * K + k) * (size_t)M * M;
+            for (int ky = 0; ky < ksz; ++ky) {
+                const int oy = up * y - pad + ky;
+                if (oy < 0 || oy >= M) continue;
+                const float fy = 1.f - fabsf((float)ky - center) / factor;
+                for (int kx = 0; kx < ksz; ++kx) {
+                    const int ox = up * x - pad + kx;
+                    if (ox < 0 || ox >= M) continue;
+                    const float fx = 1.f - fabsf((float)kx - center) / factor;
+                    acc += src[(size_t)oy * M + ox] * (fy * fx);
+                }
+            }
+        }
+        ElemOf<DT>::st(dsub, i, acc);
+    }
+}
+
 static inline int grid_for(long long n, int block) {
     long long b = (n + block - 1) / block;
     return (int)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
@@ -438,6 +553,39 @@ int dat_upsample2x_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* g, voi
     else
         hipLaunchKernelGGL(upsample2x_bwd_kernel<DAT_F32>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, g, dtop, frames, Ht, Wt, cstride, accumulate);
     DAT_CHECK_LAUNCH(ctx, "upsample2x_bwd");
+    return DAT_OK;
+}
+
+int dat_roi_align_bwd(dat_ctx* ctx, dat_stream s, int dtype, float* const* dfeat_levels, const int* Hs, const int* Ws,
+                      const float* scales, int n_levels, int k_min, float canon_scale, int canon_level, int T, int C,
+                      const float* rois, int R, int Tr, int t0, int pooled, int sampling_ratio, const void* dout) {
+    DAT_ENFORCE(ctx, dfeat_levels && Hs && Ws && scales && rois && dout, "roi_align_bwd: null argument");
+    DAT_ENFORCE(ctx, n_levels >= 1 && n_levels <= 4, "roi_align_bwd: n_levels %d must be 1..4", n_levels);
+    if (R == 0) return DAT_OK;
+    RoiBwdParams p;
+    for (int i = 0; i < n_levels; ++i) { p.dfeat[i] = dfeat_levels[i]; p.H[i] = Hs[i]; p.W[i] = Ws[i]; p.scale[i] = scales[i]; }
+    p.n_levels = n_levels; p.k_min = k_min; p.canon_level = canon_level; p.canon_scale = canon_scale;
+    p.T = T; p.C = C; p.rois = rois; p.R = R; p.Tr = Tr; p.t0 = t0; p.pooled = pooled; p.sampling = sampling_ratio;
+    p.dout = (const char*)dout;
+    const long long ncell = (long long)R * Tr * pooled * pooled;
+    long long blocks = (ncell + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == DAT_BF16) hipLaunchKernelGGL(roi_align_bwd_kernel<DAT_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(roi_align_bwd_kernel<DAT_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p);
+    DAT_CHECK_LAUNCH(ctx, "roi_align_bwd");
+    return DAT_OK;
+}
+
+int dat_kps_finalize_bwd(dat_ctx* ctx, dat_stream s, int dtype, const float* dout, int R, int Tr, int S, int cs, int K, int up,
+                         void* dsub) {
+    DAT_ENFORCE(ctx, dout && dsub && up >= 2 && up % 2 == 0 && 4 * K <= cs, "kps_finalize_bwd: bad argument");
+    if (R == 0) return DAT_OK;
+    const long long n = (long long)R * Tr * S * S * cs;
+    if (dtype == DAT_BF16)
+        hipLaunchKernelGGL(kps_finalize_bwd_kernel<DAT_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, dout, R, Tr, S, cs, K, up, dsub);
+    else
+        hipLaunchKernelGGL(kps_finalize_bwd_kernel<DAT_F32>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, dout, R, Tr, S, cs, K, up, dsub);
+    DAT_CHECK_LAUNCH(ctx, "kps_finalize_bwd");
     return DAT_OK;
 }
 

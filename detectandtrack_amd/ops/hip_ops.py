@@ -274,6 +274,58 @@ def sgd_momentum(w, v, grad, lr, momentum, weight_decay, is_bias):
                C.c_float(momentum), C.c_float(weight_decay), int(is_bias))
 
 
+def roi_align_bwd(dfeats, scales, dtype, rois, dout, T, Tr, t0, pooled, sampling, k_min=2, canon_scale=224., canon_level=4):
+    """dfeats: fp32 CUDA gradient maps [frames,H,W,C] per level (finest first), accumulated in place."""
+    nl = len(dfeats)
+    ptrs = (C.c_void_p * nl)(*[f.data_ptr() for f in dfeats])
+    Hs = (C.c_int * nl)(*[int(f.shape[1]) for f in dfeats])
+    Ws = (C.c_int * nl)(*[int(f.shape[2]) for f in dfeats])
+    sc = (C.c_float * nl)(*[float(v) for v in scales])
+    Cc = int(dfeats[0].shape[3])
+    assert all(f.dtype == torch.float32 and f.shape[3] == Cc for f in dfeats) and dout.shape[-1] == Cc
+    R = rois.shape[0]
+    ctx().call('dat_roi_align_bwd', _stream(), dtype, ptrs, Hs, Ws, sc, nl, k_min, C.c_float(canon_scale), canon_level, T, Cc,
+               _ptr(rois), R, Tr, t0, pooled, sampling, _ptr(dout))
+
+
+def kps_finalize_bwd(dout, dtype, R, Tr, S, cs, K, up):
+    dsub = torch.empty((R * Tr, S, S, cs), dtype=tdtype(dtype), device=dout.device)
+    ctx().call('dat_kps_finalize_bwd', _stream(), dtype, _ptr(dout), R, Tr, S, cs, K, up, _ptr(dsub))
+    return dsub
+
+
+def rpn_loss(head, dtype, A, logit_off, delta_off, labels_wide, targets_wide, inside_wide, outside_wide, cls_mult, beta,
+             bbox_mult, loss2):
+    """head [N,H,W,cs]; label arrays in the reference layouts (CUDA); returns dhead.  loss2: fp32 CUDA [2] accumulated."""
+    N, H, W, cs = head.shape
+    Hw, Ww = int(labels_wide.shape[2]), int(labels_wide.shape[3])
+    dhead = torch.empty_like(head)
+    ctx().call('dat_rpn_loss', _stream(), dtype, _ptr(head), _ptr(dhead), N, H, W, cs, A, logit_off, delta_off,
+               _ptr(labels_wide), _ptr(targets_wide), _ptr(inside_wide), _ptr(outside_wide), Hw, Ww, C.c_float(cls_mult),
+               C.c_float(beta), C.c_float(bbox_mult), _ptr(loss2))
+    return dhead
+
+
+def smooth_l1_rows(pred, dtype, D, targets, inside, outside, beta, mult, loss):
+    """pred [R, ld] (any leading shape, last dim = ld) -> dpred same shape/dtype."""
+    ld = pred.shape[-1]
+    R = pred.numel() // ld
+    dpred = torch.empty_like(pred)
+    ctx().call('dat_smooth_l1_rows', _stream(), dtype, _ptr(pred), ld, _ptr(targets), _ptr(inside), _ptr(outside), R, D,
+               C.c_float(beta), C.c_float(mult), _ptr(dpred), _ptr(loss))
+    return dpred
+
+
+def softmax_ce_rows(logits, dtype, D, labels, weights, mult, loss, correct=None, out_dtype=None):
+    ld = logits.shape[-1]
+    R = logits.numel() // ld
+    odt = dtype if out_dtype is None else out_dtype
+    dl = torch.empty(logits.shape, dtype=tdtype(odt), device=logits.device)
+    ctx().call('dat_softmax_ce_rows', _stream(), dtype, _ptr(logits), ld, _ptr(labels), _ptr(weights), R, D, C.c_float(mult),
+               odt, _ptr(dl), ld, _ptr(loss), _ptr(correct))
+    return dl
+
+
 def stem_pack(data, dtype):
     """data fp32 [N,3,T,H,W] -> packed [N*T, Ho+3, Wo, 64] (see dat_hip.h)."""
     data = data.contiguous()

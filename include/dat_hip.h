@@ -222,6 +222,30 @@ int dat_zero_insert2x(dat_ctx* ctx, dat_stream s, int dtype, const void* src, vo
 /* FPN top-down backward (FPN3D.py:207-222): dtop[f,y,x,:] (+)= sum of the 2x2 block of g [frames, 2Ht, 2Wt, cstride] */
 int dat_upsample2x_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* g, void* dtop, int frames, int Ht, int Wt,
                        int cstride, int accumulate);
+/* RoIAlign backward (same sampling as dat_roi_align): dout [R*Tr, P, P, C] is scattered with fp32 atomics into the
+ * per-level fp32 gradient maps dfeat_levels[l] [frames, Hs[l], Ws[l], C] (accumulated, caller zeroes them). */
+int dat_roi_align_bwd(dat_ctx* ctx, dat_stream s, int dtype, float* const* dfeat_levels, const int* Hs, const int* Ws,
+                      const float* scales, int n_levels, int k_min, float canon_scale, int canon_level, int T, int C,
+                      const float* rois, int R, int Tr, int t0, int pooled, int sampling_ratio, const void* dout);
+/* backward of dat_kps_finalize: dout fp32 [R, Tr*K, M, M] -> dsub [R*Tr, S, S, cs] (channels >= 4K zero) */
+int dat_kps_finalize_bwd(dat_ctx* ctx, dat_stream s, int dtype, const float* dout, int R, int Tr, int S, int cs, int K, int up,
+                         void* dsub);
+/* ---- losses: value + gradient w.r.t. the prediction in one pass (model_builder.py:481-494, 612-636, 873-889; FPN.py:282-321) */
+/* RPN losses of one level on the fused head tensor [N, H, W, cstride] (logits at logit_off + a, deltas at delta_off + a*4 + c):
+ * SigmoidCrossEntropyLoss on the logits (labels int32 (N, A, Hw, Ww), -1 = ignore) and SmoothL1Loss on the deltas (targets /
+ * inside / outside weights fp32 (N, 4A, Hw, Ww)); the wide label arrays are narrowed to H x W by indexing (SpatialNarrowAs).
+ * dhead gets the gradient of (loss_cls + loss_bbox) for every channel; loss2[0] += loss_cls, loss2[1] += loss_bbox. */
+int dat_rpn_loss(dat_ctx* ctx, dat_stream s, int dtype, const void* head, void* dhead, int N, int H, int W, int cstride, int A,
+                 int logit_off, int delta_off, const int* labels_wide, const float* targets_wide, const float* inside_wide,
+                 const float* outside_wide, int Hw, int Ww, float cls_scale_over_norm, float bbox_beta,
+                 float bbox_scale_over_n, float* loss2);
+/* SmoothL1Loss on row-major predictions [R, ld] (D used columns); *loss += scale_over_n * sum(out * l(in * (pred - tgt))) */
+int dat_smooth_l1_rows(dat_ctx* ctx, dat_stream s, int dtype, const void* pred, int ld, const float* targets, const float* inside,
+                       const float* outside, int R, int D, float beta, float scale_over_n, void* dpred, float* loss);
+/* SoftmaxWithLoss over rows [R, ld] (D classes), labels int32 [R], optional weights [R]; dlogits [R, dl_ld] in dl_dtype;
+ * *loss += scale_over_norm * sum_i -w_i log p_i[label_i]; *correct += #(argmax == label) when non-NULL (Accuracy op). */
+int dat_softmax_ce_rows(dat_ctx* ctx, dat_stream s, int dtype, const void* logits, int ld, const int* labels, const float* weights,
+                        int R, int D, float scale_over_norm, int dl_dtype, void* dlogits, int dl_ld, float* loss, int* correct);
 /* MomentumSGDUpdate + the reference's gradient pre-processing (model_builder.py:954-985): biases: grad *= 2, no decay;
  * weights: grad += weight_decay * w;  v = momentum*v + lr*grad;  w -= v.  All fp32. */
 int dat_sgd_momentum(dat_ctx* ctx, dat_stream s, float* w, float* v, const float* grad, long long n, float lr, float momentum,

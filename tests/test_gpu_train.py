@@ -123,3 +123,88 @@ def test_sgd_momentum_matches_reference_update(ops):
         ops.sgd_momentum(wd_, vd, gd, lr, mu, wd, is_bias)
         np.testing.assert_allclose(vd.cpu().numpy(), nv.numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(wd_.cpu().numpy(), nw.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_losses_match_torch(ops):
+    g = torch.Generator().manual_seed(9)
+    # ---- RPN: sigmoid CE (ignore = -1) + smooth L1 on a fused head tensor, labels "wide" and narrowed by indexing ----
+    N, H, W, A, cs = 1, 7, 9, 3, 64
+    Hw, Ww = 8, 12
+    head = torch.randn((N, H, W, cs), generator=g)
+    labels = torch.randint(-1, 2, (N, A, Hw, Ww), generator=g, dtype=torch.int32)
+    tgt = torch.randn((N, 4 * A, Hw, Ww), generator=g)
+    w_in = (torch.rand((N, 4 * A, Hw, Ww), generator=g) > 0.5).float()
+    w_out = w_in * 0.125
+    cls_mult, beta, bbox_mult = 1.0 / 256, 1.0 / 9, 0.5
+    hr = head.clone().requires_grad_(True)
+    logit = hr[..., :A].permute(0, 3, 1, 2)
+    lab = labels[:, :, :H, :W]
+    valid = lab >= 0
+    l_cls = (F.binary_cross_entropy_with_logits(logit, lab.clamp(min=0).float(), reduction='none') * valid).sum() * cls_mult
+    d = hr[..., A:5 * A].permute(0, 3, 1, 2)
+    v = w_in[:, :, :H, :W] * (d - tgt[:, :, :H, :W])
+    l1 = torch.where(v.abs() < beta, 0.5 * v * v / beta, v.abs() - 0.5 * beta)
+    l_box = (w_out[:, :, :H, :W] * l1).sum() * bbox_mult
+    (l_cls + l_box).backward()
+    loss2 = torch.zeros(2).cuda()
+    dhead = ops.rpn_loss(head.cuda(), ops.F32, A, 0, A, labels.cuda(), tgt.cuda(), w_in.cuda(), w_out.cuda(), cls_mult, beta,
+                         bbox_mult, loss2)
+    np.testing.assert_allclose(loss2.cpu().numpy(), [l_cls.item(), l_box.item()], rtol=1e-5)
+    np.testing.assert_allclose(dhead.cpu().numpy(), hr.grad.numpy(), atol=1e-7)
+    # ---- smooth L1 rows (box head) ----
+    R, D, ld = 37, 8, 64
+    pred = torch.randn((1, 1, R, ld), generator=g)
+    t2, wi2 = torch.randn((R, D), generator=g), (torch.rand((R, D), generator=g) > 0.3).float()
+    wo2 = wi2 * 0.01
+    pr = pred.clone().requires_grad_(True)
+    v = wi2 * (pr[0, 0, :, :D] - t2)
+    ref = (wo2 * torch.where(v.abs() < 1.0, 0.5 * v * v, v.abs() - 0.5)).sum() * 0.25
+    ref.backward()
+    loss = torch.zeros(1).cuda()
+    dp = ops.smooth_l1_rows(pred.cuda(), ops.F32, D, t2.cuda(), wi2.cuda(), wo2.cuda(), 1.0, 0.25, loss)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(dp.cpu().numpy(), pr.grad.numpy(), atol=1e-7)
+    # ---- softmax CE rows: classes (no weights) and spatial 56*56 (weights) ----
+    for R, D, ld, weighted in ((50, 2, 64, False), (34, 3136, 3136, True)):
+        logits = torch.randn((R, ld), generator=g) * 3
+        lab = torch.randint(0, D, (R,), generator=g, dtype=torch.int32)
+        w = (torch.rand(R, generator=g) > 0.4).float() if weighted else None
+        norm = float(w.sum()) if weighted else float(R)
+        lr_ = logits.clone().requires_grad_(True)
+        nll = F.cross_entropy(lr_[:, :D], lab.long(), reduction='none')
+        ref = ((nll * w).sum() if weighted else nll.sum()) / norm * 0.5
+        ref.backward()
+        loss = torch.zeros(1).cuda()
+        correct = torch.zeros(1, dtype=torch.int32).cuda()
+        dl = ops.softmax_ce_rows(logits.cuda(), ops.F32, D, lab.cuda(), None if w is None else w.cuda(), 0.5 / norm, loss, correct)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), lr_.grad.numpy(), atol=1e-7)
+        assert correct.item() == int((logits[:, :D].argmax(1) == lab.long()).sum())
+
+
+def test_roi_align_and_kps_tail_backward(ops):
+    """Adjoint tests: <f(x), u> == <x, f^T(u)> for the two linear ops (RoIAlign over 2 FPN levels, keypoint tail)."""
+    g = torch.Generator().manual_seed(4)
+    C = 64
+    feats = [torch.randn((2, 24, 32, C), generator=g).cuda(), torch.randn((2, 12, 16, C), generator=g).cuda()]
+    rois = torch.tensor([[0, 4.3, 5.1, 60.7, 70.2], [1, 10.0, 3.0, 200.0, 150.0], [0, 100.5, 40.2, 127.0, 95.0],
+                         [1, -3.0, -2.0, 30.0, 20.0]], dtype=torch.float32).cuda()
+    scales = [0.25, 0.125]
+    y = ops.roi_align(feats, scales, ops.F32, rois, T=1, Tr=1, t0=0, pooled=7, sampling=2, k_min=2, canon_scale=56., canon_level=3)
+    u = torch.randn(y.shape, generator=g).cuda()
+    dfeats = [torch.zeros_like(f) for f in feats]
+    ops.roi_align_bwd(dfeats, scales, ops.F32, rois, u, T=1, Tr=1, t0=0, pooled=7, sampling=2, k_min=2, canon_scale=56.,
+                      canon_level=3)
+    lhs = (y * u).sum().item()
+    rhs = sum((f * d).sum().item() for f, d in zip(feats, dfeats))
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert all(d.abs().sum().item() > 0 for d in dfeats)
+    R, Tr, S, cs, K, up = 3, 2, 14, 128, 17, 2
+    sub = torch.randn((R * Tr, S, S, cs), generator=g).cuda()
+    out = ops.kps_finalize(sub, ops.F32, R, Tr, K, up)
+    u = torch.randn(out.shape, generator=g).cuda()
+    dsub = ops.kps_finalize_bwd(u, ops.F32, R, Tr, S, cs, K, up)
+    lhs = (out * u).sum().item()
+    rhs = (sub[..., :4 * K] * dsub[..., :4 * K]).sum().item()
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert dsub[..., 4 * K:].abs().max().item() == 0
