@@ -70,6 +70,23 @@ def add_fpn_rpn_outputs(model, blobs_in, dim_in, spatial_scales, time_dim=1):
                                     anchors=anchors, spatial_scale=sc)
 
 
+def add_fpn_rpn_losses(model, time_dim=1):
+    """:282-321 (shared with FPN3D): per level SigmoidCrossEntropyLoss on the objectness logits (normalize = 0, scaled by
+    1 / NUM_GPUS / RPN_BATCH_SIZE_PER_IM / IMS_PER_BATCH) and SmoothL1Loss (beta 1/9) on the deltas; the full-sized
+    ("wide") label arrays of the data loader are narrowed to the level's H x W inside the loss kernel."""
+    from detectandtrack_amd.modeling.detector import Op
+    for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1):
+        s = str(lvl)
+        model.net.add(Op('RpnLoss',
+                         ['rpn_cls_logits_fpn' + s, 'rpn_bbox_pred_fpn' + s, 'rpn_labels_int32_wide_fpn' + s,
+                          'rpn_bbox_targets_wide_fpn' + s, 'rpn_bbox_inside_weights_wide_fpn' + s,
+                          'rpn_bbox_outside_weights_wide_fpn' + s],
+                         ['loss_rpn_cls_fpn' + s, 'loss_rpn_bbox_fpn' + s],
+                         cls_scale=1. / cfg.NUM_GPUS / cfg.TRAIN.RPN_BATCH_SIZE_PER_IM / cfg.TRAIN.IMS_PER_BATCH,
+                         normalize=0, beta=1. / 9., bbox_scale=1. / cfg.NUM_GPUS / time_dim))
+        model.losses = sorted(set(model.losses + ['loss_rpn_cls_fpn' + s, 'loss_rpn_bbox_fpn' + s]))
+
+
 def map_rois_to_fpn_levels(rois, k_min, k_max):
     """Eqn.(1) of the FPN paper on the (tube-mean) box area (reference :349-360)."""
     s = np.sqrt(box_utils.boxes_area(rois))

@@ -224,7 +224,9 @@ class DetectionModelHelper(object):
         return self.net.add(Op('Relu', [blob_in], [blob_out]))
 
     def StopGradient(self, blob_in, blob_out):
-        return str(blob_out)  # inference graph: no-op (ResNet3D.py:273-274)
+        """ResNet3D.py:273-274: no gradient flows below this blob (frozen conv1 / res2).  A marker: no kernel."""
+        self.net.add(Op('StopGradient', [str(blob_in)], [str(blob_out)]))
+        return str(blob_out)
 
     def MaxPool(self, blob_in, blob_out, kernels=None, pads=None, strides=None, kernel=None, pad=0, stride=1):
         if kernels is None:
@@ -307,7 +309,12 @@ class DetectionModelHelper(object):
               ['rpn_roi_probs_fpn%d' % l for l in range(k_min, k_max + 1)]
         outs = ['rois'] + ['rois_fpn%d' % l for l in range(cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL + 1)] + \
                ['rois_idx_restore_int32']
-        self.net.add(Op('CollectAndDistributeFpnRpnProposals', ins, outs))
+        if self.train:   # detector.py:185-196: also reads roidb + im_info and emits the sampled training blobs
+            ins += ['roidb', 'im_info']
+            outs = ['rois', 'labels_int32', 'bbox_targets', 'bbox_inside_weights', 'bbox_outside_weights']
+            if cfg.MODEL.KEYPOINTS_ON:
+                outs += ['keypoint_rois', 'keypoint_locations_int32', 'keypoint_weights', 'keypoint_loss_normalizer']
+        self.net.add(Op('CollectAndDistributeFpnRpnProposals', ins, outs, train=bool(self.train)))
         return outs
 
     def RoIFeatureTransform(self, blobs_in, blob_out, blob_rois='rois', method='RoIPoolF', resolution=7,

@@ -91,8 +91,10 @@ def time_pool_blobs(blob_conv, model, body_head_link):
 def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_func, add_roi_mask_head_func=None,
                                   add_roi_keypoint_head_func=None, freeze_conv_body=False):
     """:179-306 (single replica; the reference loops this over NUM_GPUS name scopes for training)."""
-    if model.train:
-        raise NotImplementedError('training graph (losses + data-parallel update) is the next hot-path row')
+    if model.train and (not cfg.FPN.FPN_ON or not cfg.MODEL.FASTER_RCNN or
+                        (cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '')):
+        raise NotImplementedError('training graph: end-to-end Faster R-CNN on FPN with 2D heads (2D models, or a 3D body '
+                                  'linked by slice-center / avg) is built; C4 / tube-head training is a next row')
     blob_conv, dim_conv, spatial_scale_conv = add_conv_body_func(model)
     if cfg.MODEL.VIDEO_ON:
         blob_conv = time_pool_blobs(blob_conv, model, cfg.VIDEO.BODY_HEAD_LINK)
@@ -106,6 +108,8 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
     if cfg.MODEL.FASTER_RCNN:
         if cfg.FPN.FPN_ON:
             fpn_lib.add_fpn_rpn_outputs(model, blob_conv, dim_conv, spatial_scale_conv, time_dim=out_time_dim)
+            if model.train:
+                FPN.add_fpn_rpn_losses(model, time_dim=out_time_dim)
             model.CollectAndDistributeFpnRpnProposals()
         else:
             add_rpn_outputs(model, blob_conv, dim_conv, spatial_scale_conv, nd=head_3d, time_dim=out_time_dim)
@@ -118,6 +122,8 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
 
     blob_frcn, dim_frcn, _ = add_roi_frcn_head_func(model, blob_conv, dim_conv, spatial_scale_conv)
     add_fast_rcnn_outputs(model, blob_frcn, dim_frcn, is_head_3d=head_3d, time_dim=out_time_dim)
+    if model.train:
+        add_fast_rcnn_losses(model, time_dim=out_time_dim)
 
     if cfg.MODEL.MASK_ON:
         raise NotImplementedError('mask branch out of scope (core/test.py:916-917 raises for tubes)')
@@ -126,11 +132,33 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
         n_bbox_ops = len(model.net.ops)
         blob_krcnn, dim_krcnn, _ = add_roi_keypoint_head_func(model, blob_conv, dim_conv, spatial_scale_conv)
         add_heatmap_outputs(model, blob_krcnn, dim_krcnn, time_dim=out_time_dim, is_head_3d=head_3d)
-        # inference: the keypoint branch is its own net, run only on the surviving detections (:264-267, :994-1021)
-        model.keypoint_net = Net('keypoint_net', model)
-        model.keypoint_net.ops = model.net.ops[n_bbox_ops:]
-        model.net.ops = model.net.ops[:n_bbox_ops]
+        if model.train:
+            # training: the keypoint branch stays in the main net and gets its loss (:269-273)
+            add_heatmap_losses(model, time_dim=out_time_dim)
+        else:
+            # inference: the keypoint branch is its own net, run only on the surviving detections (:264-267, :994-1021)
+            model.keypoint_net = Net('keypoint_net', model)
+            model.keypoint_net.ops = model.net.ops[n_bbox_ops:]
+            model.net.ops = model.net.ops[:n_bbox_ops]
     return model
+
+
+# ---- losses (:481-494, :873-889; RPN: FPN.py:282-321) -----------------------------------------------------------------
+def add_fast_rcnn_losses(model, time_dim=1):
+    model.net.add(_op('SoftmaxLoss', ['cls_score', 'labels_int32'], ['cls_prob', 'loss_cls', 'accuracy_cls'],
+                      scale=1. / cfg.NUM_GPUS))
+    model.net.add(_op('SmoothL1Loss', ['bbox_pred', 'bbox_targets', 'bbox_inside_weights', 'bbox_outside_weights'],
+                      ['loss_bbox'], beta=1.0, scale=1. / cfg.NUM_GPUS / time_dim))
+    model.losses = sorted(set(model.losses + ['loss_cls', 'loss_bbox']))
+    model.metrics = sorted(set(model.metrics + ['accuracy_cls']))
+
+
+def add_heatmap_losses(model, time_dim=1):
+    """kps_score (R, K, M, M) -> (R*K, M*M) rows; SoftmaxWithLoss across SPACE with per-keypoint weights; the loss is
+    not scaled by time_dim (:884-887)."""
+    model.net.add(_op('KeypointLoss', ['kps_score', 'keypoint_locations_int32', 'keypoint_weights'],
+                      ['kps_prob', 'loss_kps'], scale=cfg.KRCNN.LOSS_WEIGHT / cfg.NUM_GPUS))
+    model.losses = sorted(set(model.losses + ['loss_kps']))
 
 
 # ---- Fast R-CNN outputs (:426-478) ----------------------------------------------------------------------------------
@@ -156,7 +184,8 @@ def add_fast_rcnn_outputs(model, blob_in, dim, is_head_3d, time_dim=1):
         model.net.add(_op('TubeDeltasToRows', [b], ['bbox_pred']))
     else:
         model.FC(blob_in, 'cls_score', dim, model.num_classes, weight_init=g01, bias_init=z)
-        model.Softmax('cls_score', 'cls_prob', engine='CUDNN')
+        if not model.train:   # training fuses the softmax into the loss for stability (:445-448)
+            model.Softmax('cls_score', 'cls_prob', engine='CUDNN')
         model.FC(blob_in, 'bbox_pred', dim, model.num_classes * 4, weight_init=g001, bias_init=z)
 
 

@@ -1,0 +1,430 @@
+"""Training executor: forward with losses, backward over the recorded graph, momentum-SGD update and
+the data-parallel gradient exchange.
+
+Reference: `model_builder.build_data_parallel_model` (:908-952: AddGradientOperators + NCCLAllreduce/muji) and
+`add_parameter_update_ops` (:954-985), losses :481-494 / :612-636 / :873-889 and FPN.py:282-321, run by
+tools/train_net.py:120-170.  Here one process drives one GPU: the backward pass walks the op list in reverse and launches
+the training kernels of `csrc/train_ops.hip` / `csrc/losses.hip` (conv weight gradient GEMMs, data gradient through the
+forward MFMA kernel, fused ReLU/bias backward, RoIAlign / FPN top-down / keypoint-tail backward, loss value + gradient),
+gradients are summed across ranks with ONE bucketed `torch.distributed.all_reduce` per bucket (RCCL over xGMI; the only
+collective on this path, losses are pre-divided by NUM_GPUS exactly like the reference) and every rank applies the
+identical local update.
+
+Gradient semantics follow the reference's ops: AffineChannelNd has no scale/bias gradient
+(lib/ops/affine_channel_nd_op.cc:29-37 'TODO'), StopGradient freezes conv1/res2 (ResNet3D.py:273-274), rois are
+constants (no gradient through GenerateProposals), biases get 2x gradient and no weight decay (:968-974).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from detectandtrack_amd.core.config import cfg
+from detectandtrack_amd.ops import hip_ops as ops
+from detectandtrack_amd.workspace import Executor, Blob, _dt, _w5, _count
+
+logger = logging.getLogger(__name__)
+
+
+class TrainExecutor(Executor):
+    """Forward (inherits the inference handlers) + loss ops + backward + update for one net on one workspace."""
+
+    def __init__(self, ws, net):
+        super(TrainExecutor, self).__init__(ws, net)
+        self.grads = {}          # blob name -> list of gradient tensors (blob layout; activation dtype or fp32)
+        self.param_grads = {}    # param name -> fp32 CUDA tensor (reference blob layout)
+        self.losses = {}         # loss blob name -> fp32 CUDA scalar tensor
+        self.metrics = {}
+        self._cg = {}
+        # blobs at or below the StopGradient marker (frozen trunk): no gradient is computed for them or their producers
+        self.no_grad = {'data'}
+        stop = [i for i, op in enumerate(net.ops) if op.type == 'StopGradient']
+        if stop:
+            for op in net.ops[:stop[-1] + 1]:
+                self.no_grad.update(op.outputs)
+
+    # ---- forward additions ---------------------------------------------------------------------------------------------
+    def op_StopGradient(self, i, op):
+        pass
+
+    def _head_blob_of(self, logits_name):
+        for first, (lo, do, gi) in self._fused.items():
+            if lo.outputs[0] == logits_name:
+                return lo.outputs[0] + '+' + do.outputs[0], lo, do
+        raise KeyError(logits_name)
+
+    def _loss_buf(self, names):
+        t = torch.zeros(len(names), dtype=torch.float32, device=self.ws.device)
+        for j, n in enumerate(names):
+            self.losses[n] = t[j:j + 1]
+        return t
+
+    def op_RpnLoss(self, i, op):
+        ws, a = self.ws, op.args
+        head_name, lo, do = self._head_blob_of(op.inputs[0])
+        head = ws.blobs[head_name]
+        A = lo.args['dim_out']
+        labels, tgt, w_in, w_out = [ws.blobs[n] for n in op.inputs[2:6]]
+        cls_mult = a['cls_scale']
+        if a['normalize']:
+            lab = labels.host if labels.host is not None else labels.t.cpu().numpy()
+            f, h, w, _ = head.t.shape
+            cls_mult /= max(1.0, float((lab[:, :, :h, :w] >= 0).sum()))
+        n_batch = head.N
+        loss2 = self._loss_buf(op.outputs)
+        dhead = ops.rpn_loss(head.t, head.dt, A, 0, A, labels.t, tgt.t, w_in.t, w_out.t, cls_mult, a['beta'],
+                             a['bbox_scale'] / n_batch, loss2)
+        self._add_grad(head_name, dhead)
+
+    def op_SoftmaxLoss(self, i, op):
+        ws, a = self.ws, op.args
+        x = ws.blobs[op.inputs[0]]            # rows [1,1,R,cs]
+        labels = ws.blobs[op.inputs[1]]
+        R = x.t.shape[2]
+        loss = self._loss_buf([op.outputs[1]])
+        correct = torch.zeros(1, dtype=torch.int32, device=ws.device)
+        d = ops.softmax_ce_rows(x.t, x.dt, x.C, labels.t, None, a['scale'] / max(R, 1), loss, correct)
+        self.metrics[op.outputs[2]] = (correct, R)
+        self._add_grad(op.inputs[0], d)
+
+    def op_SmoothL1Loss(self, i, op):
+        ws, a = self.ws, op.args
+        x = ws.blobs[op.inputs[0]]
+        tgt, w_in, w_out = [ws.blobs[n] for n in op.inputs[1:4]]
+        R = x.t.shape[2]
+        loss = self._loss_buf(op.outputs)
+        d = ops.smooth_l1_rows(x.t, x.dt, x.C, tgt.t, w_in.t, w_out.t, a['beta'], a['scale'] / max(R, 1), loss)
+        self._add_grad(op.inputs[0], d)
+
+    def op_KeypointLoss(self, i, op):
+        ws, a = self.ws, op.args
+        x = ws.blobs[op.inputs[0]]            # 'mat' fp32 [R, K, M, M]
+        loc, wts = ws.blobs[op.inputs[1]], ws.blobs[op.inputs[2]]
+        R, K, M, _ = x.t.shape
+        w_host = wts.host if wts.host is not None else wts.t.cpu().numpy()
+        norm = float(np.sum(w_host))
+        loss = self._loss_buf([op.outputs[1]])
+        logits = x.t.view(R * K, M * M)
+        mult = a['scale'] / norm if norm > 0 else 0.0
+        d = ops.softmax_ce_rows(logits, ops.F32, M * M, loc.t.view(-1), wts.t.view(-1), mult, loss)
+        self._add_grad(op.inputs[0], d.view(R, K, M, M))
+
+    def op_CollectAndDistributeFpnRpnProposals(self, i, op):
+        if not op.args.get('train'):
+            return super(TrainExecutor, self).op_CollectAndDistributeFpnRpnProposals(i, op)
+        ws = self.ws
+        self._run_rpn()
+        rois, probs, counts = self._rpn_out
+        out, n_out = ops.collect_rois(rois, probs, counts, cfg.TRAIN.RPN_POST_NMS_TOP_N)
+        rois_np = out[:int(n_out.item())].cpu().numpy()
+        im_info = ws.blobs['im_info']
+        info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
+        sampler = getattr(ws, 'train_sampler', None)
+        assert sampler is not None, 'training needs ws.train_sampler(rois, im_info) -> dict of sampled blobs ' \
+                                    '(roi_data.fast_rcnn.add_fast_rcnn_blobs on the roidb entry of this clip)'
+        blobs = sampler(rois_np, info)
+        for name in op.outputs:
+            if name in blobs:
+                ws.FeedBlob(name, np.ascontiguousarray(blobs[name]))
+
+    # ---- gradient bookkeeping ---------------------------------------------------------------------------------------------
+    def _add_grad(self, name, t):
+        self.grads.setdefault(name, []).append(t)
+
+    def _take_grad(self, name, dtype):
+        """-> (dy, dy2 | None) in the activation dtype, or (None, None)."""
+        lst = self.grads.pop(name, None)
+        if not lst:
+            return None, None
+        tdt = ops.tdtype(dtype)
+        lst = [t if t.dtype == tdt else t.to(tdt) for t in lst]
+        while len(lst) > 2:
+            b = lst.pop()
+            lst[-1] = lst[-1] + b
+        return lst[0], (lst[1] if len(lst) > 1 else None)
+
+    def _pgrad(self, name, t):
+        t = t.reshape(self.ws.params[name].shape) if name in self.ws.params else t
+        if name in self.param_grads:
+            self.param_grads[name] += t
+        else:
+            self.param_grads[name] = t.clone()
+
+    def _master(self, name):
+        """fp32 device master copy of a parameter (reference blob layout)."""
+        return self.ws.dev_param(name)
+
+    def _trainable(self, pname):
+        h = self.net._helper
+        return pname is not None and pname in set(h.TrainableParams())
+
+    # ---- backward -----------------------------------------------------------------------------------------------------------
+    def backward(self):
+        for i in range(len(self.net.ops) - 1, -1, -1):
+            op = self.net.ops[i]
+            if i in self._skip and i not in self._fused:
+                continue
+            if op.outputs and all(o in self.no_grad for o in op.outputs):
+                continue
+            h = getattr(self, 'bwd_' + op.type, None)
+            if h is not None:
+                h(i, op)
+        self.grads.clear()
+
+    def _conv_grad(self, key, w5, scale, strides, pads, dt, x_cs, g_cs):
+        k = (self.net.name, key, x_cs, g_cs)
+        if k not in self._cg:
+            self._cg[k] = ops.ConvGrad(w5, scale, strides, pads, dt, x_cs, g_cs)
+        return self._cg[k]
+
+    def bwd_Conv(self, i, op):
+        ws, a = self.ws, op.args
+        if i in self._fused:
+            return self._bwd_rpn_head(i)
+        out = op.outputs[0]
+        y = ws.blobs[out]
+        dy, dy2 = self._take_grad(out, y.dt)
+        if dy is None:
+            return
+        xin = ws.blobs[op.inputs[0]]
+        assert not xin.t2c and y.keyframe is None, 'training with time->channel heads / key-frame DCE is not supported'
+        cout = a['dim_out']
+        train_b = a['b'] if (a['b'] and self._trainable(a['b'])) else None
+        dbias = torch.zeros(cout, dtype=torch.float32, device=ws.device) if train_b else None
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, cout, relu=a['relu'], dy2=dy2, dbias=dbias)
+        if train_b:
+            self._pgrad(train_b, dbias)
+        if a['residual']:
+            if a['res_mode'] == 2:
+                self._add_grad(a['residual'], ops.upsample2x_bwd(g, y.dt))
+            else:
+                self._add_grad(a['residual'], g)
+        w5 = self._master(a['w'])
+        w5 = w5 if w5.dim() == 5 else w5.unsqueeze(2)
+        scale = self._master(a['scale']) if a['scale'] else None
+        cg = self._conv_grad(i, w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
+        cg.w, cg.scale, cg._data_layer = w5.float(), scale, None     # weights change every iteration
+        if self._trainable(a['w']):
+            dW, _ = cg.weight(xin.t, g, xin.T)
+            self._pgrad(a['w'], dW)
+        if op.inputs[0] not in self.no_grad:
+            f, H, W, _ = xin.t.shape
+            self._add_grad(op.inputs[0], cg.data(g, xin.T, H, W))
+
+    def _bwd_rpn_head(self, i):
+        ws = self.ws
+        lo, do, gi = self._fused[i]
+        name = lo.outputs[0] + '+' + do.outputs[0]
+        y = ws.blobs[name]
+        dy, dy2 = self._take_grad(name, y.dt)
+        if dy is None:
+            return
+        xin = ws.blobs[lo.inputs[0]]
+        A, D = lo.args['dim_out'], do.args['dim_out']
+        dbias = torch.zeros(A + D, dtype=torch.float32, device=ws.device)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, A + D, relu=False, dy2=dy2, dbias=dbias)
+        w = torch.cat([self._master(lo.args['w']).reshape(A, -1), self._master(do.args['w']).reshape(D, -1)], dim=0)
+        w5 = w.view(A + D, -1, 1, 1, 1)
+        cg = self._conv_grad(('rpnhead', i), w5, None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
+        cg.w, cg._data_layer = w5.float(), None
+        dW, _ = cg.weight(xin.t, g, xin.T)
+        self._pgrad(lo.args['w'], dW[:A])
+        self._pgrad(do.args['w'], dW[A:])
+        self._pgrad(lo.args['b'], dbias[:A])
+        self._pgrad(do.args['b'], dbias[A:])
+        f, H, W, _ = xin.t.shape
+        self._add_grad(lo.inputs[0], cg.data(g, xin.T, H, W))
+
+    def bwd_FC(self, i, op):
+        ws, a = self.ws, op.args
+        out = op.outputs[0]
+        y = ws.blobs[out]
+        dy, dy2 = self._take_grad(out, y.dt)
+        if dy is None:
+            return
+        x = ws.blobs[op.inputs[0]]
+        dbias = torch.zeros(a['dim_out'], dtype=torch.float32, device=ws.device)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, a['dim_out'], relu=a['relu'], dy2=dy2, dbias=dbias)
+        self._pgrad(a['b'], dbias)
+        w = self._master(a['w'])
+        if x.kind == 'fmap':   # flattened RoI features: reference order (c, t, h, w), ours (t, h, w, c)
+            f, p, p2, cs = x.t.shape
+            xin = x.t.view(1, 1, f // x.T, x.T * p * p2 * cs)
+            wk = w.view(w.shape[0], x.C, x.T, p, p2).permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
+        else:
+            xin, wk = x.t, w
+        cin_real = wk.shape[1]
+        if xin.shape[3] != cin_real:     # channel-padded rows: pad the weight columns
+            wk = torch.nn.functional.pad(wk, (0, xin.shape[3] - cin_real))
+        cg = self._conv_grad(i, wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous(), None, (1, 1), (0, 0, 0), y.dt,
+                             xin.shape[3], g.shape[3])
+        cg.w, cg._data_layer = wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous().float(), None
+        dW, _ = cg.weight(xin, g, 1)
+        dW = dW.reshape(dW.shape[0], -1)[:, :cin_real]
+        if x.kind == 'fmap':
+            dW = dW.view(w.shape[0], x.T, p, p2, x.C).permute(0, 4, 1, 2, 3).reshape(w.shape)
+        self._pgrad(a['w'], dW)
+        if op.inputs[0] not in self.no_grad:
+            dx = cg.data(g, 1, 1, xin.shape[2])
+            if x.kind == 'fmap':
+                dx = dx[..., :cin_real].reshape(x.t.shape)
+            self._add_grad(op.inputs[0], dx)
+
+    def bwd_ConvTranspose(self, i, op):
+        ws, a = self.ws, op.args
+        out = op.outputs[0]
+        y = ws.blobs[out]
+        dy, dy2 = self._take_grad(out, y.dt)
+        if dy is None:
+            return
+        x = ws.blobs[op.inputs[0]]
+        K, Cin = a['dim_out'], a['dim_in']
+        dbias4 = torch.zeros(4 * K, dtype=torch.float32, device=ws.device)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, 4 * K, relu=False, dy2=dy2, dbias=dbias4)
+        self._pgrad(a['b'], dbias4.view(4, K).sum(0))
+        w = self._master(a['w'])                       # [Cin, K, 4, 4]
+        w3 = ops.deconv_k4s2_as_conv3x3(w)             # [4K, Cin, 1, 3, 3]
+        cg = self._conv_grad(i, w3, None, (1, 1), (0, 1, 1), y.dt, x.t.shape[3], g.shape[3])
+        cg.w, cg._data_layer = w3.float(), None
+        dW3, _ = cg.weight(x.t, g, 1)                  # [4K, Cin, 1, 3, 3]
+        # transpose of the sub-pixel weight map (elementwise.hip deconv_k4s2_weights_kernel): every (ky, kx) of the 4x4
+        # kernel appears exactly once, at sub-pixel (a, b) = ((ky+1)&1, (kx+1)&1), tap dy = (a + 1 - ky) / 2
+        dw = torch.zeros_like(w)
+        d4 = dW3.view(2, 2, K, Cin, 3, 3)
+        for ky in range(4):
+            aa = (ky + 1) & 1
+            ty = (aa + 1 - ky) // 2 + 1
+            for kx in range(4):
+                bb = (kx + 1) & 1
+                tx = (bb + 1 - kx) // 2 + 1
+                dw[:, :, ky, kx] = d4[aa, bb, :, :, ty, tx].t()
+        self._pgrad(a['w'], dw)
+        f, H, W, _ = x.t.shape
+        self._add_grad(op.inputs[0], cg.data(g, 1, H, W))
+
+    def bwd_BilinearInterpolation(self, i, op):
+        ws = self.ws
+        lst = self.grads.pop(op.outputs[0], None)
+        if not lst:
+            return
+        d = lst[0] if len(lst) == 1 else sum(lst[1:], lst[0])
+        x = ws.blobs[op.inputs[0]]
+        f, S, _, cs = x.t.shape
+        K, up = op.args['dim'], op.args['up_scale']
+        self._add_grad(op.inputs[0], ops.kps_finalize_bwd(d.contiguous(), x.dt, x.N, x.T, S, cs, K, up))
+
+    def bwd_TimeToBatch(self, i, op):
+        if op.outputs[0] in self.grads:
+            self.grads.setdefault(op.inputs[0], []).extend(self.grads.pop(op.outputs[0]))
+
+    bwd_Alias = bwd_TimeToBatch
+
+    def bwd_RoIFeatureTransform(self, i, op):
+        ws, a = self.ws, op.args
+        y = ws.blobs[op.outputs[0]]
+        dy, dy2 = self._take_grad(op.outputs[0], y.dt)
+        if dy is None:
+            return
+        if dy2 is not None:
+            dy = dy + dy2
+        names = op.inputs[:a['n_feat']]
+        feats = [ws.blobs[n] for n in names]
+        rois = ws.blobs[op.inputs[-1]]
+        rt = rois.t.view(-1, rois.t.shape[-1]).float().contiguous()
+        R = _count(rois) if rois.count is not None else rt.shape[0]
+        Tr = (rt.shape[1] - 1) // 4
+        accs = []
+        for n, f in zip(names, feats):
+            acc = None
+            for t in self.grads.get(n, []):
+                if t.dtype == torch.float32 and getattr(t, '_roi_acc', False):
+                    acc = t
+            if acc is None:
+                acc = torch.zeros(f.t.shape, dtype=torch.float32, device=ws.device)
+                acc._roi_acc = True
+                self._add_grad(n, acc)
+            accs.append(acc)
+        ops.roi_align_bwd(accs, a['scales'], y.dt, rt[:R], dy, T=feats[0].T, Tr=Tr, t0=0, pooled=a['resolution'],
+                          sampling=a['sampling_ratio'], k_min=cfg.FPN.ROI_MIN_LEVEL,
+                          canon_scale=float(cfg.FPN.ROI_CANONICAL_SCALE), canon_level=cfg.FPN.ROI_CANONICAL_LEVEL)
+
+    def bwd_SliceKeyFrame(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        dy, dy2 = self._take_grad(op.outputs[0], x.dt)
+        if dy is None:
+            return
+        if dy2 is not None:
+            dy = dy + dy2
+        k = op.args['keyframe']
+        g = torch.zeros_like(x.t)
+        f, h, w, c = x.t.shape
+        g.view(x.N, x.T, h, w, c)[:, k] = dy.view(x.N, h, w, c)
+        self._add_grad(op.inputs[0], g)
+
+    def bwd_MaxPool(self, i, op):
+        """Only the P6 'sub-sampling' pool (kernel 1, stride 2; FPN3D.py:155-164) sits above the frozen trunk."""
+        a = op.args
+        x = self.ws.blobs[op.inputs[0]]
+        dy, dy2 = self._take_grad(op.outputs[0], x.dt)
+        if dy is None:
+            return
+        assert a['k'] == 1 and a['stride'] == 2 and a['pad'] == 0, 'max-pool backward above the frozen trunk: P6 only'
+        if dy2 is not None:
+            dy = dy + dy2
+        g = torch.zeros_like(x.t)
+        g[:, ::2, ::2] = dy
+        self._add_grad(op.inputs[0], g)
+
+    # ---- update ---------------------------------------------------------------------------------------------------------------
+    def loss_values(self):
+        return {k: float(v.item()) for k, v in self.losses.items()}
+
+
+class Trainer(object):
+    """One training process (one GPU): forward + backward + gradient all-reduce + momentum SGD on device fp32 masters
+    (tools/train_net.py:120-170, model_builder.py:908-985)."""
+
+    BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound: few, large buckets
+
+    def __init__(self, model, ws, dist=None):
+        self.model, self.ws, self.dist = model, ws, dist
+        self.momentum = {}
+        self.trainable = list(model.TrainableParams())
+        self.biases = set(model.biases)
+        self.iter = 0
+
+    def step(self, lr):
+        ws = self.ws
+        ex = TrainExecutor(ws, self.model.net)
+        ex.run()
+        ex.backward()
+        grads = ex.param_grads
+        names = [n for n in self.trainable if n in grads]
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self._all_reduce([grads[n] for n in names])
+        for n in names:
+            w = ws.dev_param(n)
+            if n not in self.momentum:
+                self.momentum[n] = torch.zeros_like(w)
+            ops.sgd_momentum(w.view(-1), self.momentum[n].view(-1), grads[n].contiguous().view(-1), lr, cfg.SOLVER.MOMENTUM,
+                             cfg.SOLVER.WEIGHT_DECAY, n in self.biases)
+        ws._layers.clear()            # packed weights are re-derived from the updated device masters on the next forward
+        self.iter += 1
+        return ex
+
+    def _all_reduce(self, tensors):
+        """Bucketed sum all-reduce (losses are already divided by NUM_GPUS, model_builder.py:932-942)."""
+        bucket, size = [], 0
+        for t in tensors + [None]:
+            if t is None or size + t.numel() * 4 > self.BUCKET_BYTES:
+                if bucket:
+                    flat = torch.cat([b.reshape(-1) for b in bucket])
+                    self.dist.all_reduce(flat)
+                    off = 0
+                    for b in bucket:
+                        b.copy_(flat[off:off + b.numel()].view_as(b))
+                        off += b.numel()
+                bucket, size = [], 0
+            if t is not None:
+                bucket.append(t)
+                size += t.numel() * 4

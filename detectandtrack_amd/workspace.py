@@ -42,6 +42,7 @@ class Workspace(object):
         self._layers = {}       # (net name, op index) -> prepared ConvLayer etc.
         self._dev_params = {}
         self.conv_log = None    # when a list: (name, algorithmic flops) per conv launch (bench roofline leg)
+        self.train_sampler = None   # training: callable(rois, im_info) -> sampled Fast R-CNN blobs (training.py)
 
     # ---- reference workspace API -------------------------------------------------------------------------------
     def FeedBlob(self, name, arr):
@@ -103,6 +104,7 @@ class Workspace(object):
         w.blobs = {}
         w.params, w.nets, w._layers, w._dev_params = self.params, self.nets, self._layers, self._dev_params
         w.conv_log = None
+        w.train_sampler = self.train_sampler
         return w
 
     # ---- parameters -----------------------------------------------------------------------------------------------
@@ -115,6 +117,12 @@ class Workspace(object):
         self.params[name] = np.asarray(arr, dtype=np.float32)
         self._dev_params.pop(name, None)
         self._layers.clear()
+
+    def params_from_device(self, names=None):
+        """Copy the device fp32 masters (updated in place by training) back into the host parameter dict (checkpoints)."""
+        for n in (names if names is not None else list(self._dev_params)):
+            if n in self._dev_params:
+                self.params[n] = self._dev_params[n].cpu().numpy()
 
 
 def _unscoped(name):
@@ -133,6 +141,11 @@ def _dt():
 def _w5(w):
     w = np.asarray(w, dtype=np.float32)
     return w if w.ndim == 5 else w[:, :, None]  # 2D conv weight [o,i,k,k] -> [o,i,1,k,k]
+
+
+def _w5d(w):
+    """device variant: the fp32 master tensor (trained in place, training.Trainer) viewed as [o,i,kt,k,k]"""
+    return w if w.dim() == 5 else w.unsqueeze(2)
 
 
 class Executor(object):
@@ -258,7 +271,7 @@ class Executor(object):
             return self._conv_over_time_channels(i, op, xin)
 
         def build():
-            w = ops.torch.from_numpy(_w5(ws.params[a['w']])).to(ws.device)
+            w = _w5d(ws.dev_param(a['w']))
             scale = ws.dev_param(a['scale']) if a['scale'] else None
             bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
             return ops.ConvLayer(w, scale, bias, stride=a['strides'], pads=a['pads'], relu=a['relu'], dtype=dt,
@@ -290,10 +303,10 @@ class Executor(object):
         T, C = xin.T, xin.C
 
         def build():
-            w = np.asarray(ws.params[a['w']], dtype=np.float32).reshape(a['dim_out'], T, C, 1, 1).transpose(0, 2, 1, 3, 4)
+            w = ws.dev_param(a['w']).reshape(a['dim_out'], T, C, 1, 1).permute(0, 2, 1, 3, 4).contiguous()
             bias = ws.dev_param(a['b']) if a['b'] else None
-            return ops.ConvLayer(ops.torch.from_numpy(np.ascontiguousarray(w)).to(ws.device), None, bias, stride=(1, 1),
-                                 pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.t.shape[3])
+            return ops.ConvLayer(w, None, bias, stride=(1, 1), pads=(0, 0, 0), relu=a['relu'], dtype=dt,
+                                 cin_stride=xin.t.shape[3])
         layer = self._layer(i, build)
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
         y = layer(xin.t, T=T, out_t=(0, 1))
@@ -312,7 +325,7 @@ class Executor(object):
         def build():
             scale = ws.dev_param(a['scale']) if a['scale'] else None
             bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
-            lay = ops.stem_layer(ops.torch.from_numpy(_w5(ws.params[a['w']])).to(ws.device), scale, bias, dt)
+            lay = ops.stem_layer(_w5d(ws.dev_param(a['w'])), scale, bias, dt)
             lay.relu = a['relu']
             return lay
         layer = self._layer(i, build)
@@ -331,12 +344,12 @@ class Executor(object):
         A = lo.args['dim_out']
 
         def build():
-            w = np.concatenate([_w5(ws.params[lo.args['w']]), _w5(ws.params[do.args['w']])], axis=0)
+            w = torch.cat([_w5d(ws.dev_param(lo.args['w'])), _w5d(ws.dev_param(do.args['w']))], dim=0)
             if xin.t2c:   # [O, T*C, 1, 1, 1] over time-moved-to-channels -> [O, C, T, 1, 1]
-                w = np.ascontiguousarray(w.reshape(w.shape[0], xin.T, xin.C, 1, 1).transpose(0, 2, 1, 3, 4))
-            b = np.concatenate([ws.params[lo.args['b']], ws.params[do.args['b']]], axis=0)
-            return ops.ConvLayer(ops.torch.from_numpy(w).to(ws.device), None, ops.torch.from_numpy(b).to(ws.device),
-                                 stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt, cin_stride=xin.t.shape[3])
+                w = w.reshape(w.shape[0], xin.T, xin.C, 1, 1).permute(0, 2, 1, 3, 4).contiguous()
+            b = torch.cat([ws.dev_param(lo.args['b']), ws.dev_param(do.args['b'])], dim=0)
+            return ops.ConvLayer(w, None, b, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt,
+                                 cin_stride=xin.t.shape[3])
         layer = self._layer(('rpnhead', i), build)
         if xin.t2c:
             self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
@@ -375,6 +388,9 @@ class Executor(object):
 
     def op_TimeToBatch(self, i, op):
         self.ws.blobs[op.outputs[0]] = self.ws.blobs[op.inputs[0]]
+
+    def op_StopGradient(self, i, op):
+        pass   # marker for the training executor (ResNet3D.py:273-274); nothing to run
 
     def op_TimeToChannel(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
@@ -504,13 +520,12 @@ class Executor(object):
             xin, perm = x.t, None
 
         def build():
-            w = np.asarray(ws.params[a['w']], dtype=np.float32)
+            w = ws.dev_param(a['w'])
             if perm is not None:  # reference flattens NC[T]HW (c, t, h, w); our RoI features are (t, h, w, c)
                 c, tt, hh, ww = perm
-                w = w.reshape(w.shape[0], c, tt, hh, ww).transpose(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
-            return ops.ConvLayer(ops.torch.from_numpy(np.ascontiguousarray(w[:, :, None, None, None])).to(ws.device), None,
-                                 ws.dev_param(a['b']), stride=(1, 1), pads=(0, 0, 0), relu=a['relu'], dtype=dt,
-                                 cin_stride=xin.shape[3])
+                w = w.reshape(w.shape[0], c, tt, hh, ww).permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
+            return ops.ConvLayer(w.reshape(w.shape[0], -1, 1, 1, 1).contiguous(), None, ws.dev_param(a['b']), stride=(1, 1),
+                                 pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.shape[3])
         layer = self._layer(i, build)
         self._log_conv(op.outputs[0], layer, 1, 1, xin.shape[2])
         y = layer(xin, T=1)

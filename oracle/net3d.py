@@ -29,6 +29,8 @@ from .roi_align import roi_align_2d, roi_align_tube
 
 
 def _t(a):
+    if isinstance(a, torch.Tensor):   # oracle/train_ref.py passes leaf tensors so that autograd sees the weights
+        return a
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 

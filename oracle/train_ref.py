@@ -1,0 +1,116 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): torch-autograd restatement of the reference's TRAINING graph for the
+FPN / 2D-head keypoint R-CNN, used to check the HIP backward pass parameter by parameter.
+
+Follows lib/modeling/model_builder.py:179-306 (train branch), losses :481-494, :873-889, FPN.py:282-321; loss op
+semantics restated from the public Caffe2 / Detectron operators (SigmoidCrossEntropyLoss with -1 = ignore,
+SmoothL1Loss with inside/outside weights normalised by dim 0, SoftmaxWithLoss normalised by N or by the weight sum).
+Parity status: unpinned (no reference implementation of these Caffe2 ops exists in the tree).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import proposals as prop
+from .net3d import Net
+
+
+def roi_align_2d_torch(feat, rois, pooled, spatial_scale, sampling_ratio):
+    """Differentiable legacy RoIAlign (oracle/roi_align.py roi_align_2d restated with torch gathers).
+    feat (N, C, H, W) tensor, rois (R, 5) ndarray -> (R, C, P, P)."""
+    N, C, H, W = feat.shape
+    outs = []
+    sc = np.float32(spatial_scale)
+    for r in range(rois.shape[0]):
+        b = int(rois[r, 0])
+        x1, y1, x2, y2 = [np.float32(v) * sc for v in rois[r, 1:5]]
+        rw = np.float32(max(x2 - x1, np.float32(1.)))
+        rh = np.float32(max(y2 - y1, np.float32(1.)))
+        bh, bw = rh / np.float32(pooled), rw / np.float32(pooled)
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / pooled))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / pooled))
+        ys = (y1 + np.arange(pooled, dtype=np.float32)[:, None] * bh +
+              (np.arange(gh, dtype=np.float32)[None, :] + np.float32(.5)) * bh / np.float32(gh)).reshape(-1)
+        xs = (x1 + np.arange(pooled, dtype=np.float32)[:, None] * bw +
+              (np.arange(gw, dtype=np.float32)[None, :] + np.float32(.5)) * bw / np.float32(gw)).reshape(-1)
+
+        def axis(v, size):
+            valid = (v >= -1.0) & (v <= size)
+            v = np.maximum(v, 0)
+            lo = v.astype(np.int64)
+            hi = lo + 1
+            edge = lo >= size - 1
+            lo = np.where(edge, size - 1, lo)
+            hi = np.where(edge, size - 1, hi)
+            v = np.where(edge, lo.astype(np.float32), v)
+            l = (v - lo).astype(np.float32)
+            return lo, hi, l, valid
+        ylo, yhi, ly, yv = axis(ys, H)
+        xlo, xhi, lx, xv = axis(xs, W)
+        f = feat[b]
+        ly_t, lx_t = torch.from_numpy(ly)[:, None], torch.from_numpy(lx)[None, :]
+        v = ((1 - ly_t) * (1 - lx_t)) * f[:, ylo][:, :, xlo] + ((1 - ly_t) * lx_t) * f[:, ylo][:, :, xhi] + \
+            (ly_t * (1 - lx_t)) * f[:, yhi][:, :, xlo] + (ly_t * lx_t) * f[:, yhi][:, :, xhi]
+        v = v * torch.from_numpy((yv[:, None] & xv[None, :]).astype(np.float32))
+        v = v.view(C, pooled, gh, pooled, gw).sum(dim=(2, 4)) / float(gh * gw)
+        outs.append(v)
+    return torch.stack(outs) if outs else feat.new_zeros((0, C, pooled, pooled))
+
+
+def roi_feat_fpn_torch(levels_p5_to_p2, rois, pooled, sampling):
+    lvls = prop.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+    out = [None] * rois.shape[0]
+    for lvl in range(2, 6):
+        idx = np.where(lvls == lvl)[0]
+        if len(idx) == 0:
+            continue
+        f = roi_align_2d_torch(levels_p5_to_p2[5 - lvl], rois[idx], pooled, 1. / 2. ** lvl, sampling)
+        for j, i in enumerate(idx):
+            out[i] = f[j]
+    return torch.stack(out)
+
+
+def smooth_l1(pred, tgt, w_in, w_out, beta):
+    v = w_in * (pred - tgt)
+    return (w_out * torch.where(v.abs() < beta, 0.5 * v * v / beta, v.abs() - 0.5 * beta)).sum()
+
+
+def training_losses(weights, opts, data, im_info, labels, sampled, cfg_scalars):
+    """weights: dict name -> torch leaf tensors; labels: dict of the 'wide' RPN label arrays per level; sampled: dict with
+    rois, labels_int32, bbox_targets, bbox_inside_weights, bbox_outside_weights, keypoint_rois, keypoint_locations_int32,
+    keypoint_weights.  cfg_scalars: num_gpus, rpn_batch, ims_per_batch, kps_loss_weight.  Returns dict loss name -> tensor."""
+    net = Net(weights, opts)
+    net.body(torch.from_numpy(data))
+    p2d = net.time_link(net.fpn())                    # [P6, P5, P4, P3, P2] 2-D maps
+    ng = cfg_scalars['num_gpus']
+    losses = {}
+    for lvl in range(2, 7):
+        x = p2d[6 - lvl]
+        h = F.relu(net.conv2d(x, 'conv_rpn_fpn2', 3, 1, 1))
+        logits = net.conv2d(h, 'rpn_cls_logits_fpn2', 1)
+        deltas = net.conv2d(h, 'rpn_bbox_pred_fpn2', 1)
+        H, W = logits.shape[2:]
+        lab = torch.from_numpy(labels['rpn_labels_int32_wide_fpn%d' % lvl][:, :, :H, :W])
+        valid = (lab >= 0).float()
+        ce = F.binary_cross_entropy_with_logits(logits, lab.clamp(min=0).float(), reduction='none')
+        losses['loss_rpn_cls_fpn%d' % lvl] = (ce * valid).sum() / ng / cfg_scalars['rpn_batch'] / cfg_scalars['ims_per_batch']
+        t, wi, wo = [torch.from_numpy(labels['rpn_bbox_%s_wide_fpn%d' % (k, lvl)][:, :, :H, :W])
+                     for k in ('targets', 'inside_weights', 'outside_weights')]
+        losses['loss_rpn_bbox_fpn%d' % lvl] = smooth_l1(deltas, t, wi, wo, 1. / 9.) / logits.shape[0] / ng
+    rois = sampled['rois']
+    feat = roi_feat_fpn_torch(p2d[1:], rois, opts['frcn_res'], opts['frcn_sampling'])
+    x = F.relu(net.fc(feat, 'fc6'))
+    x = F.relu(net.fc(x, 'fc7'))
+    cls_score, bbox_pred = net.fc(x, 'cls_score'), net.fc(x, 'bbox_pred')
+    R = rois.shape[0]
+    losses['loss_cls'] = F.cross_entropy(cls_score, torch.from_numpy(sampled['labels_int32']).long(), reduction='sum') / R / ng
+    losses['loss_bbox'] = smooth_l1(bbox_pred, torch.from_numpy(sampled['bbox_targets']),
+                                    torch.from_numpy(sampled['bbox_inside_weights']),
+                                    torch.from_numpy(sampled['bbox_outside_weights']), 1.0) / R / ng
+    kfeat = roi_feat_fpn_torch(p2d[1:], sampled['keypoint_rois'], opts['kps_res'], opts['kps_sampling'])
+    kps = net.kps_head_2d(kfeat)                      # (Rk, K, M, M)
+    Rk, K, M, _ = kps.shape
+    w = torch.from_numpy(sampled['keypoint_weights']).reshape(-1)
+    nll = F.cross_entropy(kps.reshape(Rk * K, M * M), torch.from_numpy(sampled['keypoint_locations_int32']).reshape(-1).long(),
+                          reduction='none')
+    losses['loss_kps'] = (nll * w).sum() / w.sum() * cfg_scalars['kps_loss_weight'] / ng
+    return losses

@@ -208,3 +208,103 @@ def test_roi_align_and_kps_tail_backward(ops):
     rhs = (sub[..., :4 * K] * dsub[..., :4 * K]).sum().item()
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs)), (lhs, rhs)
     assert dsub[..., 4 * K:].abs().max().item() == 0
+
+
+def _synthetic_training_blobs(T, H, W, rs, n_rois=24, n_kp=4, K=17, M=56):
+    """Label blobs in the reference's layouts: 'wide' RPN labels per FPN level and the sampled Fast R-CNN / keypoint blobs."""
+    labels = {}
+    A = 3
+    for lvl in range(2, 7):
+        s = 2 ** lvl
+        hw, ww = int(np.ceil(H / float(s))) + 1, int(np.ceil(W / float(s))) + 2          # wider than the head output
+        lab = -np.ones((1, A, hw, ww), dtype=np.int32)
+        pick = rs.rand(1, A, hw, ww)
+        lab[pick < 0.25] = 0
+        lab[pick < 0.05] = 1
+        w_in = np.repeat((lab == 1).astype(np.float32), 4, axis=1)
+        labels['rpn_labels_int32_wide_fpn%d' % lvl] = lab
+        labels['rpn_bbox_targets_wide_fpn%d' % lvl] = (rs.randn(1, 4 * A, hw, ww) * 0.3).astype(np.float32)
+        labels['rpn_bbox_inside_weights_wide_fpn%d' % lvl] = w_in
+        labels['rpn_bbox_outside_weights_wide_fpn%d' % lvl] = w_in / 64.0
+    x1, y1 = rs.uniform(0, W * 0.6, n_rois), rs.uniform(0, H * 0.6, n_rois)
+    bw, bh = rs.uniform(6, W * 0.7, n_rois), rs.uniform(6, H * 0.7, n_rois)
+    rois = np.stack([np.zeros(n_rois), x1, y1, np.minimum(x1 + bw, W - 1), np.minimum(y1 + bh, H - 1)], 1).astype(np.float32)
+    lab = (rs.rand(n_rois) < 0.4).astype(np.int32)
+    tgt = np.zeros((n_rois, 8), np.float32)
+    w_in = np.zeros((n_rois, 8), np.float32)
+    tgt[lab == 1, 4:] = rs.randn(int(lab.sum()), 4) * 0.5
+    w_in[lab == 1, 4:] = 1.0
+    kp_rois = rois[np.where(lab == 1)[0][:n_kp]].copy()
+    sampled = {
+        'rois': rois, 'labels_int32': lab, 'bbox_targets': tgt, 'bbox_inside_weights': w_in,
+        'bbox_outside_weights': (w_in > 0).astype(np.float32), 'keypoint_rois': kp_rois,
+        'keypoint_locations_int32': rs.randint(0, M * M, (kp_rois.shape[0] * K, 1)).astype(np.int32),
+        'keypoint_weights': (rs.rand(kp_rois.shape[0] * K, 1) < 0.7).astype(np.float32),
+        'keypoint_loss_normalizer': np.array([1.0], np.float32),
+    }
+    return labels, sampled
+
+
+def test_train_step_gradients_match_oracle_autograd(ops):
+    """One forward + backward of the FPN3D / 2D-head keypoint R-CNN training graph (fp32 parity mode) against torch autograd
+    on the oracle's restatement: every loss value and the gradient of every trainable parameter."""
+    from tests.model_util import fpn3d_kps_cfg, build_product, synthetic_clip, oracle_opts
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.training import TrainExecutor
+    from oracle import train_ref
+    T, H, W = 2, 64, 96
+    c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=100, post=30)
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 100, 'RPN_POST_NMS_TOP_N': 30, 'IMS_PER_BATCH': 1}
+    c['NUM_GPUS'] = 1
+    from detectandtrack_amd.core.config import cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    weights = net_utils.synthetic_params(model, 3)
+    for k, v in weights.items():
+        ws.set_param(k, v)
+    rs = np.random.RandomState(7)
+    labels, sampled = _synthetic_training_blobs(T, H, W, rs)
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    for k, v in labels.items():
+        ws.FeedBlob(k, v)
+    ws.train_sampler = lambda rois, info: sampled
+    ex = TrainExecutor(ws, model.net)
+    ex.run()
+    ex.backward()
+    got_losses = ex.loss_values()
+
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True) for k, v in weights.items()}
+    ref_losses = train_ref.training_losses(
+        wt, oracle_opts('18', T, 3, 'slice-center', 100, 30), data, im_info, labels, sampled,
+        dict(num_gpus=1, rpn_batch=cfg.TRAIN.RPN_BATCH_SIZE_PER_IM, ims_per_batch=1, kps_loss_weight=cfg.KRCNN.LOSS_WEIGHT))
+    sum(ref_losses.values()).backward()
+    for k in sorted(ref_losses):
+        print('%-22s %.6f  (oracle %.6f)' % (k, got_losses[k], ref_losses[k].item()))
+        np.testing.assert_allclose(got_losses[k], ref_losses[k].item(), rtol=2e-4, atol=1e-6)
+    trainable = set(model.TrainableParams())
+    frozen_prefix = ('conv1', 'res_conv1', 'res2_')
+    checked = 0
+    for name in sorted(trainable):
+        if name.startswith(frozen_prefix):
+            assert name not in ex.param_grads, 'gradient for a parameter below StopGradient: ' + name
+            continue
+        assert name in ex.param_grads, 'no gradient for ' + name
+        ref = wt[name].grad
+        assert ref is not None, name
+        got = ex.param_grads[name].cpu()
+        denom = max(float(ref.abs().max()), 1e-8)
+        err = float((got - ref).abs().max()) / denom
+        assert err < 2e-3, '%s: rel err %.3e (|ref|max %.3e)' % (name, err, denom)
+        checked += 1
+    print('checked gradients of %d parameters' % checked)
+    assert checked > 40
