@@ -1,0 +1,130 @@
+"""RPN training labels per FPN level (reference lib/roi_data/rpn.py:82-387).
+
+For one clip: every anchor of the level-ordered "field of anchors" gets label 1 / 0 / -1 (fg: best anchor of each gt or
+IoU >= RPN_POSITIVE_OVERLAP; bg: IoU < RPN_NEGATIVE_OVERLAP; sub-sampled to RPN_BATCH_SIZE_PER_IM with at most
+RPN_FG_FRACTION foreground), fg anchors get bbox_transform_inv targets, inside weights 1 (x visibility), outside weights
+1 / #sampled.  Output arrays are "wide": field_size x field_size per level (the loss narrows them to the head's H x W).
+"""
+from collections import namedtuple
+
+import numpy as np
+import numpy.random as npr
+
+from detectandtrack_amd.core.config import cfg
+from detectandtrack_amd.modeling.generate_anchors import generate_anchors
+import detectandtrack_amd.utils.boxes as box_utils
+
+FieldOfAnchors = namedtuple('FieldOfAnchors', ['field_of_anchors', 'num_cell_anchors', 'stride', 'field_size'])
+_foa_cache = {}
+
+
+def get_field_of_anchors(stride, anchor_sizes, anchor_aspect_ratios, time_dim):
+    """:213-252: cell anchors shifted over a field_size^2 grid that covers TRAIN.MAX_SIZE padded to the coarsest stride."""
+    key = (stride, tuple(anchor_sizes), tuple(anchor_aspect_ratios), time_dim, cfg.TRAIN.MAX_SIZE, cfg.FPN.COARSEST_STRIDE)
+    if key in _foa_cache:
+        return _foa_cache[key]
+    cell = generate_anchors(stride=stride, sizes=anchor_sizes, aspect_ratios=anchor_aspect_ratios, time_dim=time_dim)
+    A = cell.shape[0]
+    fpn_max = cfg.FPN.COARSEST_STRIDE * np.ceil(cfg.TRAIN.MAX_SIZE / float(cfg.FPN.COARSEST_STRIDE))
+    field = int(np.ceil(fpn_max / float(stride)))
+    sh = np.arange(0, field) * stride
+    sx, sy = np.meshgrid(sh, sh)
+    shifts = np.vstack((sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel())).transpose()
+    shifts = np.tile(shifts, (1, time_dim))
+    K = shifts.shape[0]
+    foa_arr = (cell.reshape((1, A, 4 * time_dim)) + shifts.reshape((1, K, 4 * time_dim)).transpose((1, 0, 2)))
+    foa = FieldOfAnchors(foa_arr.reshape((K * A, 4 * time_dim)).astype(np.float32), A, stride, field)
+    _foa_cache[key] = foa
+    return foa
+
+
+def fpn_fields(time_dim):
+    k_max, k_min = cfg.FPN.RPN_MAX_LEVEL, cfg.FPN.RPN_MIN_LEVEL
+    return [get_field_of_anchors(2. ** lvl, (cfg.FPN.RPN_ANCHOR_START_SIZE * 2. ** (lvl - k_min),), cfg.FPN.RPN_ASPECT_RATIOS,
+                                 time_dim) for lvl in range(k_min, k_max + 1)]
+
+
+def _unmap(data, count, inds, fill=0):
+    if count == len(inds):
+        return data
+    ret = np.full((count,) + data.shape[1:], fill, dtype=data.dtype)
+    ret[inds] = data
+    return ret
+
+
+def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=npr):
+    """:254-370 -> list (one dict per level) of rpn_labels_int32_wide (1, A, F, F), rpn_bbox_{targets,inside_weights,
+    outside_weights}_wide (1, 4TA, F, F)."""
+    all_anchors = np.concatenate([f.field_of_anchors for f in foas])
+    total = all_anchors.shape[0]
+    T = all_anchors.shape[1] // 4
+    st = cfg.TRAIN.RPN_STRADDLE_THRESH
+    if st >= 0:
+        inside = np.where(np.all(all_anchors[:, 0::4] >= -st, axis=1) & np.all(all_anchors[:, 1::4] >= -st, axis=1) &
+                          np.all(all_anchors[:, 2::4] < im_width + st, axis=1) &
+                          np.all(all_anchors[:, 3::4] < im_height + st, axis=1))[0]
+    else:
+        inside = np.arange(total)
+    anchors = all_anchors[inside]
+    n = len(inside)
+    labels = np.full((n,), -1, dtype=np.int32)
+    if visible_tracks is None:
+        visible_tracks = np.full((gt_boxes.shape[0], T), True)
+    a2g_max = np.zeros((n,), dtype=np.float32)
+    a2g_arg = np.zeros((n,), dtype=np.int64)
+    if len(gt_boxes) > 0 and n > 0:
+        ov = box_utils.bbox_overlaps(anchors, gt_boxes.astype(np.float32))
+        a2g_arg = ov.argmax(axis=1)
+        a2g_max = ov[np.arange(n), a2g_arg]
+        g2a_max = ov[ov.argmax(axis=0), np.arange(ov.shape[1])]
+        labels[np.where(ov == g2a_max)[0]] = 1          # every gt keeps its best anchor(s)
+        labels[a2g_max >= cfg.TRAIN.RPN_POSITIVE_OVERLAP] = 1
+    num_fg = int(cfg.TRAIN.RPN_FG_FRACTION * cfg.TRAIN.RPN_BATCH_SIZE_PER_IM)
+    fg = np.where(labels == 1)[0]
+    if len(fg) > num_fg:
+        labels[rng.choice(fg, size=(len(fg) - num_fg), replace=False)] = -1
+    fg = np.where(labels == 1)[0]
+    num_bg = cfg.TRAIN.RPN_BATCH_SIZE_PER_IM - np.sum(labels == 1)
+    bg = np.where(a2g_max < cfg.TRAIN.RPN_NEGATIVE_OVERLAP)[0]
+    if len(bg) > num_bg:
+        labels[bg[rng.randint(len(bg), size=num_bg)]] = 0
+    targets = np.zeros((n, 4 * T), dtype=np.float32)
+    w_in = np.zeros((n, 4 * T), dtype=np.float32)
+    w_out = np.zeros((n, 4 * T), dtype=np.float32)
+    if len(fg) > 0:
+        targets[fg] = box_utils.bbox_transform_inv(anchors[fg], gt_boxes[a2g_arg[fg]].astype(np.float32),
+                                                   (1.0, 1.0, 1.0, 1.0)).astype(np.float32)
+        w_in[fg] = np.repeat(visible_tracks[a2g_arg[fg]].astype(np.float32), 4, axis=1)
+    num_examples = max(int(np.sum(labels >= 0)), 1)
+    w_out[labels >= 0] = 1.0 / num_examples
+    labels = _unmap(labels, total, inside, fill=-1)
+    targets = _unmap(targets, total, inside)
+    w_in = _unmap(w_in, total, inside)
+    w_out = _unmap(w_out, total, inside)
+    out, start = [], 0
+    for foa in foas:
+        F, A = foa.field_size, foa.num_cell_anchors
+        end = start + F * F * A
+        out.append(dict(
+            rpn_labels_int32_wide=np.ascontiguousarray(labels[start:end].reshape((1, F, F, A)).transpose(0, 3, 1, 2)),
+            rpn_bbox_targets_wide=np.ascontiguousarray(targets[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2)),
+            rpn_bbox_inside_weights_wide=np.ascontiguousarray(w_in[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2)),
+            rpn_bbox_outside_weights_wide=np.ascontiguousarray(w_out[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2))))
+        start = end
+    return out
+
+
+def add_rpn_blobs(blobs, im_scale, entry, rng=npr):
+    """:138-199 for one clip (IMS_PER_BATCH = 1): fills rpn_*_wide_fpn<l> and im_info."""
+    T = entry['boxes'].shape[-1] // 4
+    foas = fpn_fields(T)
+    im_h, im_w = np.round(entry['height'] * im_scale), np.round(entry['width'] * im_scale)
+    gt = np.where((entry['gt_classes'] > 0) & (entry['is_crowd'] == 0))[0]
+    gt_rois = entry['boxes'][gt] * im_scale
+    vis = entry['track_visible'][gt] if 'track_visible' in entry else None
+    per_level = get_rpn_blobs(im_h, im_w, foas, gt_rois, vis, rng)
+    for i, lvl in enumerate(range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)):
+        for k, v in per_level[i].items():
+            blobs[k + '_fpn' + str(lvl)] = v
+    blobs['im_info'] = np.array([[im_h, im_w, im_scale]], dtype=np.float32)
+    return blobs

@@ -320,3 +320,39 @@ def test_multi_gpu_sharding_protocol_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     assert order == list(range(11)) and tmax == 2.0
+
+
+def _allreduce_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from detectandtrack_amd.training import Trainer
+    t = Trainer.__new__(Trainer)
+    t.dist = dist
+    t.BUCKET_BYTES = 4096          # force several buckets
+    g = torch.Generator().manual_seed(100 + rank)
+    tensors = [torch.randn(n, generator=g) for n in (7, 300, 1500, 64, 2000, 5)]
+    local = [x.clone() for x in tensors]
+    t._all_reduce(tensors)
+    q.put((rank, [x.numpy() for x in local], [x.numpy() for x in tensors]))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_buckets_gloo_world2():
+    """The training exchange step (model_builder.py:932-942): bucketed sum all-reduce over 2 ranks on the gloo backend."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+    (_, l0, r0), (_, l1, r1) = res
+    for a, b, x, y in zip(l0, l1, r0, r1):
+        np.testing.assert_allclose(x, a + b, rtol=1e-6)
+        np.testing.assert_allclose(y, a + b, rtol=1e-6)

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Training entry point — mirror of reference tools/train_net.py:60-170.
+
+    python tools/train_net.py --cfg configs/x.yaml [--iters N] [KEY VAL ...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_net.py --cfg ...
+
+One process per GPU; every rank trains on its own clips (NUM_GPUS in the config must equal the world size: the losses
+are divided by it, model_builder.py:932-942) and the gradients are summed with bucketed RCCL all-reduces before the
+identical local momentum-SGD update (training.Trainer).  The PoseTrack loader (lib/datasets, pycocotools) is not
+available offline: clips and ground truth come from roi_data.synthetic (seeded boxes + 17 keypoints per person), which
+has the roidb record layout, so a real loader only has to yield (frames, entry) pairs.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+import _path  # noqa
+from detectandtrack_amd.core.config import cfg, cfg_from_file, cfg_from_list, assert_and_infer_cfg, get_output_dir
+from detectandtrack_amd.modeling import model_builder
+from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+from detectandtrack_amd.utils import lr_policy, net as net_utils, dist as dist_utils
+from detectandtrack_amd import workspace
+from detectandtrack_amd.training import Trainer
+
+logger = logging.getLogger('train_net')
+
+
+def synthetic_clip_and_entry(T, h, w, seed):
+    rs = np.random.RandomState(seed)
+    frames = rs.randint(0, 255, (1, 3, T, h // 8 + 1, w // 8 + 1)).astype(np.float32)
+    data = np.repeat(np.repeat(frames, 8, axis=3), 8, axis=4)[:, :, :, :h, :w]
+    data = data - np.asarray(cfg.PIXEL_MEANS, dtype=np.float32).reshape(1, 3, 1, 1, 1)
+    return np.ascontiguousarray(data), synthetic.synthetic_roidb_entry(h, w, n_persons=4, seed=seed)
+
+
+def feed_clip(ws, data, entry, rng):
+    blobs = rpn_data.add_rpn_blobs({}, 1.0, entry, rng)
+    ws.FeedBlob('data', data)
+    for k, v in blobs.items():
+        ws.FeedBlob(k, v)
+    ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+
+
+def main():
+    logging.basicConfig(level=logging.INFO)
+    p = argparse.ArgumentParser(description='Train a detection network on the MI355X')
+    p.add_argument('--cfg', dest='cfg_file', required=True)
+    p.add_argument('--iters', type=int, default=0, help='override SOLVER.MAX_ITER')
+    p.add_argument('--height', type=int, default=256)
+    p.add_argument('--width', type=int, default=320)
+    p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
+    args = p.parse_args()
+    cfg_from_file(args.cfg_file)
+    if args.opts:
+        cfg_from_list(args.opts)
+    assert_and_infer_cfg()
+    rank, _local, world = dist_utils.env_rank_world()
+    dist = dist_utils.init_process_group() if world > 1 else None
+    assert cfg.NUM_GPUS == world, 'NUM_GPUS (%d) must equal the number of ranks (%d)' % (cfg.NUM_GPUS, world)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    ws = workspace.GlobalWorkspace()
+    if cfg.TRAIN.WEIGHTS and os.path.exists(cfg.TRAIN.WEIGHTS):
+        net_utils.initialize_from_weights_file(model, ws, cfg.TRAIN.WEIGHTS)
+    else:
+        net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)      # identical on every rank
+    trainer = Trainer(model, ws, dist)
+    T = max(cfg.VIDEO.NUM_FRAMES, 1) if cfg.MODEL.VIDEO_ON else 1
+    rng = np.random.RandomState(cfg.RNG_SEED + rank)
+    max_iter = args.iters or cfg.SOLVER.MAX_ITER
+    out_dir = get_output_dir(training=True)
+    t0 = time.time()
+    for it in range(max_iter):
+        lr = lr_policy.get_lr_at_iter(it)
+        data, entry = synthetic_clip_and_entry(T, args.height, args.width, seed=1000 * rank + it)
+        feed_clip(ws, data, entry, rng)
+        ex = trainer.step(lr)
+        if it % 20 == 0 or it == max_iter - 1:
+            lv = ex.loss_values()
+            logger.info('rank %d iter %d lr %.5f loss %.4f (%s) %.2f s/iter', rank, it, lr, sum(lv.values()),
+                        ' '.join('%s %.3f' % (k.replace('loss_', ''), v) for k, v in sorted(lv.items())),
+                        (time.time() - t0) / (it + 1))
+        if rank == 0 and (it + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+            ws.params_from_device()
+            net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_iter%d.pkl' % it), model, ws)
+    if rank == 0:
+        ws.params_from_device()
+        net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_final.pkl'), model, ws)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
