@@ -106,11 +106,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
     char* bt = smem + 128 * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave & 1, wave_n = wave >> 1;
+    // taps fastest, then channel tiles, K-split slowest: the blocks resident together read the SAME K-chunk of the gT / xT rows
+    // (a tap only shifts the xT window by a few elements), so the chunk is fetched from HBM once and re-read from L2
     unsigned bid = blockIdx.x;
-    const int split = bid % p.ksplit; bid /= p.ksplit;
+    const int tap = bid % p.ntaps; bid /= p.ntaps;
     const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
     const int co_t = bid % p.n_co_tiles;
-    const int tap = bid / p.n_co_tiles;
+    const int split = bid / p.n_co_tiles;
     const long long ksteps = p.K / CK;
     const long long s_lo = ksteps * split / p.ksplit, s_hi = ksteps * (split + 1) / p.ksplit;
 
@@ -174,7 +176,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
         }
     }
 #undef LOAD_TILES
-    // D[i = co][j = ci]: lane holds column ci = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // D[i = co][j = ci]: lane holds column ci = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Partial tiles go to Gt[tap][co][ci] (ci contiguous: a wave's 64 atomics land in 2 lines instead of 64); the finish kernel
+    // transposes to the reference weight layout.  With a single K split the tile is complete: plain stores.
+    float* Gt = p.G + (size_t)tap * p.Cout * p.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -184,9 +189,24 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_t * 128 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (co < p.Cout) atomicAdd(p.G + ((size_t)co * p.Cin + ci) * p.ntaps + tap, acc[i][j][r]);
+                if (co >= p.Cout) continue;
+                if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[i][j][r]);
+                else Gt[(size_t)co * p.Cin + ci] = acc[i][j][r];
             }
         }
+}
+
+// Gt[tap][co][ci] -> dW[co][ci][tap] * scale[co] (the fused AffineChannelNd scale; NULL = 1)
+__global__ void wgrad_finish_kernel(const float* __restrict__ Gt, const float* __restrict__ scale, float* __restrict__ dW, int Cout,
+                                    int Cin, int ntaps) {
+    const long long total = (long long)Cout * Cin * ntaps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % ntaps);
+        const long long r = i / ntaps;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float v = Gt[((size_t)tap * Cout + co) * Cin + ci];
+        dW[i] = scale ? v * scale[co] : v;
+    }
 }
 
 // ---- elementwise backward pieces -----------------------------------------------------------------------------------------------
@@ -206,16 +226,46 @@ __global__ void relu_bwd_kernel(const void* __restrict__ dy, const void* __restr
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long long pos = i / nq;
         const int c = (int)(i - pos * nq) * 4;
-        float v[4], o[4];
+        float v[4], o[4] = {1.f, 1.f, 1.f, 1.f};
+        const size_t at = (size_t)pos * cs + c;
+        if (DT == DAT_BF16) {
+            const uint2 a = ((const uint2*)dy)[at >> 2];
+            v[0] = bf2f((uint16_t)(a.x & 0xffff)); v[1] = bf2f((uint16_t)(a.x >> 16));
+            v[2] = bf2f((uint16_t)(a.y & 0xffff)); v[3] = bf2f((uint16_t)(a.y >> 16));
+            if (dy2) {
+                const uint2 b = ((const uint2*)dy2)[at >> 2];
+                v[0] += bf2f((uint16_t)(b.x & 0xffff)); v[1] += bf2f((uint16_t)(b.x >> 16));
+                v[2] += bf2f((uint16_t)(b.y & 0xffff)); v[3] += bf2f((uint16_t)(b.y >> 16));
+            }
+            if (relu) {
+                const uint2 q = ((const uint2*)y)[at >> 2];
+                o[0] = bf2f((uint16_t)(q.x & 0xffff)); o[1] = bf2f((uint16_t)(q.x >> 16));
+                o[2] = bf2f((uint16_t)(q.y & 0xffff)); o[3] = bf2f((uint16_t)(q.y >> 16));
+            }
+        } else {
+            const float4 a = ((const float4*)dy)[at >> 2];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            if (dy2) {
+                const float4 b = ((const float4*)dy2)[at >> 2];
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (relu) {
+                const float4 q = ((const float4*)y)[at >> 2];
+                o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = ElemOf<DT>::ld(dy, pos * cs + c + e);
-            if (dy2) v[e] += ElemOf<DT>::ld(dy2, pos * cs + c + e);
-            o[e] = relu ? ElemOf<DT>::ld(y, pos * cs + c + e) : 1.f;
-            if (relu && !(o[e] > 0.f)) v[e] = 0.f;
-            if (c + e >= C) v[e] = 0.f;
-            ElemOf<DT>::st(g, pos * cs + c + e, v[e]);
+            if ((relu && !(o[e] > 0.f)) || c + e >= C) v[e] = 0.f;
             s[e] += v[e];
+        }
+        if (DT == DAT_BF16) {
+            uint2 w;
+            w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            ((uint2*)g)[at >> 2] = w;
+        } else {
+            ((float4*)g)[at >> 2] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     if (!dbias) return;
@@ -436,11 +486,12 @@ size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, in
     wgrad_geom(d, &Ho, &Wo, &Tq, &Hq, &Wq, &Qtot, &Qa, &nc);
     const int s = d->stride_h;
     const size_t es = dat_esize(d->dtype);
-    return ((size_t)Cout_real + (size_t)Cin_real * s * s * nc) * (size_t)Qa * es + 256;
+    return ((size_t)Cout_real + (size_t)Cin_real * s * s * nc) * (size_t)Qa * es + 512 +
+           (size_t)Cout_real * Cin_real * d->KT * d->KH * d->KW * sizeof(float);
 }
 
 int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
-                     int Cin_real, int Cout_real, void* workspace, float* dW) {
+                     int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW) {
     DAT_ENFORCE(ctx, d && x && g && workspace && dW, "conv3d_wgrad: null argument");
     DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_wgrad: bad dtype %d", d->dtype);
     DAT_ENFORCE(ctx, d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2), "conv3d_wgrad: stride %dx%d", d->stride_h, d->stride_w);
@@ -457,6 +508,7 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     char* gT = (char*)workspace;
     char* xT = gT + (((size_t)Cout_real * Qa * es + 255) & ~(size_t)255);
     const size_t plane_bytes = (size_t)Cin_real * Qa * es;
+    float* Gt = (float*)(xT + (((size_t)s * s * nc * plane_bytes + 255) & ~(size_t)255));
 
     PackParams pp;
     pp.clips = clips; pp.Tq = Tq; pp.Hq = Hq; pp.Wq = Wq; pp.Qtot = Qtot; pp.Qa = Qa;
@@ -483,7 +535,7 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
 
     WgradParams wp;
     memset(&wp, 0, sizeof(wp));
-    wp.gT = gT; wp.xT = xT; wp.G = dW; wp.Cout = Cout_real; wp.Cin = Cin_real;
+    wp.gT = gT; wp.xT = xT; wp.G = Gt; wp.Cout = Cout_real; wp.Cin = Cin_real;
     wp.ntaps = d->KT * d->KH * d->KW; wp.Qa = Qa;
     const int ck = d->dtype == DAT_BF16 ? 64 : 32;
     wp.K = (Qtot + ck - 1) / ck * ck;
@@ -500,15 +552,18 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
             }
     const long long tiles = (long long)wp.ntaps * wp.n_co_tiles * wp.n_ci_tiles;
     const long long ksteps = wp.K / ck;
-    long long ks = (2048 + tiles - 1) / tiles;          // aim at ~4 blocks per CU slot
-    if (ks > ksteps / 8) ks = ksteps / 8;               // at least 8 K-steps per block
+    long long ks = 1024 / tiles;                        // ~2 rounds of the 512 resident blocks; every split costs a partial tile
+    if (ks > ksteps / 16) ks = ksteps / 16;             // at least 16 K-steps per block
     if (ks < 1) ks = 1;
     wp.ksplit = (int)ks;
-    if (hipMemsetAsync(dW, 0, (size_t)Cout_real * Cin_real * wp.ntaps * sizeof(float), st) != hipSuccess)
+    const size_t g_elems = (size_t)Cout_real * Cin_real * wp.ntaps;
+    if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
         DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
     const unsigned nblocks = (unsigned)(tiles * ks);
     if (d->dtype == DAT_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<DAT_BF16>, dim3(nblocks), dim3(NT), 0, st, wp);
     else hipLaunchKernelGGL(wgrad_gemm_kernel<DAT_F32>, dim3(nblocks), dim3(NT), 0, st, wp);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                       Cout_real, Cin_real, wp.ntaps);
     DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad gemm");
     return DAT_OK;
 }

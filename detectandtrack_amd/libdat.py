@@ -77,7 +77,7 @@ _PROTOS = {
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc), _i, _i]),
-    'dat_conv3d_wgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p, _p]),
+    'dat_conv3d_wgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p, _p, _p]),
     'dat_relu_bias_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i]),
     'dat_zero_insert2x': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i]),
     'dat_upsample2x_bwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i]),

@@ -211,19 +211,21 @@ class ConvGrad(object):
         d.relu, d.res_mode, d.out_t0, d.out_tn = 0, 0, 0, 0
         return d
 
-    def weight(self, x, g, T):
-        """x [frames,H,W,x_cstride], g [frames,Ho,Wo,g_cstride] -> (dW fp32 [Cout,Cin,KT,KH,KW], dscale fp32 [Cout] | None)"""
+    def weight(self, x, g, T, want_dscale=False):
+        """x [frames,H,W,x_cstride], g [frames,Ho,Wo,g_cstride] -> (dW fp32 [Cout,Cin,KT,KH,KW] (already x scale),
+        dscale fp32 [Cout] | None)"""
         frames, H, W, _ = x.shape
         d = self._fwd_desc(frames, T, H, W)
         nbytes = L.lib().dat_conv3d_wgrad_workspace_bytes(C.byref(d), self.cin, self.cout)
         wsb = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        G = torch.empty(self.w.shape, dtype=torch.float32, device=x.device)
+        dW = torch.empty(self.w.shape, dtype=torch.float32, device=x.device)
         ctx().call('dat_conv3d_wgrad', _stream(), C.byref(d), _ptr(x), _ptr(g), self.g_cstride, self.cin, self.cout,
-                   _ptr(wsb), _ptr(G))
-        if self.scale is None:
-            return G, None
-        dscale = (G * self.w).sum(dim=(1, 2, 3, 4))
-        return G * self.scale.view(-1, 1, 1, 1, 1), dscale
+                   _ptr(self.scale), _ptr(wsb), _ptr(dW))
+        if self.scale is None or not want_dscale:
+            return dW, None
+        # dL/dscale[c] = <w[c], G[c]> with G = dW / scale (the reference's AffineChannelNd has no such gradient; test hook)
+        dscale = (dW * self.w).sum(dim=(1, 2, 3, 4)) / self.scale
+        return dW, dscale
 
     def data(self, g, T, H, W, accumulate_into=None):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given)."""

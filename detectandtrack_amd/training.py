@@ -128,20 +128,34 @@ class TrainExecutor(Executor):
                 ws.FeedBlob(name, np.ascontiguousarray(blobs[name]))
 
     # ---- gradient bookkeeping ---------------------------------------------------------------------------------------------
-    def _add_grad(self, name, t):
-        self.grads.setdefault(name, []).append(t)
+    # A gradient of a T-frame feature map may cover only a WINDOW of frames [lo, lo + n) (everything else is exactly zero):
+    # with BODY_HEAD_LINK 'slice-center' the heads read one frame, so the FPN post-hoc convs (60 % of the forward FLOPs)
+    # receive a 1-frame gradient and hand a 3-frame gradient down; each kT = 3 conv widens the window by its temporal reach.
+    def _add_grad(self, name, t, lo=0):
+        self.grads.setdefault(name, []).append((t, lo))
 
     def _take_grad(self, name, dtype):
-        """-> (dy, dy2 | None) in the activation dtype, or (None, None)."""
+        """-> (dy, lo) with dy in the activation dtype covering frames [lo, lo + dy.shape[0]), or (None, 0)."""
         lst = self.grads.pop(name, None)
         if not lst:
-            return None, None
+            return None, 0
         tdt = ops.tdtype(dtype)
-        lst = [t if t.dtype == tdt else t.to(tdt) for t in lst]
-        while len(lst) > 2:
-            b = lst.pop()
-            lst[-1] = lst[-1] + b
-        return lst[0], (lst[1] if len(lst) > 1 else None)
+        lo = min(l for _, l in lst)
+        hi = max(l + t.shape[0] for t, l in lst)
+        if len(lst) == 1:
+            t, l = lst[0]
+            return (t if t.dtype == tdt else t.to(tdt)), l
+        acc = None
+        for t, l in lst:
+            if t.shape[0] == hi - lo and acc is None and t.dtype == tdt and not getattr(t, '_roi_acc', False):
+                acc = t.clone()
+                lst = [(a, b) for a, b in lst if a is not t]
+                break
+        if acc is None:
+            acc = torch.zeros((hi - lo,) + tuple(lst[0][0].shape[1:]), dtype=tdt, device=lst[0][0].device)
+        for t, l in lst:
+            acc[l - lo:l - lo + t.shape[0]] += t if t.dtype == tdt else t.to(tdt)
+        return acc, lo
 
     def _pgrad(self, name, t):
         t = t.reshape(self.ws.params[name].shape) if name in self.ws.params else t
@@ -171,62 +185,68 @@ class TrainExecutor(Executor):
                 h(i, op)
         self.grads.clear()
 
-    def _conv_grad(self, key, w5, scale, strides, pads, dt, x_cs, g_cs):
-        k = (self.net.name, key, x_cs, g_cs)
-        if k not in self._cg:
-            self._cg[k] = ops.ConvGrad(w5, scale, strides, pads, dt, x_cs, g_cs)
-        return self._cg[k]
-
     def bwd_Conv(self, i, op):
         ws, a = self.ws, op.args
         if i in self._fused:
             return self._bwd_rpn_head(i)
         out = op.outputs[0]
         y = ws.blobs[out]
-        dy, dy2 = self._take_grad(out, y.dt)
+        dy, lo = self._take_grad(out, y.dt)
         if dy is None:
             return
         xin = ws.blobs[op.inputs[0]]
         assert not xin.t2c and y.keyframe is None, 'training with time->channel heads / key-frame DCE is not supported'
+        n = dy.shape[0]
+        full = (lo == 0 and n == y.t.shape[0])
+        assert full or xin.N == 1, 'frame-window gradients assume one clip per forward (TRAIN.IMS_PER_BATCH 1)'
         cout = a['dim_out']
         train_b = a['b'] if (a['b'] and self._trainable(a['b'])) else None
         dbias = torch.zeros(cout, dtype=torch.float32, device=ws.device) if train_b else None
-        g = ops.relu_bias_bwd(dy, y.t, y.dt, cout, relu=a['relu'], dy2=dy2, dbias=dbias)
+        g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=a['relu'], dbias=dbias)
         if train_b:
             self._pgrad(train_b, dbias)
         if a['residual']:
             if a['res_mode'] == 2:
-                self._add_grad(a['residual'], ops.upsample2x_bwd(g, y.dt))
+                self._add_grad(a['residual'], ops.upsample2x_bwd(g, y.dt), lo)
             else:
-                self._add_grad(a['residual'], g)
+                self._add_grad(a['residual'], g, lo)
+        # frames of the input this gradient window reaches through the temporal taps
+        pt = a['pads'][0]
+        T = xin.T if xin.N == 1 else xin.t.shape[0]
+        ilo, ihi = (max(0, lo - pt), min(T, lo + n + pt)) if xin.N == 1 else (0, xin.t.shape[0])
+        x_win = xin.t[ilo:ihi]
+        if (ilo, ihi) != (lo, lo + n):
+            g_emb = torch.zeros((ihi - ilo,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            g_emb[lo - ilo:lo - ilo + n] = g
+        else:
+            g_emb = g
+        Tw = (ihi - ilo) if xin.N == 1 else xin.T
         w5 = self._master(a['w'])
         w5 = w5 if w5.dim() == 5 else w5.unsqueeze(2)
         scale = self._master(a['scale']) if a['scale'] else None
-        cg = self._conv_grad(i, w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
-        cg.w, cg.scale, cg._data_layer = w5.float(), scale, None     # weights change every iteration
+        cg = ops.ConvGrad(w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
         if self._trainable(a['w']):
-            dW, _ = cg.weight(xin.t, g, xin.T)
+            dW, _ = cg.weight(x_win, g_emb, Tw)
             self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             f, H, W, _ = xin.t.shape
-            self._add_grad(op.inputs[0], cg.data(g, xin.T, H, W))
+            self._add_grad(op.inputs[0], cg.data(g_emb, Tw, H, W), ilo)
 
     def _bwd_rpn_head(self, i):
         ws = self.ws
         lo, do, gi = self._fused[i]
         name = lo.outputs[0] + '+' + do.outputs[0]
         y = ws.blobs[name]
-        dy, dy2 = self._take_grad(name, y.dt)
+        dy, _lo = self._take_grad(name, y.dt)
         if dy is None:
             return
         xin = ws.blobs[lo.inputs[0]]
         A, D = lo.args['dim_out'], do.args['dim_out']
         dbias = torch.zeros(A + D, dtype=torch.float32, device=ws.device)
-        g = ops.relu_bias_bwd(dy, y.t, y.dt, A + D, relu=False, dy2=dy2, dbias=dbias)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, A + D, relu=False, dbias=dbias)
         w = torch.cat([self._master(lo.args['w']).reshape(A, -1), self._master(do.args['w']).reshape(D, -1)], dim=0)
         w5 = w.view(A + D, -1, 1, 1, 1)
-        cg = self._conv_grad(('rpnhead', i), w5, None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
-        cg.w, cg._data_layer = w5.float(), None
+        cg = ops.ConvGrad(w5, None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
         dW, _ = cg.weight(xin.t, g, xin.T)
         self._pgrad(lo.args['w'], dW[:A])
         self._pgrad(do.args['w'], dW[A:])
@@ -239,12 +259,12 @@ class TrainExecutor(Executor):
         ws, a = self.ws, op.args
         out = op.outputs[0]
         y = ws.blobs[out]
-        dy, dy2 = self._take_grad(out, y.dt)
+        dy, _lo = self._take_grad(out, y.dt)
         if dy is None:
             return
         x = ws.blobs[op.inputs[0]]
         dbias = torch.zeros(a['dim_out'], dtype=torch.float32, device=ws.device)
-        g = ops.relu_bias_bwd(dy, y.t, y.dt, a['dim_out'], relu=a['relu'], dy2=dy2, dbias=dbias)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, a['dim_out'], relu=a['relu'], dbias=dbias)
         self._pgrad(a['b'], dbias)
         w = self._master(a['w'])
         if x.kind == 'fmap':   # flattened RoI features: reference order (c, t, h, w), ours (t, h, w, c)
@@ -256,9 +276,8 @@ class TrainExecutor(Executor):
         cin_real = wk.shape[1]
         if xin.shape[3] != cin_real:     # channel-padded rows: pad the weight columns
             wk = torch.nn.functional.pad(wk, (0, xin.shape[3] - cin_real))
-        cg = self._conv_grad(i, wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous(), None, (1, 1), (0, 0, 0), y.dt,
-                             xin.shape[3], g.shape[3])
-        cg.w, cg._data_layer = wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous().float(), None
+        cg = ops.ConvGrad(wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous(), None, (1, 1), (0, 0, 0), y.dt, xin.shape[3],
+                          g.shape[3])
         dW, _ = cg.weight(xin, g, 1)
         dW = dW.reshape(dW.shape[0], -1)[:, :cin_real]
         if x.kind == 'fmap':
@@ -274,18 +293,17 @@ class TrainExecutor(Executor):
         ws, a = self.ws, op.args
         out = op.outputs[0]
         y = ws.blobs[out]
-        dy, dy2 = self._take_grad(out, y.dt)
+        dy, _lo = self._take_grad(out, y.dt)
         if dy is None:
             return
         x = ws.blobs[op.inputs[0]]
         K, Cin = a['dim_out'], a['dim_in']
         dbias4 = torch.zeros(4 * K, dtype=torch.float32, device=ws.device)
-        g = ops.relu_bias_bwd(dy, y.t, y.dt, 4 * K, relu=False, dy2=dy2, dbias=dbias4)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, 4 * K, relu=False, dbias=dbias4)
         self._pgrad(a['b'], dbias4.view(4, K).sum(0))
         w = self._master(a['w'])                       # [Cin, K, 4, 4]
         w3 = ops.deconv_k4s2_as_conv3x3(w)             # [4K, Cin, 1, 3, 3]
-        cg = self._conv_grad(i, w3, None, (1, 1), (0, 1, 1), y.dt, x.t.shape[3], g.shape[3])
-        cg.w, cg._data_layer = w3.float(), None
+        cg = ops.ConvGrad(w3, None, (1, 1), (0, 1, 1), y.dt, x.t.shape[3], g.shape[3])
         dW3, _ = cg.weight(x.t, g, 1)                  # [4K, Cin, 1, 3, 3]
         # transpose of the sub-pixel weight map (elementwise.hip deconv_k4s2_weights_kernel): every (ky, kx) of the 4x4
         # kernel appears exactly once, at sub-pixel (a, b) = ((ky+1)&1, (kx+1)&1), tap dy = (a + 1 - ky) / 2
@@ -304,10 +322,9 @@ class TrainExecutor(Executor):
 
     def bwd_BilinearInterpolation(self, i, op):
         ws = self.ws
-        lst = self.grads.pop(op.outputs[0], None)
-        if not lst:
+        d, _lo = self._take_grad(op.outputs[0], ops.F32)
+        if d is None:
             return
-        d = lst[0] if len(lst) == 1 else sum(lst[1:], lst[0])
         x = ws.blobs[op.inputs[0]]
         f, S, _, cs = x.t.shape
         K, up = op.args['dim'], op.args['up_scale']
@@ -322,11 +339,9 @@ class TrainExecutor(Executor):
     def bwd_RoIFeatureTransform(self, i, op):
         ws, a = self.ws, op.args
         y = ws.blobs[op.outputs[0]]
-        dy, dy2 = self._take_grad(op.outputs[0], y.dt)
+        dy, _lo = self._take_grad(op.outputs[0], y.dt)
         if dy is None:
             return
-        if dy2 is not None:
-            dy = dy + dy2
         names = op.inputs[:a['n_feat']]
         feats = [ws.blobs[n] for n in names]
         rois = ws.blobs[op.inputs[-1]]
@@ -336,7 +351,7 @@ class TrainExecutor(Executor):
         accs = []
         for n, f in zip(names, feats):
             acc = None
-            for t in self.grads.get(n, []):
+            for t, _l in self.grads.get(n, []):
                 if t.dtype == torch.float32 and getattr(t, '_roi_acc', False):
                     acc = t
             if acc is None:
@@ -350,12 +365,13 @@ class TrainExecutor(Executor):
 
     def bwd_SliceKeyFrame(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
-        dy, dy2 = self._take_grad(op.outputs[0], x.dt)
+        dy, _lo = self._take_grad(op.outputs[0], x.dt)
         if dy is None:
             return
-        if dy2 is not None:
-            dy = dy + dy2
         k = op.args['keyframe']
+        if x.N == 1:
+            self._add_grad(op.inputs[0], dy, k)          # a one-frame window: no zero-filled T-frame tensor
+            return
         g = torch.zeros_like(x.t)
         f, h, w, c = x.t.shape
         g.view(x.N, x.T, h, w, c)[:, k] = dy.view(x.N, h, w, c)
@@ -365,15 +381,13 @@ class TrainExecutor(Executor):
         """Only the P6 'sub-sampling' pool (kernel 1, stride 2; FPN3D.py:155-164) sits above the frozen trunk."""
         a = op.args
         x = self.ws.blobs[op.inputs[0]]
-        dy, dy2 = self._take_grad(op.outputs[0], x.dt)
+        dy, lo = self._take_grad(op.outputs[0], x.dt)
         if dy is None:
             return
         assert a['k'] == 1 and a['stride'] == 2 and a['pad'] == 0, 'max-pool backward above the frozen trunk: P6 only'
-        if dy2 is not None:
-            dy = dy + dy2
-        g = torch.zeros_like(x.t)
+        g = torch.zeros((dy.shape[0],) + tuple(x.t.shape[1:]), dtype=x.t.dtype, device=x.t.device)
         g[:, ::2, ::2] = dy
-        self._add_grad(op.inputs[0], g)
+        self._add_grad(op.inputs[0], g, lo)
 
     # ---- update ---------------------------------------------------------------------------------------------------------------
     def loss_values(self):

@@ -206,11 +206,12 @@ int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, con
 /* Weight gradient of a conv described like dat_conv3d_fwd (same-T, stride 1 or 2):
  *   dW[co][ci][kt][kh][kw] = sum_p g[p][co] * x[p (+) tap][ci]      (fp32, reference blob layout, overwritten)
  * x: the conv input NDHWC (channel stride d->Cin), g: gradient w.r.t. the conv output NDHWC (channel stride
- * g_cstride).  Replaces Caffe2's ConvGradient filter path reached through AddGradientOperators
+ * g_cstride); scale (fp32 [Cout] or NULL) multiplies row co: the fused AffineChannelNd scale when g is the gradient
+ * w.r.t. the affine OUTPUT.  Replaces Caffe2's ConvGradient filter path reached through AddGradientOperators
  * (model_builder.py:908-952).  workspace: dat_conv3d_wgrad_workspace_bytes() bytes of device memory. */
 size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, int Cout_real);
 int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
-                     int Cin_real, int Cout_real, void* workspace, float* dW);
+                     int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW);
 /* g = (dy [+ dy2]) * (y > 0 if relu) over [npos][cstride] (channels >= C zeroed); dbias[c] += sum_p g (may be NULL).
  * Relu backward on the fused conv's output + the bias / AffineChannelNd-bias reduction
  * (affine_channel_nd_op.cu:74-92). */

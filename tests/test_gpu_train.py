@@ -65,7 +65,7 @@ def test_conv_backward_matches_autograd(ops, case, dtype_name):
     xd = _ndhwc(x, cs_x, tdt)
     gd = _ndhwc(gy, cs_g, tdt)
     cg = ops.ConvGrad(w.cuda(), scale.cuda(), (st, st), pads, dt, cs_x, cs_g)
-    dW, dscale = cg.weight(xd, gd, T)
+    dW, dscale = cg.weight(xd, gd, T, want_dscale=True)
     tol = 2e-4 if dtype_name == 'fp32' else 2e-2
     ref_dw = wr.grad
     err = (dW.cpu() - ref_dw).abs().max() / max(ref_dw.abs().max(), 1e-6)
