@@ -213,6 +213,72 @@ def main():
 
     np.savez_compressed(os.path.join(HERE, 'reference_host.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_host.npz'), len(out), 'arrays')
+    golden_roi_data(cfg)
+
+
+def golden_roi_data(cfg):
+    """Training label generation of the REAL reference (lib/roi_data/rpn.py, fast_rcnn.py, keypoint_rcnn.py,
+    datasets/json_dataset.py:_merge_proposal_boxes_into_roidb, utils/keypoints.py:keypoints_to_heatmap_labels) on a seeded
+    synthetic roidb record -> tests/golden/reference_roi_data.npz.  numpy.random is seeded right before each reference call; the
+    host restatement (detectandtrack_amd/roi_data) consumes the global generator in the same order."""
+    import numpy.random as npr
+    import scipy.sparse
+    import roi_data.rpn as rrpn
+    import roi_data.fast_rcnn as rfr
+    import datasets.json_dataset as jd
+    cfg.FPN.FPN_ON = True
+    cfg.FPN.MULTILEVEL_RPN = True
+    cfg.FPN.MULTILEVEL_ROIS = True
+    cfg.MODEL.KEYPOINTS_ON = True
+    cfg.MODEL.NUM_CLASSES = 2
+    cfg.KRCNN.NUM_KEYPOINTS = 17
+    cfg.KRCNN.HEATMAP_SIZE = 56
+    cfg.TRAIN.MAX_SIZE = 333
+    cfg.TRAIN.BATCH_SIZE_PER_IM = 64
+    H, W, n = 256, 320, 5
+    rs = np.random.RandomState(21)
+    bw, bh = rs.uniform(0.15, 0.5, n) * W, rs.uniform(0.25, 0.8, n) * H
+    x1, y1 = rs.uniform(0, 1, n) * (W - bw - 1), rs.uniform(0, 1, n) * (H - bh - 1)
+    boxes = np.stack([x1, y1, x1 + bw, y1 + bh], axis=1).astype(np.float32)
+    kps = np.zeros((n, 3, 17), dtype=np.int32)
+    kps[:, 0, :] = (x1[:, None] + rs.uniform(-0.1, 1.1, (n, 17)) * bw[:, None]).astype(np.int32)
+    kps[:, 1, :] = (y1[:, None] + rs.uniform(-0.1, 1.1, (n, 17)) * bh[:, None]).astype(np.int32)
+    kps[:, 2, :] = rs.randint(0, 3, (n, 17))
+    ov = np.zeros((n, 2), dtype=np.float32)
+    ov[:, 1] = 1.0
+    out = dict(rd_boxes=boxes, rd_kps=kps, rd_hw=np.array([H, W]))
+    # ---- RPN labels ------------------------------------------------------------------------------------------------------
+    foas = []
+    for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1):
+        foas.append(rrpn._get_field_of_anchors(2. ** lvl, (cfg.FPN.RPN_ANCHOR_START_SIZE * 2. ** (lvl - cfg.FPN.RPN_MIN_LEVEL),),
+                                               cfg.FPN.RPN_ASPECT_RATIOS, 1))
+    all_anchors = np.concatenate([f.field_of_anchors for f in foas])
+    npr.seed(77)
+    blobs = rrpn._get_rpn_blobs(float(H), float(W), foas, all_anchors, boxes, np.full((n, 1), True))
+    for i, b in enumerate(blobs):
+        for k, v in b.items():
+            if 'vis' not in k:
+                out['rd_%s_fpn%d' % (k, i + 2)] = v
+    # ---- proposals -> roidb -> sampled rois + keypoint targets ---------------------------------------------------------------
+    props = np.clip(boxes[rs.randint(0, n, 300)] + rs.randn(300, 4) * 18, 0, [W - 1, H - 1, W - 1, H - 1]).astype(np.float32)
+    props = props[(props[:, 2] > props[:, 0] + 2) & (props[:, 3] > props[:, 1] + 2)]
+    out['rd_props'] = props
+    entry = dict(boxes=boxes.copy(), gt_classes=np.ones((n,), np.int32), is_crowd=np.zeros((n,), np.bool_),
+                 gt_overlaps=scipy.sparse.csr_matrix(ov), box_to_gt_ind_map=np.arange(n, dtype=np.int32),
+                 gt_keypoints=kps.copy(), seg_areas=np.zeros((n,), np.float32), segms=[[] for _ in range(n)],
+                 height=H, width=W)
+    roidb = [entry]
+    jd._merge_proposal_boxes_into_roidb(roidb, [props])
+    jd._add_class_assignments(roidb)
+    out['rd_merged_max_overlaps'] = roidb[0]['max_overlaps']
+    out['rd_merged_b2g'] = roidb[0]['box_to_gt_ind_map']
+    npr.seed(78)
+    np.random.seed(78)
+    sb = rfr._sample_rois(roidb[0], 1.0, 0)
+    for k, v in sb.items():
+        out['rd_s_' + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, 'reference_roi_data.npz'), **out)
+    print('wrote', os.path.join(HERE, 'reference_roi_data.npz'), len(out), 'arrays')
 
 
 if __name__ == '__main__':

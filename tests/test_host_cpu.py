@@ -356,3 +356,51 @@ def test_gradient_allreduce_buckets_gloo_world2():
     for a, b, x, y in zip(l0, l1, r0, r1):
         np.testing.assert_allclose(x, a + b, rtol=1e-6)
         np.testing.assert_allclose(y, a + b, rtol=1e-6)
+
+
+def test_roi_data_matches_the_real_reference_golden():
+    """detectandtrack_amd/roi_data (host label generation for training) against vectors produced by the REAL reference
+    lib/roi_data + json_dataset + utils/keypoints under py3 shims (tests/golden/make_golden.py:golden_roi_data): same seeded
+    numpy.random stream, so labels / sampled rois / keypoint cells must be identical."""
+    import numpy.random as npr
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.roi_data import rpn, fast_rcnn
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_roi_data.npz'))
+    reset_cfg()
+    cfg.FPN.FPN_ON = cfg.FPN.MULTILEVEL_RPN = cfg.FPN.MULTILEVEL_ROIS = True
+    cfg.MODEL.KEYPOINTS_ON = True
+    cfg.MODEL.NUM_CLASSES = 2
+    cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.HEATMAP_SIZE = 17, 56
+    cfg.TRAIN.MAX_SIZE, cfg.TRAIN.BATCH_SIZE_PER_IM = 333, 64
+    H, W = [int(v) for v in g['rd_hw']]
+    boxes, kps, props = g['rd_boxes'], g['rd_kps'], g['rd_props']
+    n = boxes.shape[0]
+    foas = rpn.fpn_fields(1)
+    npr.seed(77)
+    per_level = rpn.get_rpn_blobs(float(H), float(W), foas, boxes, np.full((n, 1), True), npr)
+    for i, b in enumerate(per_level):
+        for k, v in b.items():
+            ref = g['rd_%s_fpn%d' % (k, i + 2)]
+            assert v.shape == ref.shape and v.dtype == ref.dtype, (k, i, v.shape, ref.shape, v.dtype, ref.dtype)
+            if 'labels' in k:
+                np.testing.assert_array_equal(v, ref)
+            else:
+                np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-7)
+    ov = np.zeros((n, 2), np.float32)
+    ov[:, 1] = 1.0
+    entry = dict(boxes=boxes.copy(), gt_classes=np.ones((n,), np.int32), is_crowd=np.zeros((n,), np.bool_), gt_overlaps=ov,
+                 box_to_gt_ind_map=np.arange(n, dtype=np.int32), gt_keypoints=kps.copy(), height=H, width=W)
+    e = fast_rcnn.merge_proposals_into_entry(entry, props)
+    np.testing.assert_allclose(e['max_overlaps'], g['rd_merged_max_overlaps'], rtol=1e-6)
+    np.testing.assert_array_equal(e['box_to_gt_ind_map'], g['rd_merged_b2g'])
+    npr.seed(78)
+    sb = fast_rcnn.sample_rois(e, 1.0, 0, npr)
+    for k in ('labels_int32', 'rois', 'bbox_targets', 'bbox_inside_weights', 'bbox_outside_weights', 'keypoint_rois',
+              'keypoint_locations_int32', 'keypoint_weights'):
+        ref = g['rd_s_' + k]
+        assert sb[k].shape == ref.shape, (k, sb[k].shape, ref.shape)
+        if sb[k].dtype.kind == 'i':
+            np.testing.assert_array_equal(sb[k], ref, err_msg=k)
+        else:
+            np.testing.assert_allclose(sb[k], ref, rtol=1e-5, atol=1e-6, err_msg=k)
+    reset_cfg()
