@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform in an SGPR: LDS-DMA bases (M0) need no per-issue v_readfirstlane
     const int wave_n = wave % WAVES_N;
     const int wave_p = wave / WAVES_N;
 
