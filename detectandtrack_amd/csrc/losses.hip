@@ -35,13 +35,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 struct RpnLossParams {
-    const void* head;   // [N, H, W, cs]: logits at logit_off + a, deltas at delta_off + a*4 + c
+    const void* head;   // [N*Th, H, W, cs]: logits at logit_off + a, deltas at delta_off + ...
     void* dhead;        // same layout; every channel written (zeros outside logits/deltas)
     const int* labels;  // (N, A, Hw, Ww)
-    const float* tgt;   // (N, 4A, Hw, Ww)
+    const float* tgt;   // (N, 4*T*A, Hw, Ww), channel (a*T + t)*4 + c  (model_builder.py:545-563)
     const float* w_in;
     const float* w_out;
     int dtype, N, H, W, cs, A, logit_off, delta_off, Hw, Ww;
+    int T;              // tube length of the anchors
+    int per_frame;      // 1: the head keeps T frames per clip; logits are averaged over them, frame t holds the deltas
+                        //    (a*4 + c) of tube slot t.  0: one frame per clip with 4*T*A delta channels
     float cls_mult;     // scale / norm
     float bbox_beta, bbox_mult;   // scale / N
     float* loss;        // [2]: cls, bbox (accumulated with atomics)
@@ -49,28 +52,39 @@ struct RpnLossParams {
 
 __global__ __launch_bounds__(256) void rpn_loss_kernel(const RpnLossParams p) {
     __shared__ float red[256];
-    const long long npos = (long long)p.N * p.H * p.W;
+    const int Th = p.per_frame ? p.T : 1;                  // frames per clip in the head tensor
+    const int nd = p.per_frame ? 4 * p.A : 4 * p.A * p.T;  // delta channels per frame
+    const long long npos = (long long)p.N * Th * p.H * p.W;
+    const size_t fstride = (size_t)p.H * p.W * p.cs;
     float lc = 0.f, lb = 0.f;
     for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < npos; pos += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(pos % p.W);
         const int y = (int)((pos / p.W) % p.H);
-        const int n = (int)(pos / ((long long)p.W * p.H));
+        const int f = (int)(pos / ((long long)p.W * p.H));
+        const int n = f / Th, t = f - n * Th;
         const size_t base = (size_t)pos * p.cs;
         for (int c = 0; c < p.cs; ++c) {
             const bool is_logit = c >= p.logit_off && c < p.logit_off + p.A;
-            const bool is_delta = c >= p.delta_off && c < p.delta_off + 4 * p.A;
+            const bool is_delta = c >= p.delta_off && c < p.delta_off + nd;
             float grad = 0.f;
             if (is_logit) {
                 const int a = c - p.logit_off;
-                const int t = p.labels[(((size_t)n * p.A + a) * p.Hw + y) * p.Ww + x];
-                if (t >= 0) {
-                    const float v = ldf(p.head, p.dtype, base + c);
-                    lc += fmaxf(v, 0.f) - v * (float)t + log1pf(expf(-fabsf(v)));
-                    grad = (1.f / (1.f + expf(-v)) - (float)t) * p.cls_mult;
+                const int lab = p.labels[(((size_t)n * p.A + a) * p.Hw + y) * p.Ww + x];
+                if (lab >= 0) {
+                    float v = ldf(p.head, p.dtype, base + c);
+                    if (p.per_frame) {      // TimePool 'avg' of the logits (model_builder.py:532): every frame gets d/T
+                        v = 0.f;
+                        const size_t b0 = base - (size_t)t * fstride;
+                        for (int tt = 0; tt < Th; ++tt) v += ldf(p.head, p.dtype, b0 + (size_t)tt * fstride + c);
+                        v /= (float)Th;
+                    }
+                    if (t == 0) lc += fmaxf(v, 0.f) - v * (float)lab + log1pf(expf(-fabsf(v)));
+                    grad = (1.f / (1.f + expf(-v)) - (float)lab) * p.cls_mult / (float)Th;
                 }
             } else if (is_delta) {
                 const int ch = c - p.delta_off;
-                const size_t li = (((size_t)n * 4 * p.A + ch) * p.Hw + y) * p.Ww + x;
+                const int lch = p.per_frame ? ((ch >> 2) * p.T + t) * 4 + (ch & 3) : ch;
+                const size_t li = (((size_t)n * 4 * p.A * p.T + lch) * p.Hw + y) * p.Ww + x;
                 const float wi = p.w_in[li], wo = p.w_out[li];
                 const float v = wi * (ldf(p.head, p.dtype, base + c) - p.tgt[li]);
                 const float av = fabsf(v);
@@ -164,18 +178,20 @@ __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const void* logits
 extern "C" {
 
 int dat_rpn_loss(dat_ctx* ctx, dat_stream s, int dtype, const void* head, void* dhead, int N, int H, int W, int cstride, int A,
-                 int logit_off, int delta_off, const int* labels_wide, const float* targets_wide, const float* inside_wide,
+                 int T, int per_frame, int logit_off, int delta_off, const int* labels_wide, const float* targets_wide, const float* inside_wide,
                  const float* outside_wide, int Hw, int Ww, float cls_scale_over_norm, float bbox_beta,
                  float bbox_scale_over_n, float* loss2) {
     DAT_ENFORCE(ctx, head && dhead && labels_wide && targets_wide && inside_wide && outside_wide && loss2, "rpn_loss: null argument");
     DAT_ENFORCE(ctx, Hw >= H && Ww >= W, "rpn_loss: wide labels %dx%d smaller than the head %dx%d", Hw, Ww, H, W);
-    DAT_ENFORCE(ctx, logit_off + A <= cstride && delta_off + 4 * A <= cstride, "rpn_loss: head channels exceed the stride");
+    DAT_ENFORCE(ctx, T >= 1 && logit_off + A <= cstride && delta_off + 4 * A * (per_frame ? 1 : T) <= cstride,
+                "rpn_loss: head channels exceed the stride");
     RpnLossParams p;
     p.head = head; p.dhead = dhead; p.labels = labels_wide; p.tgt = targets_wide; p.w_in = inside_wide; p.w_out = outside_wide;
     p.dtype = dtype; p.N = N; p.H = H; p.W = W; p.cs = cstride; p.A = A; p.logit_off = logit_off; p.delta_off = delta_off;
+    p.T = T; p.per_frame = per_frame;
     p.Hw = Hw; p.Ww = Ww; p.cls_mult = cls_scale_over_norm; p.bbox_beta = bbox_beta; p.bbox_mult = bbox_scale_over_n;
     p.loss = loss2;
-    const long long npos = (long long)N * H * W;
+    const long long npos = (long long)N * (per_frame ? T : 1) * H * W;
     long long blocks = (npos + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p);

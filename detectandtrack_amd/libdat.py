@@ -85,7 +85,7 @@ _PROTOS = {
     'dat_roi_align_bwd': (_i, [_p, _p, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f, _i, _i, _i,
                                _p, _i, _i, _i, _i, _i, _p]),
     'dat_kps_finalize_bwd': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
-    'dat_rpn_loss': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p]),
+    'dat_rpn_loss': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p]),
     'dat_smooth_l1_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p]),
     'dat_softmax_ce_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p]),
 }

@@ -91,10 +91,11 @@ def time_pool_blobs(blob_conv, model, body_head_link):
 def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_func, add_roi_mask_head_func=None,
                                   add_roi_keypoint_head_func=None, freeze_conv_body=False):
     """:179-306 (single replica; the reference loops this over NUM_GPUS name scopes for training)."""
-    if model.train and (not cfg.FPN.FPN_ON or not cfg.MODEL.FASTER_RCNN or
-                        (cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '')):
+    if model.train and (not cfg.MODEL.FASTER_RCNN or
+                        (cfg.FPN.FPN_ON and cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '')):
         raise NotImplementedError('training graph: end-to-end Faster R-CNN on FPN with 2D heads (2D models, or a 3D body '
-                                  'linked by slice-center / avg) is built; C4 / tube-head training is a next row')
+                                  'linked by slice-center / avg) and on the C4 bodies (2D or tube heads, the shipped 3D '
+                                  'configs) is built; training the FPN tube-head extension is not')
     blob_conv, dim_conv, spatial_scale_conv = add_conv_body_func(model)
     if cfg.MODEL.VIDEO_ON:
         blob_conv = time_pool_blobs(blob_conv, model, cfg.VIDEO.BODY_HEAD_LINK)
@@ -113,6 +114,8 @@ def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_f
             model.CollectAndDistributeFpnRpnProposals()
         else:
             add_rpn_outputs(model, blob_conv, dim_conv, spatial_scale_conv, nd=head_3d, time_dim=out_time_dim)
+            if model.train:
+                add_rpn_losses(model, time_dim=out_time_dim)
 
     if cfg.FPN.FPN_ON:
         assert cfg.FPN.RPN_MIN_LEVEL == cfg.FPN.ROI_MIN_LEVEL
@@ -178,7 +181,8 @@ def add_fast_rcnn_outputs(model, blob_in, dim, is_head_3d, time_dim=1):
         c = model.ConvNd(blob_in, 'cls_score_1', dim, model.num_classes, [1, 1, 1], pads=2 * [0, 0, 0],
                          strides=[1, 1, 1], weight_init=g01, bias_init=z)
         model.TimeMean(c, 'cls_score')
-        model.Softmax('cls_score', 'cls_prob', engine='CUDNN')
+        if not model.train:
+            model.Softmax('cls_score', 'cls_prob', engine='CUDNN')
         b = model.ConvNd(blob_in, 'bbox_pred_1', dim, 4 * model.num_classes, [1, 1, 1], pads=2 * [0, 0, 0],
                          strides=[1, 1, 1], weight_init=g01, bias_init=z)
         model.net.add(_op('TubeDeltasToRows', [b], ['bbox_pred']))
@@ -223,6 +227,22 @@ def add_rpn_outputs(model, blob_in, dim_in, spatial_scale, nd=False, time_dim=1)
                                 anchors=anchors, spatial_scale=spatial_scale)
     if cfg.MODEL.FASTER_RCNN and not model.train:
         model.net.Alias('rpn_rois', 'rois')
+    elif cfg.MODEL.FASTER_RCNN:
+        # training: sample labelled rois from the in-network proposals (ops/generate_proposal_labels.py:23-37)
+        outs = ['rois', 'labels_int32', 'bbox_targets', 'bbox_inside_weights', 'bbox_outside_weights']
+        if cfg.MODEL.KEYPOINTS_ON:
+            outs += ['keypoint_rois', 'keypoint_locations_int32', 'keypoint_weights', 'keypoint_loss_normalizer']
+        model.net.add(_op('GenerateProposalLabels', ['rpn_rois', 'roidb', 'im_info'], outs))
+
+
+def add_rpn_losses(model, time_dim=1):
+    """:612-636 (single-level RPN, 2D or tube): SigmoidCrossEntropyLoss (normalised by the number of non-ignored anchors) and
+    SmoothL1Loss (beta 1/9) on the narrowed 'wide' label arrays."""
+    model.net.add(_op('RpnLoss', ['rpn_cls_logits', 'rpn_bbox_pred', 'rpn_labels_int32_wide', 'rpn_bbox_targets_wide',
+                                  'rpn_bbox_inside_weights_wide', 'rpn_bbox_outside_weights_wide'],
+                      ['loss_rpn_cls', 'loss_rpn_bbox'], cls_scale=1. / cfg.NUM_GPUS, normalize=1, beta=1. / 9.,
+                      bbox_scale=1. / cfg.NUM_GPUS / time_dim))
+    model.losses = sorted(set(model.losses + ['loss_rpn_cls', 'loss_rpn_bbox']))
 
 
 # ---- keypoint heatmap outputs (:755-870) ----------------------------------------------------------------------------------

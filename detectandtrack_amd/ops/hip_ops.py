@@ -297,12 +297,14 @@ def kps_finalize_bwd(dout, dtype, R, Tr, S, cs, K, up):
 
 
 def rpn_loss(head, dtype, A, logit_off, delta_off, labels_wide, targets_wide, inside_wide, outside_wide, cls_mult, beta,
-             bbox_mult, loss2):
-    """head [N,H,W,cs]; label arrays in the reference layouts (CUDA); returns dhead.  loss2: fp32 CUDA [2] accumulated."""
-    N, H, W, cs = head.shape
+             bbox_mult, loss2, T=1, per_frame=False):
+    """head [N (*T if per_frame),H,W,cs]; label arrays in the reference layouts (CUDA); returns dhead.  loss2: fp32 CUDA [2]
+    accumulated."""
+    F_, H, W, cs = head.shape
+    N = F_ // T if per_frame else F_
     Hw, Ww = int(labels_wide.shape[2]), int(labels_wide.shape[3])
     dhead = torch.empty_like(head)
-    ctx().call('dat_rpn_loss', _stream(), dtype, _ptr(head), _ptr(dhead), N, H, W, cs, A, logit_off, delta_off,
+    ctx().call('dat_rpn_loss', _stream(), dtype, _ptr(head), _ptr(dhead), N, H, W, cs, A, T, int(per_frame), logit_off, delta_off,
                _ptr(labels_wide), _ptr(targets_wide), _ptr(inside_wide), _ptr(outside_wide), Hw, Ww, C.c_float(cls_mult),
                C.c_float(beta), C.c_float(bbox_mult), _ptr(loss2))
     return dhead

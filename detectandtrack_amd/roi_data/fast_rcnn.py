@@ -80,7 +80,9 @@ def _within_box(points, boxes):
 
 
 def add_keypoint_blobs(blobs, e, fg_rois_per_image, im_scale, batch_idx, rng):
-    """roi_data/keypoint_rcnn.py:32-86 (T = 1 boxes)."""
+    """roi_data/keypoint_rcnn.py:32-86.  Tubes: boxes are (n, 4T), keypoints (n, 3, K*T); the visibility / within-box test
+    uses the FIRST frame's box against all T*K keypoints exactly like the reference's _within_box (:88-99), the heatmap
+    targets are built per frame and concatenated along the keypoint axis (:62-73)."""
     gt_inds = np.where(e['gt_classes'] > 0)[0]
     gtk = e['gt_keypoints']
     ind_kp = gt_inds[e['box_to_gt_ind_map']]
@@ -98,11 +100,17 @@ def add_keypoint_blobs(blobs, e, fg_rois_per_image, im_scale, batch_idx, rng):
     for i in range(len(rois)):
         if b2g[i] >= 0:
             kps[i] = gtk[b2g[i]]
-    heat, wts = keypoints_to_heatmap_labels(kps, rois)
+    T = rois.shape[-1] // 4
+    K = gtk.shape[2] // T
+    heats, wts = [], []
+    for t in range(T):
+        h, w = keypoints_to_heatmap_labels(kps[..., t * K:(t + 1) * K], rois[..., t * 4:(t + 1) * 4])
+        heats.append(h)
+        wts.append(w)
+    heat, wt = np.concatenate(heats, axis=-1), np.concatenate(wts, axis=-1)
     blobs['keypoint_rois'] = np.hstack((batch_idx * np.ones((len(rois), 1), np.float32), rois * im_scale)).astype(np.float32)
     blobs['keypoint_locations_int32'] = heat.reshape(-1, 1).astype(np.int32)
-    blobs['keypoint_weights'] = wts.reshape(-1, 1).astype(np.float32)
-    # :88-99 keypoint_loss_normalizer (only used with KRCNN.NORMALIZE_BY_VISIBLE_KEYPOINTS False in Detectron)
+    blobs['keypoint_weights'] = wt.reshape(-1, 1).astype(np.float32)
     blobs['keypoint_loss_normalizer'] = np.array([1.0], dtype=np.float32)
 
 

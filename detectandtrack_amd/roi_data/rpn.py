@@ -94,7 +94,7 @@ def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=
     if len(fg) > 0:
         targets[fg] = box_utils.bbox_transform_inv(anchors[fg], gt_boxes[a2g_arg[fg]].astype(np.float32),
                                                    (1.0, 1.0, 1.0, 1.0)).astype(np.float32)
-        w_in[fg] = np.repeat(visible_tracks[a2g_arg[fg]].astype(np.float32), 4, axis=1)
+        w_in[fg] = np.repeat(np.broadcast_to(visible_tracks[a2g_arg[fg]], (len(fg), T)).astype(np.float32), 4, axis=1)
     num_examples = max(int(np.sum(labels >= 0)), 1)
     w_out[labels >= 0] = 1.0 / num_examples
     labels = _unmap(labels, total, inside, fill=-1)
@@ -115,16 +115,20 @@ def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=
 
 
 def add_rpn_blobs(blobs, im_scale, entry, rng=npr):
-    """:138-199 for one clip (IMS_PER_BATCH = 1): fills rpn_*_wide_fpn<l> and im_info."""
+    """:138-199 for one clip (IMS_PER_BATCH = 1): fills rpn_*_wide[_fpn<l>] and im_info."""
     T = entry['boxes'].shape[-1] // 4
-    foas = fpn_fields(T)
+    multilevel = cfg.FPN.FPN_ON and cfg.FPN.MULTILEVEL_RPN
+    foas = fpn_fields(T) if multilevel else [get_field_of_anchors(cfg.RPN.STRIDE, cfg.RPN.SIZES, cfg.RPN.ASPECT_RATIOS, T)]
     im_h, im_w = np.round(entry['height'] * im_scale), np.round(entry['width'] * im_scale)
     gt = np.where((entry['gt_classes'] > 0) & (entry['is_crowd'] == 0))[0]
     gt_rois = entry['boxes'][gt] * im_scale
     vis = entry['track_visible'][gt] if 'track_visible' in entry else None
     per_level = get_rpn_blobs(im_h, im_w, foas, gt_rois, vis, rng)
-    for i, lvl in enumerate(range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)):
-        for k, v in per_level[i].items():
-            blobs[k + '_fpn' + str(lvl)] = v
+    if multilevel:
+        for i, lvl in enumerate(range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)):
+            for k, v in per_level[i].items():
+                blobs[k + '_fpn' + str(lvl)] = v
+    else:
+        blobs.update(per_level[0])
     blobs['im_info'] = np.array([[im_h, im_w, im_scale]], dtype=np.float32)
     return blobs

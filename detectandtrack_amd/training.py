@@ -48,9 +48,12 @@ class TrainExecutor(Executor):
         pass
 
     def _head_blob_of(self, logits_name):
+        """fused logits+deltas head conv feeding `logits_name` (directly, or through the tube RPN's TimeMean)"""
+        prod = self.net.producer(logits_name)
+        src = prod.inputs[0] if (prod is not None and prod.type == 'TimeMean') else logits_name
         for first, (lo, do, gi) in self._fused.items():
-            if lo.outputs[0] == logits_name:
-                return lo.outputs[0] + '+' + do.outputs[0], lo, do
+            if lo.outputs[0] == src:
+                return lo.outputs[0] + '+' + do.outputs[0], lo, do, gi
         raise KeyError(logits_name)
 
     def _loss_buf(self, names):
@@ -61,9 +64,11 @@ class TrainExecutor(Executor):
 
     def op_RpnLoss(self, i, op):
         ws, a = self.ws, op.args
-        head_name, lo, do = self._head_blob_of(op.inputs[0])
+        head_name, lo, do, gi = self._head_blob_of(op.inputs[0])
         head = ws.blobs[head_name]
         A = lo.args['dim_out']
+        per_frame = gi in self._per_frame
+        T = head.T if per_frame else do.args['dim_out'] // (4 * A)
         labels, tgt, w_in, w_out = [ws.blobs[n] for n in op.inputs[2:6]]
         cls_mult = a['cls_scale']
         if a['normalize']:
@@ -73,7 +78,7 @@ class TrainExecutor(Executor):
         n_batch = head.N
         loss2 = self._loss_buf(op.outputs)
         dhead = ops.rpn_loss(head.t, head.dt, A, 0, A, labels.t, tgt.t, w_in.t, w_out.t, cls_mult, a['beta'],
-                             a['bbox_scale'] / n_batch, loss2)
+                             a['bbox_scale'] / n_batch, loss2, T=T, per_frame=per_frame)
         self._add_grad(head_name, dhead)
 
     def op_SoftmaxLoss(self, i, op):
@@ -91,9 +96,13 @@ class TrainExecutor(Executor):
         ws, a = self.ws, op.args
         x = ws.blobs[op.inputs[0]]
         tgt, w_in, w_out = [ws.blobs[n] for n in op.inputs[1:4]]
-        R = x.t.shape[2]
         loss = self._loss_buf(op.outputs)
-        d = ops.smooth_l1_rows(x.t, x.dt, x.C, tgt.t, w_in.t, w_out.t, a['beta'], a['scale'] / max(R, 1), loss)
+        if x.kind == 'mat':      # tube box deltas regrouped to rows (TubeDeltasToRows): fp32 [R, K*T*4]
+            R, D = x.t.shape
+            d = ops.smooth_l1_rows(x.t.contiguous(), ops.F32, D, tgt.t, w_in.t, w_out.t, a['beta'], a['scale'] / max(R, 1), loss)
+        else:
+            R = x.t.shape[2]
+            d = ops.smooth_l1_rows(x.t, x.dt, x.C, tgt.t, w_in.t, w_out.t, a['beta'], a['scale'] / max(R, 1), loss)
         self._add_grad(op.inputs[0], d)
 
     def op_KeypointLoss(self, i, op):
@@ -123,6 +132,19 @@ class TrainExecutor(Executor):
         assert sampler is not None, 'training needs ws.train_sampler(rois, im_info) -> dict of sampled blobs ' \
                                     '(roi_data.fast_rcnn.add_fast_rcnn_blobs on the roidb entry of this clip)'
         blobs = sampler(rois_np, info)
+        for name in op.outputs:
+            if name in blobs:
+                ws.FeedBlob(name, np.ascontiguousarray(blobs[name]))
+
+    def op_GenerateProposalLabels(self, i, op):
+        """ops/generate_proposal_labels.py:23-37: sample labelled training rois from the RPN proposals of this clip."""
+        ws = self.ws
+        r = ws.blobs[op.inputs[0]]
+        rois_np = r.t[:_count(r)].cpu().numpy() if r.count is not None else r.t.cpu().numpy()
+        im_info = ws.blobs['im_info']
+        info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
+        assert ws.train_sampler is not None, 'training needs ws.train_sampler(rois, im_info) -> dict of sampled blobs'
+        blobs = ws.train_sampler(rois_np, info)
         for name in op.outputs:
             if name in blobs:
                 ws.FeedBlob(name, np.ascontiguousarray(blobs[name]))
@@ -329,6 +351,50 @@ class TrainExecutor(Executor):
         f, S, _, cs = x.t.shape
         K, up = op.args['dim'], op.args['up_scale']
         self._add_grad(op.inputs[0], ops.kps_finalize_bwd(d.contiguous(), x.dt, x.N, x.T, S, cs, K, up))
+
+    def bwd_TubeDeltasToRows(self, i, op):
+        """rows [R, K*T*4] -> head output [R*T, 1, 1, cs] with channels (k, xywh) per frame (model_builder.py:446-473)"""
+        x = self.ws.blobs[op.inputs[0]]
+        d, _lo = self._take_grad(op.outputs[0], ops.F32)
+        if d is None:
+            return
+        R, T, cs = x.N, x.T, x.t.shape[3]
+        K4 = x.C
+        g = torch.zeros((R, T, cs), dtype=torch.float32, device=d.device)
+        g[:, :, :K4] = d.view(R, K4 // 4, T, 4).permute(0, 2, 1, 3).reshape(R, T, K4)
+        self._add_grad(op.inputs[0], g.view(R * T, 1, 1, cs))
+
+    def bwd_TimeMean(self, i, op):
+        """scores averaged over the T frames of each RoI: every frame receives d / T"""
+        x = self.ws.blobs[op.inputs[0]]
+        y = self.ws.blobs[op.outputs[0]]
+        if y.kind != 'rows':
+            return          # the RPN's TimeMean is folded into the proposal / loss kernels
+        d, _lo = self._take_grad(op.outputs[0], ops.F32)
+        if d is None:
+            return
+        R, T, cs = x.N, x.T, x.t.shape[3]
+        g = torch.zeros((R, T, cs), dtype=torch.float32, device=d.device)
+        g[:, :, :x.C] = (d.view(R, 1, -1)[:, :, :x.C] / float(T))
+        self._add_grad(op.inputs[0], g.view(R * T, 1, 1, cs))
+
+    def bwd_SpatialMean(self, i, op):
+        x = self.ws.blobs[op.inputs[0]]
+        d, _lo = self._take_grad(op.outputs[0], x.dt)
+        if d is None:
+            return
+        f, h, w, cs = x.t.shape
+        self._add_grad(op.inputs[0], (d.view(f, 1, 1, cs).float() / float(h * w)).to(d.dtype).expand(f, h, w, cs).contiguous())
+
+    def bwd_TimePoolAvg(self, i, op):
+        """BODY_HEAD_LINK 'avg' (detector.py:559-569): every frame receives d / T"""
+        x = self.ws.blobs[op.inputs[0]]
+        d, _lo = self._take_grad(op.outputs[0], x.dt)
+        if d is None:
+            return
+        f, h, w, cs = x.t.shape
+        g = (d.view(x.N, 1, h, w, cs).float() / float(x.T)).to(d.dtype).expand(x.N, x.T, h, w, cs).reshape(f, h, w, cs)
+        self._add_grad(op.inputs[0], g.contiguous())
 
     def bwd_TimeToBatch(self, i, op):
         if op.outputs[0] in self.grads:

@@ -235,9 +235,11 @@ int dat_kps_finalize_bwd(dat_ctx* ctx, dat_stream s, int dtype, const float* dou
 /* RPN losses of one level on the fused head tensor [N, H, W, cstride] (logits at logit_off + a, deltas at delta_off + a*4 + c):
  * SigmoidCrossEntropyLoss on the logits (labels int32 (N, A, Hw, Ww), -1 = ignore) and SmoothL1Loss on the deltas (targets /
  * inside / outside weights fp32 (N, 4A, Hw, Ww)); the wide label arrays are narrowed to H x W by indexing (SpatialNarrowAs).
+ * Tube anchors (T > 1): deltas are 4*T*A channels (a, t, xywh); per_frame = 1 reads a head that keeps its T frames (logits
+ * averaged over them, frame t holds the (a, xywh) deltas of slot t -- the C4 tube RPN, model_builder.py:500-609).
  * dhead gets the gradient of (loss_cls + loss_bbox) for every channel; loss2[0] += loss_cls, loss2[1] += loss_bbox. */
 int dat_rpn_loss(dat_ctx* ctx, dat_stream s, int dtype, const void* head, void* dhead, int N, int H, int W, int cstride, int A,
-                 int logit_off, int delta_off, const int* labels_wide, const float* targets_wide, const float* inside_wide,
+                 int T, int per_frame, int logit_off, int delta_off, const int* labels_wide, const float* targets_wide, const float* inside_wide,
                  const float* outside_wide, int Hw, int Ww, float cls_scale_over_norm, float bbox_beta,
                  float bbox_scale_over_n, float* loss2);
 /* SmoothL1Loss on row-major predictions [R, ld] (D used columns); *loss += scale_over_n * sum(out * l(in * (pred - tgt))) */

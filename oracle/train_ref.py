@@ -114,3 +114,59 @@ def training_losses(weights, opts, data, im_info, labels, sampled, cfg_scalars):
                           reduction='none')
     losses['loss_kps'] = (nll * w).sum() / w.sum() * cfg_scalars['kps_loss_weight'] / ng
     return losses
+
+
+def roi_align_tube_torch(feat5, rois, pooled, spatial_scale, sampling):
+    """feat5 (N, C, T, H, W) tensor; rois (R, 4T+1) -> (R, C, T, P, P): frame t of the tube pools frame t of the features."""
+    T = feat5.shape[2]
+    outs = []
+    for t in range(T):
+        r = np.hstack((rois[:, :1], rois[:, 1 + 4 * t:5 + 4 * t])).astype(np.float32)
+        outs.append(roi_align_2d_torch(feat5[:, :, t], r, pooled, spatial_scale, sampling))
+    return torch.stack(outs, dim=2)
+
+
+def training_losses_c4_tube(weights, opts, data, labels, sampled, cfg_scalars):
+    """The shipped 3D configuration in training mode (model_builder.py:179-306 train branch with ResNet3D C4 body, tube RPN
+    :500-636, per-RoI res5 head ResNet3D.py:301-327 + :426-494, 3D keypoint head :755-889)."""
+    net = Net(weights, opts)
+    feat = net.body(torch.from_numpy(data))           # (1, C, T, H, W)
+    o = opts
+    T, kt = o['num_frames_mid'], o['kt_rpn']
+    ng = cfg_scalars['num_gpus']
+    losses = {}
+    h = F.relu(net.conv_nd(feat, 'conv_rpn', [kt, 3, 3], [1, 1, 1], [kt // 2, 1, 1]))
+    logits = net.conv_nd(h, 'rpn_cls_logits_1', [1, 1, 1], [1, 1, 1], [0, 0, 0]).mean(dim=2)
+    d = net.conv_nd(h, 'rpn_bbox_pred_1', [1, 1, 1], [1, 1, 1], [0, 0, 0])
+    N, A4, Tt, H, W = d.shape
+    A = A4 // 4
+    d = d.reshape(N, A, 4, Tt, H, W).permute(0, 1, 3, 2, 4, 5).reshape(N, A * Tt * 4, H, W)
+    lab = torch.from_numpy(labels['rpn_labels_int32_wide'][:, :, :H, :W])
+    valid = (lab >= 0).float()
+    ce = F.binary_cross_entropy_with_logits(logits, lab.clamp(min=0).float(), reduction='none')
+    losses['loss_rpn_cls'] = (ce * valid).sum() / max(float(valid.sum()), 1.0) / ng
+    t, wi, wo = [torch.from_numpy(labels['rpn_bbox_%s_wide' % k][:, :, :H, :W])
+                 for k in ('targets', 'inside_weights', 'outside_weights')]
+    losses['loss_rpn_bbox'] = smooth_l1(d, t, wi, wo, 1. / 9.) / N / ng / T
+    rois = sampled['rois']
+    R = rois.shape[0]
+    pooled = o['frcn_res']
+    x = roi_align_tube_torch(feat, rois, pooled, 1. / 16., o['frcn_sampling'])
+    dims = o['feat_dims']
+    x = net._stage(x, 4, 'res5', o['res5_blocks'], dims[3], o['res5_dim'], 1, stride_init=int(pooled / 7))
+    x = x.mean(dim=4).mean(dim=3)[:, :, :, None, None]
+    cls = net.conv_nd(x, 'cls_score_1', [1, 1, 1], [1, 1, 1], [0, 0, 0]).mean(dim=4).mean(dim=3).mean(dim=2)
+    bp = net.conv_nd(x, 'bbox_pred_1', [1, 1, 1], [1, 1, 1], [0, 0, 0])
+    K4 = bp.shape[1]
+    bp = bp.reshape(R, K4 // 4, 4, T, 1, 1).permute(0, 1, 3, 2, 4, 5).reshape(R, -1)
+    losses['loss_cls'] = F.cross_entropy(cls, torch.from_numpy(sampled['labels_int32']).long(), reduction='sum') / R / ng
+    losses['loss_bbox'] = smooth_l1(bp, torch.from_numpy(sampled['bbox_targets']), torch.from_numpy(sampled['bbox_inside_weights']),
+                                    torch.from_numpy(sampled['bbox_outside_weights']), 1.0) / R / ng / T
+    kx = roi_align_tube_torch(feat, sampled['keypoint_rois'], o['kps_res'], 1. / 16., o['kps_sampling'])
+    kps = net.kps_head_tube_feat(kx)                  # (Rk, T*K, M, M)
+    Rk, TK, M, _ = kps.shape
+    w = torch.from_numpy(sampled['keypoint_weights']).reshape(-1)
+    nll = F.cross_entropy(kps.reshape(Rk * TK, M * M), torch.from_numpy(sampled['keypoint_locations_int32']).reshape(-1).long(),
+                          reduction='none')
+    losses['loss_kps'] = (nll * w).sum() / w.sum() * cfg_scalars['kps_loss_weight'] / ng
+    return losses

@@ -363,3 +363,76 @@ def test_trainer_steps_reduce_the_loss(ops):
     assert 'conv1_w' not in ex.param_grads and 'res2_0_branch2a_w' not in ex.param_grads
     ws.params_from_device()
     assert np.abs(ws.params['fc7_w'] - w_before.cpu().numpy()).max() > 0
+
+
+def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
+    """The shipped 3D configuration (configs/video/3d/04_R-18-3D_*.yaml) in TRAINING mode: tube RPN losses on the per-frame head
+    (T-averaged logits), tube RoIAlign, per-RoI res5, T-averaged class scores, regrouped tube deltas, 3D keypoint head: all
+    losses and the gradient of every trainable parameter vs autograd on the oracle."""
+    from tests.model_util import c4_tube_kps_cfg, synthetic_clip
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    from detectandtrack_amd.training import TrainExecutor
+    from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+    from oracle import train_ref
+    from oracle.net3d import opts_for
+    T, H, W = 3, 96, 128
+    c = c4_tube_kps_cfg(T=T, dtype='fp32', pre=200, post=60)
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 200, 'RPN_POST_NMS_TOP_N': 60, 'IMS_PER_BATCH': 1, 'MAX_SIZE': 128, 'BATCH_SIZE_PER_IM': 24,
+                  'RPN_STRADDLE_THRESH': -1}
+    c['NUM_GPUS'] = 1
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    weights = net_utils.synthetic_params(model, 3)
+    for k, v in weights.items():
+        ws.set_param(k, v)
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=3, seed=4, T=T)
+    rng = np.random.RandomState(0)
+    labels = rpn_data.add_rpn_blobs({}, 1.0, entry, rng)
+    data = synthetic_clip(T, H, W)
+    ws.FeedBlob('data', data)
+    for k, v in labels.items():
+        ws.FeedBlob(k, v)
+    fixed = {}
+
+    def sampler(rois, info):
+        if not fixed:
+            fixed.update(frcn_data.sample_training_blobs(entry, rois, info, rng))
+        return fixed
+    ws.train_sampler = sampler
+    ex = TrainExecutor(ws, model.net)
+    ex.run()
+    ex.backward()
+    got = ex.loss_values()
+    assert fixed['rois'].shape[1] == 4 * T + 1 and fixed['keypoint_locations_int32'].shape[0] == fixed['keypoint_rois'].shape[0] * 17 * T
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True) for k, v in weights.items()}
+    ref = train_ref.training_losses_c4_tube(
+        wt, opts_for('R18', block_counts=(2, 2, 2), kt_body=3, kt_rpn=3, kt_kps=3, body_head_link='', num_frames_mid=T),
+        data, labels, fixed, dict(num_gpus=1, kps_loss_weight=cfg.KRCNN.LOSS_WEIGHT))
+    sum(ref.values()).backward()
+    for k in sorted(ref):
+        print('%-16s %.6f  (oracle %.6f)' % (k, got[k], ref[k].item()))
+        np.testing.assert_allclose(got[k], ref[k].item(), rtol=2e-4, atol=1e-6)
+    checked, worst, errs = 0, 0.0, []
+    for name in sorted(set(model.TrainableParams())):
+        if name.startswith(('conv1', 'res_conv1', 'res2_')):
+            assert name not in ex.param_grads
+            continue
+        assert name in ex.param_grads, 'no gradient for ' + name
+        r = wt[name].grad
+        err = float((ex.param_grads[name].cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-8)
+        # the keypoint branch's gradient is sparse (a few valid keypoints x 3 frames): a single activation within 1e-7 of
+        # the ReLU threshold masked differently by the two fp32 summation orders moves a parameter's gradient by a few 1e-3
+        assert err < 1e-2, '%s: rel err %.3e' % (name, err)
+        errs.append((err, name))
+        worst = max(worst, err)
+        checked += 1
+    print('checked gradients of %d parameters, worst rel err %.2e' % (checked, worst))
+    print('largest:', ['%s %.1e' % (n, e) for e, n in sorted(errs, reverse=True)[:8]])
+    assert checked > 30 and np.median([e for e, _ in errs]) < 1e-3
