@@ -30,12 +30,12 @@ from detectandtrack_amd.training import Trainer
 logger = logging.getLogger('train_net')
 
 
-def synthetic_clip_and_entry(T, h, w, seed):
+def synthetic_clip_and_entry(T, h, w, seed, tube_T=1):
     rs = np.random.RandomState(seed)
     frames = rs.randint(0, 255, (1, 3, T, h // 8 + 1, w // 8 + 1)).astype(np.float32)
     data = np.repeat(np.repeat(frames, 8, axis=3), 8, axis=4)[:, :, :, :h, :w]
     data = data - np.asarray(cfg.PIXEL_MEANS, dtype=np.float32).reshape(1, 3, 1, 1, 1)
-    return np.ascontiguousarray(data), synthetic.synthetic_roidb_entry(h, w, n_persons=4, seed=seed)
+    return np.ascontiguousarray(data), synthetic.synthetic_roidb_entry(h, w, n_persons=4, seed=seed, T=tube_T)
 
 
 def feed_clip(ws, data, entry, rng):
@@ -71,13 +71,14 @@ def main():
         net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)      # identical on every rank
     trainer = Trainer(model, ws, dist)
     T = max(cfg.VIDEO.NUM_FRAMES, 1) if cfg.MODEL.VIDEO_ON else 1
+    tube_T = cfg.VIDEO.NUM_FRAMES_MID if (cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '') else 1   # tube heads: 4T boxes
     rng = np.random.RandomState(cfg.RNG_SEED + rank)
     max_iter = args.iters or cfg.SOLVER.MAX_ITER
     out_dir = get_output_dir(training=True)
     t0 = time.time()
     for it in range(max_iter):
         lr = lr_policy.get_lr_at_iter(it)
-        data, entry = synthetic_clip_and_entry(T, args.height, args.width, seed=1000 * rank + it)
+        data, entry = synthetic_clip_and_entry(T, args.height, args.width, seed=1000 * rank + it, tube_T=tube_T)
         feed_clip(ws, data, entry, rng)
         ex = trainer.step(lr)
         if it % 20 == 0 or it == max_iter - 1:
