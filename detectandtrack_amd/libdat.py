@@ -75,6 +75,9 @@ _PROTOS = {
     'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'dat_stem_conv_weight_bytes': (C.c_size_t, [_i]),
+    'dat_stem_conv_pack_weights': (_i, [_p, _p, _i, _p, _i, _p]),
+    'dat_stem_conv': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc), _i, _i]),
     'dat_conv3d_wgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p, _p, _p]),

@@ -349,6 +349,29 @@ def stem_layer(conv1_w, scale, bias, dtype):
     return ConvLayer(w4, scale, bias, stride=(1, 1), pads=(0, 0, 0), relu=True, dtype=dtype, cin_stride=64)
 
 
+class StemConv(object):
+    """conv1 [64,3,1,7,7] + AffineChannelNd + ReLU on the NC(T)HW fp32 `data` blob in ONE kernel (dat_stem_conv)."""
+
+    def __init__(self, conv1_w, scale, bias, dtype, relu=True):
+        w = conv1_w.contiguous().float()
+        assert tuple(w.shape[1:]) == (3, 1, 7, 7) and w.shape[0] == 64, w.shape
+        self.dtype, self.relu = dtype, bool(relu)
+        self.scale = None if scale is None else scale.contiguous().float()
+        self.bias = None if bias is None else bias.contiguous().float()
+        self.packed = torch.empty(L.lib().dat_stem_conv_weight_bytes(dtype), dtype=torch.uint8, device=w.device)
+        ctx().call('dat_stem_conv_pack_weights', _stream(), dtype, _ptr(w), 64, _ptr(self.packed))
+
+    def __call__(self, data):
+        data = data.contiguous()
+        n, c, t, h, w = data.shape
+        assert c == 3 and data.dtype == torch.float32
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out = torch.empty((n * t, ho, wo, 64), dtype=tdtype(self.dtype), device=data.device)
+        ctx().call('dat_stem_conv', _stream(), self.dtype, _ptr(data), _ptr(self.packed), _ptr(self.scale), _ptr(self.bias),
+                   int(self.relu), n, t, h, w, _ptr(out))
+        return out
+
+
 def maxpool_hw(x, dtype, k, stride, pad):
     f, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1

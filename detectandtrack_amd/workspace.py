@@ -325,16 +325,10 @@ class Executor(object):
         def build():
             scale = ws.dev_param(a['scale']) if a['scale'] else None
             bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
-            lay = ops.stem_layer(_w5d(ws.dev_param(a['w'])), scale, bias, dt)
-            lay.relu = a['relu']
-            return lay
+            return ops.StemConv(_w5d(ws.dev_param(a['w'])), scale, bias, dt, relu=a['relu'])
         layer = self._layer(i, build)
-        packed = ops.stem_pack(data.float(), dt)
-        if ws.conv_log is not None:
-            ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_out'] * 3 * 49 * n * t * ho * wo,
-                                layer.hbm_bytes(packed.shape[0], packed.shape[1], packed.shape[2])))
-        y = layer(packed, T=t)
+        # (the fused stem kernel is not a conv3d_igemm launch: it is not part of the bench's per-launch conv log)
+        y = layer(data.float())
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
 
     def _rpn_head_conv(self, i):

@@ -194,6 +194,14 @@ int dat_deconv_k4s2_weights(dat_ctx* ctx, dat_stream s, const float* w, int Cin,
 int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int R, int Tr, int S, int cs, int K,
                      int up, float* out);
 
+/* ---- conv1, fused (ResNet3D.py:258-262): ConvNd [1,7,7] / [1,2,2] / pad [0,3,3] on `data` fp32 [N,3,T,H,W] + AffineChannelNd
+ * (scale, bias: fp32 [64] or NULL) + ReLU -> out [N*T, Ho, Wo, 64] in `dtype`; weights packed once by
+ * dat_stem_conv_pack_weights (dat_stem_conv_weight_bytes bytes).  Supersedes dat_stem_pack + dat_conv3d_fwd for conv1. */
+size_t dat_stem_conv_weight_bytes(int dtype);
+int dat_stem_conv_pack_weights(dat_ctx* ctx, dat_stream s, int dtype, const float* conv1_w, int Cout, void* packed);
+int dat_stem_conv(dat_ctx* ctx, dat_stream s, int dtype, const float* data, const void* w_packed, const float* scale,
+                  const float* bias, int relu, int N, int T, int H, int W, void* out);
+
 /* ---- keypoint heatmap decoding  (lib/utils/keypoints.py:94-149 heatmaps_to_keypoints, :210-216) ---- */
 /* maps fp32 [R, T*K, M, M] (kps_score), boxes fp32 [R, 4*T] image-space tubes -> out fp32 [R, 4, T*K], rows
  * (x, y, logit, prob), column t*K + k (core/test.py:875-893 concatenates the frames along the keypoint axis):

@@ -435,3 +435,27 @@ def test_heatmaps_to_keypoints_matches_host_decode(ops, T, min_size):
     np.testing.assert_array_equal(got[:, :3], ref[:, :3])
     np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-5, atol=1e-9)
     reset_cfg()
+
+
+@pytest.mark.parametrize('dtype_name', ['fp32', 'bf16'])
+def test_fused_stem_conv_matches_torch(ops, dtype_name):
+    """dat_stem_conv: conv1 [1,7,7]/s2/p3 + AffineChannelNd + ReLU straight from the NC(T)HW fp32 clip (ResNet3D.py:258-262)."""
+    import torch.nn.functional as F
+    dt = ops.F32 if dtype_name == 'fp32' else ops.BF16
+    g = torch.Generator().manual_seed(3)
+    for (N, T, H, W) in ((1, 2, 37, 53), (2, 1, 64, 96), (1, 3, 16, 70)):
+        data = torch.randn((N, 3, T, H, W), generator=g) * 50
+        w = torch.randn((64, 3, 1, 7, 7), generator=g) * 0.05
+        scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        if dtype_name == 'bf16':
+            data_r, w_r = data.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+        else:
+            data_r, w_r = data, w
+        ref = F.relu(F.conv3d(data_r, w_r, None, stride=(1, 2, 2), padding=(0, 3, 3)) * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1))
+        layer = ops.StemConv(w.cuda(), scale.cuda(), bias.cuda(), dt, relu=True)
+        y = layer(data.cuda())                       # [N*T, Ho, Wo, 64]
+        Ho, Wo = ref.shape[3], ref.shape[4]
+        got = y.float().cpu().view(N, T, Ho, Wo, 64).permute(0, 4, 1, 2, 3)
+        err = (got - ref).abs().max().item()
+        tol = 2e-3 if dtype_name == 'fp32' else 0.02 * ref.abs().max().item()
+        assert err < tol, (N, T, H, W, err, tol)
