@@ -50,6 +50,26 @@ def model_cfg(arch, T, dtype, keyframe_dce=False):
     }
 
 
+def vendor_gemm_tflops(n=8192, dtype=torch.bfloat16):
+    """What the vendor's tuned dense GEMM (torch.matmul -> hipBLASLt) reaches on THIS box right now: the practical MFMA
+    ceiling of the power-capped part, reported next to the nominal 2.5 PFLOP/s (SURVEY.md §8d asks for both).  Measurement
+    only, never on the product path."""
+    try:
+        a = torch.randn(n, n, device='cuda', dtype=dtype)
+        b = torch.randn(n, n, device='cuda', dtype=dtype)
+        torch.matmul(a, b)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.matmul(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        return round(2.0 * n ** 3 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    except Exception:
+        return None
+
+
 def pmc_traffic(a, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     produced by tools/prof_round.sh + tools/pmc_summary.py on this exact workload); None when the run's workload or
@@ -323,6 +343,8 @@ def main():
         'shader_clock_mhz': round(getattr(prof, 'shader_mhz', 0.0), 1),
         'peak_at_measured_clock': round(peak * getattr(prof, 'shader_mhz', 0.0) / 2400.0, 1),
         'frac_at_measured_clock': round(achieved / (peak * prof.shader_mhz / 2400.0), 4) if getattr(prof, 'shader_mhz', 0.0) > 0 else None,
+        # the vendor's tuned dense bf16 GEMM on this very box (hipBLASLt 8192^3): the practical, power-capped MFMA ceiling
+        'vendor_gemm_tflops_same_box': vendor_gemm_tflops() if a.dtype == 'bf16' else None,
         'launches_per_step': dom_n // max(prof_steps, 1),
         'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
         'algorithmic_tflop_per_step': round(dom_fl / max(prof_steps, 1) / 1e12, 4),
