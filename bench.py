@@ -364,7 +364,7 @@ def main():
                    'parallelism': 'clip-sharded x%d (no data-path collective)' % a.gpus},
         'roofline': roofline,
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and a.gpus == 1:     # the CPU baseline is timed on rank 0 of the single-GPU run only
         out['cpu_baseline'] = cpu_baseline(a.arch, T)
         out['cpu_tracker'] = cpu_tracker_baseline()
     print(json.dumps(out), flush=True)
