@@ -279,6 +279,33 @@ def golden_roi_data(cfg):
         out['rd_s_' + k] = np.asarray(v)
     np.savez_compressed(os.path.join(HERE, 'reference_roi_data.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_roi_data.npz'), len(out), 'arrays')
+    golden_posetrack_json(cfg)
+
+
+def golden_posetrack_json(cfg):
+    """lib/core/mpii_eval_engine.py:_convert_data_to_annorect_struct on seeded detections, for every KP_CONF_TYPE ->
+    tests/golden/reference_posetrack_annorect.json (inputs included)."""
+    import json
+    sys.modules.setdefault('tqdm', types.ModuleType('tqdm'))
+    sys.modules['tqdm'].tqdm = lambda x, **k: x
+    import core.mpii_eval_engine as ref
+    rs = np.random.RandomState(5)
+    n = 6
+    boxes = np.hstack([rs.uniform(0, 300, (n, 4)), rs.uniform(0.2, 1.0, (n, 1))]).astype(np.float32)
+    poses = [np.vstack([rs.uniform(0, 300, (2, 17)), rs.uniform(-2, 8, (1, 17)), rs.uniform(0, 1, (1, 17))]).astype(np.float32)
+             for _ in range(n)]
+    tracks = [int(v) for v in rs.randint(0, 50, n)]
+    out = {'boxes': boxes.tolist(), 'poses': [p.tolist() for p in poses], 'tracks': tracks, 'cases': []}
+    for conf_type in ('global', 'local', 'scaled'):
+        for thr in (-float('inf'), 1.95):
+            cfg.TRACKING.KP_CONF_TYPE = conf_type
+            cfg.EVAL.EVAL_MPII_KPT_THRESHOLD = thr
+            res = ref._convert_data_to_annorect_struct(boxes, poses, tracks)
+            out['cases'].append({'conf_type': conf_type, 'thr': thr if thr > -1e30 else None, 'annorect': res})
+    out['empty'] = ref._convert_data_to_annorect_struct(np.zeros((0, 5), np.float32), [], [])
+    with open(os.path.join(HERE, 'reference_posetrack_annorect.json'), 'w') as f:
+        json.dump(out, f, default=float)   # 'local' / 'scaled' scores are np.float32 in the reference
+    print('wrote reference_posetrack_annorect.json', len(out['cases']), 'cases')
 
 
 if __name__ == '__main__':

@@ -404,3 +404,36 @@ def test_roi_data_matches_the_real_reference_golden():
         else:
             np.testing.assert_allclose(sb[k], ref, rtol=1e-5, atol=1e-6, err_msg=k)
     reset_cfg()
+
+
+def test_posetrack_annorect_matches_the_real_reference_golden():
+    """core/mpii_eval_engine.convert_data_to_annorect_struct (the per-frame structure of the JSON poseval reads) against the
+    REAL reference function run under py3 shims (tests/golden/reference_posetrack_annorect.json), all KP_CONF_TYPEs."""
+    import json
+    import tempfile
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.core import mpii_eval_engine as me
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_posetrack_annorect.json')) as f:
+        g = json.load(f)
+    reset_cfg()
+    boxes = np.asarray(g['boxes'], dtype=np.float32)
+    poses = [np.asarray(p, dtype=np.float32) for p in g['poses']]
+    for case in g['cases']:
+        cfg.TRACKING.KP_CONF_TYPE = case['conf_type']
+        cfg.EVAL.EVAL_MPII_KPT_THRESHOLD = -float('inf') if case['thr'] is None else case['thr']
+        got = json.loads(json.dumps(me.convert_data_to_annorect_struct(boxes, poses, g['tracks'])))
+        assert got == case['annorect'], case['conf_type']
+    assert me.convert_data_to_annorect_struct(np.zeros((0, 5), np.float32), [], []) == g['empty']
+    # the per-video files
+    reset_cfg()
+    names = ['images/vidA/%06d.jpg' % i for i in range(3)] + ['images/vidB/000000.jpg']
+    dets = {'all_boxes': [[], [boxes, boxes[:2], np.zeros((0, 5), np.float32), boxes[:1]]],
+            'all_keyps': [[], [poses, poses[:2], [], poses[:1]]],
+            'all_tracks': [[], [g['tracks'], g['tracks'][:2], [], g['tracks'][:1]]]}
+    with tempfile.TemporaryDirectory() as d:
+        files = me.write_posetrack_json(names, dets, d)
+        assert sorted(os.path.basename(f) for f in files) == ['vidA.json', 'vidB.json']
+        with open(os.path.join(d, 'vidA.json')) as f:
+            a = json.load(f)['annolist']
+        assert [e['imagenum'] for e in a] == [[0], [1], [2]] and a[2]['annorect'][0]['score'] == [0]
+    reset_cfg()
