@@ -64,7 +64,8 @@ struct ConvParams {
     int tab_rowoff[32];       // LDS row offset of this tap inside the plane patch
     short tab_dy[32], tab_dx[32];  // input offset of the plane's patch cell (0,0) relative to (ih0, iw0)
     unsigned tab_new;         // bit i: entry i starts a new plane (patch reload)
-    unsigned pw_magic;        // ceil(2^32 / PW): row / PW == umulhi(row, pw_magic) for row, PW < 2^16
+    unsigned pw_magic;        // ceil(2^32 / PW): row / PW == umulhi(row, pw_magic) for row, PW < 2^16; 0 when PW == 1 (2^32 does
+                              // not fit: a 1-wide patch of a KW == 1 conv made every row decode to patch row 0)
     int n_cchunks;            // Cin / CK
     int ksplit;               // split-K over the (kt, channel-chunk) sequence; > 1 => fp32 partials to `part`
     float* part;              // [ksplit][frames*Ho*Wo][Cout] fp32 (split-K only)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                     if (it < npatch_items) {
                         const int row = it >> 3;
                         const int slot = (it ^ (row >> 1)) & 7;
-                        const int prow = (int)__umulhi((unsigned)row, p.pw_magic), pcol = row - prow * p.PW;
+                        const int prow = p.pw_magic ? (int)__umulhi((unsigned)row, p.pw_magic) : row, pcol = row - prow * p.PW;
                         const int ih = py0 + prow * p.psh, iw = px0 + pcol * p.psw;
                         const char* src = p.zeros;
                         if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
@@ -633,7 +634,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
             }
         p.tab_n = n;
     }
-    p.pw_magic = (unsigned)((0x100000000ull + (unsigned)p.PW - 1) / (unsigned)p.PW);
+    p.pw_magic = p.PW == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)p.PW - 1) / (unsigned)p.PW);
     p.n_cchunks = p.Cin / Mma<DT>::CK;
     {
         static int abl = -1;

@@ -459,3 +459,78 @@ def test_fused_stem_conv_matches_torch(ops, dtype_name):
         err = (got - ref).abs().max().item()
         tol = 2e-3 if dtype_name == 'fp32' else 0.02 * ref.abs().max().item()
         assert err < tol, (N, T, H, W, err, tol)
+
+
+@pytest.mark.parametrize('dtype_name', ['fp32', 'bf16'])
+def test_conv_one_pixel_wide_tiles(ops, dtype_name):
+    """Regression: tiles that are ONE output column wide (KW == 1 convs on maps whose height is a multiple of the tile height and
+    whose width is odd, and the 4x1 stem formulation from Ho = 128 up) decode patch rows with PW == 1, where the magic-number
+    division constant 2^32 / PW does not fit 32 bits."""
+    import torch.nn.functional as F
+    dt = ops.F32 if dtype_name == 'fp32' else ops.BF16
+    tdt = ops.tdtype(dt)
+    g = torch.Generator().manual_seed(8)
+    for (cin, cout, k, H, W) in ((64, 64, (1, 4, 1), 131, 7), (64, 128, (1, 1, 1), 128, 5), (64, 64, (1, 1, 1), 256, 3)):
+        x = torch.randn((1, cin, 2, H, W), generator=g)
+        w = torch.randn((cout, cin) + k, generator=g) * (1.0 / (cin * k[1])) ** 0.5
+        if dtype_name == 'bf16':
+            x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+        ref = F.conv3d(x, w, None)
+        lay = ops.ConvLayer(w.cuda(), None, None, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt)
+        xd = x.permute(0, 2, 3, 4, 1).reshape(2, H, W, cin).to(tdt).cuda().contiguous()
+        y = lay(xd, T=2).float().cpu()
+        got = y.view(1, 2, ref.shape[3], ref.shape[4], -1)[..., :cout].permute(0, 4, 1, 2, 3)
+        err = (got - ref).abs().max().item()
+        assert err < (1e-3 if dtype_name == 'fp32' else 0.03 * ref.abs().max().item()), (cin, cout, k, H, W, err)
+    # the packed-stem formulation at a height that selects 128 x 1 tiles
+    data = torch.rand((1, 3, 1, 256, 96), generator=g) * 255 - 110
+    w7 = torch.randn((64, 3, 1, 7, 7), generator=g) * 0.025
+    ref = F.relu(F.conv3d(data.to(torch.bfloat16).float() if dtype_name == 'bf16' else data,
+                          w7.to(torch.bfloat16).float() if dtype_name == 'bf16' else w7, None, stride=(1, 2, 2), padding=(0, 3, 3)))
+    old = ops.stem_layer(w7.cuda(), torch.ones(64).cuda(), torch.zeros(64).cuda(), dt)
+    y = old(ops.stem_pack(data.cuda(), dt), T=1).float().cpu().view(1, 1, 128, 48, 64).permute(0, 4, 1, 2, 3)
+    assert (y - ref).abs().max().item() < (1e-2 if dtype_name == 'fp32' else 0.02 * ref.abs().max().item())
+
+
+def test_full_size_layers_spot_checked(ops):
+    """Size-independent check at the BENCH sizes (8 x 768 x 1344 clip, R-18 FPN3D): every distinct conv layer shape runs at full
+    size through the planner's own tile / split-K choice, and 48 random output positions (all channels) are compared with a direct
+    evaluation of the receptive-field dot products.  (The small-shape parity tests cannot see tile-shape-dependent bugs such as the
+    one-column-tile patch decoding fixed in round 1.)"""
+    sys_path = __import__('sys').path
+    import os
+    sys_path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_layers
+    g = torch.Generator(device='cuda').manual_seed(12)
+    T = 8
+    for (name, cin, cout, k, st, hi, wi, cnt) in bench_layers.layer_list('R18', T, 768, 1344, 3):
+        pads = (k[0] // 2, k[1] // 2, k[2] // 2) if name != 'stem_k4x1' else (0, 0, 0)
+        w = torch.randn((cout, cin) + tuple(k), device='cuda', generator=g) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
+        w = w.to(torch.bfloat16).float()
+        bias = torch.randn(cout, device='cuda', generator=g)
+        layer = ops.ConvLayer(w, None, bias, stride=(st, st), pads=pads, relu=False, dtype=ops.BF16)
+        x = torch.randn((T, hi, wi, layer.cin), device='cuda', generator=g).to(torch.bfloat16)
+        y = layer(x, T=T).float()
+        ho, wo = layer.out_hw(hi, wi)
+        xf = x.float()
+        worst = 0.0
+        idx = torch.randint(0, T * ho * wo, (48,), device='cuda', generator=g).tolist() + [0, T * ho * wo - 1, wo - 1, (ho - 1) * wo]
+        for p_ in idx:
+            f, r = divmod(p_, ho * wo)
+            oh, ow = divmod(r, wo)
+            acc = bias.clone()
+            for kt in range(k[0]):
+                ft = f + kt - pads[0]
+                if ft < 0 or ft >= T:
+                    continue
+                for kh in range(k[1]):
+                    ih = oh * st + kh - pads[1]
+                    if ih < 0 or ih >= hi:
+                        continue
+                    for kw in range(k[2]):
+                        iw = ow * st + kw - pads[2]
+                        if iw < 0 or iw >= wi:
+                            continue
+                        acc += w[:, :, kt, kh, kw] @ xf[ft, ih, iw, :cin]
+            worst = max(worst, (y[f, oh, ow, :cout] - acc).abs().max().item() / max(1.0, acc.abs().max().item()))
+        assert worst < 0.02, (name, worst)

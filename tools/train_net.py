@@ -53,6 +53,7 @@ def main():
     p.add_argument('--iters', type=int, default=0, help='override SOLVER.MAX_ITER')
     p.add_argument('--height', type=int, default=256)
     p.add_argument('--width', type=int, default=320)
+    p.add_argument('--reference-init', action='store_true', help='initialise from the builders\' init specs instead of synthetic_params')
     p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
     args = p.parse_args()
     cfg_from_file(args.cfg_file)
@@ -67,8 +68,13 @@ def main():
     ws = workspace.GlobalWorkspace()
     if cfg.TRAIN.WEIGHTS and os.path.exists(cfg.TRAIN.WEIGHTS):
         net_utils.initialize_from_weights_file(model, ws, cfg.TRAIN.WEIGHTS)
+    elif args.reference_init:
+        net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)      # the builders' init specs (MSRA / Gaussian), every rank alike
     else:
-        net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)      # identical on every rank
+        # no checkpoint offline: a well-conditioned deterministic init (the reference always starts from pre-trained weights;
+        # its from-scratch init on raw pixels with identity AffineChannel layers diverges at the shipped learning rates)
+        for k, v in net_utils.synthetic_params(model, cfg.RNG_SEED).items():
+            ws.set_param(k, v)
     trainer = Trainer(model, ws, dist)
     T = max(cfg.VIDEO.NUM_FRAMES, 1) if cfg.MODEL.VIDEO_ON else 1
     tube_T = cfg.VIDEO.NUM_FRAMES_MID if (cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '') else 1   # tube heads: 4T boxes
