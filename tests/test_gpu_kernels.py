@@ -534,3 +534,76 @@ def test_full_size_layers_spot_checked(ops):
                         acc += w[:, :, kt, kh, kw] @ xf[ft, ih, iw, :cin]
             worst = max(worst, (y[f, oh, ow, :cout] - acc).abs().max().item() / max(1.0, acc.abs().max().item()))
         assert worst < 0.02, (name, worst)
+
+
+def test_rpn_proposals_at_bench_size_vs_oracle(ops):
+    """GenerateProposals + NMS + collect at the BENCH level sizes (768 x 1344: 257 796 anchors over P2..P6, pre/post 1000) against
+    the oracle; continuous random scores (tie-free), so the kept sets must agree box for box."""
+    from oracle import proposals as op
+    from oracle.anchors import generate_anchors
+    rs = np.random.RandomState(31)
+    H0, W0 = 768, 1344
+    im_info = np.array([[H0, W0, 1.0]], np.float32)
+    specs, ref_r, ref_p = [], [], []
+    for lvl in range(2, 7):
+        H, W = int(np.ceil(H0 / 2. ** lvl)), int(np.ceil(W0 / 2. ** lvl))
+        anchors = generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2))
+        scores = rs.uniform(0.001, 0.999, (1, 3, H, W)).astype(np.float32)
+        deltas = (rs.randn(1, 12, H, W) * 0.3).astype(np.float32)
+        head, _ = _head_tensor(ops, scores, deltas, 0)
+        lg = ops.to_ncdhw(head, 0, 1, 3, 1).cpu().numpy()[:, :, 0]
+        probs_dev = (1.0 / (1.0 + np.exp(-lg.astype(np.float32)))).astype(np.float32)
+        r, p = op.generate_proposals(probs_dev, deltas, im_info, anchors, 1. / 2 ** lvl, 1000, 1000, 0.7, 0)
+        ref_r.append(r)
+        ref_p.append(p)
+        specs.append(ops.RpnLevelSpec(head, H, W, 3, 1, float(2 ** lvl), 64, 0, 3, 0, _dev(anchors.astype(np.float32))))
+    rois, probs, counts = ops.rpn_proposals(specs, 0, im_info[0], 1000, 1000, 0.7, 0.)
+    cnt = counts.cpu().numpy()
+    for i in range(5):
+        assert cnt[i] == ref_r[i].shape[0], (i, cnt[i], ref_r[i].shape)
+        np.testing.assert_allclose(rois[i, :cnt[i]].cpu().numpy(), ref_r[i], atol=3e-3)
+    out, n_out = ops.collect_rois(rois, probs, counts, 1000)
+    exp = op.collect(ref_r, ref_p, 1000)
+    assert int(n_out.item()) == exp.shape[0] == 1000
+    np.testing.assert_allclose(out[:1000].cpu().numpy(), exp, atol=3e-3)
+
+
+def test_fused_stem_and_maxpool_at_bench_size(ops):
+    """conv1 + pool1 on a full 8 x 768 x 1344 clip vs torch on the CPU (bf16 operands)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    data = torch.rand((1, 3, 8, 768, 1344), generator=g) * 255 - 110
+    w = torch.randn((64, 3, 1, 7, 7), generator=g) * 0.025
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    ref = F.relu(F.conv3d(data.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), None, stride=(1, 2, 2), padding=(0, 3, 3)) *
+                 scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1))
+    y = ops.StemConv(w.cuda(), scale.cuda(), bias.cuda(), ops.BF16, relu=True)(data.cuda())
+    got = y.float().cpu().view(1, 8, 384, 672, 64).permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max().item() < 0.02 * ref.abs().max().item()
+    pool = ops.maxpool_hw(y, ops.BF16, 3, 2, 1).float().cpu().view(1, 8, 192, 336, 64).permute(0, 4, 1, 2, 3)
+    ref_pool = F.max_pool3d(got, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+    assert (pool - ref_pool).abs().max().item() == 0.0
+
+
+def test_roi_align_at_bench_size_vs_oracle(ops):
+    """RoIAlign over the P2..P5 maps of a 768 x 1344 clip (256 channels, 1000 rois, 7x7 and 14x14): 24 rois checked against the
+    oracle (legacy RoIAlign, per-RoI FPN level)."""
+    from oracle import proposals as op
+    from oracle.roi_align import roi_align_2d
+    rs = np.random.RandomState(17)
+    H0, W0 = 768, 1344
+    feats = [rs.randn(1, 256, 1, H0 // 2 ** l, W0 // 2 ** l).astype(np.float32) for l in range(2, 6)]
+    R = 1000
+    x1, y1 = rs.uniform(0, W0 * 0.8, R), rs.uniform(0, H0 * 0.8, R)
+    w, h = np.exp(rs.uniform(np.log(8), np.log(900), R)), np.exp(rs.uniform(np.log(8), np.log(700), R))
+    rois = np.stack([np.zeros(R), x1, y1, np.minimum(x1 + w, W0 - 1), np.minimum(y1 + h, H0 - 1)], 1).astype(np.float32)
+    lvls = op.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+    assert len(np.unique(lvls)) == 4
+    fds = [ops.to_ndhwc(_dev(f), 0) for f in feats]
+    for pooled in (7, 14):
+        out = ops.roi_align(fds, [1. / 2 ** l for l in range(2, 6)], 0, _dev(rois), T=1, Tr=1, t0=0, pooled=pooled, sampling=2)
+        out = out.cpu().numpy().transpose(0, 3, 1, 2)
+        for i in list(range(0, R, 50)) + [R - 1, 1, 2, 3]:
+            l = int(lvls[i])
+            ref = roi_align_2d(feats[l - 2][:, :, 0], rois[i:i + 1], pooled, 1. / 2 ** l, 2)[0]
+            assert np.abs(out[i] - ref).max() < 1e-4, (pooled, i, l)
