@@ -245,3 +245,25 @@ def test_fpn3d_tube_heads_match_oracle():
     err = np.abs(kps - ref).max()
     print('FPN tube kps_score max-abs %.3e (ref max %.2f)' % (err, np.abs(ref).max()))
     assert err < 1e-3
+
+
+def test_bf16_forward_at_bench_size_close_to_oracle():
+    """The BENCH configuration end to end (R-18 FPN3D, 8 x 768 x 1344 clip, bf16): body + FPN blobs against the oracle graph run on
+    the host at full size (a few seconds), plus a decoded-keypoint sanity pass through the engine path."""
+    T, H, W = 8, 768, 1344
+    c = fpn3d_kps_cfg('18', T=T, dtype='bf16', pre=1000, post=1000)
+    model, ws, weights = build_product(c)
+    data = synthetic_clip(T, H, W)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', np.array([[H, W, 1.0]], dtype=np.float32))
+    ws.RunNet(model.net.name)
+    net, pyr = _oracle_pyramid(weights, '18', data, T, pre=1000, post=1000)
+    for n in ('pool1', 'res2_1_sum', 'res3_1_sum', 'res5_1_sum', 'fpn_res5_1_sum', 'fpn_res3_1_sum', 'fpn_res2_1_sum'):
+        got, ref = ws.FetchBlob(n), net.blobs[n].numpy()
+        assert got.shape == ref.shape, (n, got.shape, ref.shape)
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        print('bench-size bf16 %-16s max-abs/max %.3e' % (n, rel))
+        assert rel < 0.06, (n, rel)
+    rois = ws.FetchBlob('rois')
+    assert rois.shape == (1000, 5) and np.isfinite(rois).all()
+    assert (rois[:, 3] >= rois[:, 1]).all() and rois[:, 1:].min() >= 0 and rois[:, 3].max() <= W - 1 and rois[:, 4].max() <= H - 1
