@@ -101,9 +101,7 @@ template <int DT>
 __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) {
     constexpr int ES = ElemOf<DT>::size;
     constexpr int CK = MmaT<DT>::CK;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 128 * ROWB];
-    char* at = smem;
-    char* bt = smem + 128 * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * ROWB];   // double buffer of (A tile, B tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave & 1, wave_n = wave >> 1;
     // taps fastest, then channel tiles, K-split slowest: the blocks resident together read the SAME K-chunk of the gT / xT rows
@@ -116,20 +114,35 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
     const long long ksteps = p.K / CK;
     const long long s_lo = ksteps * split / p.ksplit, s_hi = ksteps * (split + 1) / p.ksplit;
 
-    // this thread stages 4 x 16 B of each tile: rows (tid >> 3) + 32*i, slot tid & 7
-    const int r0 = tid >> 3, slot = tid & 7;
+    // Both tiles stream global -> LDS by LDS-DMA into a double buffer (one barrier per K step, the tiles of step s+1 land while
+    // step s computes).  One wave-instruction lands 8 rows x 128 B lane-linearly, so the XOR swizzle of the fragment reads is
+    // applied on the source side: lane (row, phys slot) fetches logical slot phys ^ ((row >> 1) & 7).  The xT rows start at an
+    // element offset that is only 4-byte aligned (tap offset): dword alignment is all the DMA needs.
+    const int r0 = tid >> 3;                                   // row of item 0; item i: r0 + 32*i
+    const int lslot = (tid & 7) ^ ((tid >> 4) & 7);            // logical slot this lane fetches ((row >> 1) & 7 is i-independent)
     const char* arow[4];
     const char* brow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = min(co_t * 128 + r0 + 32 * i, p.Cout - 1);     // clamped rows are masked at the store
         const int ci = min(ci_t * 128 + r0 + 32 * i, p.Cin - 1);
-        arow[i] = p.gT + ((size_t)co * p.Qa) * ES + slot * 16;
-        brow[i] = p.xT + p.tap_base[tap] + ((size_t)ci * p.Qa + p.tap_off[tap]) * ES + slot * 16;
+        arow[i] = p.gT + ((size_t)co * p.Qa) * ES + lslot * 16;
+        brow[i] = p.xT + p.tap_base[tap] + ((size_t)ci * p.Qa + p.tap_off[tap]) * ES + lslot * 16;
     }
-    int lds_w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lds_w[i] = swz(r0 + 32 * i, slot);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#define TILE_DMA(S_, BUF_)                                                                                          \
+    {                                                                                                               \
+        const size_t ko_ = (size_t)(S_) * CK * ES;                                                                  \
+        char* ad_ = smem + (BUF_) * (2 * 128 * ROWB) + wv * (8 * ROWB);                                             \
+        char* bd_ = ad_ + 128 * ROWB;                                                                               \
+        _Pragma("unroll")                                                                                           \
+        for (int i_ = 0; i_ < 4; ++i_) {                                                                            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(arow[i_] + ko_), (lptr_t)(ad_ + i_ * 32 * ROWB), 16, 0, 0);   \
+            __builtin_amdgcn_global_load_lds((gptr_t)(brow[i_] + ko_), (lptr_t)(bd_ + i_ * 32 * ROWB), 16, 0, 0);   \
+        }                                                                                                           \
+    }
 
     const int khalf = lane >> 5;
     int a_off[2][4], b_off[2][4];
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             a_off[i][ks] = swz(wave_m * 64 + i * 32 + (lane & 31), ks * 2 + khalf);
-            b_off[i][ks] = swz(wave_n * 64 + i * 32 + (lane & 31), ks * 2 + khalf);
+            b_off[i][ks] = 128 * ROWB + swz(wave_n * 64 + i * 32 + (lane & 31), ks * 2 + khalf);
         }
     f32x16_t acc[2][2];
 #pragma unroll
@@ -148,34 +161,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define LOAD_TILES(S_)                                                     \
-    {                                                                      \
-        const size_t ko_ = (size_t)(S_) * CK * ES;                         \
-        ra0 = *(const uint4*)(arow[0] + ko_); ra1 = *(const uint4*)(arow[1] + ko_); \
-        ra2 = *(const uint4*)(arow[2] + ko_); ra3 = *(const uint4*)(arow[3] + ko_); \
-        rb0 = *(const uint4*)(brow[0] + ko_); rb1 = *(const uint4*)(brow[1] + ko_); \
-        rb2 = *(const uint4*)(brow[2] + ko_); rb3 = *(const uint4*)(brow[3] + ko_); \
-    }
-    if (s_lo < s_hi) LOAD_TILES(s_lo);
+    if (s_lo < s_hi) TILE_DMA(s_lo, 0);
     for (long long s = s_lo; s < s_hi; ++s) {
-        __syncthreads();     // previous step's fragment reads are done
-        *(uint4*)(at + lds_w[0]) = ra0; *(uint4*)(at + lds_w[1]) = ra1; *(uint4*)(at + lds_w[2]) = ra2; *(uint4*)(at + lds_w[3]) = ra3;
-        *(uint4*)(bt + lds_w[0]) = rb0; *(uint4*)(bt + lds_w[1]) = rb1; *(uint4*)(bt + lds_w[2]) = rb2; *(uint4*)(bt + lds_w[3]) = rb3;
-        __syncthreads();
-        if (s + 1 < s_hi) LOAD_TILES(s + 1);
+        const int buf = (int)((s - s_lo) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step s landed ...
+        __syncthreads();                                      // ... and everybody's; previous step's fragment reads are done
+        if (s + 1 < s_hi) TILE_DMA(s + 1, buf ^ 1);
+        const char* tb = smem + buf * (2 * 128 * ROWB);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = *(const uint4*)(at + a_off[i][ks]); b[i] = *(const uint4*)(bt + b_off[i][ks]); }
+            for (int i = 0; i < 2; ++i) { a[i] = *(const uint4*)(tb + a_off[i][ks]); b[i] = *(const uint4*)(tb + b_off[i][ks]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) MmaT<DT>::step(a[i], b[j], acc[i][j]);
         }
     }
-#undef LOAD_TILES
+#undef TILE_DMA
     // D[i = co][j = ci]: lane holds column ci = lane&31; register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Partial tiles go to Gt[tap][co][ci] (ci contiguous: a wave's 64 atomics land in 2 lines instead of 64); the finish kernel
     // transposes to the reference weight layout.  With a single K split the tile is complete: plain stores.
