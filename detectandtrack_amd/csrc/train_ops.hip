@@ -91,6 +91,7 @@ struct WgradParams {
     int Cout, Cin, ntaps;
     long long Qa;         // row length (elements)
     long long K;          // number of q to reduce (multiple of CK)
+    long long k_begin;    // first q of the reduction (multiple of CK): g is known to be zero before it
     int ksplit;
     int n_ci_tiles, n_co_tiles;
     long long tap_off[32];     // element offset into the B row (already reduced by the copy's shift)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define TILE_DMA(S_, BUF_)                                                                                          \
     {                                                                                                               \
-        const size_t ko_ = (size_t)(S_) * CK * ES;                                                                  \
+        const size_t ko_ = ((size_t)p.k_begin + (size_t)(S_) * CK) * ES;                                           \
         char* ad_ = smem + (BUF_) * (2 * 128 * ROWB) + wv * (8 * ROWB);                                             \
         char* bd_ = ad_ + 128 * ROWB;                                                                               \
         _Pragma("unroll")                                                                                           \
@@ -546,6 +547,18 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     wp.ntaps = d->KT * d->KH * d->KW; wp.Qa = Qa;
     const int ck = d->dtype == DAT_BF16 ? 64 : 32;
     wp.K = (Qtot + ck - 1) / ck * ck;
+    wp.k_begin = 0;
+    // d->out_t0 / out_tn (optional): g is non-zero only in frames [out_t0, out_t0 + out_tn) of the clip (a key-frame gradient
+    // embedded in its temporal window): reduce over those frames' positions only
+    if (d->out_tn > 0 && clips == 1) {
+        DAT_ENFORCE(ctx, d->out_t0 >= 0 && d->out_t0 + d->out_tn <= d->T, "conv3d_wgrad: gradient frames [%d, %d) outside T %d",
+                    d->out_t0, d->out_t0 + d->out_tn, d->T);
+        const long long fq = (long long)Hq * Wq;
+        const long long b0 = (long long)d->out_t0 * fq / ck * ck;
+        const long long e0 = ((long long)(d->out_t0 + d->out_tn) * fq + ck - 1) / ck * ck;
+        wp.k_begin = b0;
+        wp.K = (e0 < wp.K ? e0 : wp.K) - b0;
+    }
     wp.n_co_tiles = (Cout_real + 127) / 128; wp.n_ci_tiles = (Cin_real + 127) / 128;
     for (int kt = 0; kt < d->KT; ++kt)
         for (int kh = 0; kh < d->KH; ++kh)

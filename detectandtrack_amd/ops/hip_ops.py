@@ -211,11 +211,13 @@ class ConvGrad(object):
         d.relu, d.res_mode, d.out_t0, d.out_tn = 0, 0, 0, 0
         return d
 
-    def weight(self, x, g, T, want_dscale=False):
+    def weight(self, x, g, T, want_dscale=False, g_frames=None):
         """x [frames,H,W,x_cstride], g [frames,Ho,Wo,g_cstride] -> (dW fp32 [Cout,Cin,KT,KH,KW] (already x scale),
         dscale fp32 [Cout] | None)"""
         frames, H, W, _ = x.shape
         d = self._fwd_desc(frames, T, H, W)
+        if g_frames is not None and frames == T:      # g is zero outside frames [t0, t0 + n) of the (single) clip
+            d.out_t0, d.out_tn = int(g_frames[0]), int(g_frames[1])
         nbytes = L.lib().dat_conv3d_wgrad_workspace_bytes(C.byref(d), self.cin, self.cout)
         wsb = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         dW = torch.empty(self.w.shape, dtype=torch.float32, device=x.device)

@@ -248,7 +248,7 @@ class TrainExecutor(Executor):
         scale = self._master(a['scale']) if a['scale'] else None
         cg = ops.ConvGrad(w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
         if self._trainable(a['w']):
-            dW, _ = cg.weight(x_win, g_emb, Tw)
+            dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=(lo - ilo, n) if xin.N == 1 else None)
             self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             f, H, W, _ = xin.t.shape

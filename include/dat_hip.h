@@ -214,7 +214,8 @@ int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, con
 /* Weight gradient of a conv described like dat_conv3d_fwd (same-T, stride 1 or 2):
  *   dW[co][ci][kt][kh][kw] = sum_p g[p][co] * x[p (+) tap][ci]      (fp32, reference blob layout, overwritten)
  * x: the conv input NDHWC (channel stride d->Cin), g: gradient w.r.t. the conv output NDHWC (channel stride
- * g_cstride); scale (fp32 [Cout] or NULL) multiplies row co: the fused AffineChannelNd scale when g is the gradient
+ * g_cstride); d->out_t0 / out_tn > 0 (one clip) declare that g is non-zero only in those frames, which restricts the
+ * reduction to their positions; scale (fp32 [Cout] or NULL) multiplies row co: the fused AffineChannelNd scale when g is the gradient
  * w.r.t. the affine OUTPUT.  Replaces Caffe2's ConvGradient filter path reached through AddGradientOperators
  * (model_builder.py:908-952).  workspace: dat_conv3d_wgrad_workspace_bytes() bytes of device memory. */
 size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, int Cout_real);
