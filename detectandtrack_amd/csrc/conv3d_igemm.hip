@@ -50,6 +50,7 @@ struct ConvParams {
     const char* zeros;          // >= 16 zero bytes (what a halo lane of the patch LDS-DMA fetches)
     int frames, T, H, W, Cin;   // frames = OUTPUT frames (clips * otn)
     int ot0, otn;               // output frames per clip: t in [ot0, ot0 + otn)
+    int in_lo, in_hi;           // input frames outside [in_lo, in_hi) of the clip are known to be zero: their temporal taps are skipped
     int Ho, Wo, Cout, out_cs, Cout_pad;
     int KT, KH, KW, sh, sw, pt, ph, pw;
     int relu, res_mode;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 
     // valid temporal taps for this output frame
     int kt_lo = 0, kt_hi = p.KT - 1;
-    while (kt_lo < p.KT && (t + kt_lo - p.pt) < 0) ++kt_lo;
-    while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.T) --kt_hi;
+    while (kt_lo < p.KT && (t + kt_lo - p.pt) < p.in_lo) ++kt_lo;
+    while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.in_hi) --kt_hi;
     const int n_kt = kt_hi - kt_lo + 1;
     const int ntap = p.KH * p.KW;      // weight taps per kt
     const int ntab = p.tab_n;          // == ntap, in plane order
@@ -767,6 +768,9 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     p.res = (const char*)residual; p.y = (char*)y;
     p.zeros = (const char*)ctx->zeros;
     p.clk = ctx->prof_enabled ? (unsigned long long*)((char*)ctx->zeros + 256) : nullptr;
+    p.in_lo = d->in_tn > 0 ? d->in_t0 : 0;
+    p.in_hi = d->in_tn > 0 ? d->in_t0 + d->in_tn : d->T;
+    DAT_ENFORCE(ctx, p.in_lo >= 0 && p.in_hi <= d->T, "conv3d_fwd: non-zero input frames [%d, %d) outside T %d", p.in_lo, p.in_hi, d->T);
     p.ot0 = d->out_tn > 0 ? d->out_t0 : 0;
     p.otn = d->out_tn > 0 ? d->out_tn : d->T;
     DAT_ENFORCE(ctx, p.ot0 >= 0 && p.ot0 + p.otn <= d->T, "conv3d_fwd: output frames [%d, %d) outside T %d", p.ot0,

@@ -25,7 +25,7 @@ class DatError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         'dtype', 'frames', 'T', 'H', 'W', 'Cin', 'Cout', 'out_cstride', 'KT', 'KH', 'KW',
-        'stride_h', 'stride_w', 'pad_t', 'pad_h', 'pad_w', 'relu', 'res_mode', 'out_t0', 'out_tn')]
+        'stride_h', 'stride_w', 'pad_t', 'pad_h', 'pad_w', 'relu', 'res_mode', 'out_t0', 'out_tn', 'in_t0', 'in_tn')]
 
 
 class RoiLevel(C.Structure):

@@ -128,7 +128,7 @@ class ConvLayer(object):
         ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(w), self.cout_real, self.cin_real,
                    _ptr(self.packed))
 
-    def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None, out_t=None):
+    def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None, out_t=None, in_t=None):
         d = L.ConvDesc()
         d.dtype = self.dtype
         d.frames, d.T, d.H, d.W, d.Cin = frames, T, H, W, self.cin
@@ -140,6 +140,7 @@ class ConvLayer(object):
         d.relu = int(self.relu if relu is None else relu)
         d.res_mode = res_mode
         d.out_t0, d.out_tn = out_t if out_t is not None else (0, 0)
+        d.in_t0, d.in_tn = in_t if in_t is not None else (0, 0)
         return d
 
     def out_hw(self, H, W):
@@ -164,14 +165,14 @@ class ConvLayer(object):
             b += oframes * (ho // 2) * (wo // 2) * self.cstride * es
         return float(b)
 
-    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None):
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None):
         """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored."""
         frames, H, W, cin = x.shape
         assert cin == self.cin, 'channel stride %d != layer Cin %d' % (cin, self.cin)
         assert x.dtype == tdtype(self.dtype) and x.is_contiguous()
         if res_mode is None:
             res_mode = 1 if residual is not None else 0
-        d = self.desc(frames, T, H, W, res_mode, out_t=out_t)
+        d = self.desc(frames, T, H, W, res_mode, out_t=out_t, in_t=in_t)
         ho, wo = self.out_hw(H, W)
         oframes = frames if out_t is None else frames // T * out_t[1]
         if out is None:
@@ -208,7 +209,7 @@ class ConvGrad(object):
         d.KT, d.KH, d.KW = self.kt, self.kh, self.kw
         d.stride_h, d.stride_w = self.stride
         d.pad_t, d.pad_h, d.pad_w = self.pads
-        d.relu, d.res_mode, d.out_t0, d.out_tn = 0, 0, 0, 0
+        d.relu, d.res_mode, d.out_t0, d.out_tn, d.in_t0, d.in_tn = 0, 0, 0, 0, 0, 0
         return d
 
     def weight(self, x, g, T, want_dscale=False, g_frames=None):
@@ -229,7 +230,7 @@ class ConvGrad(object):
         dscale = (dW * self.w).sum(dim=(1, 2, 3, 4)) / self.scale
         return dW, dscale
 
-    def data(self, g, T, H, W, accumulate_into=None):
+    def data(self, g, T, H, W, accumulate_into=None, g_frames=None):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given)."""
         if self._data_layer is None:
             w = self.w if self.scale is None else self.w * self.scale.view(-1, 1, 1, 1, 1)
@@ -248,9 +249,10 @@ class ConvGrad(object):
         else:
             gz = g
         lay = self._data_layer
+        in_t = g_frames if (g_frames is not None and frames == T) else None   # zero frames of g: their temporal taps are skipped
         if accumulate_into is not None:
-            return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into)
-        return lay(gz, T=T)
+            return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into, in_t=in_t)
+        return lay(gz, T=T, in_t=in_t)
 
 
 def relu_bias_bwd(dy, y, dtype, C_real, relu=True, dy2=None, dbias=None):

@@ -252,7 +252,7 @@ class TrainExecutor(Executor):
             self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             f, H, W, _ = xin.t.shape
-            self._add_grad(op.inputs[0], cg.data(g_emb, Tw, H, W), ilo)
+            self._add_grad(op.inputs[0], cg.data(g_emb, Tw, H, W, g_frames=(lo - ilo, n) if xin.N == 1 else None), ilo)
 
     def _bwd_rpn_head(self, i):
         ws = self.ws

@@ -87,6 +87,8 @@ typedef struct {
                                 compactly as [N*out_tn, Ho, Wo, C] (the frames a following SliceKeyFrame keeps,
                                 FPN3D.py:170-183 'slice-center'); out_tn == 0: all T frames.  residual (if any) is
                                 indexed like the output */
+    int in_t0, in_tn;        /* in_tn > 0: input frames outside [in_t0, in_t0+in_tn) of every clip are known to be ZERO (a key-frame
+                                gradient embedded in its temporal window): the temporal taps that would read them are skipped */
 } dat_conv_desc;
 
 int dat_conv3d_out_shape(const dat_conv_desc* d, int* Ho, int* Wo);
