@@ -55,15 +55,17 @@ struct PackParams {
 template <int DT>
 __global__ __launch_bounds__(256) void cq_pack_kernel(const PackParams p) {
     typedef typename ElemOf<DT>::type E;
-    __shared__ E tile[64][65];
+    constexpr int V = 16 / ElemOf<DT>::size;          // elements per 16-byte vector (8 bf16 / 4 fp32)
+    constexpr int PITCH = 64 + V;                     // LDS row pitch in elements: keeps rows 16-B aligned, rotates banks
+    __shared__ __attribute__((aligned(16))) E tile[64 * PITCH];
     const long long q0 = (long long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-    // load: 64 positions x 64 channels (channel-contiguous reads)
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int ql = i >> 6, cl = i & 63;
+    // load: 64 positions x 64 channels, one 16-byte vector of channels per thread-iteration (channel-contiguous reads)
+    for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+        const int ql = i / (64 / V), cv = (i - ql * (64 / V)) * V;
         const long long q = q0 + ql + p.shift;
-        E v = 0;
-        if (q < p.Qtot && c0 + cl < p.C) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < p.Qtot && c0 + cv < p.C) {
             long long r = q;
             const int xx = (int)(r % p.Wq); r /= p.Wq;
             const int yy = (int)(r % p.Hq); r /= p.Hq;
@@ -71,15 +73,31 @@ __global__ __launch_bounds__(256) void cq_pack_kernel(const PackParams p) {
             const int n = (int)(r / p.Tq);
             const int t = tf - p.ot, y = p.st * yy + p.oy, x = p.st * xx + p.ox;
             if (t >= 0 && t < p.T && y >= 0 && y < p.Hs && x >= 0 && x < p.Ws)
-                v = ((const E*)p.src)[(((size_t)(n * p.T + t) * p.Hs + y) * p.Ws + x) * p.cs + c0 + cl];
+                v = *(const uint4*)((const E*)p.src + (((size_t)(n * p.T + t) * p.Hs + y) * p.Ws + x) * p.cs + c0 + cv);
         }
-        tile[ql][cl] = v;
+        *(uint4*)(tile + ql * PITCH + cv) = v;        // channel strides are multiples of 4 (8 for bf16 tensors): aligned
     }
     __syncthreads();
-    // store: each channel row gets 64 consecutive q
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int cl = i >> 6, ql = i & 63;
-        if (c0 + cl < p.C && q0 + ql < p.Qa) ((E*)p.dst)[(size_t)(c0 + cl) * p.Qa + q0 + ql] = tile[ql][cl];
+    // store: each channel row gets 64 consecutive q, 16 bytes (V positions) per thread-iteration
+    for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+        const int cl = i / (64 / V), qv = (i - cl * (64 / V)) * V;
+        if (c0 + cl >= p.C) continue;
+        E e[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) e[j] = tile[(qv + j) * PITCH + cl];
+        E* dst = (E*)p.dst + (size_t)(c0 + cl) * p.Qa + q0 + qv;
+        if (q0 + qv + V <= p.Qa) {
+            uint4 o;
+            if constexpr (V == 8) {
+                o.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16); o.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                o.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16); o.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            } else {
+                o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
+            }
+            *(uint4*)dst = o;
+        } else {
+            for (int j = 0; j < V && q0 + qv + j < p.Qa; ++j) dst[j] = e[j];
+        }
     }
 }
 
@@ -505,7 +523,7 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     DAT_ENFORCE(ctx, d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2), "conv3d_wgrad: stride %dx%d", d->stride_h, d->stride_w);
     DAT_ENFORCE(ctx, d->frames % d->T == 0 && d->pad_t * 2 + 1 == d->KT, "conv3d_wgrad: needs same-T convs");
     DAT_ENFORCE(ctx, d->KT * d->KH * d->KW <= 32, "conv3d_wgrad: %d taps exceed 32", d->KT * d->KH * d->KW);
-    DAT_ENFORCE(ctx, d->Cin % 4 == 0 && g_cstride % 4 == 0, "conv3d_wgrad: channel strides must be multiples of 4");
+    DAT_ENFORCE(ctx, d->Cin % 8 == 0 && g_cstride % 8 == 0, "conv3d_wgrad: channel strides must be multiples of 8");
     hipStream_t st = (hipStream_t)s_;
     int Ho, Wo, Tq, Hq, Wq, nc;
     long long Qtot, Qa;
