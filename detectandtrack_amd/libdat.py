@@ -90,6 +90,8 @@ _PROTOS = {
     'dat_kps_finalize_bwd': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_rpn_loss': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p]),
     'dat_smooth_l1_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p]),
+    'dat_anchor_overlaps': (_i, [_p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _p, _p, _p, _p]),
+    'dat_scatter_words': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _i]),
     'dat_softmax_ce_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p]),
 }
 EXPORTS = sorted(_PROTOS)

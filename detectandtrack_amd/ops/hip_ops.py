@@ -334,6 +334,27 @@ def softmax_ce_rows(logits, dtype, D, labels, weights, mult, loss, correct=None,
     return dl
 
 
+def anchor_overlaps(anchors, gts, T, im_h, im_w, straddle, out=None):
+    """Device half of the RPN anchor labelling (dat_anchor_overlaps): anchors [n,4T], gts [G,4T] fp32 CUDA ->
+    (a2g_max [n] fp32 (-1 = outside the image), a2g_arg [n] int32, best [n] uint8)."""
+    n, G = anchors.shape[0], gts.shape[0]
+    assert anchors.dtype == gts.dtype == torch.float32 and anchors.is_contiguous() and gts.is_contiguous()
+    assert anchors.shape[1] == 4 * T and (G == 0 or gts.shape[1] == 4 * T)
+    if out is None:
+        out = (torch.empty(n, dtype=torch.float32, device=anchors.device), torch.empty(n, dtype=torch.int32, device=anchors.device),
+               torch.empty(n, dtype=torch.uint8, device=anchors.device))
+    gmax = torch.empty(max(G, 1), dtype=torch.int32, device=anchors.device)
+    ctx().call('dat_anchor_overlaps', _stream(), _ptr(anchors), n, _ptr(gts) if G else None, G, T, C.c_float(im_h), C.c_float(im_w),
+               C.c_float(straddle), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(gmax))
+    return out
+
+
+def scatter_words(dst, offsets, values):
+    """dst.view(32-bit words)[offsets[i]] = values[i] (dat_scatter_words); dst any 4-byte dtype, offsets int32, values 4-byte."""
+    assert dst.element_size() == 4 and values.element_size() == 4 and offsets.dtype == torch.int32 and dst.is_contiguous()
+    ctx().call('dat_scatter_words', _stream(), _ptr(dst), C.c_longlong(dst.numel()), _ptr(offsets), _ptr(values), offsets.numel())
+
+
 def stem_pack(data, dtype):
     """data fp32 [N,3,T,H,W] -> packed [N*T, Ho+3, Wo, 64] (see dat_hip.h)."""
     data = data.contiguous()

@@ -52,12 +52,22 @@ def _unmap(data, count, inds, fill=0):
     return ret
 
 
-def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=npr):
-    """:254-370 -> list (one dict per level) of rpn_labels_int32_wide (1, A, F, F), rpn_bbox_{targets,inside_weights,
-    outside_weights}_wide (1, 4TA, F, F)."""
-    all_anchors = np.concatenate([f.field_of_anchors for f in foas])
+def all_field_anchors(foas):
+    """The level-ordered concatenation of the fields (cached: it is a pure function of the config)."""
+    key = tuple(id(f) for f in foas)
+    if key not in _all_cache:
+        _all_cache[key] = np.ascontiguousarray(np.concatenate([f.field_of_anchors for f in foas]))
+    return _all_cache[key]
+
+
+_all_cache = {}
+
+
+def anchor_overlap_stats(all_anchors, im_height, im_width, gt_boxes):
+    """:283-305 on the host -> (inside, a2g_max, a2g_arg, best): indices of the anchors inside the image (straddle
+    filter), their max IoU / first arg-max over the gts, and whether they attain some gt's maximum.  The device half
+    (ops.anchor_overlaps = dat_anchor_overlaps) returns the same four arrays bit for bit."""
     total = all_anchors.shape[0]
-    T = all_anchors.shape[1] // 4
     st = cfg.TRAIN.RPN_STRADDLE_THRESH
     if st >= 0:
         inside = np.where(np.all(all_anchors[:, 0::4] >= -st, axis=1) & np.all(all_anchors[:, 1::4] >= -st, axis=1) &
@@ -65,19 +75,99 @@ def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=
                           np.all(all_anchors[:, 3::4] < im_height + st, axis=1))[0]
     else:
         inside = np.arange(total)
-    anchors = all_anchors[inside]
     n = len(inside)
-    labels = np.full((n,), -1, dtype=np.int32)
-    if visible_tracks is None:
-        visible_tracks = np.full((gt_boxes.shape[0], T), True)
     a2g_max = np.zeros((n,), dtype=np.float32)
     a2g_arg = np.zeros((n,), dtype=np.int64)
+    best = np.zeros((n,), dtype=bool)
     if len(gt_boxes) > 0 and n > 0:
-        ov = box_utils.bbox_overlaps(anchors, gt_boxes.astype(np.float32))
+        ov = box_utils.bbox_overlaps(all_anchors[inside], gt_boxes.astype(np.float32))
         a2g_arg = ov.argmax(axis=1)
         a2g_max = ov[np.arange(n), a2g_arg]
         g2a_max = ov[ov.argmax(axis=0), np.arange(ov.shape[1])]
-        labels[np.where(ov == g2a_max)[0]] = 1          # every gt keeps its best anchor(s)
+        best[np.where(ov == g2a_max)[0]] = True          # every gt keeps its best anchor(s)
+    return inside, a2g_max, a2g_arg, best
+
+
+class SparseRpnLabels(object):
+    """The <= RPN_BATCH_SIZE_PER_IM sampled anchors of one clip: everything else in the dense "wide" blobs is the fill
+    value (label -1, zeros).  idx indexes the level-ordered field; targets / w_in are [m, 4T]; w_out is one scalar."""
+
+    def __init__(self, foas, idx, labels, targets, w_in, w_out):
+        self.foas, self.idx, self.labels, self.targets, self.w_in, self.w_out = foas, idx, labels, targets, w_in, w_out
+        starts = np.cumsum([0] + [f.field_size * f.field_size * f.num_cell_anchors for f in foas])
+        self.level = np.searchsorted(starts, idx, side='right') - 1
+        local = idx - starts[self.level]
+        A = np.array([f.num_cell_anchors for f in foas])[self.level]
+        F = np.array([f.field_size for f in foas])[self.level]
+        self.a, cell = local % A, local // A
+        self.y, self.x = cell // F, cell % F
+
+    def count_in_window(self, level, h, w):
+        """#(labels >= 0) inside the head's h x w window of one level (the SpatialNarrowAs + normalisation of the loss)."""
+        return int(np.sum((self.level == level) & (self.y < h) & (self.x < w)))
+
+    def dense(self):
+        """:343-368 -> one dict per level of rpn_labels_int32_wide (1, A, F, F) and rpn_bbox_{targets,inside_weights,
+        outside_weights}_wide (1, 4TA, F, F)."""
+        out = []
+        T4 = self.targets.shape[1]
+        for l, foa in enumerate(self.foas):
+            F, A = foa.field_size, foa.num_cell_anchors
+            lab = np.full((1, A, F, F), -1, dtype=np.int32)
+            tgt = np.zeros((1, A * T4, F, F), dtype=np.float32)
+            w_in = np.zeros((1, A * T4, F, F), dtype=np.float32)
+            w_out = np.zeros((1, A * T4, F, F), dtype=np.float32)
+            m = np.where(self.level == l)[0]
+            if len(m):
+                a, y, x = self.a[m], self.y[m], self.x[m]
+                lab[0, a, y, x] = self.labels[m]
+                ch = a[:, None] * T4 + np.arange(T4)[None, :]
+                tgt[0, ch, y[:, None], x[:, None]] = self.targets[m]
+                w_in[0, ch, y[:, None], x[:, None]] = self.w_in[m]
+                w_out[0, ch, y[:, None], x[:, None]] = self.w_out
+            out.append(dict(rpn_labels_int32_wide=lab, rpn_bbox_targets_wide=tgt, rpn_bbox_inside_weights_wide=w_in,
+                            rpn_bbox_outside_weights_wide=w_out))
+        return out
+
+    def scatter_plan(self):
+        """Word offsets and 32-bit values of every non-fill element in ONE flat buffer that holds, level after level,
+        [labels | targets | inside | outside] in the dense layout; and each blob's (offset, shape) in that buffer."""
+        T4 = self.targets.shape[1]
+        views, base = [], 0
+        offs, vals = [], []
+        for l, foa in enumerate(self.foas):
+            F, A = foa.field_size, foa.num_cell_anchors
+            ff = F * F
+            o_lab, o_t, o_i, o_o = base, base + A * ff, base + A * ff * (1 + T4), base + A * ff * (1 + 2 * T4)
+            views.append(dict(rpn_labels_int32_wide=(o_lab, (1, A, F, F)), rpn_bbox_targets_wide=(o_t, (1, A * T4, F, F)),
+                              rpn_bbox_inside_weights_wide=(o_i, (1, A * T4, F, F)),
+                              rpn_bbox_outside_weights_wide=(o_o, (1, A * T4, F, F))))
+            base += A * ff * (1 + 3 * T4)
+            m = np.where(self.level == l)[0]
+            if len(m):
+                a, pix = self.a[m], self.y[m] * F + self.x[m]
+                ch = ((a[:, None] * T4 + np.arange(T4)[None, :]) * ff + pix[:, None]).ravel()
+                offs += [o_lab + a * ff + pix, o_t + ch, o_i + ch, o_o + ch]
+                vals += [self.labels[m].astype(np.int32).view(np.uint32), self.targets[m].astype(np.float32).ravel().view(np.uint32),
+                         self.w_in[m].astype(np.float32).ravel().view(np.uint32),
+                         np.full(len(ch), self.w_out, dtype=np.float32).view(np.uint32)]
+        offs = np.concatenate(offs).astype(np.int32) if offs else np.zeros((0,), np.int32)
+        vals = np.concatenate(vals).astype(np.uint32) if vals else np.zeros((0,), np.uint32)
+        return offs, vals, views, base
+
+
+def sample_rpn_labels(foas, stats, gt_boxes, visible_tracks=None, rng=npr):
+    """:306-342: fg = best anchors of each gt or IoU >= RPN_POSITIVE_OVERLAP, bg = IoU < RPN_NEGATIVE_OVERLAP, both
+    sub-sampled (the only two RNG draws); targets / weights of the sampled anchors -> SparseRpnLabels."""
+    all_anchors = all_field_anchors(foas)
+    inside, a2g_max, a2g_arg, best = stats
+    n = len(inside)
+    T = all_anchors.shape[1] // 4
+    labels = np.full((n,), -1, dtype=np.int32)
+    if visible_tracks is None:
+        visible_tracks = np.full((gt_boxes.shape[0], T), True)
+    if len(gt_boxes) > 0 and n > 0:
+        labels[best] = 1
         labels[a2g_max >= cfg.TRAIN.RPN_POSITIVE_OVERLAP] = 1
     num_fg = int(cfg.TRAIN.RPN_FG_FRACTION * cfg.TRAIN.RPN_BATCH_SIZE_PER_IM)
     fg = np.where(labels == 1)[0]
@@ -88,30 +178,22 @@ def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=
     bg = np.where(a2g_max < cfg.TRAIN.RPN_NEGATIVE_OVERLAP)[0]
     if len(bg) > num_bg:
         labels[bg[rng.randint(len(bg), size=num_bg)]] = 0
-    targets = np.zeros((n, 4 * T), dtype=np.float32)
-    w_in = np.zeros((n, 4 * T), dtype=np.float32)
-    w_out = np.zeros((n, 4 * T), dtype=np.float32)
+    sel = np.where(labels >= 0)[0]                       # superset of fg (a bg draw may turn an fg anchor into 0)
+    targets = np.zeros((len(sel), 4 * T), dtype=np.float32)
+    w_in = np.zeros((len(sel), 4 * T), dtype=np.float32)
     if len(fg) > 0:
-        targets[fg] = box_utils.bbox_transform_inv(anchors[fg], gt_boxes[a2g_arg[fg]].astype(np.float32),
-                                                   (1.0, 1.0, 1.0, 1.0)).astype(np.float32)
-        w_in[fg] = np.repeat(np.broadcast_to(visible_tracks[a2g_arg[fg]], (len(fg), T)).astype(np.float32), 4, axis=1)
-    num_examples = max(int(np.sum(labels >= 0)), 1)
-    w_out[labels >= 0] = 1.0 / num_examples
-    labels = _unmap(labels, total, inside, fill=-1)
-    targets = _unmap(targets, total, inside)
-    w_in = _unmap(w_in, total, inside)
-    w_out = _unmap(w_out, total, inside)
-    out, start = [], 0
-    for foa in foas:
-        F, A = foa.field_size, foa.num_cell_anchors
-        end = start + F * F * A
-        out.append(dict(
-            rpn_labels_int32_wide=np.ascontiguousarray(labels[start:end].reshape((1, F, F, A)).transpose(0, 3, 1, 2)),
-            rpn_bbox_targets_wide=np.ascontiguousarray(targets[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2)),
-            rpn_bbox_inside_weights_wide=np.ascontiguousarray(w_in[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2)),
-            rpn_bbox_outside_weights_wide=np.ascontiguousarray(w_out[start:end].reshape((1, F, F, A * 4 * T)).transpose(0, 3, 1, 2))))
-        start = end
-    return out
+        pos = np.searchsorted(sel, fg)
+        targets[pos] = box_utils.bbox_transform_inv(all_anchors[inside[fg]], gt_boxes[a2g_arg[fg]].astype(np.float32),
+                                                    (1.0, 1.0, 1.0, 1.0)).astype(np.float32)
+        w_in[pos] = np.repeat(np.broadcast_to(visible_tracks[a2g_arg[fg]], (len(fg), T)).astype(np.float32), 4, axis=1)
+    w_out = np.float32(1.0 / max(len(sel), 1))
+    return SparseRpnLabels(foas, inside[sel], labels[sel], targets, w_in, w_out)
+
+
+def get_rpn_blobs(im_height, im_width, foas, gt_boxes, visible_tracks=None, rng=npr):
+    """:254-370 on the host -> list (one dict per level) of the dense wide blobs."""
+    stats = anchor_overlap_stats(all_field_anchors(foas), im_height, im_width, gt_boxes)
+    return sample_rpn_labels(foas, stats, gt_boxes, visible_tracks, rng).dense()
 
 
 def add_rpn_blobs(blobs, im_scale, entry, rng=npr):

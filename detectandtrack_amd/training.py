@@ -72,9 +72,12 @@ class TrainExecutor(Executor):
         labels, tgt, w_in, w_out = [ws.blobs[n] for n in op.inputs[2:6]]
         cls_mult = a['cls_scale']
         if a['normalize']:
-            lab = labels.host if labels.host is not None else labels.t.cpu().numpy()
             f, h, w, _ = head.t.shape
-            cls_mult /= max(1.0, float((lab[:, :, :h, :w] >= 0).sum()))
+            if hasattr(labels.host, 'count_in_window'):     # roi_data.loader: the sampled anchors are known sparsely
+                cls_mult /= max(1.0, float(labels.host.count_in_window(h, w)))
+            else:
+                lab = labels.host if labels.host is not None else labels.t.cpu().numpy()
+                cls_mult /= max(1.0, float((lab[:, :, :h, :w] >= 0).sum()))
         n_batch = head.N
         loss2 = self._loss_buf(op.outputs)
         dhead = ops.rpn_loss(head.t, head.dt, A, 0, A, labels.t, tgt.t, w_in.t, w_out.t, cls_mult, a['beta'],

@@ -265,6 +265,17 @@ int dat_softmax_ce_rows(dat_ctx* ctx, dat_stream s, int dtype, const void* logit
 int dat_sgd_momentum(dat_ctx* ctx, dat_stream s, float* w, float* v, const float* grad, long long n, float lr, float momentum,
                      float weight_decay, int is_bias);
 
+/* ---- training input pipeline: RPN anchor labelling, device half -------------------------------------
+ * Replaces the O(anchors x gts) part of reference lib/roi_data/rpn.py:283-312: the straddle filter (:283-291), the Cython
+ * IoU lib/utils/cython_bbox.pyx:16-57 averaged over the tube's frames (lib/utils/boxes.py:60-69), anchor->gt max / first
+ * arg-max (:297-299), gt->anchor max (:300-303) and the "anchors that attain a gt's max" flags (:304-305).
+ * anchors [n, 4T] and gts [G, 4T] fp32 on the device; a2g_max [n] is -1 for anchors outside the image (straddle < 0 keeps
+ * all); a2g_arg [n]; best_flag [n] bytes; gt_max [G] workspace (float bits).  Results are bit-identical to the host code. */
+int dat_anchor_overlaps(dat_ctx* ctx, dat_stream s, const float* anchors, int n, const float* gts, int G, int T, float im_h, float im_w,
+                        float straddle, float* a2g_max, int* a2g_arg, unsigned char* best_flag, unsigned int* gt_max);
+/* dst[offsets[i]] = values[i] for 32-bit words (sparse RPN labels -> the dense "wide" label blobs of rpn.py:343-368) */
+int dat_scatter_words(dat_ctx* ctx, dat_stream s, void* dst, long long dst_words, const int* offsets, const void* values, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -439,3 +439,109 @@ def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
     print('checked gradients of %d parameters, worst rel err %.2e' % (checked, worst))
     print('largest:', ['%s %.1e' % (n, e) for e, n in sorted(errs, reverse=True)[:8]])
     assert checked > 30 and np.median([e for e, _ in errs]) < 1e-3
+
+
+def _label_cfg(kind, max_size):
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.MODEL.KEYPOINTS_ON = True
+    cfg.MODEL.NUM_CLASSES = 2
+    cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.HEATMAP_SIZE = 17, 56
+    cfg.TRAIN.MAX_SIZE, cfg.TRAIN.BATCH_SIZE_PER_IM = max_size, 64
+    if kind == 'fpn':
+        cfg.FPN.FPN_ON = cfg.FPN.MULTILEVEL_RPN = cfg.FPN.MULTILEVEL_ROIS = True
+    return cfg
+
+
+@pytest.mark.parametrize('kind,tube_T,h,w,persons,straddle', [
+    ('fpn', 1, 200, 320, 3, 0), ('fpn', 1, 200, 320, 0, 0), ('fpn', 1, 768, 1344, 8, 0), ('fpn', 1, 256, 320, 70, -1),
+    ('c4', 2, 200, 320, 4, 0), ('c4', 3, 240, 256, 5, -1)])
+def test_device_anchor_labelling_is_bit_identical_to_the_host(ops, kind, tube_T, h, w, persons, straddle):
+    """dat_anchor_overlaps (straddle filter + Cython-order IoU + arg-max + best-anchor flags over the whole field, up to
+    ~450 k anchors at the bench size) against roi_data.rpn.anchor_overlap_stats — which is pinned to the real reference by
+    tests/golden/reference_roi_data.npz — and, downstream, identical dense label blobs from the scatter path."""
+    from detectandtrack_amd.core.config import reset_cfg
+    from detectandtrack_amd.roi_data import loader, rpn, synthetic
+    cfg = _label_cfg(kind, max(h, w))
+    cfg.TRAIN.RPN_STRADDLE_THRESH = straddle
+    entry = synthetic.synthetic_roidb_entry(h, w, n_persons=max(persons, 1), seed=9, T=tube_T)
+    if persons == 0:
+        for k in ('boxes', 'gt_classes', 'is_crowd', 'gt_keypoints', 'gt_overlaps', 'box_to_gt_ind_map', 'track_visible'):
+            if k in entry:
+                entry[k] = entry[k][:0]
+    T, foas, names, im_h, im_w, gt, vis, im_info = loader._fields_and_gt(entry, 1.0)
+    host = rpn.anchor_overlap_stats(rpn.all_field_anchors(foas), im_h, im_w, gt)
+    dev = loader.device_overlap_stats(foas, im_h, im_w, gt, torch.device('cuda', 0))
+    print('anchors', rpn.all_field_anchors(foas).shape, 'inside', len(host[0]), 'gts', len(gt), 'best', int(host[3].sum()))
+    for name, a, b in zip(('inside', 'a2g_max', 'a2g_arg', 'best'), host, dev):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    # the whole minibatch on the device == the host path with the same RNG
+    data = np.random.RandomState(1).randn(1, 3, 2, h, w).astype(np.float32)
+    sp_h, per_level, _, _ = loader.label_clip_host(entry, 1.0, np.random.RandomState(4))
+    sp_d, blobs, names_d = loader.label_clip_device(data, entry, 1.0, np.random.RandomState(4), torch.device('cuda', 0), {})
+    assert names == names_d
+    np.testing.assert_array_equal(sp_h.idx, sp_d.idx)
+    np.testing.assert_array_equal(blobs['data'].cpu().numpy(), data)
+    for lvl, suffix in zip(per_level, names):
+        for k, v in lvl.items():
+            got = blobs[k + suffix].cpu().numpy()
+            assert got.dtype == v.dtype and got.shape == v.shape
+            np.testing.assert_array_equal(got, v, err_msg=k + suffix)
+    reset_cfg()
+
+
+def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops):
+    """tools/train_net.py's two input paths: RoIDataLoader minibatches (device labels, worker streams, sparse loss
+    normaliser) and the synchronous host rpn.add_rpn_blobs feed give the same losses for the same clips and RNG."""
+    from tests.model_util import fpn3d_kps_cfg
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    from detectandtrack_amd.training import Trainer
+    from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+    from detectandtrack_amd.roi_data.loader import RoIDataLoader
+    from tests.model_util import synthetic_clip
+    T, H, W = 2, 128, 160
+    c = fpn3d_kps_cfg('18', T=T, dtype='fp32')
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 400, 'RPN_POST_NMS_TOP_N': 200, 'IMS_PER_BATCH': 1, 'MAX_SIZE': 160,
+                  'BATCH_SIZE_PER_IM': 64, 'RPN_STRADDLE_THRESH': 0}
+    c['NUM_GPUS'] = 1
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+
+    def source(i):
+        return synthetic_clip(T, H, W) + np.float32(i), synthetic.synthetic_roidb_entry(H, W, n_persons=2 + i, seed=5 + i), 1.0
+
+    def run(use_loader):
+        model = model_builder.create(cfg.MODEL.TYPE, train=True)
+        workspace.ResetWorkspace()
+        ws = workspace.GlobalWorkspace()
+        for k, v in net_utils.synthetic_params(model, 3).items():
+            ws.set_param(k, v)
+        trainer = Trainer(model, ws)
+        loader = RoIDataLoader(source, num_items=3, num_workers=2, queue_size=2, device=torch.cuda.current_device(), seed=21)
+        out = []
+        try:
+            for it in range(3):
+                mb = loader.get_next_minibatch(timeout=120)
+                if use_loader:
+                    mb.feed(ws)
+                else:   # same clip, same RNG seed, labelled synchronously on the host
+                    data, entry, _ = source(loader._clip_index(it))
+                    rng = np.random.RandomState((21 + 104729 * (it + 1)) % 2 ** 32)
+                    ws.FeedBlob('data', data)
+                    for k, v in rpn_data.add_rpn_blobs({}, 1.0, entry, rng).items():
+                        ws.FeedBlob(k, v)
+                    ws.train_sampler = (lambda e, r: lambda rois, info: frcn_data.sample_training_blobs(e, rois, info, r))(entry, rng)
+                out.append(trainer.step(lr=0.001).loss_values())
+        finally:
+            loader.shutdown()
+        return out
+    a, b = run(True), run(False)
+    for la, lb in zip(a, b):
+        assert sorted(la) == sorted(lb)
+        for k in la:
+            assert np.isfinite(la[k]) and abs(la[k] - lb[k]) <= 5e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    reset_cfg()

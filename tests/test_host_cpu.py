@@ -437,3 +437,90 @@ def test_posetrack_annorect_matches_the_real_reference_golden():
             a = json.load(f)['annolist']
         assert [e['imagenum'] for e in a] == [[0], [1], [2]] and a[2]['annorect'][0]['score'] == [0]
     reset_cfg()
+
+
+def _loader_cfg(tube_T=1):
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.MODEL.KEYPOINTS_ON = True
+    cfg.MODEL.NUM_CLASSES = 2
+    cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.HEATMAP_SIZE = 17, 56
+    cfg.TRAIN.MAX_SIZE, cfg.TRAIN.BATCH_SIZE_PER_IM = 333, 64
+    if tube_T == 1:
+        cfg.FPN.FPN_ON = cfg.FPN.MULTILEVEL_RPN = cfg.FPN.MULTILEVEL_ROIS = True
+    return cfg
+
+
+def _loader_source(tube_T=1, h=200, w=320):
+    from detectandtrack_amd.roi_data import synthetic
+
+    def source(i):
+        rs = np.random.RandomState(500 + i)
+        data = rs.randn(1, 3, 2, h, w).astype(np.float32)
+        return data, synthetic.synthetic_roidb_entry(h, w, n_persons=1 + i % 4, seed=i, T=tube_T), 1.0
+    return source
+
+
+@pytest.mark.parametrize('tube_T', [1, 2])
+def test_sparse_rpn_labels_dense_and_scatter_plan_agree(tube_T):
+    """The three consumers of the sparse labels — host dense blobs (the golden-pinned layout), the flat-buffer scatter plan
+    the device path uses, and the loss normaliser's window count — describe the same tensors."""
+    from detectandtrack_amd.core.config import reset_cfg
+    from detectandtrack_amd.roi_data import loader
+    _loader_cfg(tube_T)
+    _, entry, _ = _loader_source(tube_T)(3)
+    sparse, per_level, names, im_info = loader.label_clip_host(entry, 1.0, np.random.RandomState(5))
+    assert len(sparse.idx) > 0 and (sparse.labels == 1).any() and (sparse.labels == 0).any()
+    offs, vals, views, words = sparse.scatter_plan()
+    flat = np.zeros((words,), np.uint32)
+    for lv in views:
+        o, shape = lv['rpn_labels_int32_wide']
+        flat[o:o + int(np.prod(shape))] = np.uint32(0xFFFFFFFF)
+    flat[offs] = vals
+    for l, (lv, dense) in enumerate(zip(views, per_level)):
+        for name, (o, shape) in lv.items():
+            got = flat[o:o + int(np.prod(shape))].view(dense[name].dtype).reshape(shape)
+            np.testing.assert_array_equal(got, dense[name], err_msg='%s level %d' % (name, l))
+        lab = dense['rpn_labels_int32_wide']
+        for (h, w) in ((lab.shape[2], lab.shape[3]), (lab.shape[2] // 2, lab.shape[3] // 3)):
+            assert sparse.count_in_window(l, h, w) == int((lab[:, :, :h, :w] >= 0).sum())
+    reset_cfg()
+
+
+def test_roi_data_loader_is_ordered_and_reproducible():
+    """roi_data.loader (reference lib/roi_data/loader.py): the k-th minibatch is the same for any worker count, equals the
+    synchronous rpn.add_rpn_blobs labelling of the same clip with the same RNG, every clip of an epoch is visited once, and
+    a failing source surfaces in the consumer."""
+    from detectandtrack_amd.core.config import reset_cfg
+    from detectandtrack_amd.roi_data import loader, rpn
+    _loader_cfg(1)
+    src = _loader_source(1)
+    runs = []
+    for workers in (1, 3):
+        ld = loader.RoIDataLoader(src, num_items=5, num_workers=workers, queue_size=3, device=None, seed=11)
+        mbs = [ld.get_next_minibatch(timeout=60) for _ in range(10)]
+        ld.shutdown()
+        runs.append(mbs)
+    seen = []
+    for a, b in zip(*runs):
+        assert a.index == b.index and sorted(a.blobs) == sorted(b.blobs)
+        for k in a.blobs:
+            np.testing.assert_array_equal(a.blobs[k], b.blobs[k], err_msg=k)
+        seen.append(int(a.entry['boxes'].shape[0]))
+    # epoch coverage: the permutation visits the 5 clips once per epoch (identify a clip by its data tensor)
+    for ep in (0, 1):
+        sums = sorted(float(m.blobs['data'].sum()) for m in runs[0][5 * ep:5 * ep + 5])
+        assert sums == sorted(float(src(i)[0].sum()) for i in range(5))
+    # the same labels as the synchronous host path with that minibatch's RNG
+    m = runs[0][2]
+    ref = rpn.add_rpn_blobs({}, 1.0, m.entry, np.random.RandomState((11 + 104729 * 3) % 2 ** 32))
+    for k, v in ref.items():
+        np.testing.assert_array_equal(m.blobs[k], v, err_msg=k)
+
+    def bad(i):
+        raise ValueError('no such clip')
+    ld = loader.RoIDataLoader(bad, num_items=2, num_workers=2, device=None, seed=0)
+    with pytest.raises(ValueError):
+        ld.get_next_minibatch(timeout=60)
+    ld.shutdown()
+    reset_cfg()
