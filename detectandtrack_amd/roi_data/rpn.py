@@ -44,14 +44,6 @@ def fpn_fields(time_dim):
                                  time_dim) for lvl in range(k_min, k_max + 1)]
 
 
-def _unmap(data, count, inds, fill=0):
-    if count == len(inds):
-        return data
-    ret = np.full((count,) + data.shape[1:], fill, dtype=data.dtype)
-    ret[inds] = data
-    return ret
-
-
 def all_field_anchors(foas):
     """The level-ordered concatenation of the fields (cached: it is a pure function of the config)."""
     key = tuple(id(f) for f in foas)
