@@ -96,7 +96,10 @@ template <> struct Mma<DAT_F32> {
 __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + (((slot ^ (row >> 1)) & 7) << 4); }
 
 // BN = output channels per block, BP = output positions per block, WAVES_N x WAVES_P = 4 waves.
-template <int DT, int BN, int BP, int WAVES_N>
+// TPS = spatial taps per step: a step costs ~1 us of fixed work (barrier, weight-DMA issue, table look-ups, LDS read
+// latency) whatever the tile, so thin layers (64 -> 64 channels: 8 MFMAs per wave and tap) run 3 taps per step from a
+// 3 x 8 KB weight stage; wide tiles keep 1 tap per step (their weight stages would not leave room for 2 blocks per CU).
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
     constexpr int CK = Mma<DT>::CK;
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     unsigned long long clk_c0 = 0, clk_r0 = 0;
     if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wbuf = smem;                       // 2 x BN x 128 B
-    char* patch = smem + 2 * BN * ROWB;      // PH*PW x 128 B
+    char* wbuf = smem;                             // 2 stages x TPS taps x BN x 128 B
+    char* patch = smem + 2 * TPS * BN * ROWB;      // PH*PW x 128 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     const int ntab = p.tab_n;          // == ntap, in plane order
     const int npatch = n_kt * p.n_cchunks;                 // (kt, channel chunk) patches of this output frame
     const int pi_lo = (npatch * split) / p.ksplit, pi_hi = (npatch * (split + 1)) / p.ksplit;
-    const int total = (pi_hi - pi_lo) * ntab;
+    const int total = (pi_hi - pi_lo) * (ntab / TPS);     // steps of TPS taps (the launcher guarantees ntab % TPS == 0)
 
     const size_t w_tap_stride = (size_t)p.Cout_pad * p.Cin * ES;  // bytes between taps
     const int npatch_items = p.PH * p.PW * 8;
@@ -202,10 +205,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #define DAT_PATCH_AUX 0
 #endif
 #define P_DMA(SRC_, DST_) __builtin_amdgcn_global_load_lds((gptr_t)(SRC_), (lptr_t)(DST_), 16, 0, DAT_PATCH_AUX)
-#define W_PREFETCH(KT_, CC_, TAP_, BUF_)                                                                        \
-    {                                                                                                           \
-        const char* wbase_ = p.w + ((size_t)((KT_) * ntap + (TAP_)) * w_tap_stride + (size_t)(CC_) * CK * ES + w_blk_off); \
-        char* wdst_ = wbuf + (BUF_) * BN * ROWB + wave * (8 * ROWB);                                            \
+#define W_PREFETCH(KT_, CC_, TI_, BUF_)                                                                         \
+    _Pragma("unroll") for (int u_ = 0; u_ < TPS; ++u_) {                                                        \
+        const char* wbase_ = p.w + ((size_t)((KT_) * ntap + p.tab_tap[(TI_) + u_]) * w_tap_stride + (size_t)(CC_) * CK * ES + w_blk_off); \
+        char* wdst_ = wbuf + ((BUF_) * TPS + u_) * BN * ROWB + wave * (8 * ROWB);                               \
         W_DMA(wbase_ + w_thr_off, wdst_);                                                                       \
         W_DMA(wbase_ + (w_thr_off + w_item_stride), wdst_ + 32 * ROWB);                                         \
         if (W_ITEMS == 4) {                                                                                     \
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
         if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
         int kt = kt_lo + pi_lo / p.n_cchunks + kshift, cc = pi_lo % p.n_cchunks, ti = 0;
         if (kt >= kt_hi_x) kt -= n_kt;
-        W_PREFETCH(kt, cc, p.tab_tap[0], 0);
+        W_PREFETCH(kt, cc, 0, 0);
         const int nchunks = (npatch_items + 63) >> 6;    // 1-KiB LDS-DMA pieces (8 patch rows each)
 #ifdef DAT_CONV_TRACE
         unsigned long long tr_reload = 0, tr_wait = 0, tr_bar = 0, tr_issue = 0, tr_mma = 0, tr_t;
@@ -273,48 +276,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             __syncthreads();
             TR_ADD(tr_bar);
             // advance to the next (kt, cc, table entry) and prefetch its weight tile (lands during this step's MFMAs)
-            const int tapoff = p.tab_rowoff[ti];
-            int nti = ti + 1, ncc = cc, nkt = kt;
+            int nti = ti + TPS, ncc = cc, nkt = kt;
             if (nti == ntab) {
                 nti = 0;
                 if (++ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
             }
             // (issuing the pieces between the k-slices' MFMAs instead measured 7 % slower: a DMA issue stalls the MFMA stream)
-            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, p.tab_tap[nti], (step + 1) & 1);
+            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, nti, (step + 1) & 1);
 
             TR_ADD(tr_issue);
-            // ---- compute this tap: 4 k-slices of 16 B per row, fragments double-buffered in registers ----
-            const char* wb = wbuf + (step & 1) * BN * ROWB;
-            // patch fragment of (row, k-slice ks, k-half): 16-B slot (2*ks + khalf) ^ ((row >> 1) & 7) of the row's line
-            const char* bp[PT];
-            int bx[PT];
-#pragma unroll
-            for (int j = 0; j < PT; ++j) {
-                const int row = rowbase[j] + tapoff;
-                const int g = (row >> 1) & 7;
-                bp[j] = patch + (row * PPITCH + ((khalf ^ (g & 1)) << 4));
-                bx[j] = g >> 1;
-            }
-            uint4 a[2][MT], b[2][PT];
+            // ---- compute the step's taps: 4 k-slices of 16 B per row each, fragments double-buffered in registers ----
             // the co-resident block's wave on this SIMD is usually in its load phase: let the MFMA stream win arbitration
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
+            for (int u = 0; u < TPS; ++u) {
+                const int tapoff = p.tab_rowoff[ti + u];
+                const char* wb = wbuf + ((step & 1) * TPS + u) * BN * ROWB;
+                // patch fragment of (row, k-slice ks, k-half): 16-B slot (2*ks + khalf) ^ ((row >> 1) & 7) of the row's line
+                const char* bp[PT];
+                int bx[PT];
 #pragma unroll
-            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j] + (bx[j] << 5));
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks < 3) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
-#pragma unroll
-                    for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (((ks + 1) ^ bx[j]) << 5));
+                for (int j = 0; j < PT; ++j) {
+                    const int row = rowbase[j] + tapoff;
+                    const int g = (row >> 1) & 7;
+                    bp[j] = patch + (row * PPITCH + ((khalf ^ (g & 1)) << 4));
+                    bx[j] = g >> 1;
                 }
+                uint4 a[2][MT], b[2][PT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
 #pragma unroll
-                    for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
+                for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j] + (bx[j] << 5));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int cur = ks & 1, nxt = cur ^ 1;
+                    if (ks < 3) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (((ks + 1) ^ bx[j]) << 5));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
+                }
             }
             __builtin_amdgcn_s_setprio(0);
             ti = nti; cc = ncc; kt = nkt;
@@ -603,7 +609,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
     return best;
 }
 
-template <int DT, int BN, int BP, int WAVES_N>
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1>
 int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
     const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW);
     p.th_log2 = tc.th_log2;
@@ -660,7 +666,8 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     }
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
     p.nblocks = (unsigned)nblocks;
-    size_t lds = (size_t)2 * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
+    DAT_ENFORCE(ctx, p.tab_n % TPS == 0 && (TPS == 1 || p.tab_new == 1u), "conv3d: %d taps per step need one stride plane of a multiple of %d taps", TPS, TPS);
+    size_t lds = (size_t)2 * TPS * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
     if (lds < 4 * 32 * (64 * 4 + 16)) lds = 4 * 32 * (64 * 4 + 16);                                   // epilogue staging slices
     {
         static int pad = -1;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
@@ -669,7 +676,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     }
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
-    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N>;
+    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -836,7 +843,14 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         hipEventRecord(e0, st);
     }
     int rc;
-    if (d->dtype == DAT_BF16) {
+    static int tps3 = -1;
+    if (tps3 < 0) { const char* e = getenv("DAT_CONV_TPS"); tps3 = e ? (atoi(e) == 3) : 1; }
+    // thin layers (<= 64 output channels, dense 3x3 spatial taps): 3 taps per step
+    const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3;
+    if (thin3) {
+        tag += 3;   // (dtype digit + 3: the 3-taps-per-step variant)
+        rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 64, 128, 1, 3>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 64, 128, 1, 3>(ctx, st, p, 7, ksplit);
+    } else if (d->dtype == DAT_BF16) {
         if (big)
             rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8, ksplit);
         else

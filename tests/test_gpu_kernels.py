@@ -70,6 +70,7 @@ CONV_CASES = [
     ('1x1', 1, 2, 12, 20, 64, 128, (1, 1, 1), (1, 1), False, 0, True),
     ('3x3_2d', 1, 1, 17, 23, 64, 64, (1, 3, 3), (1, 1), True, 0, True),
     ('3x3x3', 1, 4, 14, 18, 64, 128, (3, 3, 3), (1, 1), True, 1, True),
+    ('3x3x3_thin', 1, 4, 14, 18, 128, 64, (3, 3, 3), (1, 1), True, 1, True),    # 3 taps per step, 6 patches
     ('3x3x3_c256', 1, 3, 9, 21, 128, 256, (3, 3, 3), (1, 1), False, 0, False),
     ('3x3_s2', 1, 2, 20, 28, 64, 128, (3, 3, 3), (2, 2), True, 0, True),
     ('1x1_s2', 1, 2, 20, 28, 128, 256, (1, 1, 1), (2, 2), False, 0, True),
