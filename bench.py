@@ -212,10 +212,7 @@ def cpu_baseline(arch, T, seconds_budget=15.0):
 def cpu_tracker_baseline():
     """Host Hungarian tracker (stays on the host by design, tools/compute_tracks.py) on the synthetic detection
     set of BASELINE.md §4: 50 videos x 100 frames x ~8 persons, single core as the reference runs it."""
-    try:
-        from detectandtrack_amd.core import tracking_engine as te
-    except Exception as e:  # tracker not built yet
-        return {'error': repr(e)}
+    from detectandtrack_amd.core import tracking_engine as te
     return te.benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3)
 
 

@@ -5,9 +5,10 @@ body/head functions named in the YAML (`MODEL.CONV_BODY: FPN3D.add_fpn_ResNet18_
 in this module's globals.  The result is a DetectionModelHelper whose `.net` / `.keypoint_net` /
 `.conv_body_net` are recorded op lists executed by `detectandtrack_amd.workspace` on the MI355X.
 
-Inference graphs are complete.  Training-only pieces (losses :481-498/:612-660/:873-905, data-parallel replicas +
-gradient all-reduce + MomentumSGDUpdate :908-985, roi data loader) are the next hot-path row
-and raise NotImplementedError here.
+Inference graphs are complete.  `create(type, train=True)` adds the training pieces of §8 a12: the loss ops (:481-498 / :612-660 /
+:873-905), GenerateProposalLabels and StopGradient; gradients, the all-reduce and MomentumSGDUpdate (:908-985) live in
+`detectandtrack_amd.training`, the input pipeline in `detectandtrack_amd.roi_data.loader`.  Only the FPN tube-head extension has no
+training graph yet (build_generic_fast_rcnn_model raises).
 """
 import logging
 
