@@ -92,11 +92,8 @@ def time_pool_blobs(blob_conv, model, body_head_link):
 def build_generic_fast_rcnn_model(model, add_conv_body_func, add_roi_frcn_head_func, add_roi_mask_head_func=None,
                                   add_roi_keypoint_head_func=None, freeze_conv_body=False):
     """:179-306 (single replica; the reference loops this over NUM_GPUS name scopes for training)."""
-    if model.train and (not cfg.MODEL.FASTER_RCNN or
-                        (cfg.FPN.FPN_ON and cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '')):
-        raise NotImplementedError('training graph: end-to-end Faster R-CNN on FPN with 2D heads (2D models, or a 3D body '
-                                  'linked by slice-center / avg) and on the C4 bodies (2D or tube heads, the shipped 3D '
-                                  'configs) is built; training the FPN tube-head extension is not')
+    if model.train and not cfg.MODEL.FASTER_RCNN:
+        raise NotImplementedError('training graph: end-to-end Faster R-CNN only (pre-computed proposal training needs the dataset layer)')
     blob_conv, dim_conv, spatial_scale_conv = add_conv_body_func(model)
     if cfg.MODEL.VIDEO_ON:
         blob_conv = time_pool_blobs(blob_conv, model, cfg.VIDEO.BODY_HEAD_LINK)

@@ -270,6 +270,26 @@ class TrainExecutor(Executor):
         dbias = torch.zeros(A + D, dtype=torch.float32, device=ws.device)
         g = ops.relu_bias_bwd(dy, y.t, y.dt, A + D, relu=False, dbias=dbias)
         w = torch.cat([self._master(lo.args['w']).reshape(A, -1), self._master(do.args['w']).reshape(D, -1)], dim=0)
+        if xin.t2c:
+            # heads over time-moved-to-channels (FPN tube RPN, channel index t*C + c): one 1x1 weight slice per input frame;
+            # the head has ONE output frame per clip, every input frame gets its own data gradient
+            assert xin.N == 1, 'tube RPN training assumes one clip per forward (TRAIN.IMS_PER_BATCH 1)'
+            T, C = xin.T, xin.C
+            f, H, W, cs = xin.t.shape
+            wT = w.view(A + D, T, C)
+            dWs, dxs = [], []
+            for t in range(T):
+                cg = ops.ConvGrad(wT[:, t].reshape(A + D, C, 1, 1, 1).contiguous(), None, (1, 1), (0, 0, 0), y.dt, cs, g.shape[3])
+                dW_t, _ = cg.weight(xin.t[t:t + 1], g, 1)
+                dWs.append(dW_t.reshape(A + D, C))
+                dxs.append(cg.data(g, 1, H, W))
+            dW = torch.stack(dWs, dim=1).reshape(A + D, T * C)
+            self._pgrad(lo.args['w'], dW[:A])
+            self._pgrad(do.args['w'], dW[A:])
+            self._pgrad(lo.args['b'], dbias[:A])
+            self._pgrad(do.args['b'], dbias[A:])
+            self._add_grad(lo.inputs[0], torch.cat(dxs, dim=0))
+            return
         w5 = w.view(A + D, -1, 1, 1, 1)
         cg = ops.ConvGrad(w5, None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
         dW, _ = cg.weight(xin.t, g, xin.T)
@@ -279,6 +299,13 @@ class TrainExecutor(Executor):
         self._pgrad(do.args['b'], dbias[A:])
         f, H, W, _ = xin.t.shape
         self._add_grad(lo.inputs[0], cg.data(g, xin.T, H, W))
+
+    def bwd_TimeToChannel(self, i, op):
+        # a re-interpretation of the same [T, H, W, C] tensor: the gradient passes through unchanged
+        x = self.ws.blobs[op.inputs[0]]
+        dy, lo = self._take_grad(op.outputs[0], x.dt)
+        if dy is not None:
+            self._add_grad(op.inputs[0], dy, lo)
 
     def bwd_FC(self, i, op):
         ws, a = self.ws, op.args

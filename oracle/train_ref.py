@@ -170,3 +170,64 @@ def training_losses_c4_tube(weights, opts, data, labels, sampled, cfg_scalars):
                           reduction='none')
     losses['loss_kps'] = (nll * w).sum() / w.sum() * cfg_scalars['kps_loss_weight'] / ng
     return losses
+
+
+def roi_feat_fpn_tube_torch(pyr_p5_to_p2, rois, pooled, sampling):
+    """Multi-level tube RoIAlign with autograd: level by the tube's mean area (FPN.py:349-360), frame t of the tube pools
+    frame t of that level (detector.py:256-310) -> (R, C, T, P, P)."""
+    lvls = prop.map_rois_to_fpn_levels(rois[:, 1:], 2, 5)
+    out = [None] * rois.shape[0]
+    for lvl in range(2, 6):
+        idx = np.where(lvls == lvl)[0]
+        if len(idx) == 0:
+            continue
+        f = roi_align_tube_torch(pyr_p5_to_p2[5 - lvl], rois[idx], pooled, 1. / 2. ** lvl, sampling)
+        for j, i in enumerate(idx):
+            out[i] = f[j]
+    return torch.stack(out)
+
+
+def training_losses_fpn_tube(weights, opts, data, labels, sampled, cfg_scalars):
+    """Training mode of the declared FPN tube-head extension (the design of the reference's dead
+    FPN3D.py:232-330 + tube rois on the 2-MLP head, head_builder.py:29-33, + the 3D keypoint head): per-level losses with
+    the scaling of FPN.py:282-321, box / keypoint losses as in the 3D branch of model_builder.py (:481-494 with
+    1/time_dim on the box regression, :873-889)."""
+    net = Net(weights, opts)
+    net.body(torch.from_numpy(data))
+    pyr = net.fpn()                                   # [P6, P5, P4, P3, P2], (1, C, T, H, W)
+    o = opts
+    T, kt = o['num_frames_mid'], o['kt_rpn']
+    ng = cfg_scalars['num_gpus']
+    losses = {}
+    for lvl in range(2, 7):
+        x = pyr[6 - lvl]
+        h = F.relu(F.conv3d(x, weights['conv_rpn_fpn2_w'], weights['conv_rpn_fpn2_b'], stride=1, padding=(kt // 2, 1, 1)))
+        N, C, Tt, H, W = h.shape
+        h2 = h.permute(0, 2, 1, 3, 4).reshape(N, Tt * C, H, W)          # channel index t*C + c (detector.py:480-491)
+        logits = net.conv2d(h2, 'rpn_cls_logits_fpn2', 1)
+        deltas = net.conv2d(h2, 'rpn_bbox_pred_fpn2', 1)
+        lab = torch.from_numpy(labels['rpn_labels_int32_wide_fpn%d' % lvl][:, :, :H, :W])
+        valid = (lab >= 0).float()
+        ce = F.binary_cross_entropy_with_logits(logits, lab.clamp(min=0).float(), reduction='none')
+        losses['loss_rpn_cls_fpn%d' % lvl] = (ce * valid).sum() / ng / cfg_scalars['rpn_batch'] / cfg_scalars['ims_per_batch']
+        t, wi, wo = [torch.from_numpy(labels['rpn_bbox_%s_wide_fpn%d' % (k, lvl)][:, :, :H, :W])
+                     for k in ('targets', 'inside_weights', 'outside_weights')]
+        losses['loss_rpn_bbox_fpn%d' % lvl] = smooth_l1(deltas, t, wi, wo, 1. / 9.) / N / ng / T
+    rois = sampled['rois']
+    R = rois.shape[0]
+    feat = roi_feat_fpn_tube_torch(pyr[1:], rois, o['frcn_res'], o['frcn_sampling'])     # (R, C, T, 7, 7)
+    x = F.relu(net.fc(feat.reshape(R, -1), 'fc6'))
+    x = F.relu(net.fc(x, 'fc7'))
+    cls_score, bbox_pred = net.fc(x, 'cls_score'), net.fc(x, 'bbox_pred')
+    losses['loss_cls'] = F.cross_entropy(cls_score, torch.from_numpy(sampled['labels_int32']).long(), reduction='sum') / R / ng
+    losses['loss_bbox'] = smooth_l1(bbox_pred, torch.from_numpy(sampled['bbox_targets']),
+                                    torch.from_numpy(sampled['bbox_inside_weights']),
+                                    torch.from_numpy(sampled['bbox_outside_weights']), 1.0) / R / ng / T
+    kfeat = roi_feat_fpn_tube_torch(pyr[1:], sampled['keypoint_rois'], o['kps_res'], o['kps_sampling'])
+    kps = net.kps_head_tube_feat(kfeat)               # (Rk, T*K, M, M)
+    Rk, TK, M, _ = kps.shape
+    w = torch.from_numpy(sampled['keypoint_weights']).reshape(-1)
+    nll = F.cross_entropy(kps.reshape(Rk * TK, M * M), torch.from_numpy(sampled['keypoint_locations_int32']).reshape(-1).long(),
+                          reduction='none')
+    losses['loss_kps'] = (nll * w).sum() / w.sum() * cfg_scalars['kps_loss_weight'] / ng
+    return losses

@@ -545,3 +545,75 @@ def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops):
         for k in la:
             assert np.isfinite(la[k]) and abs(la[k] - lb[k]) <= 5e-4 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
     reset_cfg()
+
+
+def test_fpn_tube_train_step_gradients_match_oracle_autograd(ops):
+    """The declared FPN tube-head extension in TRAINING mode: per-level tube RPN losses on heads over
+    time-moved-to-channels, tube labels from roi_data, tube RoIAlign on the pyramid, fc6 over T*C*49, 3D keypoint head: every
+    loss and the gradient of every trainable parameter vs autograd on the oracle (fp32 parity mode)."""
+    from tests.model_util import fpn3d_tube_kps_cfg, synthetic_clip, oracle_opts
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    from detectandtrack_amd.training import TrainExecutor
+    from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+    from oracle import train_ref
+    T, H, W = 2, 96, 128
+    c = fpn3d_tube_kps_cfg(T=T, pre=200, post=60)
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 200, 'RPN_POST_NMS_TOP_N': 60, 'IMS_PER_BATCH': 1, 'MAX_SIZE': 128, 'BATCH_SIZE_PER_IM': 24,
+                  'RPN_STRADDLE_THRESH': -1}
+    c['NUM_GPUS'] = 1
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    weights = net_utils.synthetic_params(model, 3)
+    for k, v in weights.items():
+        ws.set_param(k, v)
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=3, seed=4, T=T)
+    rng = np.random.RandomState(0)
+    labels = rpn_data.add_rpn_blobs({}, 1.0, entry, rng)
+    assert labels['rpn_bbox_targets_wide_fpn3'].shape[1] == 3 * 4 * T
+    data = synthetic_clip(T, H, W)
+    ws.FeedBlob('data', data)
+    for k, v in labels.items():
+        ws.FeedBlob(k, v)
+    fixed = {}
+
+    def sampler(rois, info):
+        if not fixed:
+            fixed.update(frcn_data.sample_training_blobs(entry, rois, info, rng))
+        return fixed
+    ws.train_sampler = sampler
+    ex = TrainExecutor(ws, model.net)
+    ex.run()
+    ex.backward()
+    got = ex.loss_values()
+    assert fixed['rois'].shape[1] == 4 * T + 1 and fixed['bbox_targets'].shape[1] == 2 * 4 * T
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True) for k, v in weights.items()}
+    ref = train_ref.training_losses_fpn_tube(
+        wt, oracle_opts('18', T, 3, '', 200, 60), data, labels, fixed,
+        dict(num_gpus=1, rpn_batch=cfg.TRAIN.RPN_BATCH_SIZE_PER_IM, ims_per_batch=1, kps_loss_weight=cfg.KRCNN.LOSS_WEIGHT))
+    sum(ref.values()).backward()
+    for k in sorted(ref):
+        print('%-22s %.6f  (oracle %.6f)' % (k, got[k], ref[k].item()))
+        np.testing.assert_allclose(got[k], ref[k].item(), rtol=2e-4, atol=1e-6)
+    checked, errs = 0, []
+    for name in sorted(set(model.TrainableParams())):
+        if name.startswith(('conv1', 'res_conv1', 'res2_')):
+            assert name not in ex.param_grads
+            continue
+        assert name in ex.param_grads, 'no gradient for ' + name
+        r = wt[name].grad
+        assert r is not None, name
+        err = float((ex.param_grads[name].cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-8)
+        assert err < (3e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e' % (name, err)
+        errs.append((err, name))
+        checked += 1
+    print('checked gradients of %d parameters, median rel err %.2e' % (checked, float(np.median([e for e, _ in errs]))))
+    print('largest:', ['%s %.1e' % (n, e) for e, n in sorted(errs, reverse=True)[:6]])
+    assert checked > 40 and np.median([e for e, _ in errs]) < 1e-3
+    reset_cfg()
