@@ -238,7 +238,10 @@ def _build_defaults():
     # output; True computes just that frame of convs whose output is consumed solely by SliceKeyFrame (identical
     # rois / scores / heatmaps, the unread frames of fpn_res*_sum are never materialised)
     # DEVICE_KPS_DECODE: heatmaps_to_keypoints (utils/keypoints.py:94-149) runs on the GPU; False = the reference's host loop
-    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True})
+    # FRAME_TRUNK_CACHE (opt-in, frames kept): conv1 / pool1 / res2 have no temporal extent (ResNet3D.py:258-275, time kernel 1),
+    # so their output for a FRAME does not depend on the clip around it; sliding-window inference (one clip per key frame,
+    # stride 1, utils/video.py:149-201) re-uses it instead of recomputing (and re-uploading) T-1 of T frames per clip
+    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0})
     return c
 
 

@@ -63,8 +63,33 @@ def _get_blobs(im, rois):
     return blobs, im_scale_factors
 
 
-def im_detect_bbox(model, im, boxes=None):
-    """(:158-252) returns scores (R x K), pred_boxes (R x 4TK), im_scales."""
+def im_detect_bbox(model, im, boxes=None, frame_ids=None):
+    """(:158-252) returns scores (R x K), pred_boxes (R x 4TK), im_scales.
+
+    frame_ids (one hashable id per frame of the clip, e.g. (video, frame index)) with cfg.HIP.FRAME_TRUNK_CACHE > 0: only the
+    frames whose per-frame trunk output (conv1 / pool1 / res2) is not cached are pre-processed, uploaded and run through
+    the trunk; consecutive clips of a sliding window share T-1 of T frames.  Results are identical to the plain path."""
+    ws = workspace.GlobalWorkspace()
+    if frame_ids is not None and cfg.HIP.FRAME_TRUNK_CACHE > 0 and boxes is None and cfg.MODEL.VIDEO_ON:
+        assert len(frame_ids) == len(im), (len(frame_ids), len(im))
+        new_ids = ws.trunk_missing(frame_ids)
+        first = {}
+        for j, fid in enumerate(frame_ids):
+            first.setdefault(fid, j)
+        # (a clip with nothing new still needs one pre-processed frame for the blob geometry)
+        sub = [im[first[fid]] for fid in (new_ids or list(frame_ids)[:1])]
+        nf, cfg.VIDEO.NUM_FRAMES = cfg.VIDEO.NUM_FRAMES, len(sub)      # im_list_to_blob groups len(sub) frames per clip
+        try:
+            inputs, im_scales = _get_blobs(sub, None)
+        finally:
+            cfg.VIDEO.NUM_FRAMES = nf
+        if not new_ids:
+            inputs.pop('data')
+        for k, v in inputs.items():
+            workspace.FeedBlob(k, v)
+        ws.trunk_request = (list(frame_ids), new_ids)
+        workspace.RunNet(model.net.Proto().name)
+        return _read_bbox_outputs(im, im_scales)
     inputs, im_scales = _get_blobs(im, boxes)
     for k, v in inputs.items():
         workspace.FeedBlob(k, v)
@@ -174,15 +199,15 @@ def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes):
     return cls_keyps
 
 
-def im_detect_all(model, im, box_proposals, timers=None):
-    """(:897-957)"""
+def im_detect_all(model, im, box_proposals, timers=None, frame_ids=None):
+    """(:897-957); frame_ids: see im_detect_bbox."""
     if timers is None:
         timers = defaultdict(Timer)
     if cfg.TEST.COMPETITION_MODE:
         raise NotImplementedError('test-time augmentation (COMPETITION_MODE) is out of the hot-path scope; the '
                                   'shipped configs set TEST.COMPETITION_MODE False')
     timers['im_detect_bbox'].tic()
-    scores, boxes, im_scales = im_detect_bbox(model, im, box_proposals)
+    scores, boxes, im_scales = im_detect_bbox(model, im, box_proposals, frame_ids=frame_ids)
     timers['im_detect_bbox'].toc()
     timers['misc_bbox'].tic()
     scores, boxes, cls_boxes = box_results_with_nms_and_limit(scores, boxes)

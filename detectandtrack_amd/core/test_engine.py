@@ -72,7 +72,7 @@ def test_net(roidb, ind_range=None, output_dir=None):
     all_boxes, all_segms, all_keyps = empty_results(num_classes, len(part))
     timers = defaultdict(Timer)
     for i, entry in enumerate(part):
-        cls_boxes_i, cls_segms_i, cls_keyps_i = im_detect_all(model, load_clip(entry), None, timers)
+        cls_boxes_i, cls_segms_i, cls_keyps_i = im_detect_all(model, load_clip(entry), None, timers, frame_ids=entry.get('frame_ids'))
         extend_results(i, all_boxes, cls_boxes_i)
         if cls_keyps_i is not None:
             extend_results(i, all_keyps, cls_keyps_i)

@@ -7,6 +7,7 @@ converts back to the reference's NC[T]HW fp32 layout, so engine code written aga
 same arrays.  One process drives one GPU (reference inference model: one subprocess per GPU,
 lib/utils/subprocess.py:38-63).  There is no CPU execution path.
 """
+import collections
 import logging
 
 import numpy as np
@@ -43,6 +44,8 @@ class Workspace(object):
         self._dev_params = {}
         self.conv_log = None    # when a list: (name, algorithmic flops) per conv launch (bench roofline leg)
         self.train_sampler = None   # training: callable(rois, im_info) -> sampled Fast R-CNN blobs (training.py)
+        self.trunk_cache = collections.OrderedDict()   # frame id -> (per-frame trunk output, C, dtype)  (cfg.HIP.FRAME_TRUNK_CACHE)
+        self.trunk_request = None   # (frame ids of the next clip, ids of the frames in the fed `data` blob)
 
     # ---- reference workspace API -------------------------------------------------------------------------------
     def FeedBlob(self, name, arr):
@@ -95,6 +98,17 @@ class Workspace(object):
         self.blobs.clear()
         self._layers.clear()
         self._dev_params.clear()
+        self.trunk_cache.clear()
+        self.trunk_request = None
+
+    def trunk_missing(self, frame_ids):
+        """Frame ids of a clip whose per-frame trunk output is not cached (first occurrences, in clip order)."""
+        seen, out = set(), []
+        for fid in frame_ids:
+            if fid not in self.trunk_cache and fid not in seen:
+                seen.add(fid)
+                out.append(fid)
+        return out
 
     def fork(self):
         """A second blob namespace over the SAME parameters / packed layers / nets: lets two clips be in flight on
@@ -105,6 +119,7 @@ class Workspace(object):
         w.params, w.nets, w._layers, w._dev_params = self.params, self.nets, self._layers, self._dev_params
         w.conv_log = None
         w.train_sampler = self.train_sampler
+        w.trunk_cache, w.trunk_request = self.trunk_cache, None
         return w
 
     # ---- parameters -----------------------------------------------------------------------------------------------
@@ -159,10 +174,75 @@ class Executor(object):
     def run(self):
         self._plan_rpn_siblings()
         self._plan_keyframe_dce()
+        start = self._run_cached_trunk()
         for i, op in enumerate(self.net.ops):
-            if i in self._skip:
+            if i < start or i in self._skip:
                 continue
             getattr(self, 'op_' + op.type)(i, op)
+
+    # ---- per-frame trunk cache (cfg.HIP.FRAME_TRUNK_CACHE) -----------------------------------------------------------
+    @staticmethod
+    def trunk_split(net):
+        """(n_ops, blob): the leading ops of `net` that act on every frame independently (the [1,7,7] stem, spatial
+        pooling, convs with time kernel 1 and their fused affine / residual / ReLU, StopGradient) and the single blob
+        later ops read from them; (0, None) when the net has no such prefix."""
+        n_max, produced = 0, []
+        have = set()
+        for op in net.ops:
+            a = op.args if isinstance(op.args, dict) else {}
+            ok = (op.type == 'Conv' and a.get('kernels', [2])[0] == 1 and op.inputs[0] in have | {'data'} and
+                  (not a.get('residual') or a['residual'] in have) and not a.get('res_mode') == 2) or \
+                 (op.type in ('MaxPool', 'StopGradient') and op.inputs[0] in have)
+            if not ok:
+                break
+            have.update(op.outputs)
+            produced.append(set(op.outputs))
+            n_max += 1
+        for n in range(n_max, 0, -1):       # the longest prefix with exactly one blob read by the rest of the net
+            made = set().union(*produced[:n])
+            live = set()
+            for op in net.ops[n:]:
+                a = op.args if isinstance(op.args, dict) else {}
+                for b in list(op.inputs) + ([a['residual']] if a.get('residual') else []):
+                    if b in made:
+                        live.add(b)
+            if len(live) == 1:
+                return n, live.pop()
+        return 0, None
+
+    def _run_cached_trunk(self):
+        """With a trunk request (ws.trunk_request = (frame ids of the clip, ids of the frames in the fed `data` blob)): run
+        the per-frame prefix on the NEW frames only, keep their output per frame id (LRU), assemble the clip's blob from
+        the cache and return the index of the first op that still has to run."""
+        ws = self.ws
+        req = getattr(ws, 'trunk_request', None)
+        if req is None:
+            return 0
+        ws.trunk_request = None
+        n, live = self.trunk_split(self.net)
+        assert n > 0 and not cfg.HIP.KEYFRAME_DCE, 'frame-trunk cache: no per-frame prefix in this net (or combined with KEYFRAME_DCE)'
+        ids, new_ids = req
+        cache = ws.trunk_cache
+        if new_ids:
+            assert ws.blobs['data'].t.shape[2] == len(new_ids), (ws.blobs['data'].t.shape, len(new_ids))
+            for i in range(n):
+                if i not in self._skip:
+                    getattr(self, 'op_' + self.net.ops[i].type)(i, self.net.ops[i])
+            out = ws.blobs[live]
+            assert out.N == 1 and out.t.shape[0] == len(new_ids)
+            for j, fid in enumerate(new_ids):
+                cache[fid] = (out.t[j:j + 1], out.C, out.dt)
+                cache.move_to_end(fid)
+        frames = []
+        for fid in ids:
+            assert fid in cache, 'frame %r is neither cached nor among the new frames' % (fid,)
+            cache.move_to_end(fid)
+            frames.append(cache[fid])
+        t = torch.cat([f[0] for f in frames], dim=0)
+        ws.blobs[live] = Blob(t, 'fmap', 1, len(ids), frames[0][1], frames[0][2], True)
+        while len(cache) > max(int(cfg.HIP.FRAME_TRUNK_CACHE), len(set(ids))):
+            cache.popitem(last=False)
+        return n
 
     # ---- RPN head sibling fusion: logits + deltas 1x1 convs on the same input run as ONE conv ------------------------
     def _plan_rpn_siblings(self):

@@ -116,6 +116,49 @@ def test_im_detect_all_surface():
         np.testing.assert_allclose(a[3], b[3], rtol=2e-5)
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_frame_trunk_cache_gives_identical_sliding_window_results(dtype):
+    """cfg.HIP.FRAME_TRUNK_CACHE: conv1 / pool1 / res2 have no temporal extent, so a sliding window (one clip per key frame,
+    stride 1, border frames replicated, reference utils/video.py:149-201) re-uses their per-frame output.  Detections and
+    keypoints of every clip must be IDENTICAL to the plain path, while only the new frame of each clip runs the trunk."""
+    from detectandtrack_amd.core import test as test_engine
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.workspace import Executor
+    T, n_frames = 4, 7
+    model, ws, _ = build_product(fpn3d_kps_cfg('18', T=T, dtype=dtype))
+    cfg.TEST.SCALES = (64,)
+    cfg.TEST.MAX_SIZE = 128
+    cfg.TEST.SCORE_THRESH = 0.0
+    assert Executor.trunk_split(model.net) == (7, 'res2_1_sum')
+    rs = np.random.RandomState(0)
+    video = [rs.randint(0, 255, (60, 90, 3)).astype(np.uint8) for _ in range(n_frames)]
+    clips = []
+    for key in range(n_frames):          # clip around every key frame, border frames replicated
+        ids = [min(max(key - T // 2 + j, 0), n_frames - 1) for j in range(T)]
+        clips.append(ids)
+    plain = [test_engine.im_detect_all(model, [video[i] for i in ids], None) for ids in clips]
+    cfg.HIP.FRAME_TRUNK_CACHE = 6
+    stem_frames = []
+    orig = Executor._stem
+
+    def counting_stem(self, i, op, xin):
+        stem_frames.append(int(xin.t.shape[2]))
+        return orig(self, i, op, xin)
+    Executor._stem = counting_stem
+    try:
+        cached = [test_engine.im_detect_all(model, [video[i] for i in ids], None, frame_ids=[('vid0', i) for i in ids]) for ids in clips]
+    finally:
+        Executor._stem = orig
+        cfg.HIP.FRAME_TRUNK_CACHE = 0
+    assert sum(stem_frames) == n_frames, stem_frames          # every video frame went through the trunk exactly once
+    assert len(ws.trunk_cache) <= 6
+    for (b0, _, k0), (b1, _, k1) in zip(plain, cached):
+        np.testing.assert_array_equal(b0[1], b1[1])
+        assert len(k0[1]) == len(k1[1])
+        for a, b in zip(k0[1], k1[1]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_c4_tube_forward_matches_oracle():
     """The shipped 3D configuration (configs/video/3d/04_R-18-3D_*.yaml): 3D C4 body -> tube RPN (logits averaged
     over T, per-frame deltas) -> tube RoIAlign -> per-RoI res5 -> T-averaged class scores / per-frame box deltas,
