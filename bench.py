@@ -228,7 +228,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
-    ap.add_argument('--pipeline', type=int, default=2, help='clips in flight per GPU (1 = strictly sequential)')
+    ap.add_argument('--pipeline', type=int, default=3, help='clips in flight per GPU (1 = strictly sequential)')
     ap.add_argument('--keyframe-dce', action='store_true',
                     help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '
                          '(identical detections; NOT the default, the default materialises every frame like the reference)')
