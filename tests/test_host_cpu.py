@@ -524,3 +524,22 @@ def test_roi_data_loader_is_ordered_and_reproducible():
         ld.get_next_minibatch(timeout=60)
     ld.shutdown()
     reset_cfg()
+
+
+def test_trunk_split_finds_the_per_frame_prefix():
+    """Executor.trunk_split (cfg.HIP.FRAME_TRUNK_CACHE): conv1 / pool1 / res2 (time kernel 1, ResNet3D.py:258-275) form the
+    per-frame prefix with ONE live-out blob; a 2D model is per-frame up to the first multi-consumer point as well."""
+    from tests.model_util import fpn3d_kps_cfg
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.workspace import Executor
+    for arch, want in (('18', (7, 'res2_1_sum')), ('50', (13, 'res2_2_sum'))):
+        reset_cfg()
+        cfg_from_cfg(fpn3d_kps_cfg(arch, T=4))
+        assert_and_infer_cfg()
+        m = model_builder.create(cfg.MODEL.TYPE, train=False)
+        n, live = Executor.trunk_split(m.net)
+        assert (n, live) == want
+        assert all(op.args.get('kernels', [1])[0] == 1 for op in m.net.ops[:n] if op.type == 'Conv')
+        assert m.net.ops[n].type == 'Conv' and m.net.ops[n].inputs[0] == live
+    reset_cfg()
