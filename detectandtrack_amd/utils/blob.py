@@ -5,7 +5,7 @@ from detectandtrack_amd.core.config import cfg
 import detectandtrack_amd.utils.image as image_utils
 
 
-def im_list_to_blob(ims):
+def im_list_to_blob(ims, num_frames=None):
     """List of HxWx3 (BGR, mean-subtracted) images -> NCHW blob, zero-padded to a common size (a multiple of
     FPN.COARSEST_STRIDE when FPN is on, :47-50); video models get (B, C, T, H, W) (:59-61)."""
     if not isinstance(ims, list):
@@ -20,7 +20,7 @@ def im_list_to_blob(ims):
         blob[i, 0:im.shape[0], 0:im.shape[1], :] = im
     blob = blob.transpose((0, 3, 1, 2))
     if cfg.MODEL.VIDEO_ON:
-        blob = image_utils.move_batch_to_time(blob, cfg.VIDEO.NUM_FRAMES)
+        blob = image_utils.move_batch_to_time(blob, num_frames or cfg.VIDEO.NUM_FRAMES)
     return blob
 
 
