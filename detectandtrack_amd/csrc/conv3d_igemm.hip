@@ -575,6 +575,9 @@ __global__ void stem_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// plan overrides: -1 = read DAT_CONV_BP / DAT_CONV_KSPLIT once, 0 = planner, else forced (dat_conv3d_tune_plan)
+int g_force_bp = -1, g_force_ks = -1;
+
 struct TileChoice {
     int th_log2, tw_log2;
 };
@@ -796,7 +799,8 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     // A block runs steps = ceil(npatch/ks) * taps tap-steps; 2 blocks share a CU (512 slots).  Measured on MI355X:
     // a BP=128 step costs ~1.35 us, a BP=256 step ~2.15 us (2x the work).  The grid runs in "rounds" of 512 blocks;
     // with few rounds the last partial round costs a full one.  Split-K adds an fp32 partial round trip.
-    static int force_bp = -1, force_ks = -1;
+    int& force_bp = g_force_bp;
+    int& force_ks = g_force_ks;
     if (force_bp < 0) {
         const char* e = getenv("DAT_CONV_BP");
         force_bp = e ? atoi(e) : 0;
@@ -868,6 +872,13 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         ctx->prof_n++;
     }
     return rc;
+}
+
+int dat_conv3d_tune_plan(int positions_per_block, int ksplit) {
+    if ((positions_per_block != 0 && positions_per_block != 128 && positions_per_block != 256) || ksplit < 0 || ksplit > 8) return DAT_ERR_ARG;
+    g_force_bp = positions_per_block;
+    g_force_ks = ksplit;
+    return DAT_OK;
 }
 
 int dat_stem_pack(dat_ctx* ctx, dat_stream s, const float* data, void* packed, int dtype, int N, int T, int H, int W) {

@@ -196,6 +196,11 @@ int dat_deconv_k4s2_weights(dat_ctx* ctx, dat_stream s, const float* w, int Cin,
 int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int R, int Tr, int S, int cs, int K,
                      int up, float* out);
 
+/* Tuning hook (not a reference interface): override the launch plan of dat_conv3d_fwd for the calls that follow --
+ * positions per block 128 | 256 and the split-K factor 1..8; 0 = back to the built-in makespan model.  Used by
+ * tools/tune_plan.py to check the model against measured per-layer timings. */
+int dat_conv3d_tune_plan(int positions_per_block, int ksplit);
+
 /* ---- conv1, fused (ResNet3D.py:258-262): ConvNd [1,7,7] / [1,2,2] / pad [0,3,3] on `data` fp32 [N,3,T,H,W] + AffineChannelNd
  * (scale, bias: fp32 [64] or NULL) + ReLU -> out [N*T, Ho, Wo, 64] in `dtype`; weights packed once by
  * dat_stem_conv_pack_weights (dat_stem_conv_weight_bytes bytes).  Supersedes dat_stem_pack + dat_conv3d_fwd for conv1. */
