@@ -11,7 +11,6 @@ import numpy.random as npr
 
 from detectandtrack_amd.core.config import cfg
 import detectandtrack_amd.utils.boxes as box_utils
-import detectandtrack_amd.utils.keypoints as keypoint_utils
 
 
 def merge_proposals_into_entry(entry, proposals):

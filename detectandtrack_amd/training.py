@@ -21,7 +21,7 @@ import torch
 
 from detectandtrack_amd.core.config import cfg
 from detectandtrack_amd.ops import hip_ops as ops
-from detectandtrack_amd.workspace import Executor, Blob, _dt, _w5, _count
+from detectandtrack_amd.workspace import Executor, _count
 
 logger = logging.getLogger(__name__)
 

@@ -248,7 +248,7 @@ def _synthetic_training_blobs(T, H, W, rs, n_rois=24, n_kp=4, K=17, M=56):
 def test_train_step_gradients_match_oracle_autograd(ops):
     """One forward + backward of the FPN3D / 2D-head keypoint R-CNN training graph (fp32 parity mode) against torch autograd
     on the oracle's restatement: every loss value and the gradient of every trainable parameter."""
-    from tests.model_util import fpn3d_kps_cfg, build_product, synthetic_clip, oracle_opts
+    from tests.model_util import fpn3d_kps_cfg, synthetic_clip, oracle_opts
     from detectandtrack_amd.core.config import cfg
     from detectandtrack_amd.training import TrainExecutor
     from oracle import train_ref

@@ -3,8 +3,6 @@ import ast
 import glob
 import os
 import re
-import subprocess
-import sys
 
 import numpy as np
 import pytest

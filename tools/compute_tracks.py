@@ -6,7 +6,7 @@ import logging
 import pickle
 
 import _path  # noqa
-from detectandtrack_amd.core.config import cfg, cfg_from_file, cfg_from_list, assert_and_infer_cfg, get_output_dir
+from detectandtrack_amd.core.config import cfg_from_file, cfg_from_list, assert_and_infer_cfg, get_output_dir
 from detectandtrack_amd.core.tracking_engine import run_posetrack_tracking
 
 

@@ -11,9 +11,7 @@ and the dataset).  `--multi-gpu-testing` shards clips over the ranks of a torch.
 """
 import argparse
 import logging
-import os
 import pickle
-import sys
 
 import numpy as np
 

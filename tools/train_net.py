@@ -13,7 +13,6 @@ has the roidb record layout, so a real loader only has to yield (frames, entry) 
 import argparse
 import logging
 import os
-import sys
 import time
 
 import numpy as np
