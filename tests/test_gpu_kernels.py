@@ -135,6 +135,32 @@ def test_conv3d(ops, case, dtype):
     assert err < tol
 
 
+def test_conv3d_forced_plans_agree(ops):
+    """dat_conv3d_tune_plan: every launch plan (128 / 256 positions per block, split-K 1..4) of a res4-like layer computes the same
+    convolution — fp32 mode vs torch within 2e-4, and the plans among themselves (only the split-K summation order differs)."""
+    from detectandtrack_amd import libdat as L
+    rs = np.random.RandomState(11)
+    N, T, H, W, Cin, Cout, k = 1, 4, 24, 40, 256, 256, (3, 3, 3)
+    x = rs.randn(N, Cin, T, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, *k) * np.sqrt(2.0 / (Cin * 27))).astype(np.float32)
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    ref = _conv_ref(x, w, None, bias, None, (1, 1), (1, 1, 1), True)
+    layer = ops.ConvLayer(_dev(w), None, _dev(bias), stride=(1, 1), pads=(1, 1, 1), relu=True, dtype=0)
+    xd = ops.to_ndhwc(_dev(x), 0)
+    outs = {}
+    try:
+        for bp, ks in ((0, 0), (128, 1), (256, 1), (128, 2), (256, 3), (128, 4)):
+            assert L._lib.dat_conv3d_tune_plan(bp, ks) == 0
+            outs[(bp, ks)] = ops.to_ncdhw(layer(xd, T=T), 0, N, Cout, T).cpu().numpy()
+        assert L._lib.dat_conv3d_tune_plan(64, 1) != 0          # rejected: not a tile size
+    finally:
+        L._lib.dat_conv3d_tune_plan(0, 0)
+    for key, got in outs.items():
+        err = np.abs(got - ref).max()
+        assert err < 2e-4, (key, err)
+    np.testing.assert_array_equal(outs[(128, 1)], outs[(256, 1)])   # same K order, different tiling: bit-identical
+
+
 @pytest.mark.parametrize('dtype', [0, 1])
 def test_stem_conv1(ops, dtype):
     rs = np.random.RandomState(5)
