@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
             if (DT == DAT_BF16) {
                 uint32_t o[CPL / 2];
 #pragma unroll
-                for (int e2 = 0; e2 < CPL / 2; ++e2) o[e2] = (uint32_t)f2bf(v[2 * e2]) | ((uint32_t)f2bf(v[2 * e2 + 1]) << 16);
+                for (int e2 = 0; e2 < CPL / 2; ++e2) o[e2] = f2bf2(v[2 * e2], v[2 * e2 + 1]);
                 if (nch == CPL && (p.out_cs & 7) == 0) {
                     *(uint4*)yp = make_uint4(o[0], o[1], o[2], o[3]);
                 } else {
@@ -493,8 +493,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (DT == DAT_BF16) {
             uint2 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            o.x = f2bf2(v[0], v[1]);
+            o.y = f2bf2(v[2], v[3]);
             *(uint2*)(y + (opos * out_cs + c) * 2) = o;
         } else {
             *(float4*)(y + (opos * out_cs + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -548,8 +548,8 @@ __global__ void stem_pack_kernel(const float* __restrict__ data, void* __restric
         }
         uint4 o;
         if (DT == DAT_BF16) {
-            o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            o.z = f2bf(v[4 % V]) | ((uint32_t)f2bf(v[5 % V]) << 16); o.w = f2bf(v[6 % V]) | ((uint32_t)f2bf(v[7 % V]) << 16);
+            o.x = f2bf2(v[0], v[1]); o.y = f2bf2(v[2], v[3]);
+            o.z = f2bf2(v[4 % V], v[5 % V]); o.w = f2bf2(v[6 % V], v[7 % V]);
         } else {
             o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
         }

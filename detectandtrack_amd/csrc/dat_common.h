@@ -48,11 +48,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer-arithmetic
+// version it replaces cost ~8 VALU operations per element and dominated the epilogue of the memory-bound layers
+typedef __bf16 dat_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float dat_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+// two values -> one packed dword (lo in bits 0-15)
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    const dat_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dat_bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

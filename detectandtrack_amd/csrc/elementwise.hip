@@ -125,8 +125,8 @@ __global__ void maxpool_hw_kernel(const void* __restrict__ x, void* __restrict__
         }
         uint4 o;
         if (DT == DAT_BF16) {
-            o.x = f2bf(m[0]) | ((uint32_t)f2bf(m[1]) << 16); o.y = f2bf(m[2]) | ((uint32_t)f2bf(m[3]) << 16);
-            o.z = f2bf(m[4 % V]) | ((uint32_t)f2bf(m[5 % V]) << 16); o.w = f2bf(m[6 % V]) | ((uint32_t)f2bf(m[7 % V]) << 16);
+            o.x = f2bf2(m[0], m[1]); o.y = f2bf2(m[2], m[3]);
+            o.z = f2bf2(m[4 % V], m[5 % V]); o.w = f2bf2(m[6 % V], m[7 % V]);
         } else {
             o.x = __float_as_uint(m[0]); o.y = __float_as_uint(m[1]); o.z = __float_as_uint(m[2]); o.w = __float_as_uint(m[3]);
         }

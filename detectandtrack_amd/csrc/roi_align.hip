@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
             }
             uint4 o;
             if (DT == DAT_BF16) {
-                o.x = f2bf(acc[0] * inv) | ((uint32_t)f2bf(acc[1] * inv) << 16);
-                o.y = f2bf(acc[2] * inv) | ((uint32_t)f2bf(acc[3] * inv) << 16);
-                o.z = f2bf(acc[4 % V] * inv) | ((uint32_t)f2bf(acc[5 % V] * inv) << 16);
-                o.w = f2bf(acc[6 % V] * inv) | ((uint32_t)f2bf(acc[7 % V] * inv) << 16);
+                o.x = f2bf2(acc[0] * inv, acc[1] * inv);
+                o.y = f2bf2(acc[2] * inv, acc[3] * inv);
+                o.z = f2bf2(acc[4 % V] * inv, acc[5 % V] * inv);
+                o.w = f2bf2(acc[6 % V] * inv, acc[7 % V] * inv);
             } else {
                 o.x = __float_as_uint(acc[0] * inv); o.y = __float_as_uint(acc[1] * inv);
                 o.z = __float_as_uint(acc[2] * inv); o.w = __float_as_uint(acc[3] * inv);

@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
             }
             char* yp = p.out + ((((size_t)f * p.Ho + oh) * p.Wo + ow) * 64 + sl_c) * ES;
             if (DT == DAT_BF16) {
-                *(uint4*)yp = make_uint4((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16),
-                                         (uint32_t)f2bf(v[4 % CPL]) | ((uint32_t)f2bf(v[5 % CPL]) << 16),
-                                         (uint32_t)f2bf(v[6 % CPL]) | ((uint32_t)f2bf(v[7 % CPL]) << 16));
+                *(uint4*)yp = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]),
+                                         f2bf2(v[4 % CPL], v[5 % CPL]),
+                                         f2bf2(v[6 % CPL], v[7 % CPL]));
             } else {
                 *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
             }

@@ -287,8 +287,8 @@ __global__ void relu_bwd_kernel(const void* __restrict__ dy, const void* __restr
         }
         if (DT == DAT_BF16) {
             uint2 w;
-            w.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            w.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            w.x = f2bf2(v[0], v[1]);
+            w.y = f2bf2(v[2], v[3]);
             ((uint2*)g)[at >> 2] = w;
         } else {
             ((float4*)g)[at >> 2] = make_float4(v[0], v[1], v[2], v[3]);

@@ -135,6 +135,63 @@ def test_conv3d(ops, case, dtype):
     assert err < tol
 
 
+PW_CASES = [
+    # name, T, H, W, Cin, Cout, relu, res_mode, affine   (HBM-bound pointwise layers at a realistic number of positions)
+    ('lateral_up2', 2, 126, 162, 64, 256, False, 2, False),
+    ('expander_sum', 3, 100, 140, 128, 512, True, 1, True),
+    ('cout_200', 2, 128, 160, 256, 200, True, 0, True),
+    ('cin_192', 2, 130, 160, 192, 256, False, 0, False),
+]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', PW_CASES, ids=[c[0] for c in PW_CASES])
+def test_conv3d_large_pointwise_layers(ops, case, dtype):
+    """1x1x1 stride-1 convs with tens of thousands of positions (FPN laterals, bottleneck expanders): ragged last tile, Cout not
+    a multiple of 128, 1-4 channel chunks, both residual modes, the hardware bf16 rounding of the epilogue; a forced launch plan
+    must give the identical result (same K order)."""
+    from detectandtrack_amd import libdat as L
+    name, T, H, W, Cin, Cout, relu, res_mode, affine = case
+    rs = np.random.RandomState(abs(hash(name)) % 1000)
+    x = rs.randn(1, Cin, T, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 1, 1, 1) * np.sqrt(2.0 / Cin)).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32) if affine else None
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    res = res_small = None
+    if res_mode == 1:
+        res = rs.randn(1, Cout, T, H, W).astype(np.float32)
+    elif res_mode == 2:
+        res_small = rs.randn(1, Cout, T, H // 2, W // 2).astype(np.float32)
+        res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    if dtype == 1:
+        q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+        x, w = q(x), q(w)
+        if res is not None:
+            res = q(res)
+            res_small = q(res_small) if res_small is not None else None
+    ref = _conv_ref(x, w, scale, bias, res, (1, 1), (0, 0, 0), relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(1, 1), pads=(0, 0, 0),
+                          relu=relu, dtype=dtype)
+    xd = ops.to_ndhwc(_dev(x), dtype)
+    rd = None
+    if res_mode == 1:
+        rd = ops.to_ndhwc(_dev(res), dtype, layer.cstride)
+    elif res_mode == 2:
+        rd = ops.to_ndhwc(_dev(res_small), dtype, layer.cstride)
+    got = ops.to_ncdhw(layer(xd, T=T, residual=rd, res_mode=res_mode), dtype, 1, Cout, T).cpu().numpy()
+    try:
+        assert L._lib.dat_conv3d_tune_plan(128, 1) == 0
+        gen = ops.to_ncdhw(layer(xd, T=T, residual=rd, res_mode=res_mode), dtype, 1, Cout, T).cpu().numpy()
+    finally:
+        L._lib.dat_conv3d_tune_plan(0, 0)
+    err = np.abs(got - ref).max()
+    tol = 2e-4 if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    print('pointwise %s dtype=%d max-abs err %.3e (ref max %.2f), vs forced plan %.3e' % (name, dtype, err, np.abs(ref).max(),
+                                                                                            np.abs(got - gen).max()))
+    assert err < tol
+    np.testing.assert_array_equal(got, gen)
+
+
 def test_conv3d_forced_plans_agree(ops):
     """dat_conv3d_tune_plan: every launch plan (128 / 256 positions per block, split-K 1..4) of a res4-like layer computes the same
     convolution — fp32 mode vs torch within 2e-4, and the plans among themselves (only the split-K summation order differs)."""
