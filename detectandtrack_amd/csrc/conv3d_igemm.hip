@@ -367,6 +367,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
         bi[e] = (!part_mode && p.bias && ok) ? p.bias[c_st + e] : 0.f;
     }
     const size_t npos_all = (size_t)p.frames * p.Ho * p.Wo;
+    // addresses = block-uniform 64-bit base (SGPRs: frame, tile origin) + a 32-bit per-lane offset inside the frame (the launcher
+    // checks that one frame of output / partials is < 2 GB): the stores take the "SGPR base + VGPR offset" form and the
+    // epilogue's per-store 64-bit multiply-add chains (a third of its VALU work) disappear
+    const size_t tile_pos = ((size_t)f * p.Ho + oh0) * p.Wo + ow0;
+    char* const ybase = p.y + tile_pos * p.out_cs * ES;
+    const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * ES
+                                              : p.res + tile_pos * p.out_cs * ES;
+    float* const pbase = part_mode ? p.part + ((size_t)split * npos_all + tile_pos) * p.Cout : nullptr;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         // phase 1: accumulators -> LDS [position][channel] fp32
@@ -388,12 +396,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 v[e4 * 4 + 0] = t.x; v[e4 * 4 + 1] = t.y; v[e4 * 4 + 2] = t.z; v[e4 * 4 + 3] = t.w;
             }
             const int pos = wave_p * WP + j * 32 + pl;
-            const int oh = oh0 + (pos >> p.tw_log2), ow = ow0 + (pos & (TW - 1));
+            const int ohl = pos >> p.tw_log2, owl = pos & (TW - 1);
+            const int oh = oh0 + ohl, ow = ow0 + owl;
             if (oh >= p.Ho || ow >= p.Wo || c_st >= p.Cout || (p.ablate & 4)) continue;
-            const size_t opos = ((size_t)f * p.Ho + oh) * p.Wo + ow;
+            const unsigned lpos = (unsigned)(ohl * p.Wo + owl);   // position relative to the tile origin, same frame
             const int nch = min(CPL, p.Cout - c_st);             // multiple of 4
             if (part_mode) {   // raw fp32 partial sums; splitk_finish_kernel applies the epilogue
-                float* dst = p.part + ((size_t)split * npos_all + opos) * p.Cout + c_st;
+                float* dst = pbase + (lpos * (unsigned)p.Cout + (unsigned)c_st);
 #pragma unroll
                 for (int e4 = 0; e4 < CPL / 4; ++e4)
                     if (e4 * 4 < nch) *(float4*)(dst + e4 * 4) = make_float4(v[e4 * 4], v[e4 * 4 + 1], v[e4 * 4 + 2], v[e4 * 4 + 3]);
@@ -402,9 +411,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + bi[e];
             if (p.res_mode) {
-                size_t rpos = opos;
-                if (p.res_mode == 2) rpos = ((size_t)f * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1);
-                const char* rp = p.res + (rpos * p.out_cs + c_st) * ES;
+                unsigned rpos = lpos;
+                if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
+                const char* rp = rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES;
                 if (DT == DAT_BF16) {
 #pragma unroll
                     for (int e4 = 0; e4 < CPL / 4; ++e4)
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            char* yp = p.y + (opos * p.out_cs + c_st) * ES;
+            char* yp = ybase + (lpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES;
             if (DT == DAT_BF16) {
                 uint32_t o[CPL / 2];
 #pragma unroll
@@ -668,6 +677,8 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         nblocks *= ks;
     }
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
+    DAT_ENFORCE(ctx, (long long)p.Ho * p.Wo * std::max(p.out_cs, p.Cout) * 4 < (1ll << 31),
+                "conv3d: one output frame of %dx%dx%d exceeds the 2-GB range of the epilogue's 32-bit offsets", p.Ho, p.Wo, p.out_cs);
     p.nblocks = (unsigned)nblocks;
     DAT_ENFORCE(ctx, p.tab_n % TPS == 0 && (TPS == 1 || p.tab_new == 1u), "conv3d: %d taps per step need one stride plane of a multiple of %d taps", TPS, TPS);
     size_t lds = (size_t)2 * TPS * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
