@@ -1,47 +1,50 @@
-"""Learning-rate schedule with warm-up — mirror of reference lib/utils/lr_policy.py:19-114."""
+"""Learning-rate schedule with warm-up (behaviour of reference lib/utils/lr_policy.py:19-114, SOLVER.* keys unchanged).
+
+    get_lr_at_iter(it) = policy(it) * warm-up factor(it)          (float32, like the reference)
+
+Policies (SOLVER.LR_POLICY): 'step' (BASE_LR * GAMMA^(it // STEP_SIZE)), 'steps_with_decay' (BASE_LR * GAMMA^k in the k-th
+interval of STEPS), 'steps_with_lrs' (LRS[k]).  Warm-up over the first WARM_UP_ITERS iterations: 'constant' scales by
+WARM_UP_FACTOR, 'linear' ramps from WARM_UP_FACTOR to 1.
+"""
+import bisect
+
 import numpy as np
 
 from detectandtrack_amd.core.config import cfg
 
 
-def get_lr_at_iter(it):
-    lr = get_lr_func()(it)
-    if it < cfg.SOLVER.WARM_UP_ITERS:
-        method = cfg.SOLVER.WARM_UP_METHOD
-        if method == 'constant':
-            warmup_factor = cfg.SOLVER.WARM_UP_FACTOR
-        elif method == 'linear':
-            alpha = it / cfg.SOLVER.WARM_UP_ITERS
-            warmup_factor = cfg.SOLVER.WARM_UP_FACTOR * (1 - alpha) + alpha
-        else:
-            raise KeyError('Unknown SOLVER.WARM_UP_METHOD: {}'.format(method))
-        lr *= warmup_factor
-    return np.float32(lr)
-
-
-def lr_func_steps_with_lrs(cur_iter):
-    return cfg.SOLVER.LRS[get_step_index(cur_iter)]
-
-
-def lr_func_steps_with_decay(cur_iter):
-    return cfg.SOLVER.BASE_LR * cfg.SOLVER.GAMMA ** get_step_index(cur_iter)
-
-
-def lr_func_step(cur_iter):
-    return cfg.SOLVER.BASE_LR * cfg.SOLVER.GAMMA ** (cur_iter // cfg.SOLVER.STEP_SIZE)
-
-
 def get_step_index(cur_iter):
-    assert cfg.SOLVER.STEPS[0] == 0, 'The first step should always start at 0.'
-    steps = cfg.SOLVER.STEPS + [cfg.SOLVER.MAX_ITER]
-    for ind, step in enumerate(steps):
-        if cur_iter < step:
-            break
-    return ind - 1
+    """Index k of the STEPS interval [STEPS[k], STEPS[k+1]) that holds cur_iter (the last interval ends at MAX_ITER; an iteration
+    at or past MAX_ITER belongs to the last interval, like the reference's loop)."""
+    s = cfg.SOLVER
+    assert s.STEPS[0] == 0, 'The first step should always start at 0.'
+    bounds = list(s.STEPS) + [s.MAX_ITER]
+    return min(bisect.bisect_right(bounds, cur_iter), len(bounds) - 1) - 1
+
+
+_POLICIES = {
+    'step': lambda it: cfg.SOLVER.BASE_LR * cfg.SOLVER.GAMMA ** (it // cfg.SOLVER.STEP_SIZE),
+    'steps_with_decay': lambda it: cfg.SOLVER.BASE_LR * cfg.SOLVER.GAMMA ** get_step_index(it),
+    'steps_with_lrs': lambda it: cfg.SOLVER.LRS[get_step_index(it)],
+}
+_WARM_UP = {
+    'constant': lambda frac: cfg.SOLVER.WARM_UP_FACTOR,
+    'linear': lambda frac: cfg.SOLVER.WARM_UP_FACTOR * (1 - frac) + frac,
+}
 
 
 def get_lr_func():
-    name = 'lr_func_' + cfg.SOLVER.LR_POLICY
-    if name not in globals():
+    try:
+        return _POLICIES[cfg.SOLVER.LR_POLICY]
+    except KeyError:
         raise NotImplementedError('Unknown LR policy: {}'.format(cfg.SOLVER.LR_POLICY))
-    return globals()[name]
+
+
+def get_lr_at_iter(it):
+    lr = get_lr_func()(it)
+    n_warm = cfg.SOLVER.WARM_UP_ITERS
+    if it < n_warm:
+        if cfg.SOLVER.WARM_UP_METHOD not in _WARM_UP:
+            raise KeyError('Unknown SOLVER.WARM_UP_METHOD: {}'.format(cfg.SOLVER.WARM_UP_METHOD))
+        lr *= _WARM_UP[cfg.SOLVER.WARM_UP_METHOD](it / n_warm)
+    return np.float32(lr)

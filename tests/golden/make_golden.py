@@ -214,6 +214,29 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'reference_host.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_host.npz'), len(out), 'arrays')
     golden_roi_data(cfg)
+    golden_lr_policy(cfg)
+
+
+LR_CASES = [
+    # LR_POLICY, BASE_LR, GAMMA, STEP_SIZE, STEPS, LRS, MAX_ITER, WARM_UP_ITERS, WARM_UP_FACTOR, WARM_UP_METHOD
+    ('steps_with_decay', 0.02, 0.1, 30000, [0, 60, 80], [], 90, 20, 1.0 / 3.0, 'linear'),
+    ('steps_with_decay', 0.002, 0.5, 30000, [0, 10, 35, 70], [], 100, 0, 1.0 / 3.0, 'linear'),
+    ('steps_with_lrs', 0.02, 0.1, 30000, [0, 40, 75], [0.02, 0.004, 0.0001], 90, 15, 0.1, 'constant'),
+    ('step', 0.01, 0.3, 25, [0], [], 100, 8, 0.25, 'linear'),
+]
+
+
+def golden_lr_policy(cfg):
+    """SOLVER schedules of the REAL reference lib/utils/lr_policy.py for iterations 0 .. MAX_ITER + 9."""
+    import utils.lr_policy as lr_policy
+    out = {}
+    for i, (pol, base, gamma, step_size, steps, lrs, max_iter, wi, wf, wm) in enumerate(LR_CASES):
+        so = cfg.SOLVER
+        so.LR_POLICY, so.BASE_LR, so.GAMMA, so.STEP_SIZE, so.STEPS, so.LRS = pol, base, gamma, step_size, list(steps), list(lrs)
+        so.MAX_ITER, so.WARM_UP_ITERS, so.WARM_UP_FACTOR, so.WARM_UP_METHOD = max_iter, wi, wf, wm
+        out['lr_case%d' % i] = np.array([lr_policy.get_lr_at_iter(it) for it in range(max_iter + 10)], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, 'reference_lr_policy.npz'), **out)
+    print('wrote reference_lr_policy.npz', len(out), 'schedules')
 
 
 def golden_roi_data(cfg):

@@ -541,3 +541,30 @@ def test_trunk_split_finds_the_per_frame_prefix():
         assert all(op.args.get('kernels', [1])[0] == 1 for op in m.net.ops[:n] if op.type == 'Conv')
         assert m.net.ops[n].type == 'Conv' and m.net.ops[n].inputs[0] == live
     reset_cfg()
+
+
+def test_lr_policy_matches_the_real_reference_golden():
+    """utils/lr_policy.get_lr_at_iter against schedules produced by the REAL reference lib/utils/lr_policy.py
+    (tests/golden/make_golden.py:golden_lr_policy): all three policies, both warm-up methods, iterations past MAX_ITER."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import lr_policy
+    gdir = os.path.join(os.path.dirname(__file__), 'golden')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_cases', os.path.join(gdir, 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)                      # importing the generator only defines its tables and functions
+    cases = mg.LR_CASES
+    g = np.load(os.path.join(gdir, 'reference_lr_policy.npz'))
+    assert len(cases) == len(g.files) == 4
+    for i, (pol, base, gamma, step_size, steps, lrs, max_iter, wi, wf, wm) in enumerate(cases):
+        reset_cfg()
+        so = cfg.SOLVER
+        so.LR_POLICY, so.BASE_LR, so.GAMMA, so.STEP_SIZE, so.STEPS, so.LRS = pol, base, gamma, step_size, list(steps), list(lrs)
+        so.MAX_ITER, so.WARM_UP_ITERS, so.WARM_UP_FACTOR, so.WARM_UP_METHOD = max_iter, wi, wf, wm
+        got = np.array([lr_policy.get_lr_at_iter(it) for it in range(max_iter + 10)], dtype=np.float32)
+        np.testing.assert_array_equal(got, g['lr_case%d' % i], err_msg='case %d (%s)' % (i, pol))
+    reset_cfg()
+    cfg.SOLVER.LR_POLICY = 'cosine'
+    with pytest.raises(NotImplementedError):
+        lr_policy.get_lr_at_iter(0)
+    reset_cfg()
