@@ -1,16 +1,21 @@
-"""AttrDict: dict with attribute access (reference lib/utils/collections.py:15-27)."""
+"""AttrDict — the config tree's node type: a dict whose keys read and write as attributes (`cfg.TRAIN.MAX_SIZE`), the
+behaviour of reference lib/utils/collections.py:15-27.  Plain dict storage, so yaml / pickle / deepcopy see a dict."""
 
 
 class AttrDict(dict):
-    def __getattr__(self, name):
-        if name in self.__dict__:
-            return self.__dict__[name]
-        if name in self:
-            return self[name]
-        raise AttributeError(name)
+    __slots__ = ()
 
-    def __setattr__(self, name, value):
-        if name in self.__dict__:
-            self.__dict__[name] = value
-        else:
-            self[name] = value
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+    def __delattr__(self, key):
+        try:
+            del self[key]
+        except KeyError:
+            raise AttributeError(key)
