@@ -568,3 +568,37 @@ def test_lr_policy_matches_the_real_reference_golden():
     with pytest.raises(NotImplementedError):
         lr_policy.get_lr_at_iter(0)
     reset_cfg()
+
+
+def test_roidb_clip_source_feeds_the_loader():
+    """roi_data.minibatch.RoidbClipSource (reference roi_data/minibatch.py:59-103): frames of a roidb entry -> scaled,
+    mean-subtracted, stride-padded clip; through the loader the labels are computed at that scale."""
+    from detectandtrack_amd.core.config import reset_cfg
+    from detectandtrack_amd.roi_data import loader, rpn, synthetic
+    from detectandtrack_amd.roi_data.minibatch import RoidbClipSource
+    import detectandtrack_amd.utils.blob as blob_utils
+    cfg = _loader_cfg(1)
+    cfg.MODEL.VIDEO_ON = True
+    cfg.VIDEO.NUM_FRAMES = 2
+    cfg.TRAIN.SCALES, cfg.TRAIN.MAX_SIZE = (96,), 160
+    rs = np.random.RandomState(2)
+    roidb = []
+    for i in range(3):
+        e = synthetic.synthetic_roidb_entry(60, 90, n_persons=2, seed=i, T=1)
+        e['image'] = [rs.randint(0, 255, (60, 90, 3)).astype(np.uint8) for _ in range(2)]
+        e['flipped'] = (i == 1)
+        roidb.append(e)
+    src = RoidbClipSource(roidb, seed=5)
+    data, entry, scale = src(1)
+    assert scale == 96.0 / 60.0 and data.shape == (1, 3, 2, 96, 160) and data.dtype == np.float32   # 96 x 144 padded to /32
+    ref0, _ = blob_utils.prep_im_for_blob(roidb[1]['image'][0][:, ::-1, :], cfg.PIXEL_MEANS, [96], 160)
+    np.testing.assert_array_equal(data[0, :, 0, :96, :144], ref0[0].transpose(2, 0, 1))
+    assert np.all(data[0, :, :, :, 144:] == 0)
+    ld = loader.RoIDataLoader(src, num_items=len(src), num_workers=2, device=None, seed=3, widths=src.widths, heights=src.heights)
+    mb = ld.get_next_minibatch(timeout=60)
+    ld.shutdown()
+    np.testing.assert_allclose(mb.blobs['im_info'], [[96.0, 144.0, 1.6]])
+    want = rpn.add_rpn_blobs({}, 1.6, mb.entry, np.random.RandomState((3 + 104729) % 2 ** 32))
+    for k, v in want.items():
+        np.testing.assert_array_equal(mb.blobs[k], v, err_msg=k)
+    reset_cfg()

@@ -53,6 +53,7 @@ def main():
     p.add_argument('--iters', type=int, default=0, help='override SOLVER.MAX_ITER')
     p.add_argument('--height', type=int, default=256)
     p.add_argument('--width', type=int, default=320)
+    p.add_argument('--roidb', default='', help='pickled roidb whose entries carry their frames as arrays (entry["image"]); default: synthetic clips')
     p.add_argument('--loader-workers', type=int, default=4,
                    help='prefetch threads of the input pipeline (roi_data.loader); 0 = label every clip synchronously on the host')
     p.add_argument('--reference-init', action='store_true', help='initialise from the builders\' init specs instead of synthetic_params')
@@ -90,8 +91,16 @@ def main():
 
     def source(i):
         return pool[i % len(pool)], synthetic.synthetic_roidb_entry(args.height, args.width, n_persons=4, seed=1000 * rank + i, T=tube_T), 1.0
+    n_items, sizes = max_iter, {}
+    if args.roidb:
+        import pickle
+        from detectandtrack_amd.roi_data.minibatch import RoidbClipSource
+        with open(args.roidb, 'rb') as f:
+            source = RoidbClipSource(pickle.load(f), seed=cfg.RNG_SEED + rank)
+        n_items, sizes = len(source), dict(widths=source.widths, heights=source.heights)
+        assert args.loader_workers > 0, '--roidb needs the loader (--loader-workers > 0)'
     if args.loader_workers > 0:
-        loader = RoIDataLoader(source, num_items=max_iter, num_workers=args.loader_workers, queue_size=2 * args.loader_workers,
+        loader = RoIDataLoader(source, num_items=n_items, **sizes, num_workers=args.loader_workers, queue_size=2 * args.loader_workers,
                                device=torch.cuda.current_device(), seed=cfg.RNG_SEED + rank)
     t0 = time.time()
     for it in range(max_iter):
