@@ -27,6 +27,9 @@ def parse_args():
     p.add_argument('--multi-gpu-testing', dest='multi_gpu_testing', action='store_true')
     p.add_argument('--roidb', default='', help='pickled clip list')
     p.add_argument('--synthetic', type=int, default=0, help='use N synthetic clips')
+    p.add_argument('--synthetic-video', type=int, default=0,
+                   help='one synthetic video of N frames scored like the reference scores a video: a clip around every frame, stride 1, '
+                        'border frames replicated (entries carry frame_ids, so HIP.FRAME_TRUNK_CACHE can reuse the per-frame trunk)')
     p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
     return p.parse_args()
 
@@ -35,6 +38,19 @@ def synthetic_roidb(n, T, h=720, w=1280, seed=3):
     rs = np.random.RandomState(seed)
     return [{'image': [rs.randint(0, 255, (h, w, 3)).astype(np.uint8) for _ in range(T)], 'height': h, 'width': w,
              'name': 'images/vid%04d/%06d.jpg' % (i // 100, i % 100)} for i in range(n)]
+
+
+def synthetic_video_roidb(n_frames, T, h=720, w=1280, seed=3):
+    """Sliding-window clips over one video (reference lib/utils/video.py:149-201): the clip of key frame k holds frames
+    k - T//2 ... k - T//2 + T - 1, clamped to the video."""
+    rs = np.random.RandomState(seed)
+    video = [rs.randint(0, 255, (h, w, 3)).astype(np.uint8) for _ in range(n_frames)]
+    roidb = []
+    for k in range(n_frames):
+        ids = [min(max(k - T // 2 + j, 0), n_frames - 1) for j in range(T)]
+        roidb.append({'image': [video[i] for i in ids], 'frame_ids': [('vid0000', i) for i in ids], 'height': h, 'width': w,
+                      'name': 'images/vid0000/%06d.jpg' % k})
+    return roidb
 
 
 def main():
@@ -47,6 +63,8 @@ def main():
     if args.roidb:
         with open(args.roidb, 'rb') as f:
             roidb = pickle.load(f)
+    elif args.synthetic_video:
+        roidb = synthetic_video_roidb(args.synthetic_video, max(cfg.VIDEO.NUM_FRAMES, 1))
     else:
         roidb = synthetic_roidb(max(args.synthetic, 1), max(cfg.VIDEO.NUM_FRAMES, 1))
     out = get_output_dir(training=False)
