@@ -602,3 +602,21 @@ def test_roidb_clip_source_feeds_the_loader():
     for k, v in want.items():
         np.testing.assert_array_equal(mb.blobs[k], v, err_msg=k)
     reset_cfg()
+
+
+def test_own_configs_load_and_build():
+    """Every yaml under configs/ loads and its graph builds (training configs in training mode)."""
+    import glob
+    from detectandtrack_amd.core.config import cfg, cfg_from_file, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(__file__)), 'configs', '*.yaml')))
+    assert len(files) >= 4
+    for f in files:
+        reset_cfg()
+        cfg_from_file(f)
+        assert_and_infer_cfg()
+        train = os.path.basename(f).startswith('train_')
+        m = model_builder.create(cfg.MODEL.TYPE, train=train)
+        assert len(m.net.ops) > 40 and (train or m.keypoint_net is not None), f
+        assert cfg.TEST.RPN_PRE_NMS_TOP_N <= 4096 or train
+    reset_cfg()
