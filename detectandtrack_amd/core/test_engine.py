@@ -11,6 +11,7 @@ import pickle
 from collections import defaultdict
 
 import numpy as np
+import yaml
 
 from detectandtrack_amd.core.config import cfg, get_output_dir
 from detectandtrack_amd.core.test import im_detect_all
@@ -81,7 +82,7 @@ def test_net(roidb, ind_range=None, output_dir=None):
                         start + 1, end, len(roidb), i + 1, len(part), timers['im_detect_bbox'].average_time,
                         timers['misc_bbox'].average_time, timers['im_detect_keypoints'].average_time,
                         timers['misc_keypoints'].average_time)
-    res = dict(all_boxes=all_boxes, all_segms=all_segms, all_keyps=all_keyps)
+    res = dict(all_boxes=all_boxes, all_segms=all_segms, all_keyps=all_keyps, cfg=yaml.safe_dump(net_utils._plain(cfg)))   # (:199-204)
     if output_dir is not None:
         name = 'detection_range_%s_%s.pkl' % (start, end) if ind_range is not None else 'detections.pkl'
         with open(os.path.join(output_dir, name), 'wb') as f:
@@ -94,9 +95,11 @@ def merge_range_results(parts):
     merged = None
     for p in parts:
         if merged is None:
-            merged = {k: [list(c) for c in v] for k, v in p.items()}
+            merged = {k: (v if k == 'cfg' else [list(c) for c in v]) for k, v in p.items()}
             continue
         for k in merged:
+            if k == 'cfg':
+                continue
             for cls in range(len(merged[k])):
                 merged[k][cls] += p[k][cls]
     return merged

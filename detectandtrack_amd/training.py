@@ -509,9 +509,14 @@ class Trainer(object):
         ex.run()
         ex.backward()
         grads = ex.param_grads
-        names = [n for n in self.trainable if n in grads]
         if self.dist is not None and self.dist.get_world_size() > 1:
-            self._all_reduce([grads[n] for n in names])
+            # every rank reduces the SAME fixed list (a parameter without a gradient on this rank -- e.g. no foreground roi
+            # reached a branch -- contributes zeros), otherwise the buckets of different ranks would not line up
+            for n in self.trainable:
+                if n not in grads:
+                    grads[n] = torch.zeros_like(ws.dev_param(n))
+            self._all_reduce([grads[n] for n in self.trainable])
+        names = [n for n in self.trainable if n in grads]
         for n in names:
             w = ws.dev_param(n)
             if n not in self.momentum:
@@ -521,6 +526,16 @@ class Trainer(object):
         ws._layers.clear()            # packed weights are re-derived from the updated device masters on the next forward
         self.iter += 1
         return ex
+
+    def momentum_blobs(self):
+        """name -> host array of the momentum buffers (saved as `<param>_momentum`, reference utils/net.py:268-275)."""
+        return {n: m.detach().cpu().numpy() for n, m in self.momentum.items()}
+
+    def load_momentum(self, blobs):
+        """Restore momentum buffers read from a checkpoint (utils.net.initialize_from_weights_file(momentum=...))."""
+        for n, m in (blobs or {}).items():
+            if n in self.trainable:
+                self.momentum[n] = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(self.ws.dev_param(n).device).view_as(self.ws.dev_param(n))
 
     def _all_reduce(self, tensors):
         """Bucketed sum all-reduce (losses are already divided by NUM_GPUS, model_builder.py:932-942)."""

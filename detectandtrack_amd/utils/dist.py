@@ -35,6 +35,10 @@ def init_process_group(backend=None):
     import torch.distributed as dist
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if torch.cuda.is_available():
+        # one rank = one GPU: bind BEFORE the process group / the workspace exist (GlobalWorkspace() allocates on
+        # torch.cuda.current_device(); without this every rank would sit on GPU 0 and RCCL would see duplicate devices)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if not dist.is_initialized():
         dist.init_process_group(backend)

@@ -144,27 +144,52 @@ def load_weights_file(path):
     return src['blobs'] if 'blobs' in src else src
 
 
-def initialize_from_weights_file(model, ws, weights_file):
-    """Load every model parameter present in the file (inflating on shape mismatch); leave the rest as initialised
-    (:164-249, single GPU: no broadcast needed — one process per GPU)."""
+def initialize_from_weights_file(model, ws, weights_file, momentum=None):
+    """Overlay every model parameter present in the file on the ALREADY INITIALISED workspace (the reference runs
+    param_init_net first, then this: :164-249).  A parameter that is absent from the file keeps its init; one whose shape
+    differs is inflated onto the initialised blob and keeps its init where inflation is impossible (:95-161 return the
+    workspace blob in those branches).  `<param>_momentum` blobs, when the file has them and `momentum` (a dict) is
+    given, are returned through it for training.Trainer (:228-236).  One process per GPU: no broadcast needed."""
     src = load_weights_file(weights_file)
+    missing = [n for n in model.params if n not in ws.params]
+    if missing:   # called on a blank workspace: what the reference's param_init_net would have created
+        rs = np.random.RandomState(cfg.RNG_SEED)
+        for name in model.params:
+            spec = model.param_specs[name]
+            v = _fill(spec['init'][0], spec['init'][1], spec['shape'], rs)   # same stream as initialize_params
+            if name not in ws.params:
+                ws.set_param(name, v)
+    kept = []
     for name in model.params:
         src_name = re.sub(r'^_\[[a-z]*\]_', '', name)
         if src_name not in src:
-            if name not in ws.params:
-                raise KeyError('parameter {} missing from {} and not initialised'.format(name, weights_file))
+            kept.append(name)
             continue
         w = np.asarray(src[src_name], dtype=np.float32)
-        shape = model.param_specs[name]['shape']
-        if tuple(w.shape) != tuple(shape):
-            w = inflate_weights(w, np.zeros(shape, np.float32), src_name)
-        assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+        shape = tuple(model.param_specs[name]['shape'])
+        if tuple(w.shape) != shape:
+            target = np.asarray(ws.params[name], dtype=np.float32)
+            w = np.asarray(inflate_weights(w, target, src_name), dtype=np.float32)
+            if w is target or tuple(w.shape) != shape:
+                kept.append(name)
+                logger.info('%s: file shape %s cannot be inflated to %s, keeping the initialised value', name,
+                            np.asarray(src[src_name]).shape, shape)
+                continue
         ws.set_param(name, w)
+        if momentum is not None and src_name + '_momentum' in src:
+            m = np.asarray(src[src_name + '_momentum'], dtype=np.float32)
+            if tuple(m.shape) == shape:
+                momentum[name] = m
+    if kept:
+        logger.info('%d parameters not taken from %s (kept as initialised): %s', len(kept), weights_file, ' '.join(kept))
+    return kept
 
 
-def save_model_to_weights_file(weights_file, model, ws):
-    """:252-294."""
+def save_model_to_weights_file(weights_file, model, ws, momentum=None):
+    """:252-294: parameters, their `<param>_momentum` blobs (when given: name -> array) and the cfg yaml."""
     blobs = {name: np.asarray(ws.params[name]) for name in model.params}
+    for name, m in (momentum or {}).items():
+        blobs[name + '_momentum'] = np.asarray(m, dtype=np.float32)
     cfg_yaml = yaml.safe_dump(_plain(cfg))
     with open(weights_file, 'wb') as f:
         pickle.dump(dict(blobs=blobs, cfg=cfg_yaml), f, protocol=2)

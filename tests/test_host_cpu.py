@@ -227,6 +227,47 @@ def test_weights_file_roundtrip(tmp_path):
     reset_cfg()
 
 
+def test_backbone_only_weights_file_overlays_an_initialised_workspace(tmp_path):
+    """Fine-tuning from an ImageNet-style file (reference train_net.py:100-118, utils/net.py:164-249): parameters absent from the
+    file (fpn_*, rpn_*, heads) keep their init, 2D convs inflate, blobs that cannot be inflated (class-count mismatch) keep their
+    init instead of turning into zeros; `<param>_momentum` blobs round-trip."""
+    import pickle
+    from tests.model_util import fpn3d_kps_cfg
+    from detectandtrack_amd.utils import net as nu
+    from detectandtrack_amd.core.config import reset_cfg
+    m = _build(fpn3d_kps_cfg('18', T=2))
+
+    class WS(object):
+        def __init__(self):
+            self.params = {}
+
+        def set_param(self, k, v):
+            self.params[k] = np.asarray(v, np.float32)
+    full = WS()
+    nu.initialize_params(m, full, seed=5)
+    body = {k: (v[:, :, 1] if v.ndim == 5 and v.shape[2] == 3 else v) for k, v in full.params.items()
+            if k.startswith(('conv1', 'res'))}
+    body['cls_score_w'] = np.ones((81, 1024), np.float32)          # COCO class count: not inflatable to 2 classes
+    body['conv1_w_momentum'] = np.full(full.params['conv1_w'].shape, 0.25, np.float32)
+    f = str(tmp_path / 'imagenet.pkl')
+    with open(f, 'wb') as fh:
+        pickle.dump({'blobs': body}, fh, protocol=2)
+    ws = WS()                                                      # blank workspace: the loader must initialise it itself
+    mom = {}
+    kept = nu.initialize_from_weights_file(m, ws, f, momentum=mom)
+    assert set(ws.params) == set(m.params)
+    assert 'fpn_inner_res5_1_sum_w' in kept and 'cls_score_w' in kept and 'conv1_w' not in kept
+    assert ws.params['cls_score_w'].shape == (2, 1024) and abs(ws.params['cls_score_w'].std() - 0.01) < 3e-3   # Gaussian init kept
+    assert ws.params['rpn_cls_logits_fpn2_w'].std() > 0
+    w = ws.params['res3_0_branch2a_w']
+    assert np.all(w[:, :, 0] == 0) and np.array_equal(w[:, :, 1], full.params['res3_0_branch2a_w'][:, :, 1])
+    np.testing.assert_array_equal(mom['conv1_w'], body['conv1_w_momentum'])
+    out = str(tmp_path / 'snap.pkl')
+    nu.save_model_to_weights_file(out, m, ws, {'conv1_w': mom['conv1_w']})
+    assert 'conv1_w_momentum' in nu.load_weights_file(out)
+    reset_cfg()
+
+
 # ---- host utils ----------------------------------------------------------------------------------------------------------------
 def test_image_resize_and_blob_prep():
     from detectandtrack_amd.core.config import cfg, reset_cfg

@@ -11,8 +11,10 @@ available offline: clips and ground truth come from roi_data.synthetic (seeded b
 has the roidb record layout, so a real loader only has to yield (frames, entry) pairs.
 """
 import argparse
+import glob
 import logging
 import os
+import re
 import time
 
 import numpy as np
@@ -57,6 +59,7 @@ def main():
     p.add_argument('--loader-workers', type=int, default=4,
                    help='prefetch threads of the input pipeline (roi_data.loader); 0 = label every clip synchronously on the host')
     p.add_argument('--reference-init', action='store_true', help='initialise from the builders\' init specs instead of synthetic_params')
+    p.add_argument('--auto-resume', action='store_true', help='continue from the latest model_iter*.pkl of the output directory (parameters, momentum, LR schedule position)')
     p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
     args = p.parse_args()
     cfg_from_file(args.cfg_file)
@@ -64,26 +67,39 @@ def main():
         cfg_from_list(args.opts)
     assert_and_infer_cfg()
     rank, _local, world = dist_utils.env_rank_world()
+    torch.cuda.set_device(_local)
     dist = dist_utils.init_process_group() if world > 1 else None
     assert cfg.NUM_GPUS == world, 'NUM_GPUS (%d) must equal the number of ranks (%d)' % (cfg.NUM_GPUS, world)
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     model = model_builder.create(cfg.MODEL.TYPE, train=True)
     ws = workspace.GlobalWorkspace()
-    if cfg.TRAIN.WEIGHTS and os.path.exists(cfg.TRAIN.WEIGHTS):
-        net_utils.initialize_from_weights_file(model, ws, cfg.TRAIN.WEIGHTS)
-    elif args.reference_init:
-        net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)      # the builders' init specs (MSRA / Gaussian), every rank alike
+    assert cfg.TRAIN.IMS_PER_BATCH == 1, \
+        'one clip per forward and GPU (TRAIN.IMS_PER_BATCH 1, cf. configs/video/3d/03_*-8GPU-BATCH1.yaml:51); got %d' % cfg.TRAIN.IMS_PER_BATCH
+    resume_momentum, start_iter = {}, 0
+    if args.reference_init or (cfg.TRAIN.WEIGHTS and os.path.exists(cfg.TRAIN.WEIGHTS)):
+        # param_init_net first (the builders' init specs, every rank alike), then overlay the file (reference train_net.py:100-118):
+        # an ImageNet/COCO file has no fpn_* / rpn_* / head parameters, those keep their init
+        net_utils.initialize_params(model, ws, seed=cfg.RNG_SEED)
     else:
         # no checkpoint offline: a well-conditioned deterministic init (the reference always starts from pre-trained weights;
         # its from-scratch init on raw pixels with identity AffineChannel layers diverges at the shipped learning rates)
         for k, v in net_utils.synthetic_params(model, cfg.RNG_SEED).items():
             ws.set_param(k, v)
+    out_dir = get_output_dir(training=True)
+    weights_file = cfg.TRAIN.WEIGHTS
+    if args.auto_resume:   # latest snapshot of this output directory wins (reference train_net.py:77-98)
+        snaps = sorted(glob.glob(os.path.join(out_dir, 'model_iter*.pkl')), key=lambda f: int(re.findall(r'model_iter(\d+)', f)[-1]))
+        if snaps:
+            weights_file = snaps[-1]
+            start_iter = int(re.findall(r'model_iter(\d+)', weights_file)[-1]) + 1
+            logger.info('resuming from %s at iteration %d', weights_file, start_iter)
+    if weights_file and os.path.exists(weights_file):
+        net_utils.initialize_from_weights_file(model, ws, weights_file, momentum=resume_momentum)
     trainer = Trainer(model, ws, dist)
+    trainer.load_momentum(resume_momentum)
     T = max(cfg.VIDEO.NUM_FRAMES, 1) if cfg.MODEL.VIDEO_ON else 1
     tube_T = cfg.VIDEO.NUM_FRAMES_MID if (cfg.MODEL.VIDEO_ON and cfg.VIDEO.BODY_HEAD_LINK == '') else 1   # tube heads: 4T boxes
     rng = np.random.RandomState(cfg.RNG_SEED + rank)
     max_iter = args.iters or cfg.SOLVER.MAX_ITER
-    out_dir = get_output_dir(training=True)
     loader = None
     # synthetic "roidb" of max_iter clips per rank (a pool of distinct pixel clips, a fresh roidb entry per index); a real
     # roidb only has to provide the same source(i) -> (data, entry, im_scale) callable
@@ -103,7 +119,8 @@ def main():
         loader = RoIDataLoader(source, num_items=n_items, **sizes, num_workers=args.loader_workers, queue_size=2 * args.loader_workers,
                                device=torch.cuda.current_device(), seed=cfg.RNG_SEED + rank)
     t0 = time.time()
-    for it in range(max_iter):
+    it_steady = it = start_iter
+    for it in range(start_iter, max_iter):
         lr = lr_policy.get_lr_at_iter(it)
         if loader is not None:
             loader.get_next_minibatch().feed(ws)
@@ -111,7 +128,7 @@ def main():
             data, entry, _ = source(it)
             feed_clip(ws, data, entry, rng)
         ex = trainer.step(lr)
-        if it == min(5, max_iter - 1):
+        if it == min(start_iter + 5, max_iter - 1):
             torch.cuda.synchronize()
             t_steady, it_steady = time.time(), it
         if it % 20 == 0 or it == max_iter - 1:
@@ -121,7 +138,7 @@ def main():
                         (time.time() - t0) / (it + 1))
         if rank == 0 and (it + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0:
             ws.params_from_device()
-            net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_iter%d.pkl' % it), model, ws)
+            net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_iter%d.pkl' % it), model, ws, trainer.momentum_blobs())
     torch.cuda.synchronize()
     if max_iter - 1 > it_steady:
         logger.info('rank %d steady state: %.1f ms/iter over the last %d iterations (%s)', rank,
@@ -131,7 +148,7 @@ def main():
         loader.shutdown()
     if rank == 0:
         ws.params_from_device()
-        net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_final.pkl'), model, ws)
+        net_utils.save_model_to_weights_file(os.path.join(out_dir, 'model_final.pkl'), model, ws, trainer.momentum_blobs())
     if dist is not None:
         dist.destroy_process_group()
 
