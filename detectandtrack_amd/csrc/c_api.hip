@@ -1,4 +1,6 @@
 // Context, error text and per-launch profiling of libdat_hip (see include/dat_hip.h).
+#include <stdlib.h>
+
 #include "dat_common.h"
 
 int dat_ensure_ws(dat_ctx* ctx, size_t bytes) {
@@ -34,6 +36,15 @@ int dat_ctx_create(dat_ctx** out, int device) {
     c->ws = nullptr;
     c->ws_bytes = 0;
     c->zeros = nullptr;
+    {
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        c->force_bp = env_int("DAT_CONV_BP", 0);
+        c->force_ks = env_int("DAT_CONV_KSPLIT", 0);
+        c->dbg_tw_log2 = env_int("DAT_CONV_TW_LOG2", -1);
+        c->dbg_ablate = env_int("DAT_CONV_ABLATE", 0);
+        c->dbg_lds_pad = env_int("DAT_CONV_LDS_PAD", 0);
+        c->dbg_tps3 = env_int("DAT_CONV_TPS", 3) == 3;
+    }
     if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemset(c->zeros, 0, 512) != hipSuccess) {
         delete c;
         return DAT_ERR_ALLOC;

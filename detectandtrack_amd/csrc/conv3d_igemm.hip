@@ -584,20 +584,12 @@ __global__ void stem_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-// plan overrides: -1 = read DAT_CONV_BP / DAT_CONV_KSPLIT once, 0 = planner, else forced (dat_conv3d_tune_plan)
-int g_force_bp = -1, g_force_ks = -1;
-
 struct TileChoice {
     int th_log2, tw_log2;
 };
 
 // pick the 2^a x 2^b tile (a+b = log2(BP)) that wastes the fewest output positions, tie -> squarer patch
-TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int KW) {
-    static int force_tw = -2;
-    if (force_tw == -2) {
-        const char* e = getenv("DAT_CONV_TW_LOG2");
-        force_tw = e ? atoi(e) : -1;
-    }
+TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int KW, int force_tw) {
     if (force_tw >= 0 && force_tw <= bp_log2) return TileChoice{bp_log2 - force_tw, force_tw};
     TileChoice best{0, bp_log2};
     double best_cost = 1e30;
@@ -623,7 +615,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
 
 template <int DT, int BN, int BP, int WAVES_N, int TPS = 1>
 int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
-    const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW);
+    const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
     p.th_log2 = tc.th_log2;
     p.tw_log2 = tc.tw_log2;
     const int th = 1 << tc.th_log2, tw = 1 << tc.tw_log2;
@@ -655,11 +647,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     }
     p.pw_magic = p.PW == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)p.PW - 1) / (unsigned)p.PW);
     p.n_cchunks = p.Cin / Mma<DT>::CK;
-    {
-        static int abl = -1;
-        if (abl < 0) { const char* e = getenv("DAT_CONV_ABLATE"); abl = e ? atoi(e) : 0; }
-        p.ablate = abl;
-    }
+    p.ablate = ctx->dbg_ablate;
     p.nblk_n = p.Cout_pad / BN;
     long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
     // split-K (chosen by plan_conv): fp32 partial sums in the ctx workspace, finished by splitk_finish_kernel
@@ -683,18 +671,13 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     DAT_ENFORCE(ctx, p.tab_n % TPS == 0 && (TPS == 1 || p.tab_new == 1u), "conv3d: %d taps per step need one stride plane of a multiple of %d taps", TPS, TPS);
     size_t lds = (size_t)2 * TPS * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
     if (lds < 4 * 32 * (64 * 4 + 16)) lds = 4 * 32 * (64 * 4 + 16);                                   // epilogue staging slices
-    {
-        static int pad = -1;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
-        if (pad < 0) { const char* e = getenv("DAT_CONV_LDS_PAD"); pad = e ? atoi(e) : 0; }
-        lds += pad;
-    }
+    lds += ctx->dbg_lds_pad;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {
+        const int rc = dat_ensure_lds(ctx, (const void*)kern, 160 * 1024);
+        if (rc != DAT_OK) return rc;
     }
 #ifdef DAT_CONV_TRACE
     static unsigned long long* dbg = nullptr;
@@ -810,14 +793,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     // A block runs steps = ceil(npatch/ks) * taps tap-steps; 2 blocks share a CU (512 slots).  Measured on MI355X:
     // a BP=128 step costs ~1.35 us, a BP=256 step ~2.15 us (2x the work).  The grid runs in "rounds" of 512 blocks;
     // with few rounds the last partial round costs a full one.  Split-K adds an fp32 partial round trip.
-    int& force_bp = g_force_bp;
-    int& force_ks = g_force_ks;
-    if (force_bp < 0) {
-        const char* e = getenv("DAT_CONV_BP");
-        force_bp = e ? atoi(e) : 0;
-        const char* k = getenv("DAT_CONV_KSPLIT");
-        force_ks = k ? atoi(k) : 0;
-    }
+    const int force_bp = ctx->force_bp, force_ks = ctx->force_ks;
     const int ck = d->dtype == DAT_BF16 ? 64 : 32;
     const int ncc = d->Cin / ck;
     const int npatch = d->KT * ncc, npatch_min = (d->KT > 1 ? d->KT - 1 : 1) * ncc;
@@ -831,7 +807,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
             if (cand_bp == 256 && (small_n || ntaps == 1)) continue;   // the 64-channel and 1x1 variants do not profit
             if (force_bp && cand_bp != force_bp && !(force_bp == 256 && (small_n || ntaps == 1))) continue;
             const int lg = cand_bp == 256 ? 8 : 7;
-            const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW);
+            const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
             const long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * p.frames;
             const int ks_max = (ntaps > 1 || deep_1x1) ? (deep_1x1 ? 8 : 4) : 1;
             for (int ks = 1; ks <= ks_max && ks <= npatch_min; ++ks) {
@@ -858,8 +834,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         hipEventRecord(e0, st);
     }
     int rc;
-    static int tps3 = -1;
-    if (tps3 < 0) { const char* e = getenv("DAT_CONV_TPS"); tps3 = e ? (atoi(e) == 3) : 1; }
+    const int tps3 = ctx->dbg_tps3;
     // thin layers (<= 64 output channels, dense 3x3 spatial taps): 3 taps per step
     const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3;
     if (thin3) {
@@ -885,10 +860,12 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     return rc;
 }
 
-int dat_conv3d_tune_plan(int positions_per_block, int ksplit) {
-    if ((positions_per_block != 0 && positions_per_block != 128 && positions_per_block != 256) || ksplit < 0 || ksplit > 8) return DAT_ERR_ARG;
-    g_force_bp = positions_per_block;
-    g_force_ks = ksplit;
+int dat_conv3d_tune_plan(dat_ctx* ctx, int positions_per_block, int ksplit) {
+    if (!ctx) return DAT_ERR_ARG;
+    DAT_ENFORCE(ctx, (positions_per_block == 0 || positions_per_block == 128 || positions_per_block == 256) && ksplit >= 0 && ksplit <= 8,
+                "conv3d_tune_plan: positions per block %d / split-K %d out of range", positions_per_block, ksplit);
+    ctx->force_bp = positions_per_block;
+    ctx->force_ks = ksplit;
     return DAT_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <unordered_set>
 
 #include "../../include/dat_hip.h"
 
@@ -23,7 +24,25 @@ struct dat_ctx {
     size_t ws_bytes;
     void* zeros;           // 512 B in HBM: [0,256) zeros (conv patch loader: source of out-of-frame halo lanes),
                            // [256,272) profiling clock counters of the conv kernel
+    // Launch-plan state of THIS context (no process globals: N contexts / N devices per process are independent,
+    // SURVEY.md 8b "thread-safe per dat_ctx").  The debug knobs are read from the environment once, at dat_ctx_create.
+    int force_bp, force_ks;                 // dat_conv3d_tune_plan / DAT_CONV_BP, DAT_CONV_KSPLIT; 0 = makespan model
+    int dbg_tw_log2, dbg_ablate, dbg_lds_pad, dbg_tps3;   // DAT_CONV_TW_LOG2 (-1 = off), DAT_CONV_ABLATE, DAT_CONV_LDS_PAD, DAT_CONV_TPS
+    // kernels whose dynamic-LDS limit was already raised on this context's device (the attribute is per device)
+    std::unordered_set<const void*> lds_attr_done;
 };
+
+// raise the dynamic-LDS limit of `kern` on the ctx's device once (hipFuncSetAttribute is per device, not per process)
+static inline int dat_ensure_lds(dat_ctx* ctx, const void* kern, int bytes) {
+    if (ctx->lds_attr_done.count(kern)) return DAT_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+        return DAT_ERR_LAUNCH;
+    }
+    ctx->lds_attr_done.insert(kern);
+    return DAT_OK;
+}
 
 #define DAT_FAIL(ctx, code, ...)                                  \
     do {                                                          \

@@ -7,9 +7,11 @@
 // over RoIs in Python with cv2.resize; here one block handles one (RoI, frame, keypoint) map held in LDS and only the
 // 4 x (T*K) result rows leave the device.
 //
-// Arithmetic follows the host restatement (detectandtrack_amd/utils/image.py resize_bicubic, itself the oracle's) in the
-// same fp32 operation order -- rows first (4 taps accumulated in order), then columns -- and this file is compiled with
-// -ffp-contract=off, so the resized values, hence the argmax, are bit-identical to the host path on the same logits.
+// Arithmetic follows OpenCV's float32 resize path (oracle/resize.py restates it; opencv 3.4.1 resize.cpp HResizeCubic then
+// VResizeCubic): source coordinate f = float32((d + 0.5) * step - 0.5) with step = 1 / (dst / src) in double, the HORIZONTAL
+// pass first (4 taps of a source row, summed left to right), then the vertical combination of the 4 resampled rows; this file
+// is compiled with -ffp-contract=off, so the resized values, hence the argmax, are bit-identical to the oracle and to the
+// product's host path (detectandtrack_amd/utils/image.py) on the same logits.
 #include "dat_common.h"
 
 namespace {
@@ -30,11 +32,11 @@ __device__ __forceinline__ void cubic(float t, float c[4]) {
 }
 
 __device__ __forceinline__ void resample(int src_len, int dst_len, int d, int& i0, float& frac) {
-    const double scale = (double)src_len / (double)dst_len;
-    const double s = ((double)d + 0.5) * scale - 0.5;
-    const double fl = floor(s);
+    const double step = 1.0 / ((double)dst_len / (double)src_len);   // cv::resize: scale_x = 1. / inv_scale_x
+    const float f = (float)(((double)d + 0.5) * step - 0.5);
+    const float fl = floorf(f);
     i0 = (int)fl;
-    frac = (float)(s - fl);
+    frac = f - fl;
 }
 
 __global__ __launch_bounds__(256) void kps_decode_kernel(const KpParams p) {
@@ -70,17 +72,17 @@ __global__ __launch_bounds__(256) void kps_decode_kernel(const KpParams p) {
         resample(M, mw, x, x0, fx);
         cubic(fy, cy);
         cubic(fx, cx);
+        int xx[4];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) xx[kx] = min(max(x0 - 1 + kx, 0), M - 1);
         float v = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const int xx = min(max(x0 - 1 + kx, 0), M - 1);
-            float rowv = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const int yy = min(max(y0 - 1 + ky, 0), M - 1);
-                rowv = rowv + map[yy * M + xx] * cy[ky];
-            }
-            v = v + rowv * cx[kx];
+        for (int ky = 0; ky < 4; ++ky) {
+            const float* mrow = map + min(max(y0 - 1 + ky, 0), M - 1) * M;
+            // HResizeCubic: D[dx] = S[x-1]*a0 + S[x]*a1 + S[x+1]*a2 + S[x+2]*a3
+            const float rowv = ((mrow[xx[0]] * cx[0] + mrow[xx[1]] * cx[1]) + mrow[xx[2]] * cx[2]) + mrow[xx[3]] * cx[3];
+            // VResizeCubic: dst = S0*b0 + S1*b1 + S2*b2 + S3*b3
+            v = ky == 0 ? rowv * cy[0] : v + rowv * cy[ky];
         }
         if (v > best) { best = v; best_i = i; }      // ascending i per thread: first maximum kept
         if (v > run_m) { run_s = run_s * expf(run_m - v) + 1.f; run_m = v; }

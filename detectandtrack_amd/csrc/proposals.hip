@@ -13,16 +13,21 @@
 //                    (key, ~index) [ties: lower (h,w,a) index first]; LDS bitonic sort (descending);
 //                    decode boxes (bbox_transform), clip, min-size filter; ordered compaction
 //   K4 nms mask    : 64x64 tiles, bit j of mask[i][cb] = overlap(i, j) suppresses (>= thr boxes, > thr tubes)
-//   K5 nms scan    : one wave per level; per 64-row chunk the intra-chunk dependency chain runs in registers
-//                    (readlane), later chunks get the OR of the kept rows; emits rois in score order
+//   K5 nms scan    : one 4-wave block per level; per 64-row chunk wave 0 runs the intra-chunk dependency chain in registers
+//                    (readlane), then all waves OR the kept rows' mask words into the LDS-resident removed-bit vector
+//                    (lane = word: coalesced; 16 rows per wave); emits rois in score order
 // All floating-point box math is fp32 in the reference's operation order; this file is compiled with
 // -ffp-contract=off so no fma contraction changes a rounding (bit-exact NMS indices).
+#include <mutex>
+
 #include "dat_common.h"
 
 namespace {
 
 constexpr int MAX_LEVELS = 8;
-constexpr int MAX_SORT = 4096;   // pre_nms cap per level (LDS bitonic sort capacity of K3)
+constexpr int MAX_SORT = 16384;  // pre_nms cap per level (LDS bitonic sort capacity of K3: 16384 u64 = 128 KiB of the 160 KiB);
+                                 // covers the reference's defaults RPN_PRE_NMS_TOP_N 12000 (lib/core/config.py:110,183)
+constexpr int MAX_WORDS = MAX_SORT / 64;
 constexpr int MAX_T = 16;
 
 struct LevelState {
@@ -59,7 +64,7 @@ struct RpnParams {
     LevelDev lv[MAX_LEVELS];
     int n_levels;
     int dtype;
-    int pre_nms, post_nms, cap;
+    int pre_nms, post_nms, cap, cap_pad;   // cap_pad = pre_nms rounded up to a power of two (K3's LDS sort buffer)
     float nms_thresh, min_size_scaled, im_h, im_w, batch_idx;
     float* rois_out;
     float* probs_out;
@@ -227,7 +232,7 @@ __device__ bool decode_tube(const RpnParams& p, const LevelDev& L, unsigned idx,
 // ---- K3 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnParams p) {
     const LevelDev& L = p.lv[blockIdx.x];
-    __shared__ unsigned long long buf[MAX_SORT];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // cap_pad entries
     __shared__ unsigned hist[256];
     __shared__ unsigned cnt;
     __shared__ unsigned long long s_prefix;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnP
         const unsigned long long v = L.bnd[i];
         if ((v & 0xFFFFFFFFFFFFull) >= thr48) {
             const unsigned pos = atomicAdd(&cnt, 1u);
-            if (pos < MAX_SORT) buf[pos] = v;
+            if (pos < (unsigned)p.cap_pad) buf[pos] = v;
         }
     }
     __syncthreads();
@@ -329,14 +334,14 @@ __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnP
 // ---- K4: NMS suppression mask ---------------------------------------------------------------------------
 // overlap test in the reference's fp32 operation order.
 __device__ __forceinline__ bool suppresses(const float* bi, const float* bj, const float* ai, const float* aj, int T,
-                                           float thr) {
+                                           float thr, int strict) {
     if (T == 1) {  // cython_nms.pyx:70-84, ovr >= thresh
         const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
         const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
         const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
         const float inter = w * h;
         const float ovr = inter / (ai[0] + aj[0] - inter);
-        return ovr >= thr;
+        return strict ? (ovr > thr) : (ovr >= thr);   // strict: lib/nms/nms_kernel.cu:71 (`_nms`)
     }
     float ovT = 0.f;  // py_cpu_nms_tubes.py:35-50, keep while mean <= thresh
     for (int t = 0; t < T; ++t) {
@@ -361,6 +366,7 @@ struct NmsParams {
     NmsLevel lv[MAX_LEVELS];
     int T, cap;
     float thr;
+    int strict;      // boxes only: suppress at IoU > thr (the `_nms` CUDA kernel) instead of >= thr (cython_nms)
 };
 
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsParams p) {
@@ -391,56 +397,69 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsParams p) {
     const int jend = min(64, n - cb * 64);
     for (int j = 0; j < jend; ++j) {
         if (cb * 64 + j <= ig) continue;
-        if (suppresses(bi, cbox + j * 4 * T, ai, carea + j * T, T, p.thr)) bits |= 1ull << j;
+        if (suppresses(bi, cbox + j * 4 * T, ai, carea + j * T, T, p.thr, p.strict)) bits |= 1ull << j;
     }
     L.mask[(size_t)ig * nwords + cb] = bits;
 }
 
-// ---- K5: sequential resolution by one wave ---------------------------------------------------------------
-__global__ __launch_bounds__(64) void nms_scan_kernel(const NmsParams p) {
+// ---- K5: sequential resolution, one 4-wave block per level ------------------------------------------------------
+// The removed-bit vector (one bit per sorted box, <= 16384 bits) lives in LDS.  Per 64-row chunk b: wave 0 walks the
+// chunk's rows in order -- the dependency chain (row i is kept iff no earlier kept row suppresses it) runs on the scalar
+// unit via v_readlane of the chunk's diagonal mask word -- and publishes the kept set; then all four waves OR the kept
+// rows' mask words of the LATER chunks into the LDS vector: lane = word (consecutive lanes read consecutive words of a
+// mask row), each wave takes 16 of the 64 rows, loads unconditional with a fixed trip count so that they pipeline.
+constexpr int SCAN_THREADS = 256;
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const NmsParams p) {
     const NmsLevel& L = p.lv[blockIdx.x];
     const int n = (int)*L.n_ptr;
-    const int lane = threadIdx.x;
-    const int nwords = (n + 63) / 64;  // <= 64
-    unsigned long long remv = 0;       // lane w holds removed-bits word w
-    int nkeep = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwords = (n + 63) / 64;  // <= MAX_WORDS
+    __shared__ unsigned long long remv[MAX_WORDS];
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_nkeep;
+    for (int w = tid; w < nwords; w += SCAN_THREADS) remv[w] = 0ull;
+    if (tid == 0) s_nkeep = 0;
+    __syncthreads();
     for (int b = 0; b < nwords; ++b) {
-        const int row = b * 64 + lane;
-        const unsigned long long diag = (row < n) ? L.mask[(size_t)row * nwords + b] : 0ull;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        const unsigned rlo = (unsigned)remv, rhi = (unsigned)(remv >> 32);
-        // v_readlane (scalar path) instead of ds_bpermute shuffles: the 64-step dependency chain runs on the SALU
-        unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rhi, b) << 32) |
-                                 (unsigned)__builtin_amdgcn_readlane((int)rlo, b);
         const int rows_here = min(64, n - b * 64);
-        unsigned long long kept = 0;
-        for (int i = 0; i < rows_here; ++i) {
-            if (!((cur >> i) & 1ull)) {
-                kept |= 1ull << i;
-                cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
-                       (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+        if (wave == 0) {
+            const int row = b * 64 + lane;
+            const unsigned long long diag = (row < n) ? L.mask[(size_t)row * nwords + b] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned long long r0 = remv[b];
+            unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
+            unsigned long long kept = 0;
+            for (int i = 0; i < rows_here; ++i) {
+                if (!((cur >> i) & 1ull)) {
+                    kept |= 1ull << i;
+                    cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                           (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                }
+            }
+            const int nkeep = s_nkeep;
+            if ((kept >> lane) & 1ull) L.kept[nkeep + __popcll(kept & ((1ull << lane) - 1ull))] = row;   // in order
+            if (lane == 0) { s_kept = kept; s_nkeep = nkeep + __popcll(kept); }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        const int r_lo = wave * 16;
+        if ((kept >> r_lo) & 0xffffull) {   // this wave's 16 rows hold at least one kept row
+            for (int w = b + 1 + lane; w < nwords; w += 64) {
+                unsigned long long acc = 0;
+                const unsigned long long* mrow = L.mask + (size_t)(b * 64 + r_lo) * nwords + w;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned long long m = (r_lo + i < rows_here) ? mrow[(size_t)i * nwords] : 0ull;
+                    acc |= ((kept >> (r_lo + i)) & 1ull) ? m : 0ull;
+                }
+                if (acc) atomicOr(&remv[w], acc);
             }
         }
-        // emit kept rows of this chunk in order
-        if ((kept >> lane) & 1ull) {
-            const int rank = __popcll(kept & ((1ull << lane) - 1ull));
-            L.kept[nkeep + rank] = row;
-        }
-        nkeep += __popcll(kept);
-        // propagate: later words get the OR of the kept rows' masks.  Loads are unconditional with a fixed trip count
-        // so that they pipeline (a data-dependent `while (kept)` loop serialised one L2 round trip per kept row).
-        if (lane > b && lane < nwords) {
-            unsigned long long acc = 0;
-            const unsigned long long* mrow = L.mask + (size_t)(b * 64) * nwords + lane;
-#pragma unroll 16
-            for (int i = 0; i < 64; ++i) {
-                const unsigned long long m = (i < rows_here) ? mrow[(size_t)i * nwords] : 0ull;
-                acc |= ((kept >> i) & 1ull) ? m : 0ull;
-            }
-            remv |= acc;
-        }
+        __syncthreads();
     }
-    if (lane == 0) *L.n_keep_ptr = (unsigned)nkeep;
+    if (tid == 0) *L.n_keep_ptr = (unsigned)s_nkeep;
 }
 
 // ---- K6: emit rois of every level ---------------------------------------------------------------------------
@@ -497,10 +516,18 @@ __global__ __launch_bounds__(1024) void collect_rois_kernel(const float* rois_lv
 }
 
 // ---- generic NMS entry: sort any-order dets ---------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n, int T, float* boxes, int* orig,
+__global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n, int T, int presorted, float* boxes, int* orig,
                                                              unsigned* n_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sbuf[];
     const int cols = 4 * T + 1;
+    if (presorted) {   // `_nms` convention (lib/nms/gpu_nms.pyx:27-34): the caller sorted by score, rows are visited as given
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            orig[j] = j;
+            for (int c = 0; c < 4 * T; ++c) boxes[(size_t)j * 4 * T + c] = dets[(size_t)j * cols + c];
+        }
+        if (threadIdx.x == 0) *n_dev = (unsigned)n;
+        return;
+    }
     int npad = 1;
     while (npad < n) npad <<= 1;
     for (int i = threadIdx.x; i < npad; i += blockDim.x) {
@@ -635,6 +662,8 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
         np.lv[l].kept = L.kept; np.lv[l].n_keep_ptr = &L.state->n_keep;
     }
     p.n_levels = n_levels; p.dtype = dtype; p.pre_nms = pre_nms; p.post_nms = post_nms; p.cap = cap;
+    p.cap_pad = 1;
+    while (p.cap_pad < cap) p.cap_pad <<= 1;
     p.nms_thresh = nms_thresh;
     p.min_size_scaled = (float)((double)min_size * (double)im_info[2]);
     p.im_h = im_info[0]; p.im_w = im_info[1]; p.batch_idx = batch_idx;
@@ -646,9 +675,11 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
     hipLaunchKernelGGL(rpn_keys_hist_kernel, dim3((maxN + K0_CHUNK - 1) / K0_CHUNK, n_levels), dim3(K0_THREADS), 0, st, p);
     hipLaunchKernelGGL(rpn_find_bin_kernel, dim3(n_levels), dim3(1024), 0, st, p);
     hipLaunchKernelGGL(rpn_compact_kernel, dim3(bx, n_levels), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(rpn_select_sort_decode_kernel, dim3(n_levels), dim3(1024), 0, st, p);
+    rc = dat_ensure_lds(ctx, (const void*)rpn_select_sort_decode_kernel, MAX_SORT * 8);
+    if (rc != DAT_OK) return rc;
+    hipLaunchKernelGGL(rpn_select_sort_decode_kernel, dim3(n_levels), dim3(1024), (size_t)p.cap_pad * 8, st, p);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords_cap, nwords_cap, n_levels), dim3(64), 0, st, np);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_levels), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_levels), dim3(SCAN_THREADS), 0, st, np);
     hipLaunchKernelGGL(rpn_emit_kernel, dim3(n_levels), dim3(256), 0, st, p);
     DAT_CHECK_LAUNCH(ctx, "rpn_proposals");
     return DAT_OK;
@@ -661,10 +692,9 @@ int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const f
     int npad = 1;
     while (npad < n_levels * level_cap) npad <<= 1;
     DAT_ENFORCE(ctx, (size_t)npad * 8 <= 128 * 1024, "collect_rois: %d candidate rois exceed the 16384-entry LDS sort", n_levels * level_cap);
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)collect_rois_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr = true;
+    {
+        const int rc = dat_ensure_lds(ctx, (const void*)collect_rois_kernel, 128 * 1024);
+        if (rc != DAT_OK) return rc;
     }
     hipLaunchKernelGGL(collect_rois_kernel, dim3(1), dim3(1024), (size_t)npad * 8, (hipStream_t)s, rois_lvls, probs_lvls, counts,
                        n_levels, level_cap, roi_cols, post_nms, rois, n_out);
@@ -672,10 +702,11 @@ int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const f
     return DAT_OK;
 }
 
-int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float thresh, int* keep, int* num_keep) {
+// strict / presorted select the `_nms` (lib/nms/nms_kernel.cu) convention instead of cython_nms / py_cpu_nms_tubes
+static int nms_impl(dat_ctx* ctx, hipStream_t st, const float* dets, int n, int T, float thresh, int strict, int presorted,
+                    int* keep, int* num_keep) {
     DAT_ENFORCE(ctx, keep && num_keep, "nms: null output");
     DAT_ENFORCE(ctx, T >= 1 && T <= MAX_T, "nms: tube length %d unsupported", T);
-    hipStream_t st = (hipStream_t)s;
     if (n == 0) {
         hipMemsetAsync(num_keep, 0, sizeof(int), st);
         return DAT_OK;
@@ -696,8 +727,10 @@ int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float t
     unsigned* st_keep = st_n + 1;
     int npad = 1;
     while (npad < n) npad <<= 1;
-    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), (size_t)npad * 8, st, dets, n, T, (float*)(ws + o_boxes),
-                       (int*)(ws + o_orig), st_n);
+    if ((rc = dat_ensure_lds(ctx, (const void*)nms_sort_dets_kernel, MAX_SORT * 8)) != DAT_OK) return rc;
+    if ((rc = dat_ensure_lds(ctx, (const void*)nms_finish_kernel, MAX_SORT * 4)) != DAT_OK) return rc;
+    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), presorted ? 0 : (size_t)npad * 8, st, dets, n, T, presorted,
+                       (float*)(ws + o_boxes), (int*)(ws + o_orig), st_n);
     NmsParams np;
     memset(&np, 0, sizeof(np));
     np.lv[0].boxes = (const float*)(ws + o_boxes);
@@ -705,36 +738,77 @@ int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float t
     np.lv[0].n_ptr = st_n;
     np.lv[0].kept = (int*)(ws + o_kept);
     np.lv[0].n_keep_ptr = st_keep;
-    np.T = T; np.cap = n; np.thr = thresh;
+    np.T = T; np.cap = n; np.thr = thresh; np.strict = strict;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, 1), dim3(64), 0, st, np);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, np);
     hipLaunchKernelGGL(nms_finish_kernel, dim3(1), dim3(1024), (size_t)n * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
                        (const int*)(ws + o_orig), n, T, keep, num_keep);
     DAT_CHECK_LAUNCH(ctx, "nms");
     return DAT_OK;
 }
 
-int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
-                 float nms_overlap_thresh) {
+// host-pointer front end shared by dat_nms_host and `_nms`
+static int nms_host_impl(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                         float thresh, int strict, int presorted) {
     DAT_ENFORCE(ctx, keep_out && num_out, "_nms: null output");
     DAT_ENFORCE(ctx, boxes_dim >= 5 && (boxes_dim - 1) % 4 == 0, "_nms: boxes_dim %d must be 4T+1", boxes_dim);
     if (boxes_num == 0) { *num_out = 0; return DAT_OK; }
+    DAT_ENFORCE(ctx, boxes_host && boxes_num > 0, "_nms: null boxes");
+    if (hipSetDevice(ctx->device) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_LAUNCH, "_nms: hipSetDevice(%d) failed", ctx->device);
     const int T = (boxes_dim - 1) / 4;
     float* d_dets = nullptr;
     int* d_keep = nullptr;
     const size_t bytes = (size_t)boxes_num * boxes_dim * 4;
     if (hipMalloc(&d_dets, bytes) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed");
     if (hipMalloc(&d_keep, (size_t)(boxes_num + 1) * 4) != hipSuccess) { hipFree(d_dets); DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed"); }
-    hipMemcpy(d_dets, boxes_host, bytes, hipMemcpyHostToDevice);
-    int rc = dat_nms(ctx, nullptr, d_dets, boxes_num, T, nms_overlap_thresh, d_keep, d_keep + boxes_num);
+    int rc = DAT_OK;
+    if (hipMemcpy(d_dets, boxes_host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        ctx->last_error = "_nms: host -> device copy failed";
+        rc = DAT_ERR_LAUNCH;
+    }
+    if (rc == DAT_OK) rc = nms_impl(ctx, nullptr, d_dets, boxes_num, T, thresh, strict, presorted, d_keep, d_keep + boxes_num);
     if (rc == DAT_OK) {
-        hipDeviceSynchronize();
-        hipMemcpy(num_out, d_keep + boxes_num, 4, hipMemcpyDeviceToHost);
-        hipMemcpy(keep_out, d_keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost);
+        // blocking copies on the null stream: ordered behind the kernels above, no device-wide synchronisation
+        if (hipMemcpy(num_out, d_keep + boxes_num, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(keep_out, d_keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            ctx->last_error = "_nms: device -> host copy failed";
+            rc = DAT_ERR_LAUNCH;
+        }
     }
     hipFree(d_dets);
     hipFree(d_keep);
     return rc;
+}
+
+int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float thresh, int* keep, int* num_keep) {
+    return nms_impl(ctx, (hipStream_t)s, dets, n, T, thresh, 0, 0, keep, num_keep);
+}
+
+int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                 float nms_overlap_thresh) {
+    return nms_host_impl(ctx, keep_out, num_out, boxes_host, boxes_num, boxes_dim, nms_overlap_thresh, 0, 0);
+}
+
+// The one real C ABI of the reference tree, lib/nms/gpu_nms.hpp:3-9, with its exact prototype and conventions
+// (lib/nms/nms_kernel.cu:94-150): HOST pointers, boxes [boxes_num, 5] PRE-SORTED by score and visited as given, a box is
+// suppressed when IoU > thresh (strict, :71 -- the Cython CPU path uses >=), keep_out = positions in the given order,
+// synchronous, selects the device, errors are only printed.  One lazily created context per device, calls serialised.
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh,
+          int device_id) {
+    static std::mutex mu;
+    static dat_ctx* per_device[64] = {nullptr};
+    std::lock_guard<std::mutex> lock(mu);
+    if (num_out) *num_out = 0;
+    if (device_id < 0 || device_id >= 64) { fprintf(stderr, "_nms: device_id %d out of range\n", device_id); return; }
+    if (boxes_dim != 5) { fprintf(stderr, "_nms: boxes_dim %d != 5 (the reference kernel indexes rows of 5 floats)\n", boxes_dim); return; }
+    if (!per_device[device_id] && dat_ctx_create(&per_device[device_id], device_id) != DAT_OK) {
+        fprintf(stderr, "_nms: no usable device %d\n", device_id);
+        per_device[device_id] = nullptr;
+        return;
+    }
+    dat_ctx* ctx = per_device[device_id];
+    if (nms_host_impl(ctx, keep_out, num_out, boxes_host, boxes_num, boxes_dim, nms_overlap_thresh, 1, 1) != DAT_OK)
+        fprintf(stderr, "%s\n", dat_last_error(ctx));
 }
 
 }  // extern "C"

@@ -216,12 +216,10 @@ int dat_stem_conv(dat_ctx* ctx, dat_stream s, int dtype, const float* data, cons
     const long long nblocks = (long long)N * T * p.tiles_h * p.tiles_w;
     DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "stem_conv: grid of %lld blocks unsupported", nblocks);
     if (dtype == DAT_BF16) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<DAT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+        if (dat_ensure_lds(ctx, (const void*)stem_conv_kernel<DAT_BF16>, 64 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
         hipLaunchKernelGGL(stem_conv_kernel<DAT_BF16>, dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)s, p);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)stem_conv_kernel<DAT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+        if (dat_ensure_lds(ctx, (const void*)stem_conv_kernel<DAT_F32>, 96 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
         hipLaunchKernelGGL(stem_conv_kernel<DAT_F32>, dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)s, p);
     }
     DAT_CHECK_LAUNCH(ctx, "stem_conv");

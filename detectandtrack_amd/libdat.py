@@ -60,7 +60,7 @@ _PROTOS = {
     'dat_conv3d_packed_weight_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'dat_conv3d_pack_weights': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p]),
     'dat_conv3d_fwd': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
-    'dat_conv3d_tune_plan': (_i, [_i, _i]),
+    'dat_conv3d_tune_plan': (_i, [_p, _i, _i]),
     'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),
     'dat_stem_pack': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'dat_stem_weights': (_i, [_p, _p, _p, _i, _p]),
@@ -74,6 +74,7 @@ _PROTOS = {
     'dat_collect_rois': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'dat_nms': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
     'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
+    '_nms': (None, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f, _i]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_stem_conv_weight_bytes': (C.c_size_t, [_i]),

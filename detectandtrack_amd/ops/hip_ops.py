@@ -44,6 +44,12 @@ def ctx(device=None):
     return _CTX[key]
 
 
+def tune_plan(positions_per_block, ksplit):
+    """dat_conv3d_tune_plan on the context of the current (device, stream): forces the launch plan of the conv launches that
+    follow on THAT context (0, 0 = back to the makespan model).  Returns the C-ABI return code."""
+    return L._lib.dat_conv3d_tune_plan(ctx().h, int(positions_per_block), int(ksplit))
+
+
 # ---- toy + AffineChannelNd (the reference's own native ops) ---------------------------------------
 def zero_even(x):
     """In-place ZeroEven on a 1-D fp32 tensor (lib/ops/zero_even_op.cc:17-30 semantics)."""

@@ -34,7 +34,7 @@ def prep_im_for_blob(im, pixel_means, target_sizes, max_size):
         scale = float(target) / float(short)
         if np.round(scale * long_) > max_size:
             scale = float(max_size) / float(long_)
-        out_w, out_h = int(np.round(im.shape[1] * scale)), int(np.round(im.shape[0] * scale))
-        ims.append(image_utils.resize_bilinear(im, out_w, out_h))
+        # cv2.resize(im, None, None, fx=scale, fy=scale, INTER_LINEAR): size = round(n * scale), sampling step 1 / scale
+        ims.append(image_utils.resize_bilinear(im, fx=scale, fy=scale))
         scales.append(scale)
     return ims, scales

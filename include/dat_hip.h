@@ -160,7 +160,7 @@ typedef struct {
 /* head: conv output [frames,H,W,cstride] (fp32 or bf16) holding RAW logits (sigmoid applied here,
  * model_builder.py:583) and deltas.  anchors: fp32 [A, 4T] cell anchors (generate_anchors.py).
  * Per level l writes (score order): rois_out + l*post_nms*(4T+1), probs_out + l*post_nms, count[l].
- * Semantics: top pre_nms by score (ties: lower (h,w,a) index first) -> bbox_transform, weights 1
+ * Semantics: top pre_nms (<= 16384 per level) by score (ties: lower (h,w,a) index first) -> bbox_transform, weights 1
  * (boxes.py:141-183) -> clip (boxes.py:243-253) -> min_size*im_scale filter AND-ed over frames
  * (generate_proposals.py:184-196) -> NMS (>= thresh boxes / > thresh tubes) -> first post_nms. */
 int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
@@ -185,6 +185,12 @@ int dat_nms(dat_ctx* ctx, dat_stream s, const float* dets, int n, int T, float t
  * Synchronous; returns 0 or a DAT_ERR code (the reference only printed errors). */
 int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
                  float nms_overlap_thresh);
+/* The reference's own C symbol, exact prototype (lib/nms/gpu_nms.hpp:3-9; caller lib/nms/gpu_nms.pyx:14-34 links against it
+ * unchanged): host pointers, boxes [boxes_num, 5] pre-sorted by score, suppression at IoU > thresh (strict, as
+ * lib/nms/nms_kernel.cu:71; the Cython CPU path and dat_nms / dat_nms_host use >=), keep_out = kept row positions in the given
+ * order, synchronous, selects `device_id`, errors are printed (never returned), one internal context per device, thread-safe. */
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh,
+          int device_id);
 
 /* ---- keypoint head tail: ConvTranspose k4s2p1 (as 3x3 sub-pixel conv) + bilinear up (detector.py:348-380) -- */
 /* Expand kps_score_lowres_w fp32 [Cin, K, 4, 4] (Caffe2 ConvTranspose layout) into an equivalent 3x3 conv
@@ -196,10 +202,11 @@ int dat_deconv_k4s2_weights(dat_ctx* ctx, dat_stream s, const float* w, int Cin,
 int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int R, int Tr, int S, int cs, int K,
                      int up, float* out);
 
-/* Tuning hook (not a reference interface): override the launch plan of dat_conv3d_fwd for the calls that follow --
- * positions per block 128 | 256 and the split-K factor 1..8; 0 = back to the built-in makespan model.  Used by
+/* Tuning hook (not a reference interface): override the launch plan of the dat_conv3d_fwd calls that follow ON THIS
+ * CONTEXT -- positions per block 128 | 256 and the split-K factor 1..8; 0 = back to the built-in makespan model.
+ * Per-context state (no process globals): other contexts / devices of the process are unaffected.  Used by
  * tools/tune_plan.py to check the model against measured per-layer timings. */
-int dat_conv3d_tune_plan(int positions_per_block, int ksplit);
+int dat_conv3d_tune_plan(dat_ctx* ctx, int positions_per_block, int ksplit);
 
 /* ---- conv1, fused (ResNet3D.py:258-262): ConvNd [1,7,7] / [1,2,2] / pad [0,3,3] on `data` fp32 [N,3,T,H,W] + AffineChannelNd
  * (scale, bias: fp32 [64] or NULL) + ReLU -> out [N*T, Ho, Wo, 64] in `dtype`; weights packed once by

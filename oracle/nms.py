@@ -86,3 +86,29 @@ def nms(dets, thresh):
     if dets.shape[1] > 5:
         return nms_tubes(dets, thresh)
     return nms_boxes(dets, thresh)
+
+
+def gpu_nms_presorted(boxes, thresh):
+    """The reference's `_nms` C symbol (lib/nms/gpu_nms.hpp:3-9, implementation lib/nms/nms_kernel.cu:25-150): rows [n, 5]
+    PRE-SORTED by score are visited in the given order; row j > i is removed by a kept row i when
+    devIoU(i, j) = inter / (Sa + Sb - inter) > thresh (STRICT, :71; widths/heights +1, :28-35); returns the kept row
+    positions in order (:128-141).  Pinned by hand-checkable cases in tests/test_oracle_golden.py."""
+    b = np.ascontiguousarray(boxes, dtype=np.float32)
+    n = b.shape[0]
+    thresh = np.float32(thresh)
+    one = np.float32(1)
+    area = (b[:, 2] - b[:, 0] + one) * (b[:, 3] - b[:, 1] + one)
+    removed = np.zeros(n, dtype=bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        j = np.arange(i + 1, n)
+        w = np.maximum(np.minimum(b[i, 2], b[j, 2]) - np.maximum(b[i, 0], b[j, 0]) + one, np.float32(0))
+        h = np.maximum(np.minimum(b[i, 3], b[j, 3]) - np.maximum(b[i, 1], b[j, 1]) + one, np.float32(0))
+        inter = w * h
+        with np.errstate(divide='ignore', invalid='ignore'):
+            iou = inter / (area[i] + area[j] - inter)
+        removed[j[iou > thresh]] = True
+    return np.asarray(keep, dtype=np.int32)

@@ -180,10 +180,10 @@ def test_conv3d_large_pointwise_layers(ops, case, dtype):
         rd = ops.to_ndhwc(_dev(res_small), dtype, layer.cstride)
     got = ops.to_ncdhw(layer(xd, T=T, residual=rd, res_mode=res_mode), dtype, 1, Cout, T).cpu().numpy()
     try:
-        assert L._lib.dat_conv3d_tune_plan(128, 1) == 0
+        assert ops.tune_plan(128, 1) == 0
         gen = ops.to_ncdhw(layer(xd, T=T, residual=rd, res_mode=res_mode), dtype, 1, Cout, T).cpu().numpy()
     finally:
-        L._lib.dat_conv3d_tune_plan(0, 0)
+        ops.tune_plan(0, 0)
     err = np.abs(got - ref).max()
     tol = 2e-4 if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
     print('pointwise %s dtype=%d max-abs err %.3e (ref max %.2f), vs forced plan %.3e' % (name, dtype, err, np.abs(ref).max(),
@@ -207,11 +207,11 @@ def test_conv3d_forced_plans_agree(ops):
     outs = {}
     try:
         for bp, ks in ((0, 0), (128, 1), (256, 1), (128, 2), (256, 3), (128, 4)):
-            assert L._lib.dat_conv3d_tune_plan(bp, ks) == 0
+            assert ops.tune_plan(bp, ks) == 0
             outs[(bp, ks)] = ops.to_ncdhw(layer(xd, T=T), 0, N, Cout, T).cpu().numpy()
-        assert L._lib.dat_conv3d_tune_plan(64, 1) != 0          # rejected: not a tile size
+        assert ops.tune_plan(64, 1) != 0          # rejected: not a tile size
     finally:
-        L._lib.dat_conv3d_tune_plan(0, 0)
+        ops.tune_plan(0, 0)
     for key, got in outs.items():
         err = np.abs(got - ref).max()
         assert err < 2e-4, (key, err)
@@ -352,9 +352,7 @@ def test_nms_fuzz_and_host_wrapper(ops):
     from oracle import nms as onms
     rs = np.random.RandomState(12)
     for n in (3, 64, 65, 129, 777, 2500, 4096):
-        b = rs.uniform(0, 300, (n, 4)).astype(np.float32)
-        b[:, 2:] = b[:, :2] + rs.uniform(1, 80, (n, 2)).astype(np.float32)
-        d = np.hstack((b, rs.uniform(0, 1, (n, 1)).astype(np.float32)))
+        d = _random_dets(rs, n)
         for thr in (0.3, 0.7):
             np.testing.assert_array_equal(ops.nms(_dev(d), thr).cpu().numpy(), onms.nms_boxes(d, thr))
     # empty
@@ -368,6 +366,149 @@ def test_nms_fuzz_and_host_wrapper(ops):
     dd = np.hstack((same, rs.uniform(0, 1, (500, 1)).astype(np.float32)))
     k = ops.nms(_dev(dd), 0.5).cpu().numpy()
     assert k.tolist() == [int(np.argmax(dd[:, 4]))]
+
+
+def _random_dets(rs, n, span=300.0):
+    b = rs.uniform(0, span, (n, 4)).astype(np.float32)
+    b[:, 2:] = b[:, :2] + rs.uniform(1, 80, (n, 2)).astype(np.float32)
+    return np.hstack((b, rs.uniform(0, 1, (n, 1)).astype(np.float32)))
+
+
+@pytest.mark.parametrize('n', [4097, 8191, 12000, 16384])
+def test_nms_beyond_4096_boxes_bit_exact_vs_reference_cython(ops, n):
+    """The reference's default RPN_PRE_NMS_TOP_N is 12000 (lib/core/config.py:110,183): keep indices of the device NMS are
+    identical to the reference's own Cython (oracle/_ref, compiled from lib/utils/cython_nms.pyx) up to 16384 boxes."""
+    from oracle import build_ref
+    ref = build_ref.load()
+    assert ref is not None, 'oracle/_ref not built (run __graft_entry__.build() where /root/reference exists)'
+    rs = np.random.RandomState(n)
+    d = _random_dets(rs, n, span=2000.0)
+    for thr in (0.5, 0.7):
+        np.testing.assert_array_equal(ops.nms(_dev(d), thr).cpu().numpy(), np.asarray(ref[0].nms(d, np.float32(thr))))
+    with pytest.raises(Exception):
+        ops.nms(_dev(_random_dets(rs, 16385)), 0.5)
+
+
+def test_reference_nms_symbol_exact_prototype():
+    """`void _nms(int*, int*, const float*, int, int, float, int)` (lib/nms/gpu_nms.hpp:3-9) called through ctypes with exactly that
+    prototype, the way lib/nms/gpu_nms.pyx:14-34 binds it: pre-sorted host boxes, strict > threshold, positions out."""
+    import ctypes as C
+    from detectandtrack_amd import libdat as L
+    from oracle import nms as onms
+    fn = C.CDLL(L.LIB_PATH)._nms
+    fn.restype = None
+    fn.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_int]
+    rs = np.random.RandomState(5)
+    for n in (1, 2, 63, 64, 65, 1000, 6000, 12000):
+        d = _random_dets(rs, n, span=300.0 if n <= 1000 else 1500.0)
+        d = np.ascontiguousarray(d[np.argsort(-d[:, 4], kind='stable')])
+        for thr in (0.3, 0.7):
+            keep = np.zeros(n, np.int32)
+            num = C.c_int(-1)
+            fn(keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num), d.ctypes.data_as(C.POINTER(C.c_float)), n, 5, thr, 0)
+            np.testing.assert_array_equal(keep[:num.value], onms.gpu_nms_presorted(d, thr))
+    # the strict threshold: IoU exactly 1/3 is kept by `_nms` and removed by the >= convention of dat_nms_host
+    b = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    third = float(np.float32(50.0) / np.float32(150.0))
+    keep, num = np.zeros(2, np.int32), C.c_int(-1)
+    fn(keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num), b.ctypes.data_as(C.POINTER(C.c_float)), 2, 5, third, 0)
+    assert num.value == 2
+    assert ops.nms_host(b, third).tolist() == [0]
+    # empty input / bad device id: num_out = 0, no crash (the reference only prints)
+    num = C.c_int(-1)
+    fn(keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num), b.ctypes.data_as(C.POINTER(C.c_float)), 0, 5, 0.5, 0)
+    assert num.value == 0
+    fn(keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num), b.ctypes.data_as(C.POINTER(C.c_float)), 2, 5, 0.5, 63)
+    assert num.value == 0
+
+
+def test_two_contexts_two_threads_are_independent(ops):
+    """thread-safe per dat_ctx, N contexts per process.  Two host threads, each with its own context and HIP stream,
+    run convs (one under a forced launch plan -- plan overrides are per-context state), NMS and `_nms` concurrently; every result
+    equals the single-threaded one."""
+    import ctypes as C
+    import threading
+    from detectandtrack_amd import libdat as L
+    from oracle import nms as onms
+    rs = np.random.RandomState(21)
+    T, H, W, Cin, Cout = 2, 40, 56, 128, 128
+    x = rs.randn(1, Cin, T, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3, 3) * np.sqrt(2.0 / (Cin * 27))).astype(np.float32)
+    layer = ops.ConvLayer(_dev(w), None, None, stride=(1, 1), pads=(1, 1, 1), relu=True, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    base = layer(xd, T=T).float().cpu().numpy()
+    dets = _random_dets(rs, 3000)
+    dsorted = np.ascontiguousarray(dets[np.argsort(-dets[:, 4], kind='stable')])
+    keep_ref = onms.nms_boxes(dets, 0.5)
+    gpu_ref = onms.gpu_nms_presorted(dsorted, 0.5)
+    torch.cuda.synchronize()
+    fn = C.CDLL(L.LIB_PATH)._nms
+    fn.restype = None
+    fn.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_int]
+    errors, ctx_handles = [], []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                ctx_handles.append(ops.ctx().h.value)
+                if k == 1:
+                    assert ops.tune_plan(128, 2) == 0        # this context only
+                dd = _dev(dets)
+                for _ in range(15):
+                    y = layer(xd, T=T).float().cpu().numpy()
+                    if k == 0:
+                        np.testing.assert_array_equal(y, base)           # unaffected by the other context's plan
+                    else:
+                        np.testing.assert_allclose(y, base, atol=0.05)   # split-K: different summation order
+                    np.testing.assert_array_equal(ops.nms(dd, 0.5).cpu().numpy(), keep_ref)
+                    keep, num = np.zeros(len(dsorted), np.int32), C.c_int(-1)
+                    fn(keep.ctypes.data_as(C.POINTER(C.c_int)), C.byref(num), dsorted.ctypes.data_as(C.POINTER(C.c_float)),
+                       len(dsorted), 5, 0.5, 0)
+                    np.testing.assert_array_equal(keep[:num.value], gpu_ref)
+                if k == 1:
+                    ops.tune_plan(0, 0)
+        except Exception as e:   # noqa
+            import traceback
+            errors.append(traceback.format_exc())
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[0]
+    assert len(set(ctx_handles)) == 2, 'each (device, stream) must get its own dat_ctx'
+
+
+def test_rpn_proposals_with_the_reference_default_pre_nms_12000(ops):
+    """RPN_PRE_NMS_TOP_N 12000 / POST 2000 (the reference's defaults, lib/core/config.py:110-112,183-185) on a P2-sized level."""
+    from oracle import proposals as op
+    from oracle.anchors import generate_anchors
+    rs = np.random.RandomState(77)
+    H0, W0 = 384, 640
+    im_info = np.array([[H0, W0, 1.0]], np.float32)
+    specs, ref_r, ref_p = [], [], []
+    for lvl in (2, 3):
+        H, W = H0 >> lvl, W0 >> lvl
+        anchors = generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2))
+        scores = rs.uniform(0.001, 0.999, (1, 3, H, W)).astype(np.float32)
+        deltas = (rs.randn(1, 12, H, W) * 0.3).astype(np.float32)
+        head, _ = _head_tensor(ops, scores, deltas, 0)
+        lg = ops.to_ncdhw(head, 0, 1, 3, 1).cpu().numpy()[:, :, 0]
+        probs_dev = (1.0 / (1.0 + np.exp(-lg.astype(np.float32)))).astype(np.float32)
+        r, p = op.generate_proposals(probs_dev, deltas, im_info, anchors, 1. / 2 ** lvl, 12000, 2000, 0.7, 0)
+        ref_r.append(r)
+        ref_p.append(p)
+        specs.append(ops.RpnLevelSpec(head, H, W, 3, 1, float(2 ** lvl), 64, 0, 3, 0, _dev(anchors.astype(np.float32))))
+    rois, probs, counts = ops.rpn_proposals(specs, 0, im_info[0], 12000, 2000, 0.7, 0.)
+    cnt = counts.cpu().numpy()
+    for i in range(2):
+        assert cnt[i] == ref_r[i].shape[0], (i, cnt[i], ref_r[i].shape)
+        np.testing.assert_allclose(rois[i, :cnt[i]].cpu().numpy(), ref_r[i], atol=3e-3)
+    out, n_out = ops.collect_rois(rois, probs, counts, 2000)
+    exp = op.collect(ref_r, ref_p, 2000)
+    assert int(n_out.item()) == exp.shape[0]
+    np.testing.assert_allclose(out[:exp.shape[0]].cpu().numpy(), exp, atol=3e-3)
 
 
 def _head_tensor(ops, scores, deltas, dtype, logits=True):
@@ -490,14 +631,11 @@ def test_spatial_mean_softmax(ops):
 
 
 @pytest.mark.parametrize('T,min_size', [(1, 0), (3, 0), (1, 40)])
-def test_heatmaps_to_keypoints_matches_host_decode(ops, T, min_size):
-    """dat_heatmaps_to_keypoints vs the host restatement of utils/keypoints.py:94-149 (bicubic resize to the RoI size,
-    argmax, spatial softmax): identical cells (x, y and logit exact), probability to fp32 summation order."""
-    from detectandtrack_amd.core.config import cfg, reset_cfg
-    from detectandtrack_amd.utils import keypoints as kp
-    reset_cfg()
-    cfg.KRCNN.INFERENCE_MIN_SIZE = min_size
-    cfg.KRCNN.NUM_KEYPOINTS = 17
+def test_heatmaps_to_keypoints_matches_the_oracle(ops, T, min_size):
+    """dat_heatmaps_to_keypoints vs the ORACLE's restatement of lib/utils/keypoints.py:94-149 on top of its cv2.resize INTER_CUBIC
+    restatement (oracle/resize.py, pinned by exact-rational known answers): identical cells (x, y and logit exact), probability
+    to fp32 summation order.  No product code on the reference side of this comparison."""
+    from oracle import resize as oresize
     rs = np.random.RandomState(11)
     R, K, M = 9, 17, 56
     maps = rs.randn(R, T * K, M, M).astype(np.float32) * 2.0
@@ -513,12 +651,11 @@ def test_heatmaps_to_keypoints_matches_host_decode(ops, T, min_size):
         w, h = rs.uniform(0.4, 260, R), rs.uniform(0.4, 330, R)      # includes boxes below 1 px
         boxes[:, 4 * t:4 * t + 4] = np.stack([x1, y1, x1 + w, y1 + h], axis=1)
     got = ops.heatmaps_to_keypoints(_dev(maps), _dev(boxes), T, K, min_size).cpu().numpy()
-    ref = np.concatenate([kp.heatmaps_to_keypoints(maps[:, t * K:(t + 1) * K], boxes[:, 4 * t:4 * t + 4])
+    ref = np.concatenate([oresize.heatmaps_to_keypoints(maps[:, t * K:(t + 1) * K], boxes[:, 4 * t:4 * t + 4], min_size)
                           for t in range(T)], axis=-1)
     assert got.shape == ref.shape == (R, 4, T * K)
     np.testing.assert_array_equal(got[:, :3], ref[:, :3])
     np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=2e-5, atol=1e-9)
-    reset_cfg()
 
 
 @pytest.mark.parametrize('dtype_name', ['fp32', 'bf16'])

@@ -16,7 +16,8 @@ def test_library_exports_every_declared_symbol():
     import ctypes
     hdr = open(os.path.join(REPO, 'include', 'dat_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = sorted(set(re.findall(r'\b(dat_[a-z0-9_]+)\s*\(', hdr)))
+    declared = sorted(set(re.findall(r'\b(dat_[a-z0-9_]+|_nms)\s*\(', hdr)))   # `_nms`: the reference's own C symbol (gpu_nms.hpp:3-9)
+    assert '_nms' in declared
     assert len(declared) >= 25
     lib = ctypes.CDLL(os.path.join(REPO, 'detectandtrack_amd', 'libdat_hip.so'))
     missing = [n for n in declared if not hasattr(lib, n)]
@@ -288,6 +289,38 @@ def test_image_resize_and_blob_prep():
     assert ims[0].shape == (750, 1333, 3) and abs(sc[0] - 1333. / 1280.) < 1e-9
     blob = bu.im_list_to_blob([ims[0], ims[0]])
     assert blob.shape == (1, 3, 2, 768, 1344)
+    reset_cfg()
+
+
+def test_host_resamplers_and_keypoint_decode_match_the_cv2_oracle():
+    """The product's host cv2.resize stand-ins (utils/image.py) and heatmaps_to_keypoints (utils/keypoints.py) against the independent
+    restatement of OpenCV's algorithm in oracle/resize.py -- bit-identical images (same float32 operation order), identical
+    keypoint rows; the prep_im_for_blob path uses the GIVEN scale for the sampling step (blob.py:86-87)."""
+    from oracle import resize as R
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import image as iu, blob as bu, keypoints as ku
+    reset_cfg()
+    rs = np.random.RandomState(4)
+    for (h, w, c), (ow, oh) in (((56, 56, 17), (43, 91)), ((56, 56, 3), (200, 17)), ((9, 13, 1), (13, 9)), ((20, 31, 2), (7, 5)),
+                                ((4, 4, 1), (1, 1)), ((3, 5, 2), (64, 48))):
+        im = (rs.randn(h, w, c) * 3).astype(np.float32)
+        np.testing.assert_array_equal(iu.resize_bicubic(im, ow, oh), R.resize_cubic(im, dsize=(ow, oh)))
+        np.testing.assert_array_equal(iu.resize_bilinear(im, ow, oh), R.resize_linear(im, dsize=(ow, oh)))
+    im = rs.uniform(-120, 140, (72, 128, 3)).astype(np.float32)
+    for s in (1333.0 / 1280.0, 800.0 / 600.0, 0.37):
+        np.testing.assert_array_equal(iu.resize_bilinear(im, fx=s, fy=s), R.resize_linear(im, fx=s, fy=s))
+    frame = rs.randint(0, 255, (72, 128, 3)).astype(np.uint8)
+    ims, sc = bu.prep_im_for_blob(frame, cfg.PIXEL_MEANS, (80,), 133)
+    ref = R.resize_linear(frame.astype(np.float32) - cfg.PIXEL_MEANS, fx=sc[0], fy=sc[0])
+    np.testing.assert_array_equal(ims[0], ref)
+    # heatmap decoding (lib/utils/keypoints.py:94-149)
+    maps = (rs.randn(6, 17, 56, 56) * 2).astype(np.float32)
+    xy = rs.uniform(0, 200, (6, 2)).astype(np.float32)
+    rois = np.hstack((xy, xy + rs.uniform(0.4, 150, (6, 2)).astype(np.float32)))
+    cfg.KRCNN.NUM_KEYPOINTS = 17
+    for ms in (0, 40):
+        cfg.KRCNN.INFERENCE_MIN_SIZE = ms
+        np.testing.assert_array_equal(ku.heatmaps_to_keypoints(maps, rois), R.heatmaps_to_keypoints(maps, rois, ms))
     reset_cfg()
 
 

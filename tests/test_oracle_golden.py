@@ -119,3 +119,114 @@ def test_oracle_vs_compiled_reference_live():
         q = rs.uniform(0, 100, (17, 4)).astype(np.float32)
         q[:, 2:] = q[:, :2] + rs.uniform(1, 60, (17, 2)).astype(np.float32)
         np.testing.assert_array_equal(ob.bbox_overlaps_2d(b, q), ref_bbox.bbox_overlaps(b, q))
+
+
+def test_gpu_nms_restatement_known_answers():
+    """`_nms` (lib/nms/nms_kernel.cu): strict > threshold, rows visited as given.  Hand-checkable cases: two 10x10 boxes shifted by
+    5 px overlap 5*10 / (100 + 100 - 50) = 1/3: kept at thresh 1/3 exactly (strict), removed at any lower threshold, while the
+    Cython CPU path (>=) removes it at 1/3 too."""
+    from oracle import nms as onms
+    b = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8], [100, 100, 109, 109, 0.7]], np.float32)
+    third = np.float32(50.0) / np.float32(150.0)
+    assert onms.gpu_nms_presorted(b, third).tolist() == [0, 1, 2]
+    assert onms.gpu_nms_presorted(b, np.nextafter(third, np.float32(0))).tolist() == [0, 2]
+    assert onms.nms_boxes(b, third).tolist() == [0, 2]
+    # order matters: rows are NOT re-sorted
+    assert onms.gpu_nms_presorted(b[[1, 0, 2]], 0.3).tolist() == [0, 2]
+    assert onms.gpu_nms_presorted(np.zeros((0, 5), np.float32), 0.5).tolist() == []
+
+
+# ---- cv2.resize restatement (oracle/resize.py): known answers derived independently of the code under test -----------------
+def _keys_kernel(x, A):
+    """The published bicubic convolution kernel (Keys 1981) as exact rationals: W(x), support |x| < 2."""
+    from fractions import Fraction
+    x = abs(x)
+    if x <= 1:
+        return (A + 2) * x ** 3 - (A + 3) * x ** 2 + 1
+    if x < 2:
+        return A * x ** 3 - 5 * A * x ** 2 + 8 * A * x - 4 * A
+    return Fraction(0)
+
+
+def _exact_resize_1d(src, n_dst, kind):
+    """Exact rational 1-D resample of integer samples with the pixel-centre mapping s = (d + 1/2) * n_src / n_dst - 1/2 and border
+    replication: kind 'cubic' = sum_k src[clamp(floor(s) - 1 + k)] * W(s - (floor(s) - 1 + k)), A = -3/4; 'linear' = the two
+    neighbours weighted by the fractional distance, coordinates clamped to the sample range."""
+    from fractions import Fraction
+    import math
+    n = len(src)
+    out = []
+    for d in range(n_dst):
+        s = (Fraction(d) + Fraction(1, 2)) * Fraction(n, n_dst) - Fraction(1, 2)
+        if kind == 'linear':
+            s = min(max(s, Fraction(0)), Fraction(n - 1))
+        i0 = math.floor(s)
+        if kind == 'linear':
+            t = s - i0
+            out.append(src[i0] * (1 - t) + src[min(i0 + 1, n - 1)] * t)
+        else:
+            acc = Fraction(0)
+            for k in range(-1, 3):
+                acc += src[min(max(i0 + k, 0), n - 1)] * _keys_kernel(s - (i0 + k), Fraction(-3, 4))
+            out.append(acc)
+    return out
+
+
+def test_resize_oracle_identity_constant_and_ramp():
+    from oracle import resize as R
+    rs = np.random.RandomState(0)
+    im = rs.randn(9, 13, 3).astype(np.float32)
+    # same size: scale 1, every fractional offset 0 -> weights (0, 1, 0, 0) / (1, 0): an exact copy
+    np.testing.assert_array_equal(R.resize_cubic(im, dsize=(13, 9)), im)
+    np.testing.assert_array_equal(R.resize_linear(im, dsize=(13, 9)), im)
+    # a constant map stays constant (the four cubic weights sum to 1 up to rounding)
+    c = np.full((6, 5), 3.25, np.float32)
+    assert np.abs(R.resize_cubic(c, dsize=(17, 11)) - 3.25).max() < 2e-6
+    np.testing.assert_allclose(R.resize_linear(c, dsize=(17, 11)), 3.25, rtol=0, atol=5e-7)
+    # a ramp: INTER_LINEAR reproduces it at the sample positions away from the border.  (The Keys kernel reproduces linear
+    # functions only for A = -1/2; OpenCV's A = -3/4 does not -- what survives is the point symmetry about the centre.)
+    ramp = np.tile(np.arange(16, dtype=np.float32) * 2.0 + 1.0, (4, 1))
+    pos = (np.arange(23) + 0.5) * 16.0 / 23.0 - 0.5
+    inner = (pos >= 1) & (pos <= 13.99)
+    np.testing.assert_allclose(R.resize_linear(ramp, dsize=(23, 4))[0, inner], (pos * 2.0 + 1.0)[inner], atol=2e-5)
+    out = R.resize_cubic(ramp, dsize=(23, 4))
+    assert out[0, 11] == np.float32(16.0)
+    np.testing.assert_allclose(out[0] + out[0, ::-1], 32.0, atol=1e-5)
+    # weights at t = 1/2 (worked by hand from the kernel with A = -3/4): (-3/32, 19/32, 19/32, -3/32)
+    np.testing.assert_array_equal(R.cubic_weights(np.float32(0.5)), np.array([-0.09375, 0.59375, 0.59375, -0.09375], np.float32))
+    # [0 1 4 9] -> 7 samples: the centre sample sits at s = 1.5 -> -3/32*0 + 19/32*1 + 19/32*4 - 3/32*9 = 2.125 exactly
+    assert R.resize_cubic(np.array([[0, 1, 4, 9]], np.float32), dsize=(7, 1))[0, 3] == np.float32(2.125)
+
+
+@pytest.mark.parametrize('kind', ['cubic', 'linear'])
+def test_resize_oracle_4x4_to_7x5_against_exact_rational_arithmetic(kind):
+    """A 4 x 4 integer image resized to 7 wide x 5 high: every output pixel against the separable exact-rational evaluation of the
+    published kernels (border replication included), to float32 rounding."""
+    from fractions import Fraction
+    from oracle import resize as R
+    src = [[3, -1, 4, 1], [-5, 9, 2, -6], [5, 3, -5, 8], [9, -7, 9, 3]]
+    rows = [_exact_resize_1d([Fraction(v) for v in r], 7, kind) for r in src]          # horizontal
+    exact = [[None] * 7 for _ in range(5)]
+    for x in range(7):
+        col = _exact_resize_1d([rows[y][x] for y in range(4)], 5, kind)                # vertical
+        for y in range(5):
+            exact[y][x] = float(col[y])
+    fn = R.resize_cubic if kind == 'cubic' else R.resize_linear
+    got = fn(np.asarray(src, np.float32), dsize=(7, 5))
+    assert got.shape == (5, 7)
+    np.testing.assert_allclose(got, np.asarray(exact), rtol=0, atol=2e-5)   # float32 coordinates + float32 sums on values up to ~12
+
+
+def test_resize_oracle_scale_given_uses_the_given_scale():
+    """cv2.resize(im, None, fx=s, fy=s): output size round-half-even(n * s) and the sampling step 1/s (NOT src/dst) --
+    lib/utils/blob.py:86-87 at the PoseTrack scale 1333/1280 on a 720-row frame: 750 rows, step 0.96024 (src/dst would be 0.96)."""
+    from oracle import resize as R
+    s = 1333.0 / 1280.0
+    col = np.arange(720, dtype=np.float32).reshape(720, 1) * np.ones((1, 2), np.float32)
+    out = R.resize_linear(col, fx=1.0, fy=s)
+    assert out.shape == (750, 2)
+    pos = np.clip((np.arange(750) + 0.5) / s - 0.5, 0, 719)
+    np.testing.assert_allclose(out[:, 0], pos, atol=2e-4)
+    assert abs(out[700, 0] - ((700.5) * 720.0 / 750.0 - 0.5)) > 0.1      # the dsize-derived step would land elsewhere
+    assert R.resize_linear(np.zeros((5, 5), np.float32), fx=0.5, fy=0.5).shape == (2, 2)      # 2.5 -> 2 (half to even)
+    assert R.resize_linear(np.zeros((7, 7), np.float32), fx=0.5, fy=0.5).shape == (4, 4)      # 3.5 -> 4

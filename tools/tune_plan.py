@@ -50,14 +50,14 @@ def main():
                               pads=(k[0] // 2, k[1] // 2, k[2] // 2), relu=True, dtype=ops.BF16)
         x = torch.randn(frames, hi, wi, layer.cin, device=dev).to(torch.bfloat16)
         y = layer(x, T=Tl)
-        L._lib.dat_conv3d_tune_plan(0, 0)
+        ops.tune_plan(0, 0)
         t_model = timed(layer, x, y, Tl, a.iters)
         res = {}
         for bp in (128, 256):
             for ks in (1, 2, 3, 4, 6, 8):
-                L._lib.dat_conv3d_tune_plan(bp, ks)
+                ops.tune_plan(bp, ks)
                 res[(bp, ks)] = timed(layer, x, y, Tl, a.iters)
-        L._lib.dat_conv3d_tune_plan(0, 0)
+        ops.tune_plan(0, 0)
         t_model = min(t_model, timed(layer, x, y, Tl, a.iters))
         (bbp, bks), t_best = min(res.items(), key=lambda kv: kv[1])
         total_model += t_model * cnt
