@@ -13,7 +13,13 @@ Image decoding/resizing and the host heatmap->keypoint decoding (SURVEY.md §8f-
 Multi-GPU: clips are independent units — every rank processes its own clip stream, no
 data-path collective; the only collectives are the barrier + MAX-reduce of the timing. scaling = weak.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+Workloads (`--workload`, BASELINE.json configs): `3d_r18_fpn3d` (default: config 3, the configuration the metric is quoted
+on), `3d_r50_fpn3d` / `3d_r101_fpn3d` (config 5's model), `2d_r50_fpn` (config 2: a step = EIGHT 768 x 1344 frames, one forward
+per frame as the reference runs 2D models, lib/core/test.py:212-214).  `--mode train` (config 4) times one training iteration
+per step instead: forward + losses + backward + gradient all-reduce (RCCL when N > 1) + momentum SGD on a resident clip with
+resident labels (`training.Trainer.step`).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline` and (bf16) `accuracy_vs_fp32`.
 """
 import argparse
 import json
@@ -31,7 +37,12 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-def model_cfg(arch, T, dtype, keyframe_dce=False):
+def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False):
+    if two_d:   # BASELINE configs 1-2: pure 2D R-50-FPN keypoint R-CNN (lib/modeling/FPN.py:114-202, ResNet.py:231-266)
+        c = model_cfg(arch, 1, dtype)
+        c['MODEL'].update(CONV_BODY='FPN.add_fpn_ResNet%s_conv5_body' % arch, VIDEO_ON=False)
+        c.pop('VIDEO')
+        return c
     return {
         'MODEL': {'TYPE': 'keypoint_rcnn', 'CONV_BODY': 'FPN3D.add_fpn_ResNet%s_conv5_body' % arch,
                   'ROI_HEAD': 'head_builder.add_roi_2mlp_head', 'NUM_CLASSES': 2, 'FASTER_RCNN': True,
@@ -98,13 +109,13 @@ def synthetic_clip(T, H, W, seed):
     return (data - means).contiguous()
 
 
-def build(arch, T, dtype, keyframe_dce=False):
+def build(arch, T, dtype, keyframe_dce=False, two_d=False):
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
     from detectandtrack_amd.utils import net as net_utils
     from detectandtrack_amd import workspace
     reset_cfg()
-    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce))
+    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce, two_d))
     assert_and_infer_cfg()
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     workspace.ResetWorkspace()
@@ -172,48 +183,135 @@ class ClipPipeline(object):
         torch.cuda.synchronize()
 
 
-def cpu_baseline(arch, T, seconds_budget=15.0):
-    """The oracle (torch-CPU fp32 restatement of the reference graph) timed on the host cores on a bounded sample:
-    the same model on a reduced 8x256x320 clip (full clips take minutes on CPU)."""
+def _oracle_forward(net, data, im_info, n_box, n_kp):
+    from oracle import proposals as op
+    net.body(data)
+    p2d = net.time_link(net.fpn())
+    rois, per_level, restore = net.fpn_rpn(p2d, im_info)
+    _, pl, rs = op.distribute(rois[:n_box], 2, 5)
+    net.box_head_2mlp(net.roi_feat_fpn(p2d[1:], pl, rs, 7, 2))
+    _, pl, rs = op.distribute(rois[:n_kp], 2, 5)
+    net.kps_head_2d(net.roi_feat_fpn(p2d[1:], pl, rs, 14, 2))
+
+
+def cpu_baseline(arch, T, H, W, two_d, frames_per_step, seconds_budget=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference graph, `kind: port`) timed on the host cores on a BOUNDED sample
+    of the SAME workload: whole forward passes at the benched size (body + FPN + RPN + proposals at full size, box head on
+    1000 rois, keypoint head on 100), as many as fit the time budget (at least one)."""
     from detectandtrack_amd.core.config import cfg
     from detectandtrack_amd.modeling import model_builder
     from detectandtrack_amd.utils import net as net_utils
     from oracle.net3d import Net, opts_for
-    from oracle import proposals as op
-    H, W = 256, 320
-    cores = min(os.cpu_count() or 1, 32)   # torch-CPU conv3d stops scaling well before 256 threads
+    cores = min(os.cpu_count() or 1, 64)   # torch-CPU conv3d stops scaling well before 256 threads
     torch.set_num_threads(cores)
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     weights = net_utils.synthetic_params(model, cfg.RNG_SEED)
-    data = synthetic_clip(T, H, W, 3)
+    Tn = 1 if two_d else T
+    data = synthetic_clip(Tn, H, W, 3)
     im_info = np.array([[H, W, 1.0]], np.float32)
-    opts = opts_for('R' + arch, kt_body=3, body_head_link='slice-center', num_frames_mid=T, pre_nms_topn=1000,
-                    post_nms_topn=50)
+    opts = opts_for('R' + arch, kt_body=1 if two_d else 3, body_head_link='slice-center', num_frames_mid=Tn, pre_nms_topn=1000,
+                    post_nms_topn=1000)
     n, t0 = 0, time.time()
     while True:
-        net = Net(weights, opts)
-        net.body(data)
-        p2d = net.time_link(net.fpn())
-        rois, per_level, restore = net.fpn_rpn(p2d, im_info)
-        feat = net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2)
-        net.box_head_2mlp(feat)
-        kp = rois[:4]
-        _, pl, rs = op.distribute(kp, 2, 5)
-        net.kps_head_2d(net.roi_feat_fpn(p2d[1:], pl, rs, 14, 2))
+        _oracle_forward(Net(weights, opts), data, im_info, 1000, 100)
         n += 1
         el = time.time() - t0
-        if el > seconds_budget or n >= 64:
+        if el > seconds_budget or n >= 16:
             break
-    return {'value': n / el, 'unit': 'clips/s (reduced %dx%dx%d clips)' % (T, H, W), 'cores': cores, 'kind': 'port',
-            'sample': '%d forward passes of oracle.net3d (torch-CPU fp32, %d threads) on a %dx%dx%d clip, '
-                      '50 rois, 4 keypoint rois; %.1f s' % (n, cores, T, H, W, el)}
+    per_step = float(frames_per_step if two_d else 1)
+    return {'value': n / per_step / el, 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full-size forward pass(es) of oracle.net3d (torch-CPU fp32, %d threads) on a %s input, 1000 proposals, '
+                      '1000 box rois, 100 keypoint rois; %.1f s%s'
+                      % (n, cores, '1x3x%dx%d' % (H, W) if two_d else '1x3x%dx%dx%d' % (T, H, W), el,
+                         ' (a step of this workload = %d frames)' % frames_per_step if two_d else '')}
+
+
+def cpu_proposal_path(H, W, seconds_budget=6.0):
+    """The reference's host proposal path: GenerateProposalsOp in NumPy (lib/ops/generate_proposals.py, restated
+    in oracle/proposals.py) over the 257 796 FPN anchors of a 768 x 1344 input, NMS by the reference's OWN Cython kernel
+    (oracle/_ref, compiled from lib/utils/cython_nms.pyx) when it is present, + collect.  Single thread, like the reference."""
+    from oracle import proposals as op, nms as onms, build_ref
+    from oracle.anchors import generate_anchors
+    ref = build_ref.load()
+    rs = np.random.RandomState(3)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    lv = []
+    for lvl in range(2, 7):
+        h, w = int(np.ceil(H / 2. ** lvl)), int(np.ceil(W / 2. ** lvl))
+        lv.append((rs.uniform(0.001, 0.999, (1, 3, h, w)).astype(np.float32), (rs.randn(1, 12, h, w) * 0.3).astype(np.float32),
+                   generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2)), 1. / 2 ** lvl))
+    saved = onms.nms_boxes
+    if ref is not None:
+        onms.nms_boxes = lambda d, t: np.asarray(ref[0].nms(np.ascontiguousarray(d, np.float32), np.float32(t)))
+    try:
+        n, t0 = 0, time.time()
+        while True:
+            out = [op.generate_proposals(s_, d_, im_info, a_, sc_, 1000, 1000, 0.7, 0) for s_, d_, a_, sc_ in lv]
+            op.collect([o[0] for o in out], [o[1] for o in out], 1000)
+            n += 1
+            el = time.time() - t0
+            if el > seconds_budget:
+                break
+    finally:
+        onms.nms_boxes = saved
+    return {'value': round(1e3 * el / n, 2), 'unit': 'ms per image (257796 anchors, pre/post 1000, 5 levels)', 'cores': 1,
+            'kind': 'reference' if ref is not None else 'port',
+            'sample': '%d passes of the NumPy GenerateProposals restatement%s + collect; %.1f s'
+                      % (n, ' with the reference Cython NMS' if ref is not None else '', el)}
+
+
+def _tracker_worker(seed):
+    from detectandtrack_amd.core import tracking_engine as te
+    return te.benchmark_synthetic(n_videos=1, n_frames=100, n_persons=8, seed=seed)['seconds']
 
 
 def cpu_tracker_baseline():
-    """Host Hungarian tracker (stays on the host by design, tools/compute_tracks.py) on the synthetic detection
-    set of BASELINE.md §4: 50 videos x 100 frames x ~8 persons, single core as the reference runs it."""
+    """Host Hungarian tracker (stays on the host by design, tools/compute_tracks.py) on the synthetic detection set of
+    BASELINE.md section 4: 50 videos x 100 frames x ~8 persons -- single core as the reference runs it (tracking_engine.py:689), and
+    an all-cores variant (one video per process) on the box's cores."""
     from detectandtrack_amd.core import tracking_engine as te
-    return te.benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3)
+    one = te.benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3)
+    try:
+        import multiprocessing as mp
+        cores = min(os.cpu_count() or 1, 50)
+        t0 = time.time()
+        with mp.get_context('spawn').Pool(cores) as pool:
+            pool.map(_tracker_worker, range(50))
+        el = time.time() - t0
+        one['all_cores'] = {'value': 5000 / el, 'unit': 'frames/s', 'cores': cores, 'seconds': el,
+                            'sample': '50 videos x 100 frames, one video per process (incl. process start-up)'}
+    except Exception as e:   # noqa  (a box that cannot fork workers still reports the single-core number)
+        one['all_cores'] = {'error': repr(e)}
+    return one
+
+
+# ---- training mode (BASELINE config 4) ---------------------------------------------------------------------------------------
+def build_train(arch, T, H, W, dtype, world, rank):
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+    c = model_cfg(arch, T, dtype)
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 2000, 'RPN_POST_NMS_TOP_N': 2000, 'IMS_PER_BATCH': 1, 'MAX_SIZE': max(H, W),
+                  'BATCH_SIZE_PER_IM': 512}
+    c['NUM_GPUS'] = world
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    for k, v in net_utils.synthetic_params(model, cfg.RNG_SEED).items():    # identical on every rank
+        ws.set_param(k, v)
+    data = synthetic_clip(T, H, W, 1000 * rank + 1).cuda()
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=8, seed=1000 * rank + 1)
+    rng = np.random.RandomState(rank)
+    ws.FeedBlob('data', data)
+    for k, v in rpn_data.add_rpn_blobs({}, 1.0, entry, rng).items():
+        ws.FeedBlob(k, v)
+    ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+    return model, ws
 
 
 def main():
@@ -221,18 +319,28 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--arch', default='18', choices=['18', '50', '101'])
+    ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn'],
+                    help='default 3d_r18_fpn3d (BASELINE config 3); 2d_r50_fpn = config 2 (a step = 8 frames, one forward per frame)')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help='train: one training iteration per step (config 4)')
+    ap.add_argument('--arch', default=None, choices=['18', '50', '101'], help='shorthand for --workload 3d_r<arch>_fpn3d')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--height', type=int, default=768)
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-accuracy', action='store_true', help='skip the bf16-vs-fp32 error report (one extra fp32 forward)')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
     ap.add_argument('--pipeline', type=int, default=3, help='clips in flight per GPU (1 = strictly sequential)')
     ap.add_argument('--keyframe-dce', action='store_true',
                     help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '
                          '(identical detections; NOT the default, the default materialises every frame like the reference)')
     a = ap.parse_args()
+    if a.workload is None:
+        a.workload = '3d_r%s_fpn3d' % (a.arch or '18')
+    two_d = a.workload == '2d_r50_fpn'
+    a.arch = '50' if two_d else a.workload.split('_')[1][1:]
+    train = a.mode == 'train'
+    assert not (train and two_d), '--mode train benches the 3D FPN models (BASELINE config 4)'
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -246,54 +354,88 @@ def main():
         dist.init_process_group('nccl')
 
     from detectandtrack_amd.ops import hip_ops as ops
-    model, ws = build(a.arch, a.frames, a.dtype, a.keyframe_dce)
     T, H, W = a.frames, a.height, a.width
-    # every rank gets its own clips (weak scaling): seed by rank
-    clips = [synthetic_clip(T, H, W, 1000 * rank + i).cuda() for i in range(2)]
+    units_per_step = T if two_d else 1          # 2D: one forward per frame, T frames per step
     im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
     im_shape = (int(round(H / im_info[0, 2])), int(round(W / im_info[0, 2])), 3)
 
-    pipe = ClipPipeline(model, ws, a.pipeline)
-    torch.cuda.synchronize()
-    for i in range(a.warmup):
-        pipe.submit(clips[i % 2], im_info, im_shape)
-    pipe.drain()
+    if train:
+        from detectandtrack_amd.training import Trainer
+        model, ws = build_train(a.arch, T, H, W, a.dtype, world, rank)
+        trainer = Trainer(model, ws, dist)
+        slots = [(ws, torch.cuda.current_stream())]
 
-    # ---- timed region: EXACTLY `steps` steps, barrier + synchronize on both sides ----
-    w0, st0 = pipe.slots[0]
-    in_region = a.pipeline == 1     # per-launch events inside the timed region only when clips do not overlap
-    prof = ops.ConvProfiler(capacity=256 * max(a.steps, 1))
-    if in_region:
-        w0.conv_log = []
-        with torch.cuda.stream(st0):
-            prof.start()
+        def run_steps(n):
+            for _ in range(n):
+                trainer.step(1e-4)
+            torch.cuda.synchronize()
+        n_det = 512
+    else:
+        model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d)
+        # every rank gets its own clips (weak scaling): seed by rank.  2D: the frames of a clip are fed one by one.
+        if two_d:
+            clips = [[synthetic_clip(1, H, W, 1000 * rank + 10 * i + f)[:, :, 0].contiguous().cuda() for f in range(T)] for i in range(2)]
+        else:
+            clips = [[synthetic_clip(T, H, W, 1000 * rank + i).cuda()] for i in range(2)]
+        pipe = ClipPipeline(model, ws, a.pipeline)
+        slots = pipe.slots
+
+        def run_steps(n):
+            for i in range(n):
+                for unit in clips[i % 2]:
+                    pipe.submit(unit, im_info, im_shape)
+            pipe.drain()
+
+    torch.cuda.synchronize()
+    run_steps(a.warmup)
+
+    # ---- timed region: EXACTLY `steps` steps, barrier + synchronize on both sides.  Every conv launch of every stream is
+    # bracketed by its own HIP-event pair (recorded on the launch stream by the C ABI, dat_prof_enable) INSIDE the region ----
+    cap = 512 * max(a.steps, 1) * units_per_step
+    profs = []
+    for w, st in slots:
+        w.conv_log = []
+        with torch.cuda.stream(st):
+            pr = ops.ConvProfiler(capacity=cap)
+            pr.start()
+            profs.append(pr)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        pipe.submit(clips[i % 2], im_info, im_shape)
-    pipe.drain()
+    run_steps(a.steps)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_det = pipe.n_det
-    prof_steps = a.steps
-    if not in_region:
-        # with >1 clip in flight a launch's event pair would also span the other stream's kernels: measure the
-        # per-launch durations on the same clips right after the timed region, one clip at a time
-        prof_steps = min(a.steps, 5)
-        seq = ClipPipeline(model, w0, 1)
-        seq.slots = [(w0, st0)]
-        w0.conv_log = []
-        with torch.cuda.stream(st0):
-            prof.start()
-        for i in range(prof_steps):
-            seq.submit(clips[i % 2], im_info, im_shape)
+    records, conv_log, mhz = [], [], []
+    for (w, st), pr in zip(slots, profs):
+        with torch.cuda.stream(st):
+            rec = pr.stop()
+        if train:   # the data-gradient launches reuse the forward kernel without a host-side log entry: take the launch's
+            # own record (flops from the descriptor's channel strides, i.e. padded channels counted; bytes unknown)
+            w.conv_log = [('conv', fl, 0.0) for _, fl, _ in rec]
+        assert len(rec) == len(w.conv_log), (len(rec), len(w.conv_log))
+        records += rec
+        conv_log += w.conv_log
+        mhz.append(getattr(pr, 'shader_mhz', 0.0))
+        w.conv_log = None
+    shader_mhz = float(np.mean([m for m in mhz if m > 0])) if any(m > 0 for m in mhz) else 0.0
+    if not train:
+        n_det = pipe.n_det
+    # strictly sequential rate (one clip in flight: host glue and its syncs exposed), outside the timed region
+    seq_rate = None
+    if not train and a.pipeline > 1 and rank == 0:
+        seq = ClipPipeline(model, slots[0][0], 1)
+        seq.slots = [slots[0]]
+        n_seq = min(a.steps, 5)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_seq):
+            for unit in clips[i % 2]:
+                seq.submit(unit, im_info, im_shape)
         seq.drain()
-    with torch.cuda.stream(st0):
-        records = prof.stop()
-    conv_log, w0.conv_log = (w0.conv_log or []), None
+        seq_rate = n_seq / (time.perf_counter() - t1)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -304,9 +446,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (conv3d_igemm, the BN=128 instantiation) from per-launch HIP events ----
-    assert len(records) == len(conv_log), (len(records), len(conv_log))
-    # dominant kernel = the conv3d_igemm instantiation with the largest total time in the timed region
+    # ---- roofline of the dominant kernel: the conv3d_igemm instantiation with the largest total time in the timed region ----
     by_tag = {}
     for (tag, _, ms), (_, fl, nbytes) in zip(records, conv_log):
         t = by_tag.setdefault(tag, [0.0, 0.0, 0, 0.0])
@@ -319,50 +459,78 @@ def main():
     if a.dump_convs:
         agg = {}
         for (tag, _, ms), (name, fl, _b) in zip(records, conv_log):
-            e = agg.setdefault(name, [0.0, 0.0, tag])
+            e = agg.setdefault(name, [0.0, 0.0, tag, 0])
             e[0] += fl
             e[1] += ms
-        for name, (fl, ms, tag) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s' % (name, tag, ms / prof_steps, fl / ms / 1e9 if ms > 0 else 0),
+            e[3] += 1
+        for name, (fl, ms, tag, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s' % (name, tag, ms / a.steps, fl / ms / 1e9 if ms > 0 else 0),
                   file=sys.stderr)
     all_fl = sum(c[1] for c in conv_log)
     all_ms = sum(ms for _, _, ms in records)
     peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    kernel_name = 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10)
+    tps = {3: ',tps3', 4: ',tps3'}.get(dom_tag % 10, '')
+    kernel_name = 'conv3d_igemm_kernel<%s,%d,%d%s>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10, tps)
+    traffic = pmc_traffic(a, 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10)) if not (train or two_d) else None
+    streams = len(slots)
     roofline = {
         'bound': 'mfma', 'kernel': kernel_name,
         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-        'traffic': pmc_traffic(a, kernel_name),
-        'algorithmic_bytes_per_launch': round(dom_bytes / max(dom_n, 1)),
+        'traffic': traffic,
+        'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload and build; bench.py cannot read PMC counters live)' if traffic else None,
+        'algorithmic_bytes_per_launch': round(dom_bytes / max(dom_n, 1)) if dom_bytes > 0 else None,
+        'measured': 'HIP-event pair around every launch, on its launch stream, inside the timed region (%d launches of this kernel)' % dom_n,
         # the part runs its MFMA kernels far below the 2.4 GHz the 2.5 PFLOP/s peak assumes: clock measured inside the
         # conv kernel (s_memtime / s_memrealtime) over the profiled launches, and the dense peak rescaled to it
-        'shader_clock_mhz': round(getattr(prof, 'shader_mhz', 0.0), 1),
-        'peak_at_measured_clock': round(peak * getattr(prof, 'shader_mhz', 0.0) / 2400.0, 1),
-        'frac_at_measured_clock': round(achieved / (peak * prof.shader_mhz / 2400.0), 4) if getattr(prof, 'shader_mhz', 0.0) > 0 else None,
+        'shader_clock_mhz': round(shader_mhz, 1),
+        'peak_at_measured_clock': round(peak * shader_mhz / 2400.0, 1),
+        'frac_at_measured_clock': round(achieved / (peak * shader_mhz / 2400.0), 4) if shader_mhz > 0 else None,
         # the vendor's tuned dense bf16 GEMM on this very box (hipBLASLt 8192^3): the practical, power-capped MFMA ceiling
         'vendor_gemm_tflops_same_box': vendor_gemm_tflops() if a.dtype == 'bf16' else None,
-        'launches_per_step': dom_n // max(prof_steps, 1),
+        'launches_per_step': round(dom_n / float(max(a.steps, 1)), 2),
         'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
-        'algorithmic_tflop_per_step': round(dom_fl / max(prof_steps, 1) / 1e12, 4),
-        'all_conv_kernels': {'tflop_per_step': round(all_fl / max(prof_steps, 1) / 1e12, 4),
-                             'ms_per_step': round(all_ms / max(prof_steps, 1), 3),
-                             'tflops': round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
+        'algorithmic_tflop_per_step': round(dom_fl / max(a.steps, 1) / 1e12, 4),
+        'all_conv_kernels': {'tflop_per_step': round(all_fl / max(a.steps, 1) / 1e12, 4),
+                             'ms_per_step_summed_over_streams': round(all_ms / max(a.steps, 1), 3),
+                             'tflops': round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+                             'note': ('%d clips are in flight on %d HIP streams: kernels of different clips overlap on the GPU, so the per-launch '
+                                      'durations summed over the streams exceed the wall-clock ms_per_step; a launch that shares the chip '
+                                      'with another stream\'s kernels is timed as it ran' % (streams, streams)) if streams > 1 else
+                                     'one stream: launch durations add up to at most the wall-clock ms_per_step'},
     }
+    value = a.gpus * a.steps / elapsed
+    if train:
+        workload = ('3D R-%s FPN3D keypoint R-CNN TRAINING iteration, 1x3x%dx%dx%d clip per step per GPU (forward + 13 losses + backward + '
+                    'gradient all-reduce + momentum SGD; 2000 proposals, 512 sampled rois; labels resident)' % (a.arch, T, H, W))
+    elif two_d:
+        workload = ('2D R-%s-FPN keypoint R-CNN inference, a step = %d frames of 1x3x%dx%d run one forward per frame '
+                    '(1000 proposals, %d detections in the last frame -> kps_score -> decoded keypoints)' % (a.arch, T, H, W, n_det))
+    else:
+        workload = ('3D R-%s FPN3D keypoint R-CNN inference, 1x3x%dx%dx%d clip per step per GPU '
+                    '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
+                    % (a.arch, T, H, W, n_det))
     out = {
-        'metric': 'clips/sec (8-frame 800px)', 'value': round(a.gpus * a.steps / elapsed, 4), 'unit': 'clips/s',
+        'metric': 'clips/sec (8-frame 800px)', 'value': round(value, 4), 'unit': 'clips/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-        'config': {'workload': '3D R-%s FPN3D keypoint R-CNN inference, 1x3x%dx%dx%d clip per step per GPU '
-                               '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
-                               % (a.arch, T, H, W, n_det),
+        'config': {'workload': workload, 'mode': a.mode, 'name': a.workload,
                    'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
-                   'clips_in_flight': a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
-                   'parallelism': 'clip-sharded x%d (no data-path collective)' % a.gpus},
+                   'clips_in_flight': 1 if train else a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
+                   'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
+                                   'clip-sharded x%d (no data-path collective)') % a.gpus},
         'roofline': roofline,
     }
-    if not a.no_cpu_baseline and a.gpus == 1:     # the CPU baseline is timed on rank 0 of the single-GPU run only
-        out['cpu_baseline'] = cpu_baseline(a.arch, T)
+    if seq_rate is not None:
+        out['sequential_clips_per_s'] = round(seq_rate, 3)      # --pipeline 1 equivalent: one clip in flight, host glue exposed
+    if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:
+        # what the benched arithmetic costs: bf16 vs the fp32 parity mode of the same model on the benched clip
+        from detectandtrack_amd.utils import precision
+        out['accuracy_vs_fp32'] = precision.bf16_vs_fp32(model, slots[0][0], clips[0][0], im_info, n_kp=100)
+    if not a.no_cpu_baseline and a.gpus == 1:     # CPU baselines are timed on rank 0 of the single-GPU run only
+        if not train:
+            out['cpu_baseline'] = cpu_baseline(a.arch, T, H, W, two_d, T)
+            out['cpu_proposal_path'] = cpu_proposal_path(H, W)
         out['cpu_tracker'] = cpu_tracker_baseline()
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -35,8 +35,9 @@ class Blob(object):
 
 
 class Workspace(object):
-    def __init__(self, device=0):
+    def __init__(self, device=0, dtype=None):
         self.device = torch.device('cuda', device)
+        self.dtype = dtype      # 'bf16' | 'fp32' arithmetic of THIS workspace; None = cfg.HIP.DTYPE at run time
         self.blobs = {}
         self.params = {}        # name -> np.ndarray (host master copy, reference blob layout)
         self.nets = {}
@@ -115,6 +116,7 @@ class Workspace(object):
         two HIP streams (host post-processing of clip i overlaps the device forward of clip i+1)."""
         w = Workspace.__new__(Workspace)
         w.device = self.device
+        w.dtype = self.dtype
         w.blobs = {}
         w.params, w.nets, w._layers, w._dev_params = self.params, self.nets, self._layers, self._dev_params
         w.conv_log = None
@@ -149,8 +151,9 @@ def _count(b):
     return int(b.count.item()) if isinstance(b.count, torch.Tensor) else int(b.count)
 
 
-def _dt():
-    return ops.BF16 if cfg.HIP.DTYPE == 'bf16' else ops.F32
+def _dt(ws=None):
+    mode = (getattr(ws, 'dtype', None) if ws is not None else None) or cfg.HIP.DTYPE
+    return ops.BF16 if mode == 'bf16' else ops.F32
 
 
 def _w5(w):
@@ -343,7 +346,7 @@ class Executor(object):
         if i in self._fused:
             return self._rpn_head_conv(i)
         xin = ws.blobs[op.inputs[0]]
-        dt = _dt()
+        dt = _dt(self.ws)
         if op.inputs[0] == 'data':
             return self._stem(i, op, xin)
         assert xin.kind == 'fmap', (op, xin.kind)
@@ -378,7 +381,7 @@ class Executor(object):
     def _conv_over_time_channels(self, i, op, xin):
         """1x1 conv on a blob whose T frames were moved into channels (index t*C + c): run as a KT = T conv with no
         temporal padding that writes output frame 0 only -- the transposed copy never exists."""
-        ws, a, dt = self.ws, op.args, _dt()
+        ws, a, dt = self.ws, op.args, _dt(self.ws)
         assert a['kernels'] == [1, 1, 1] and a['strides'] == [1, 1] and a['residual'] is None, op
         T, C = xin.T, xin.C
 
@@ -393,7 +396,7 @@ class Executor(object):
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
 
     def _stem(self, i, op, xin):
-        ws, a, dt = self.ws, op.args, _dt()
+        ws, a, dt = self.ws, op.args, _dt(self.ws)
         assert a['kernels'] == [1, 7, 7] and a['strides'] == [2, 2] and a['pads'] == [0, 3, 3] and a['dim_in'] == 3, \
             'the network input must feed the [1,7,7]/[1,2,2] stem conv (ResNet3D.py:258)'
         data = xin.t
@@ -412,7 +415,7 @@ class Executor(object):
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
 
     def _rpn_head_conv(self, i):
-        ws, dt = self.ws, _dt()
+        ws, dt = self.ws, _dt(self.ws)
         lo, do, gi = self._fused[i]
         xin = ws.blobs[lo.inputs[0]]
         A = lo.args['dim_out']
@@ -541,7 +544,7 @@ class Executor(object):
         info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
         assert info.shape[0] == 1, 'one clip per forward (reference inference is batch 1, core/test.py:212-214)'
         specs = [s for s, _ in self.pending_rpn]
-        rois, probs, counts = ops.rpn_proposals(specs, _dt(), info[0], cfg[key].RPN_PRE_NMS_TOP_N,
+        rois, probs, counts = ops.rpn_proposals(specs, _dt(self.ws), info[0], cfg[key].RPN_PRE_NMS_TOP_N,
                                                 cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
                                                 cfg[key].RPN_MIN_SIZE)
         for li, (_, op) in enumerate(self.pending_rpn):
@@ -582,7 +585,7 @@ class Executor(object):
         ws.blobs[op.outputs[0]] = b
 
     def op_FC(self, i, op):
-        ws, a, dt = self.ws, op.args, _dt()
+        ws, a, dt = self.ws, op.args, _dt(self.ws)
         x = ws.blobs[op.inputs[0]]
         if x.kind == 'fmap':
             f, p, p2, cs = x.t.shape
@@ -619,7 +622,7 @@ class Executor(object):
         self.ws.blobs[op.outputs[0]] = b
 
     def op_ConvTranspose(self, i, op):
-        ws, a, dt = self.ws, op.args, _dt()
+        ws, a, dt = self.ws, op.args, _dt(self.ws)
         x = ws.blobs[op.inputs[0]]
 
         def build():

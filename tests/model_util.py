@@ -77,3 +77,23 @@ def fpn3d_tube_kps_cfg(T=2, kt=3, pre=200, post=50, dtype='fp32'):
     d['KRCNN'].update(ROI_KEYPOINTS_HEAD='keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d',
                       NO_3D_DECONV_TIME_TO_CH=True)
     return d
+
+
+def fpn2d_kps_cfg(arch='50', pre=1000, post=1000, dtype='fp32'):
+    """BASELINE configs 1-2: the pure 2D R-50-FPN keypoint R-CNN (MODEL.VIDEO_ON False; reference lib/modeling/FPN.py:114-202,
+    ResNet.py:231-266; shipped as configs/video/2d_best/01_R101_best_hungarian.yaml with the R-101 body)."""
+    d = fpn3d_kps_cfg(arch, T=1, kt=1, link='', pre=pre, post=post, dtype=dtype)
+    d['MODEL'].update(CONV_BODY='FPN.add_fpn_ResNet%s_conv5_body' % arch, VIDEO_ON=False)
+    d.pop('VIDEO')
+    return d
+
+
+def oracle_weights_2d(weights):
+    """The oracle graph is written on 5-D blobs: 2D conv weights of the body / FPN ([o, i, k, k]) get a unit time axis."""
+    out = {}
+    for k, v in weights.items():
+        v = np.asarray(v)
+        if v.ndim == 4 and k.endswith('_w') and k.startswith(('conv1', 'res', 'fpn_')):
+            v = v[:, :, None]
+        out[k] = v
+    return out

@@ -1,0 +1,137 @@
+"""Parity at the REAL shapes of BASELINE.json's configs.
+
+  * configs 3-5 (S-C, one 1 x 3 x 8 x 768 x 1344 clip), R-18 and R-50 FPN3D, fp32 parity mode: every body / FPN blob and the
+    `kps_score` heatmaps (the north-star target: max-abs < 1e-3) against the oracle graph run on the host AT FULL SIZE --
+    the planner picks other tiles / split-K factors here than at the small shapes of test_gpu_model.py;
+  * the benched bf16 mode on the benched clip: error of `kps_score`, arg-max cells, decoded keypoints and the proposal set
+    against the fp32 mode, gated;
+  * configs 1-2: the pure 2D R-50-FPN keypoint R-CNN (reference lib/modeling/FPN.py:114-202, ResNet.py:231-266, frame-by-frame
+    inference lib/core/test.py:212-214) at S-A (1 x 3 x 800 x 1088) and S-B (768 x 1344 frames) against the oracle with T = 1.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.model_util import fpn3d_kps_cfg, fpn2d_kps_cfg, build_product, synthetic_clip, oracle_opts, oracle_weights_2d
+
+pytestmark = pytest.mark.gpu
+
+
+def _max_abs(a, b):
+    return float((torch.from_numpy(a) - b).abs().max())
+
+
+def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_names, five_d):
+    from oracle import proposals as op
+    for n in blob_names:
+        got, ref = ws.FetchBlob(n), net.blobs[n]
+        if not five_d:
+            ref = ref[:, :, 0]
+        assert got.shape == tuple(ref.shape), (n, got.shape, tuple(ref.shape))
+        err, mx = _max_abs(got, ref), float(ref.abs().max())
+        print('%-26s max-abs %.3e (ref max %.2f)' % (n, err, mx))
+        assert err < 1e-3 * max(1.0, mx), (n, err, mx)
+    p2d = net.time_link(pyr)
+    ref_rois, _, _ = net.fpn_rpn(p2d, im_info)
+    rois = ws.FetchBlob('rois')
+    assert rois.shape == ref_rois.shape, (rois.shape, ref_rois.shape)
+    from detectandtrack_amd.utils.precision import set_agreement
+    agree = set_agreement(rois[:, 1:], ref_rois[:, 1:], 0.05)
+    print('rois: %d, %.2f%% of the device rois are in the oracle set (0.05 px)' % (rois.shape[0], 100 * agree))
+    assert agree > 0.95
+    # box head + keypoint head on the DEVICE rois (oracle features, oracle heads)
+    sub = rois[:200]
+    _, per_level, restore = op.distribute(sub, 2, 5)
+    cls_prob, bbox_pred = net.box_head_2mlp(net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2))
+    np.testing.assert_allclose(ws.FetchBlob('cls_prob')[:200], cls_prob, atol=1e-4)
+    np.testing.assert_allclose(ws.FetchBlob('bbox_pred')[:200], bbox_pred, atol=1e-3)
+    kp_rois = rois[:n_kp].copy()
+    ws.FeedBlob('keypoint_rois', kp_rois)
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    _, per_level, restore = op.distribute(kp_rois, 2, 5)
+    ref = net.kps_head_2d(net.roi_feat_fpn(p2d[1:], per_level, restore, 14, 2))
+    assert kps.shape == tuple(ref.shape)
+    err = _max_abs(kps, ref)
+    print('kps_score max-abs %.3e (ref max %.2f) over %d rois' % (err, float(ref.abs().max()), n_kp))
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize('arch', ['18', '50'])
+def test_fp32_forward_at_the_bench_shape_matches_the_oracle(arch):
+    """S-C, fp32: body, FPN, proposals, box head and kps_score (< 1e-3 max-abs) at 1 x 3 x 8 x 768 x 1344."""
+    from oracle.net3d import Net
+    T, H, W = 8, 768, 1344
+    model, ws, weights = build_product(fpn3d_kps_cfg(arch, T=T, dtype='fp32', pre=1000, post=1000))
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    net = Net(weights, oracle_opts(arch, T, 3, 'slice-center', 1000, 1000))
+    net.body(torch.from_numpy(data))
+    pyr = net.fpn()
+    names = ['pool1'] + sorted(b for b in ws.Blobs() if b.endswith('_sum') and b.startswith(('res', 'fpn_res')))
+    if arch == '50':      # 16 bottleneck outputs of up to 528 MB each: the last block of every stage + the pyramid
+        names = ['pool1', 'res2_2_sum', 'res3_3_sum', 'res4_5_sum', 'res5_2_sum'] + [n for n in names if n.startswith('fpn_')]
+    _check_against_oracle(model, ws, weights, net, pyr, im_info, 12, names, True)
+
+
+def test_bf16_bench_configuration_error_against_fp32():
+    """The BENCHED arithmetic (bf16 operands, fp32 accumulation) on the benched clip against the fp32 path of the same model:
+    what `bench.py` prints as `accuracy_vs_fp32`, gated here."""
+    from detectandtrack_amd.utils import precision
+    T, H, W = 8, 768, 1344
+    model, ws, _ = build_product(fpn3d_kps_cfg('18', T=T, dtype='bf16', pre=1000, post=1000))
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
+    rep = precision.bf16_vs_fp32(model, ws, data, im_info, n_kp=100)
+    print(rep)
+    assert rep['rois_bf16'] == rep['rois_fp32'] == 1000
+    assert rep['rois_within_1px'] > 0.80, rep
+    assert rep['kps_score_max_abs_err'] < 0.05 * rep['kps_score_ref_max_abs'], rep
+    assert rep['kps_argmax_cell_identical'] > 0.90, rep
+    assert rep['keypoints_within_1px'] > 0.95, rep
+
+
+@pytest.mark.parametrize('H,W', [(800, 1088), (768, 1344)], ids=['S-A', 'S-B'])
+def test_2d_r50_fpn_matches_the_oracle(H, W):
+    """BASELINE configs 1-2: the pure 2D R-50-FPN keypoint R-CNN (MODEL.VIDEO_ON False, FPN.add_fpn_ResNet50_conv5_body), one
+    frame per forward as the reference runs it, fp32 parity mode vs the oracle graph with T = 1 / kT = 1."""
+    from oracle.net3d import Net
+    model, ws, weights = build_product(fpn2d_kps_cfg('50', dtype='fp32', pre=1000, post=1000))
+    data = synthetic_clip(1, H, W)[:, :, 0]                     # 1 x 3 x H x W, the 2D reference layout
+    im_info = np.array([[H, W, 800.0 / 600.0]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    assert ws.FetchBlob('fpn_res2_2_sum').shape == (1, 256, H // 4, W // 4)        # 4-D blobs at the boundary
+    assert ws.FetchBlob('fpn_res5_2_sum_subsampled_2x').shape == (1, 256, H // 64, W // 64)
+    net = Net(oracle_weights_2d(weights), oracle_opts('50', 1, 1, 'slice-center', 1000, 1000))
+    net.body(torch.from_numpy(data[:, :, None]))
+    pyr = net.fpn()
+    names = ['pool1', 'res2_2_sum', 'res3_3_sum', 'res4_5_sum', 'res5_2_sum', 'fpn_res5_2_sum', 'fpn_res4_5_sum',
+             'fpn_res3_3_sum', 'fpn_res2_2_sum']
+    _check_against_oracle(model, ws, weights, net, pyr, im_info, 12, names, False)
+
+
+def test_2d_r50_fpn_bf16_frames_run_through_the_engine_surface():
+    """Config 2 (S-B): eight PoseTrack-sized frames, one at a time through im_detect_all (lib/core/test.py:897-957) in the
+    benched bf16 mode; every frame yields boxes and 4 x 17 keypoint rows inside the frame."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.config import cfg
+    model, ws, _ = build_product(fpn2d_kps_cfg('50', dtype='bf16', pre=1000, post=1000))
+    cfg.TEST.SCALES = (800,)
+    cfg.TEST.MAX_SIZE = 1333
+    cfg.TEST.SCORE_THRESH = 0.0
+    rs = np.random.RandomState(0)
+    for _ in range(2):
+        frame = rs.randint(0, 255, (720, 1280, 3)).astype(np.uint8)
+        cls_boxes, _, cls_keyps = engine.im_detect_all(model, [frame], None)
+        assert ws.blobs['data'].t.shape == (1, 3, 768, 1344)
+        n = cls_boxes[1].shape[0]
+        assert 0 < n <= cfg.TEST.DETECTIONS_PER_IM and cls_boxes[1].shape[1] == 5
+        assert len(cls_keyps[1]) == n and cls_keyps[1][0].shape == (4, 17)
+        k = np.stack(cls_keyps[1])
+        assert np.isfinite(k).all() and k[:, 0].min() >= -1 and k[:, 0].max() <= 1281 and k[:, 1].max() <= 721
