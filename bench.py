@@ -183,7 +183,7 @@ class ClipPipeline(object):
         torch.cuda.synchronize()
 
 
-def _oracle_forward(net, data, im_info, n_box, n_kp):
+def cpu_oracle_forward(net, data, im_info, n_box, n_kp):
     from oracle import proposals as op
     net.body(data)
     p2d = net.time_link(net.fpn())
@@ -213,7 +213,7 @@ def cpu_baseline(arch, T, H, W, two_d, frames_per_step, seconds_budget=25.0):
                     post_nms_topn=1000)
     n, t0 = 0, time.time()
     while True:
-        _oracle_forward(Net(weights, opts), data, im_info, 1000, 100)
+        cpu_oracle_forward(Net(weights, opts), data, im_info, 1000, 100)
         n += 1
         el = time.time() - t0
         if el > seconds_budget or n >= 16:
