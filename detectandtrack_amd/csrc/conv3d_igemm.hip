@@ -99,7 +99,16 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + ((
 // TPS = spatial taps per step: a step costs ~1 us of fixed work (barrier, weight-DMA issue, table look-ups, LDS read
 // latency) whatever the tile, so thin layers (64 -> 64 channels: 8 MFMAs per wave and tap) run 3 taps per step from a
 // 3 x 8 KB weight stage; wide tiles keep 1 tap per step (their weight stages would not leave room for 2 blocks per CU).
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1>
+//
+// WD = 1 ("weights direct", the BN = 128 variants): the weight operand never touches LDS.  The packed weights are stored in
+// MFMA A-fragment order -- per (tap, 64-channel chunk, 32-row block) one 4-KiB image [k-slice][lane][16 B] -- so a wave fetches
+// the fragment of (row block, k-slice) with ONE fully coalesced 1-KiB global_load_dwordx4, straight into the registers the
+// MFMA reads.  Each fragment register is re-loaded for the NEXT tap right after the MFMAs that consumed it, so the loads have a
+// whole tap (~1000 cycles) to land.  What this removes from a tap step: the 4 LDS-DMA pieces per wave of the weight tile
+// (their ISSUE was the largest non-MFMA cost of a step), the 8 ds_read_b128 of the A fragments, the
+// 32 KB weight stage and -- because nothing a tap needs is written by another wave any more -- the per-tap barrier: the block
+// synchronises only around a patch reload (every KH*KW taps).
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
     constexpr int CK = Mma<DT>::CK;
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     unsigned long long clk_c0 = 0, clk_r0 = 0;
     if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wbuf = smem;                             // 2 stages x TPS taps x BN x 128 B
-    char* patch = smem + 2 * TPS * BN * ROWB;      // PH*PW x 128 B
+    char* wbuf = smem;                                       // 2 stages x TPS taps x BN x 128 B (WD: no weight stage)
+    char* patch = smem + (WD ? 0 : 2 * TPS * BN * ROWB);     // PH*PW x 128 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,6 +235,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a_off[i][ks] = swz(wave_n * WN + i * 32 + (lane & 31), ks * 2 + khalf);
+    // WD: this wave's A fragments in global memory: 4 KiB per (tap, channel chunk, 32-row block), this lane's 16 B inside it
+    static_assert(!WD || TPS == 1, "direct weights: one tap per step");
+    const size_t wd_cc_stride = (size_t)(p.Cout_pad >> 5) * 4096;
+    const char* const wd_lane = p.w + (size_t)((n0 + wave_n * WN) >> 5) * 4096 + lane * 16;
+#define WD_PTR(KT_, CC_, TI_) (wd_lane + ((size_t)((KT_) * ntap + p.tab_tap[(TI_)]) * p.n_cchunks + (CC_)) * wd_cc_stride)
     if (total > 0) {
         // temporal taps are visited in order of the INPUT frame index mod KT, not of kt: the blocks of output frames
         // t-1, t, t+1 (queue neighbours on one XCD) then stage the same input frame during the same third of their
@@ -235,7 +249,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
         if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
         int kt = kt_lo + pi_lo / p.n_cchunks + kshift, cc = pi_lo % p.n_cchunks, ti = 0;
         if (kt >= kt_hi_x) kt -= n_kt;
-        W_PREFETCH(kt, cc, 0, 0);
+        uint4 wa[MT][4];      // WD: the A fragments of the current tap (k-slice ks re-loaded for the next tap after its MFMAs)
+        if (WD) {
+            const char* w0 = WD_PTR(kt, cc, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wa[i][ks] = *(const uint4*)(w0 + i * 4096 + ks * 1024);
+        } else {
+            W_PREFETCH(kt, cc, 0, 0);
+        }
         const int nchunks = (npatch_items + 63) >> 6;    // 1-KiB LDS-DMA pieces (8 patch rows each)
 #ifdef DAT_CONV_TRACE
         unsigned long long tr_reload = 0, tr_wait = 0, tr_bar = 0, tr_issue = 0, tr_mma = 0, tr_t;
@@ -271,9 +294,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 }
             }
             TR_ADD(tr_reload);
-            W_COMMIT();
-            TR_ADD(tr_wait);
-            __syncthreads();
+            if (!WD || ((p.tab_new >> ti) & 1u)) {   // WD: only a patch reload needs the block to meet
+                W_COMMIT();
+                TR_ADD(tr_wait);
+                __syncthreads();
+            }
             TR_ADD(tr_bar);
             // advance to the next (kt, cc, table entry) and prefetch its weight tile (lands during this step's MFMAs)
             int nti = ti + TPS, ncc = cc, nkt = kt;
@@ -282,7 +307,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                 if (++ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
             }
             // (issuing the pieces between the k-slices' MFMAs instead measured 7 % slower: a DMA issue stalls the MFMA stream)
-            if (step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, nti, (step + 1) & 1);
+            if (!WD && step + 1 < total && !((p.ablate & 2) && step > 1)) W_PREFETCH(nkt, ncc, nti, (step + 1) & 1);
+            const char* const wnext = (step + 1 < total) ? WD_PTR(nkt, ncc, nti) : WD_PTR(kt, cc, ti);
 
             TR_ADD(tr_issue);
             // ---- compute the step's taps: 4 k-slices of 16 B per row each, fragments double-buffered in registers ----
@@ -303,23 +329,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                     bx[j] = g >> 1;
                 }
                 uint4 a[2][MT], b[2][PT];
+                if (!WD) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
+                    for (int i = 0; i < MT; ++i) a[0][i] = *(const uint4*)(wb + a_off[i][0]);
+                }
 #pragma unroll
                 for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(bp[j] + (bx[j] << 5));
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int cur = ks & 1, nxt = cur ^ 1;
                     if (ks < 3) {
+                        if (!WD) {
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
+                            for (int i = 0; i < MT; ++i) a[nxt][i] = *(const uint4*)(wb + a_off[i][ks + 1]);
+                        }
 #pragma unroll
                         for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(bp[j] + (((ks + 1) ^ bx[j]) << 5));
                     }
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < PT; ++j) Mma<DT>::step(a[cur][i], b[cur][j], acc[i][j]);
+                        for (int j = 0; j < PT; ++j) Mma<DT>::step(WD ? wa[i][ks] : a[cur][i], b[cur][j], acc[i][j]);
+                    if (WD && !((p.ablate & 2) && step > 1)) {   // this k-slice's fragments of the NEXT tap: a whole tap to land
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) wa[i][ks] = *(const uint4*)(wnext + i * 4096 + ks * 1024);
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -336,6 +370,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
         tr_k1 = __builtin_amdgcn_s_memtime();
 #endif
     }
+#undef WD_PTR
 #undef W_PREFETCH
 #undef W_COMMIT
 #undef W_DMA
@@ -513,9 +548,12 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: fp32 [Cout_real, Cin_real, KT, KH, KW] -> [tap][Cout_pad][Cin] in dtype, zero padded
+// frag = 1: MFMA A-fragment order of the WD kernel variants: [tap][channel chunk of 128 B][32-row block][k-slice][lane][16 B],
+// lane = k-half * 32 + row, the 16-B slot (2 * k-slice + k-half) of the row's 128-B chunk (what swz() addresses in the LDS path)
 template <int DT>
 __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real, int Cin_real,
-                                    int ntap, int Cout_pad, int Cin) {
+                                    int ntap, int Cout_pad, int Cin, int frag) {
+    constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;   // channels per 128-B chunk, elements per 16-B slot
     const size_t total = (size_t)ntap * Cout_pad * Cin;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = i % Cin;
@@ -523,7 +561,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
         const int tap = i / ((size_t)Cin * Cout_pad);
         float v = 0.f;
         if (co < Cout_real && ci < Cin_real) v = w[((size_t)co * Cin_real + ci) * ntap + tap];
-        ElemOf<DT>::st(out, i, v);
+        size_t dst = i;
+        if (frag) {
+            const int cc = ci / CK, cl = ci % CK, slot = cl / EPS, e = cl % EPS;
+            const int lane = (slot & 1) * 32 + (co & 31);
+            dst = (((((size_t)tap * (Cin / CK) + cc) * (Cout_pad >> 5) + (co >> 5)) * 4 + (slot >> 1)) * 64 + lane) * EPS + e;
+        }
+        ElemOf<DT>::st(out, dst, v);
     }
 }
 
@@ -613,7 +657,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
     return best;
 }
 
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1>
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0>
 int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
     const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
     p.th_log2 = tc.th_log2;
@@ -669,12 +713,12 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
                 "conv3d: one output frame of %dx%dx%d exceeds the 2-GB range of the epilogue's 32-bit offsets", p.Ho, p.Wo, p.out_cs);
     p.nblocks = (unsigned)nblocks;
     DAT_ENFORCE(ctx, p.tab_n % TPS == 0 && (TPS == 1 || p.tab_new == 1u), "conv3d: %d taps per step need one stride plane of a multiple of %d taps", TPS, TPS);
-    size_t lds = (size_t)2 * TPS * BN * ROWB + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
+    size_t lds = (WD ? 0 : (size_t)2 * TPS * BN * ROWB) + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
     if (lds < 4 * 32 * (64 * 4 + 16)) lds = 4 * 32 * (64 * 4 + 16);                                   // epilogue staging slices
     lds += ctx->dbg_lds_pad;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
-    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS>;
+    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD>;
     {
         const int rc = dat_ensure_lds(ctx, (const void*)kern, 160 * 1024);
         if (rc != DAT_OK) return rc;
@@ -712,6 +756,9 @@ int cout_pad_of(const dat_conv_desc* d) {
     return (d->Cout + bn - 1) / bn * bn;
 }
 
+// packed-weight layout of a layer: the 128-channel tile variants read A fragments straight from global memory (WD)
+bool weights_direct(const dat_ctx* ctx, const dat_conv_desc* d) { return ctx->dbg_wd && d->Cout > 64; }
+
 }  // namespace
 
 extern "C" {
@@ -742,12 +789,13 @@ int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, 
     const int cp = cout_pad_of(d);
     const size_t total = (size_t)ntap * cp * d->Cin;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    const int frag = weights_direct(ctx, d) ? 1 : 0;
     if (d->dtype == DAT_BF16)
         hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin);
+                           Cout_real, Cin_real, ntap, cp, d->Cin, frag);
     else
         hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin);
+                           Cout_real, Cin_real, ntap, cp, d->Cin, frag);
     DAT_CHECK_LAUNCH(ctx, "pack_weights");
     return DAT_OK;
 }
@@ -840,6 +888,11 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     if (thin3) {
         tag += 3;   // (dtype digit + 3: the 3-taps-per-step variant)
         rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 64, 128, 1, 3>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 64, 128, 1, 3>(ctx, st, p, 7, ksplit);
+    } else if (!small_n && weights_direct(ctx, d)) {   // 128-channel tiles, weights straight into the MFMA registers
+        if (d->dtype == DAT_BF16)
+            rc = big ? launch_conv<DAT_BF16, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit);
+        else
+            rc = big ? launch_conv<DAT_F32, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_F32, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit);
     } else if (d->dtype == DAT_BF16) {
         if (big)
             rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8, ksplit);
