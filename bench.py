@@ -6,9 +6,10 @@
 
 A "step" = one pass of the hot path over one synthetic clip that is ALREADY RESIDENT IN HBM:
 `model.net` (ResNet3D body + FPN3D + FPN RPN + on-device proposals/NMS + RoIAlign + 2-MLP box head), the
-reference's host glue between the nets (core/test.py:750-806: score threshold, per-class NMS on the device,
-top-100) and `model.keypoint_net` (RoIAlign + 8 convs + deconv + bilinear up) up to the `kps_score` blob.
-Image decoding/resizing and the host heatmap->keypoint decoding ("next") are outside the step.
+reference's glue between the nets (core/test.py:215-252, 750-806: box decode, score threshold, per-class NMS, top-100 -- on the
+device, `dat_box_results`), `model.keypoint_net` (RoIAlign + 8 convs + deconv + bilinear up) and the heatmap decode; the step ends
+with the detections' boxes and 4 x 17 keypoint rows on the host (ONE device -> host read-back per clip).  Image decoding/resizing
+is outside the step.
 
 Multi-GPU: clips are independent units — every rank processes its own clip stream, no
 data-path collective; the only collectives are the barrier + MAX-reduce of the timing. scaling = weak.
@@ -134,13 +135,29 @@ def stage_net(model, ws, data_dev, im_info):
     ws.RunNet(model.net.name)
 
 
-def stage_heads(model, ws, im_info, im_shape):
-    """Stage B: the reference's host glue (core/test.py:215-252, 750-806; NMS on the device) + `keypoint_net` + the
-    heatmap decode (on the device): the step ends with the per-detection 4 x 17 keypoint rows on the host."""
+def stage_heads_enqueue(model, ws, im_info, im_shape):
+    """Stage B, device part (no host synchronisation): the reference's glue between the nets (core/test.py:215-252, 750-806) as
+    dat_box_results, `keypoint_net` on the device-resident rois, the heatmap decode -- all enqueued behind `model.net`."""
     from detectandtrack_amd.core import test as engine
     from detectandtrack_amd import workspace as wsmod
     prev, wsmod._GLOBAL = wsmod._GLOBAL, ws          # the engine functions talk to the global workspace
     try:
+        return engine.enqueue_results_on_device(model, im_shape, float(im_info[0, 2]))
+    finally:
+        wsmod._GLOBAL = prev
+
+
+def stage_heads(model, ws, im_info, im_shape, dev=None):
+    """Stage B, the read-back: the step ends with the per-detection boxes and 4 x 17 keypoint rows on the host.  Falls back to the
+    reference's host glue (device NMS) when the device path is off or hit an exact-tie overflow."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd import workspace as wsmod
+    prev, wsmod._GLOBAL = wsmod._GLOBAL, ws
+    try:
+        if dev is not None:
+            res = engine.read_results_from_device(*dev)
+            if res is not None:
+                return sum(len(b) for b in res[0][1:])
         scores, boxes, _ = engine._read_bbox_outputs([np.zeros(im_shape, np.uint8)], np.array([im_info[0, 2]]))
         scores, boxes, cls_boxes = engine.box_results_with_nms_and_limit(scores, boxes)
         n_det = boxes.shape[0]
@@ -162,6 +179,8 @@ class ClipPipeline(object):
         self.pending = []
         self.n_det = 0
         self.i = 0
+        from detectandtrack_amd.core import test as engine
+        self.device_glue = engine.device_results_supported()
 
     def submit(self, data_dev, im_info, im_shape):
         w, st = self.slots[self.i % self.depth]
@@ -170,12 +189,13 @@ class ClipPipeline(object):
             self._finish(self.pending.pop(0))
         with torch.cuda.stream(st):
             stage_net(self.model, w, data_dev, im_info)
-        self.pending.append((w, st, im_info, im_shape))
+            dev = stage_heads_enqueue(self.model, w, im_info, im_shape) if self.device_glue else None
+        self.pending.append((w, st, im_info, im_shape, dev))
 
     def _finish(self, item):
-        w, st, im_info, im_shape = item
+        w, st, im_info, im_shape, dev = item
         with torch.cuda.stream(st):
-            self.n_det = stage_heads(self.model, w, im_info, im_shape)
+            self.n_det = stage_heads(self.model, w, im_info, im_shape, dev)
 
     def drain(self):
         while self.pending:

@@ -241,7 +241,10 @@ def _build_defaults():
     # FRAME_TRUNK_CACHE (opt-in, frames kept): conv1 / pool1 / res2 have no temporal extent (ResNet3D.py:258-275, time kernel 1),
     # so their output for a FRAME does not depend on the clip around it; sliding-window inference (one clip per key frame,
     # stride 1, utils/video.py:149-201) re-uses it instead of recomputing (and re-uploading) T-1 of T frames per clip
-    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0})
+    # DEVICE_BOX_RESULTS: the glue between model.net and model.keypoint_net (core/test.py:215-252 box decode, :750-806 score
+    # threshold / per-class NMS / DETECTIONS_PER_IM) runs on the GPU -- no host synchronisation inside a clip; False = the host path
+    c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
+                      'DEVICE_BOX_RESULTS': True})
     return c
 
 

@@ -64,7 +64,7 @@ def _get_blobs(im, rois, num_frames=None):
     return blobs, im_scale_factors
 
 
-def im_detect_bbox(model, im, boxes=None, frame_ids=None):
+def im_detect_bbox(model, im, boxes=None, frame_ids=None, fetch=True):
     """(:158-252) returns scores (R x K), pred_boxes (R x 4TK), im_scales.
 
     frame_ids (one hashable id per frame of the clip, e.g. (video, frame index)) with cfg.HIP.FRAME_TRUNK_CACHE > 0: only the
@@ -86,18 +86,19 @@ def im_detect_bbox(model, im, boxes=None, frame_ids=None):
             workspace.FeedBlob(k, v)
         ws.trunk_request = (list(frame_ids), new_ids)
         workspace.RunNet(model.net.Proto().name)
-        return _read_bbox_outputs(im, im_scales)
+        return _read_bbox_outputs(im, im_scales) if fetch else im_scales
     inputs, im_scales = _get_blobs(im, boxes)
     for k, v in inputs.items():
         workspace.FeedBlob(k, v)
     workspace.RunNet(model.net.Proto().name)
-    return _read_bbox_outputs(im, im_scales)
+    return _read_bbox_outputs(im, im_scales) if fetch else im_scales    # fetch=False: nothing read back (device post-processing)
 
 
 def _read_bbox_outputs(im, im_scales):
     assert cfg.MODEL.FASTER_RCNN and len(im_scales) == 1, 'Only single-image / single-scale batch implemented'
     rois = workspace.FetchBlob('rois')
-    boxes = rois[:, 1:] / im_scales[0]
+    # float32 / float32(scale): what the reference environment's NumPy 1.14 value-based casting computes (NumPy 2 would promote)
+    boxes = rois[:, 1:] / np.float32(im_scales[0])
     scores = workspace.FetchBlob('cls_prob')
     scores = scores.reshape([-1, scores.shape[-1]])
     time_dim = boxes.shape[-1] // 4
@@ -178,6 +179,65 @@ def keypoint_results_on_device(model, cls_boxes, ref_boxes, im_scales):
     return cls_keyps
 
 
+def device_results_supported():
+    """The device post-processing covers the configuration every shipped config uses: hard NMS, no box voting, FASTER_RCNN."""
+    return bool(cfg.HIP.DEVICE_BOX_RESULTS and cfg.MODEL.FASTER_RCNN and cfg.TEST.BBOX_REG and not cfg.TEST.SOFT_NMS.ENABLED and
+                not cfg.TEST.BBOX_VOTE.ENABLED and not cfg.TEST.SVM and not cfg.KRCNN.NMS_OKS and
+                (cfg.HIP.DEVICE_KPS_DECODE or not cfg.MODEL.KEYPOINTS_ON))
+
+
+def enqueue_results_on_device(model, im_shape, im_scale):
+    """Everything between `model.net` and the final read-back, enqueued on the current HIP stream WITHOUT a host sync:
+    dat_box_results (test.py:215-252 decode + clip, :750-806 score threshold / per-class NMS / DETECTIONS_PER_IM, :78-123 keypoint
+    rois), then -- with MODEL.KEYPOINTS_ON -- `model.keypoint_net` on the device-resident rois and the heatmap decode
+    (:584-627, :865-894).  Returns device tensors (dets [cap, 4T+2], n_out int32[2], keypoint rows [cap, 4, 17T] | None)."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    ws = workspace.GlobalWorkspace()
+    rois = ws.blobs['rois']
+    assert rois.kind == 'rois' and rois.count is not None, 'device post-processing expects the on-device proposal blob'
+    prob = workspace.blob_as_matrix(ws.blobs['cls_prob'])
+    pred = workspace.blob_as_matrix(ws.blobs['bbox_pred'])
+    cols = int(rois.t.shape[1])
+    T = (cols - 1) // 4
+    D = int(cfg.TEST.DETECTIONS_PER_IM)
+    out_cap = D if D > 0 else int(rois.t.shape[0])
+    dets, kp_rois, n_out = ops.box_results(
+        rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, float(im_scale), im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
+        float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,
+        cls_agnostic=cfg.MODEL.CLS_AGNOSTIC_BBOX_REG)
+    xy = None
+    if cfg.MODEL.KEYPOINTS_ON:
+        b = workspace.Blob(kp_rois, 'mat')
+        b.count = n_out[0:1]
+        ws.blobs['keypoint_rois'] = b
+        workspace.RunNet(model.keypoint_net.Proto().name)
+        heat = ws.blobs['kps_score'].t                       # fp32 [cap, 17 T, M, M] on the device
+        assert heat.shape[1] == cfg.KRCNN.NUM_KEYPOINTS * T, 'Heatmaps must be 17xT'
+        xy = ops.heatmaps_to_keypoints(heat.contiguous(), dets[:, :4 * T].contiguous(), T, cfg.KRCNN.NUM_KEYPOINTS,
+                                       cfg.KRCNN.INFERENCE_MIN_SIZE)
+    return dets, n_out, xy
+
+
+def read_results_from_device(dets, n_out, xy):
+    """The ONE device -> host transfer of a clip: (cls_boxes, cls_keyps) in the reference's layout, or None when exact score ties
+    at the DETECTIONS_PER_IM cut keep more rows than the device buffers hold (the caller then takes the host path)."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    n = n_out.cpu().numpy()
+    if int(n[1]) > int(n[0]):
+        return None
+    k = int(n[0])
+    d = dets[:k].cpu().numpy()
+    cls_boxes = [[] for _ in range(num_classes)]
+    cls_keyps = [[] for _ in range(num_classes)] if xy is not None else None
+    keyps = xy[:k].cpu().numpy() if xy is not None else None
+    for j in range(1, num_classes):
+        sel = np.where(d[:, -1] == j)[0]
+        cls_boxes[j] = d[sel, :-1]
+        if keyps is not None and j == keypoint_utils.get_person_class_index():
+            cls_keyps[j] = [keyps[i] for i in sel]
+    return cls_boxes, cls_keyps
+
+
 def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes):
     """(:865-894) per-frame heatmap decoding, concatenated along the keypoint axis for tubes."""
     num_classes = cfg.MODEL.NUM_CLASSES
@@ -203,9 +263,23 @@ def im_detect_all(model, im, box_proposals, timers=None, frame_ids=None):
     if cfg.TEST.COMPETITION_MODE:
         raise NotImplementedError('test-time augmentation (COMPETITION_MODE) is out of the hot-path scope; the '
                                   'shipped configs set TEST.COMPETITION_MODE False')
-    timers['im_detect_bbox'].tic()
-    scores, boxes, im_scales = im_detect_bbox(model, im, box_proposals, frame_ids=frame_ids)
-    timers['im_detect_bbox'].toc()
+    if device_results_supported() and box_proposals is None and not cfg.MODEL.MASK_ON:
+        # the whole clip is enqueued without a host synchronisation; one read-back at the end
+        timers['im_detect_bbox'].tic()
+        im_scales = im_detect_bbox(model, im, None, frame_ids=frame_ids, fetch=False)
+        dev = enqueue_results_on_device(model, im[0].shape, im_scales[0])
+        res = read_results_from_device(*dev)
+        timers['im_detect_bbox'].toc()
+        if res is not None:
+            cls_boxes, cls_keyps = res
+            if cfg.MODEL.KEYPOINTS_ON and sum(len(b) for b in cls_boxes[1:]) == 0:
+                cls_keyps = None
+            return cls_boxes, None, cls_keyps
+        scores, boxes, im_scales = _read_bbox_outputs(im, im_scales)      # ties at the cut: the reference's host path
+    else:
+        timers['im_detect_bbox'].tic()
+        scores, boxes, im_scales = im_detect_bbox(model, im, box_proposals, frame_ids=frame_ids)
+        timers['im_detect_bbox'].toc()
     timers['misc_bbox'].tic()
     scores, boxes, cls_boxes = box_results_with_nms_and_limit(scores, boxes)
     timers['misc_bbox'].toc()

@@ -1,0 +1,254 @@
+// Detection post-processing on the device (gfx950): the reference's host glue between `model.net` and `model.keypoint_net`.
+//
+// Replaces, without a host round trip,
+//   lib/core/test.py:215-252  im_detect_bbox tail: rois / im_scale, bbox_transform with MODEL.BBOX_REG_WEIGHTS
+//                             (lib/utils/boxes.py:141-202), clip_tiled_boxes to the image (:243-253);
+//   lib/core/test.py:750-806  box_results_with_nms_and_limit: per class score > TEST.SCORE_THRESH, NMS (TEST.NMS),
+//                             then TEST.DETECTIONS_PER_IM over all classes (scores >= the D-th best);
+//   lib/core/test.py:78-123   _get_rois_blob: the kept boxes * im_scale with a leading level column = `keypoint_rois`.
+// The reference fetches rois / cls_prob / bbox_pred to the host (a device sync per clip), loops over classes in NumPy, calls
+// the NMS, and feeds `keypoint_rois` back.  Here the chain is: one select+decode kernel and one NMS per foreground class, one
+// limit+emit kernel; the keypoint net then runs on the device-resident `keypoint_rois`.
+//
+// Arithmetic is fp32 in NumPy's operation order (this file is compiled with -ffp-contract=off): `rois / im_scale` is a float32
+// division by float32(scale) (value-based casting of the reference's NumPy 1.14, test.py:216), `boxes * im_scale` for the
+// keypoint rois is formed in float64 and rounded once (test.py:98,121); exp is evaluated in double and rounded once
+// (NumPy's float32 exp is within 1 ulp of that).
+#include "dat_common.h"
+#include "nms_internal.h"
+
+namespace {
+
+constexpr int DET_MAX_T = 16;
+constexpr int SEL_THREADS = 1024;
+
+struct DetParams {
+    const float* rois;      // [roi_cap, 4T+1]
+    const int* n_rois;      // device count
+    const float* prob;      // [R, prob_ld]
+    const float* pred;      // [R, pred_ld]
+    int prob_ld, pred_ld, roi_cap, T, K, cls_agnostic;
+    float wx, wy, ww, wh, xform_clip, score_thresh;
+    double im_scale;
+    float im_h, im_w;       // the UNSCALED image (clip bounds, test.py:229)
+};
+
+// one tube of class j for roi r: boxes.py:141-183 per frame, then clip (:243-253)
+__device__ void decode_tube(const DetParams& p, int r, int j, float* out) {
+    const int cols = 4 * p.T + 1;
+    const int dcls = p.cls_agnostic ? (p.K - 1) : j;       // CLS_AGNOSTIC_BBOX_REG: the last 4T columns (test.py:224-225)
+    for (int t = 0; t < p.T; ++t) {
+        const float* rb = p.rois + (size_t)r * cols + 1 + 4 * t;
+        // `rois[:, 1:] / im_scales[0]`: float32 / float32(scale) under the reference environment's NumPy 1.14 casting
+        const float sc = (float)p.im_scale;
+        const float x1 = rb[0] / sc, y1 = rb[1] / sc, x2 = rb[2] / sc, y2 = rb[3] / sc;
+        const float* d = p.pred + (size_t)r * p.pred_ld + ((size_t)dcls * p.T + t) * 4;
+        const float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
+        const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
+        const float dx = d[0] / p.wx, dy = d[1] / p.wy;
+        const float dw = fminf(d[2] / p.ww, p.xform_clip), dh = fminf(d[3] / p.wh, p.xform_clip);
+        const float pcx = dx * w + cx, pcy = dy * h + cy;
+        const float pw = (float)exp((double)dw) * w, ph = (float)exp((double)dh) * h;
+        float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
+        ox1 = fmaxf(fminf(ox1, p.im_w - 1.f), 0.f);
+        oy1 = fmaxf(fminf(oy1, p.im_h - 1.f), 0.f);
+        ox2 = fmaxf(fminf(ox2, p.im_w - 1.f), 0.f);
+        oy2 = fmaxf(fminf(oy2, p.im_h - 1.f), 0.f);
+        out[4 * t + 0] = ox1; out[4 * t + 1] = oy1; out[4 * t + 2] = ox2; out[4 * t + 3] = oy2;
+    }
+}
+
+// block-wide exclusive scan of one value per thread (SEL_THREADS threads); returns the exclusive prefix, *total = sum
+__device__ unsigned block_scan(unsigned v, unsigned* scan, unsigned* total) {
+    const int tid = threadIdx.x;
+    scan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < SEL_THREADS; off <<= 1) {
+        const unsigned a = (tid >= off) ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += a;
+        __syncthreads();
+    }
+    const unsigned incl = scan[tid];
+    *total = scan[SEL_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+// ---- per class: inds = where(scores[:, j] > thresh); dets_j = [decoded boxes[inds], scores[inds]]  (test.py:759-762), in roi order
+__global__ __launch_bounds__(SEL_THREADS) void det_select_kernel(const DetParams p, int j, float* dets, int* n_sel) {
+    __shared__ unsigned scan[SEL_THREADS];
+    const int n = min(*p.n_rois, p.roi_cap);
+    const int cols = 4 * p.T + 1;
+    const int per = (n + SEL_THREADS - 1) / SEL_THREADS;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    unsigned local = 0;
+    for (int r = lo; r < hi; ++r) local += p.prob[(size_t)r * p.prob_ld + j] > p.score_thresh ? 1u : 0u;
+    unsigned total;
+    unsigned pos = block_scan(local, scan, &total);
+    float tube[4 * DET_MAX_T];
+    for (int r = lo; r < hi; ++r) {
+        const float sc = p.prob[(size_t)r * p.prob_ld + j];
+        if (sc > p.score_thresh) {
+            decode_tube(p, r, j, tube);
+            float* o = dets + (size_t)pos * cols;
+            for (int c = 0; c < 4 * p.T; ++c) o[c] = tube[c];
+            o[4 * p.T] = sc;
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 0) *n_sel = (int)total;
+}
+
+struct EmitParams {
+    const float* dets;     // [K-1][cap][4T+1] selected dets per foreground class
+    const int* keep;       // [K-1][cap] kept rows (NMS output order)
+    const int* n_keep;     // [K-1]
+    int K, T, cap, D, out_cap;
+    double im_scale;
+    float* dets_out;       // [out_cap][4T+2]: box, score, class
+    float* kp_rois;        // [out_cap][4T+1]: level 0, box * im_scale
+    int* n_out;            // [2]: rows written (<= out_cap), rows the limit rule keeps
+};
+
+// ---- DETECTIONS_PER_IM (test.py:790-800): thresh = the D-th best kept score over all classes, keep score >= thresh; then the
+// class-major stack (test.py:802) and its keypoint rois.  One block; the D-th best score comes from an exact radix select on the
+// float bits (scores are probabilities > 0: the bit pattern is monotonic).
+__global__ __launch_bounds__(SEL_THREADS) void det_limit_emit_kernel(const EmitParams p) {
+    __shared__ unsigned scan[SEL_THREADS];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    const int tid = threadIdx.x;
+    const int cols = 4 * p.T + 1;
+    const int nc = p.K - 1;
+    int total = 0;
+    for (int c = 0; c < nc; ++c) total += p.n_keep[c];
+    unsigned thr_bits = 0u;      // keep everything
+    if (p.D > 0 && total > p.D) {
+        if (tid == 0) { s_prefix = 0u; s_need = (unsigned)p.D; }
+        __syncthreads();
+        for (int d = 3; d >= 0; --d) {
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const int shift = 8 * d;
+            const unsigned himask = d == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int c = 0; c < nc; ++c) {
+                const int m = p.n_keep[c];
+                for (int i = tid; i < m; i += SEL_THREADS) {
+                    const int row = p.keep[(size_t)c * p.cap + i];
+                    const unsigned v = __float_as_uint(p.dets[((size_t)c * p.cap + row) * cols + 4 * p.T]);
+                    if ((v & himask) == (prefix & himask)) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = s_need, cum = 0;
+                int dig = 255;
+                for (; dig >= 0; --dig) {
+                    if (cum + hist[dig] >= rem) break;
+                    cum += hist[dig];
+                }
+                s_need = rem - cum;
+                s_prefix = prefix | ((unsigned)dig << shift);
+            }
+            __syncthreads();
+        }
+        thr_bits = s_prefix;     // the D-th largest score
+    }
+    // ordered emit: classes in order, kept rows in NMS output order
+    unsigned base = 0;
+    for (int c = 0; c < nc; ++c) {
+        const int m = p.n_keep[c];
+        const int per = (m + SEL_THREADS - 1) / SEL_THREADS;
+        const int lo = tid * per, hi = min(m, lo + per);
+        unsigned local = 0;
+        for (int i = lo; i < hi; ++i) {
+            const int row = p.keep[(size_t)c * p.cap + i];
+            local += __float_as_uint(p.dets[((size_t)c * p.cap + row) * cols + 4 * p.T]) >= thr_bits ? 1u : 0u;
+        }
+        unsigned tot;
+        unsigned pos = base + block_scan(local, scan, &tot);
+        for (int i = lo; i < hi; ++i) {
+            const int row = p.keep[(size_t)c * p.cap + i];
+            const float* src = p.dets + ((size_t)c * p.cap + row) * cols;
+            if (__float_as_uint(src[4 * p.T]) >= thr_bits) {
+                if ((int)pos < p.out_cap) {
+                    float* o = p.dets_out + (size_t)pos * (cols + 1);
+                    float* k = p.kp_rois + (size_t)pos * cols;
+                    k[0] = 0.f;      // single scale: pyramid level 0 (test.py:106-123)
+                    for (int q = 0; q < 4 * p.T; ++q) {
+                        o[q] = src[q];
+                        k[1 + q] = (float)((double)src[q] * p.im_scale);
+                    }
+                    o[4 * p.T] = src[4 * p.T];
+                    o[4 * p.T + 1] = (float)(c + 1);
+                }
+                ++pos;
+            }
+        }
+        base += tot;
+    }
+    // rows past the kept ones: zero rois (the keypoint net runs on all out_cap rows)
+    for (int i = (int)base * cols + tid; i < p.out_cap * cols; i += SEL_THREADS) p.kp_rois[i] = 0.f;
+    for (int i = (int)base * (cols + 1) + tid; i < p.out_cap * (cols + 1); i += SEL_THREADS) p.dets_out[i] = 0.f;
+    if (tid == 0) {
+        p.n_out[0] = min((int)base, p.out_cap);
+        p.n_out[1] = (int)base;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+size_t dat_box_results_workspace_bytes(int roi_cap, int num_classes, int T) {
+    const int nc = num_classes > 1 ? num_classes - 1 : 1;
+    return align_up((size_t)nc * roi_cap * (4 * T + 1) * 4) + align_up((size_t)nc * roi_cap * 4) + 2 * align_up((size_t)nc * 4) +
+           dat_nms_ws_bytes(roi_cap, T);
+}
+
+int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob, int prob_ld,
+                    const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
+                    float* keypoint_rois, int* n_out) {
+    DAT_ENFORCE(ctx, rois && n_rois && cls_prob && bbox_pred && d && workspace && dets_out && keypoint_rois && n_out,
+                "box_results: null argument");
+    DAT_ENFORCE(ctx, d->num_classes >= 2 && d->T >= 1 && d->T <= DET_MAX_T, "box_results: %d classes / T %d unsupported", d->num_classes, d->T);
+    DAT_ENFORCE(ctx, roi_cap > 0 && roi_cap <= 16384 && out_cap > 0, "box_results: roi capacity %d / output capacity %d out of range", roi_cap, out_cap);
+    DAT_ENFORCE(ctx, prob_ld >= d->num_classes && pred_ld >= (d->cls_agnostic_bbox_reg ? 4 * d->T : d->num_classes * 4 * d->T),
+                "box_results: row strides %d / %d too small for %d classes x T %d", prob_ld, pred_ld, d->num_classes, d->T);
+    DAT_ENFORCE(ctx, d->im_scale > 0.f && d->nms_thresh > 0.f, "box_results: im_scale and TEST.NMS must be > 0");
+    hipStream_t st = (hipStream_t)s;
+    const int nc = d->num_classes - 1, T = d->T, cols = 4 * T + 1;
+    char* ws = (char*)workspace;
+    size_t off = 0;
+    float* dets = (float*)(ws + off); off += align_up((size_t)nc * roi_cap * cols * 4);
+    int* keep = (int*)(ws + off); off += align_up((size_t)nc * roi_cap * 4);
+    int* n_sel = (int*)(ws + off); off += align_up((size_t)nc * 4);
+    int* n_keep = (int*)(ws + off); off += align_up((size_t)nc * 4);
+    char* nms_ws = ws + off;
+    DetParams p;
+    p.rois = rois; p.n_rois = n_rois; p.prob = cls_prob; p.pred = bbox_pred;
+    p.prob_ld = prob_ld; p.pred_ld = pred_ld; p.roi_cap = roi_cap; p.T = T; p.K = d->num_classes;
+    p.cls_agnostic = d->cls_agnostic_bbox_reg;
+    p.wx = d->reg_weights[0]; p.wy = d->reg_weights[1]; p.ww = d->reg_weights[2]; p.wh = d->reg_weights[3];
+    p.xform_clip = d->xform_clip; p.score_thresh = d->score_thresh;
+    p.im_scale = (double)d->im_scale_f64;
+    p.im_h = (float)d->im_h; p.im_w = (float)d->im_w;
+    for (int c = 0; c < nc; ++c) {
+        float* dets_c = dets + (size_t)c * roi_cap * cols;
+        hipLaunchKernelGGL(det_select_kernel, dim3(1), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
+        int rc = dat_nms_impl(ctx, st, nms_ws, dets_c, 0, n_sel + c, roi_cap, T, d->nms_thresh, 0, 0, keep + (size_t)c * roi_cap, n_keep + c);
+        if (rc != DAT_OK) return rc;
+    }
+    EmitParams e;
+    e.dets = dets; e.keep = keep; e.n_keep = n_keep; e.K = d->num_classes; e.T = T; e.cap = roi_cap; e.D = d->detections_per_im;
+    e.out_cap = out_cap; e.im_scale = (double)d->im_scale_f64; e.dets_out = dets_out; e.kp_rois = keypoint_rois; e.n_out = n_out;
+    hipLaunchKernelGGL(det_limit_emit_kernel, dim3(1), dim3(SEL_THREADS), 0, st, e);
+    DAT_CHECK_LAUNCH(ctx, "box_results");
+    return DAT_OK;
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@
 #include <mutex>
 
 #include "dat_common.h"
+#include "nms_internal.h"
 
 namespace {
 
@@ -516,10 +517,15 @@ __global__ __launch_bounds__(1024) void collect_rois_kernel(const float* rois_lv
 }
 
 // ---- generic NMS entry: sort any-order dets ---------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n, int T, int presorted, float* boxes, int* orig,
-                                                             unsigned* n_dev) {
+__global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n_host, const int* n_in, int T, int presorted,
+                                                             float* boxes, int* orig, unsigned* n_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sbuf[];
     const int cols = 4 * T + 1;
+    const int n = n_in ? *n_in : n_host;       // the box count may live on the device (dat_box_results: no host round trip)
+    if (n <= 0) {
+        if (threadIdx.x == 0) *n_dev = 0u;
+        return;
+    }
     if (presorted) {   // `_nms` convention (lib/nms/gpu_nms.pyx:27-34): the caller sorted by score, rows are visited as given
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             orig[j] = j;
@@ -552,11 +558,12 @@ __global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, 
 }
 
 // kept sorted positions -> reference output convention
-__global__ __launch_bounds__(1024) void nms_finish_kernel(const int* kept, const unsigned* n_keep_ptr, const int* orig, int n,
+__global__ __launch_bounds__(1024) void nms_finish_kernel(const int* kept, const unsigned* n_keep_ptr, const int* orig, const unsigned* n_ptr,
                                                           int T, int* keep_out, int* num_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned fl[];
     __shared__ unsigned scan[1024];
-    const int nk = (int)*n_keep_ptr;
+    const int n = (int)*n_ptr;
+    const int nk = n > 0 ? (int)*n_keep_ptr : 0;
     const int tid = threadIdx.x;
     if (T > 1) {  // tubes: score order (py_cpu_nms_tubes.py returns `keep` as visited)
         for (int j = tid; j < nk; j += blockDim.x) keep_out[j] = orig[kept[j]];
@@ -702,34 +709,47 @@ int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const f
     return DAT_OK;
 }
 
-// strict / presorted select the `_nms` (lib/nms/nms_kernel.cu) convention instead of cython_nms / py_cpu_nms_tubes
-static int nms_impl(dat_ctx* ctx, hipStream_t st, const float* dets, int n, int T, float thresh, int strict, int presorted,
-                    int* keep, int* num_keep) {
+// strict / presorted select the `_nms` (lib/nms/nms_kernel.cu) convention instead of cython_nms / py_cpu_nms_tubes.
+// The number of boxes is `n` (host) or, when n_dev is given, *n_dev <= cap read on the device.  `ws` = dat_nms_ws_bytes(cap, T)
+// bytes of device scratch (nullptr: the context workspace).
+}  // extern "C"
+
+size_t dat_nms_ws_bytes(int cap, int T) {
+    const int nwords = (cap + 63) / 64;
+    return align_up(16) + align_up((size_t)cap * 4 * T * 4) + align_up((size_t)cap * 4) + align_up((size_t)cap * nwords * 8) +
+           align_up((size_t)cap * 4);
+}
+
+int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int n, const int* n_dev, int cap, int T, float thresh,
+                 int strict, int presorted, int* keep, int* num_keep) {
     DAT_ENFORCE(ctx, keep && num_keep, "nms: null output");
     DAT_ENFORCE(ctx, T >= 1 && T <= MAX_T, "nms: tube length %d unsupported", T);
-    if (n == 0) {
+    if (!n_dev) cap = n;
+    if (cap == 0) {
         hipMemsetAsync(num_keep, 0, sizeof(int), st);
         return DAT_OK;
     }
     DAT_ENFORCE(ctx, dets, "nms: null dets");
-    DAT_ENFORCE(ctx, n > 0 && n <= MAX_SORT, "nms: %d boxes exceed the supported maximum %d", n, MAX_SORT);
-    const int nwords = (n + 63) / 64;
+    DAT_ENFORCE(ctx, cap > 0 && cap <= MAX_SORT, "nms: %d boxes exceed the supported maximum %d", cap, MAX_SORT);
+    const int nwords = (cap + 63) / 64;
+    int rc;
+    if (!ws) {
+        if ((rc = ensure_ws(ctx, dat_nms_ws_bytes(cap, T))) != DAT_OK) return rc;
+        ws = (char*)ctx->ws;
+    }
     size_t off = 0;
     const size_t o_state = off; off += align_up(16);
-    const size_t o_boxes = off; off += align_up((size_t)n * 4 * T * 4);
-    const size_t o_orig = off; off += align_up((size_t)n * 4);
-    const size_t o_mask = off; off += align_up((size_t)n * nwords * 8);
-    const size_t o_kept = off; off += align_up((size_t)n * 4);
-    int rc = ensure_ws(ctx, off);
-    if (rc != DAT_OK) return rc;
-    char* ws = (char*)ctx->ws;
+    const size_t o_boxes = off; off += align_up((size_t)cap * 4 * T * 4);
+    const size_t o_orig = off; off += align_up((size_t)cap * 4);
+    const size_t o_mask = off; off += align_up((size_t)cap * nwords * 8);
+    const size_t o_kept = off; off += align_up((size_t)cap * 4);
     unsigned* st_n = (unsigned*)(ws + o_state);
     unsigned* st_keep = st_n + 1;
     int npad = 1;
-    while (npad < n) npad <<= 1;
+    while (npad < cap) npad <<= 1;
     if ((rc = dat_ensure_lds(ctx, (const void*)nms_sort_dets_kernel, MAX_SORT * 8)) != DAT_OK) return rc;
     if ((rc = dat_ensure_lds(ctx, (const void*)nms_finish_kernel, MAX_SORT * 4)) != DAT_OK) return rc;
-    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), presorted ? 0 : (size_t)npad * 8, st, dets, n, T, presorted,
+    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), presorted ? 0 : (size_t)npad * 8, st, dets, n, n_dev, T, presorted,
                        (float*)(ws + o_boxes), (int*)(ws + o_orig), st_n);
     NmsParams np;
     memset(&np, 0, sizeof(np));
@@ -738,13 +758,20 @@ static int nms_impl(dat_ctx* ctx, hipStream_t st, const float* dets, int n, int 
     np.lv[0].n_ptr = st_n;
     np.lv[0].kept = (int*)(ws + o_kept);
     np.lv[0].n_keep_ptr = st_keep;
-    np.T = T; np.cap = n; np.thr = thresh; np.strict = strict;
+    np.T = T; np.cap = cap; np.thr = thresh; np.strict = strict;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, 1), dim3(64), 0, st, np);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, np);
-    hipLaunchKernelGGL(nms_finish_kernel, dim3(1), dim3(1024), (size_t)n * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
-                       (const int*)(ws + o_orig), n, T, keep, num_keep);
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(1), dim3(1024), (size_t)cap * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
+                       (const int*)(ws + o_orig), (const unsigned*)st_n, T, keep, num_keep);
     DAT_CHECK_LAUNCH(ctx, "nms");
     return DAT_OK;
+}
+
+extern "C" {
+
+static int nms_impl(dat_ctx* ctx, hipStream_t st, const float* dets, int n, int T, float thresh, int strict, int presorted,
+                    int* keep, int* num_keep) {
+    return dat_nms_impl(ctx, st, nullptr, dets, n, nullptr, n, T, thresh, strict, presorted, keep, num_keep);
 }
 
 // host-pointer front end shared by dat_nms_host and `_nms`

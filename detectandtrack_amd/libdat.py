@@ -32,6 +32,12 @@ class RoiLevel(C.Structure):
     _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
 
 
+class DetDesc(C.Structure):
+    _fields_ = [('num_classes', C.c_int), ('T', C.c_int), ('cls_agnostic_bbox_reg', C.c_int), ('detections_per_im', C.c_int),
+                ('im_scale', C.c_float), ('im_scale_f64', C.c_double), ('im_h', C.c_int), ('im_w', C.c_int),
+                ('reg_weights', C.c_float * 4), ('xform_clip', C.c_float), ('score_thresh', C.c_float), ('nms_thresh', C.c_float)]
+
+
 class RpnLevel(C.Structure):
     _fields_ = [('H', C.c_int), ('W', C.c_int), ('A', C.c_int), ('T', C.c_int), ('feat_stride', C.c_float),
                 ('cstride', C.c_int), ('logit_off', C.c_int), ('delta_off', C.c_int), ('frame', C.c_int),
@@ -75,6 +81,8 @@ _PROTOS = {
     'dat_nms': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
     'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
     '_nms': (None, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f, _i]),
+    'dat_box_results_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
+    'dat_box_results': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, C.POINTER(DetDesc), _p, _i, _p, _p, _p]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_stem_conv_weight_bytes': (C.c_size_t, [_i]),

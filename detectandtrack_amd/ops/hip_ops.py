@@ -513,6 +513,30 @@ def nms_host(dets_np, thresh):
     return keep[:num.value]
 
 
+def box_results(rois, n_rois, cls_prob, bbox_pred, num_classes, T, im_scale, im_shape, reg_weights, xform_clip, score_thresh,
+                nms_thresh, detections_per_im, out_cap, cls_agnostic=False):
+    """dat_box_results (lib/core/test.py:215-252, 750-806, 78-123 on the device).  rois CUDA fp32 [cap, 4T+1] with the DEVICE count
+    n_rois (int32[1]); cls_prob [R, K], bbox_pred [R, K*4T] CUDA fp32.  Returns (dets [out_cap, 4T+2], keypoint_rois [out_cap, 4T+1],
+    n_out int32[2]) on the device -- no host synchronisation."""
+    cap = int(rois.shape[0])
+    d = L.DetDesc()
+    d.num_classes, d.T, d.cls_agnostic_bbox_reg, d.detections_per_im = int(num_classes), int(T), int(bool(cls_agnostic)), int(detections_per_im)
+    d.im_scale, d.im_scale_f64 = float(im_scale), float(im_scale)
+    d.im_h, d.im_w = int(im_shape[0]), int(im_shape[1])
+    for i in range(4):
+        d.reg_weights[i] = float(reg_weights[i])
+    d.xform_clip, d.score_thresh, d.nms_thresh = float(xform_clip), float(score_thresh), float(nms_thresh)
+    cols = 4 * T + 1
+    wsb = torch.empty(L.lib().dat_box_results_workspace_bytes(cap, int(num_classes), int(T)), dtype=torch.uint8, device=rois.device)
+    dets = torch.empty((out_cap, cols + 1), dtype=torch.float32, device=rois.device)
+    kp = torch.empty((out_cap, cols), dtype=torch.float32, device=rois.device)
+    n_out = torch.empty((2,), dtype=torch.int32, device=rois.device)
+    assert rois.dtype == cls_prob.dtype == bbox_pred.dtype == torch.float32 and rois.is_contiguous()
+    ctx().call('dat_box_results', _stream(), _ptr(rois), _ptr(n_rois), cap, _ptr(cls_prob), int(cls_prob.stride(0)), _ptr(bbox_pred),
+               int(bbox_pred.stride(0)), C.byref(d), _ptr(wsb), int(out_cap), _ptr(dets), _ptr(kp), _ptr(n_out))
+    return dets, kp, n_out
+
+
 def deconv_k4s2_as_conv3x3(w):
     """ConvTranspose weight fp32 [Cin, K, 4, 4] -> conv weight fp32 [4K, Cin, 1, 3, 3]."""
     cin, k = int(w.shape[0]), int(w.shape[1])

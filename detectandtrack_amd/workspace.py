@@ -142,6 +142,16 @@ class Workspace(object):
                 self.params[n] = self._dev_params[n].cpu().numpy()
 
 
+def blob_as_matrix(b):
+    """A head output as a device fp32 matrix [rows, C]: 'mat' blobs as they are, FC 'rows' blobs ([1,1,R,Cs] in the activation
+    dtype) converted on the device."""
+    if b.kind == 'mat':
+        return b.t
+    assert b.kind == 'rows', b.kind
+    r, cs = b.t.shape[2], b.t.shape[3]
+    return ops.to_ncdhw(b.t.view(r, 1, 1, cs), b.dt, r, b.C, 1).view(r, b.C)
+
+
 def _unscoped(name):
     name = str(name)
     return name[name.rfind('/') + 1:]  # 'gpu_0/rois' -> 'rois' (core.ScopedName, lib/utils/c2.py)

@@ -192,6 +192,34 @@ int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_h
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh,
           int device_id);
 
+/* ---- detection post-processing between `model.net` and `model.keypoint_net`, on the device ----------------------------------
+ * Replaces the reference's host glue (a device sync + NumPy per clip): lib/core/test.py:215-252 (rois / im_scale, bbox_transform
+ * with MODEL.BBOX_REG_WEIGHTS, clip to the image), :750-806 box_results_with_nms_and_limit (per class: score > SCORE_THRESH,
+ * NMS at TEST.NMS; then TEST.DETECTIONS_PER_IM over all classes: scores >= the D-th best) and :78-123 _get_rois_blob for the
+ * keypoint net.  Soft-NMS / box voting are not covered here (host path, lib/utils/cython_nms.pyx:98-203). */
+typedef struct {
+    int num_classes;            /* K incl. background (class 0 is skipped) */
+    int T;                      /* frames per tube (1 = boxes) */
+    int cls_agnostic_bbox_reg;  /* MODEL.CLS_AGNOSTIC_BBOX_REG: bbox_pred holds one 4T group (its last columns) */
+    int detections_per_im;      /* TEST.DETECTIONS_PER_IM (0 = no limit) */
+    float im_scale;             /* im_info scale (float32 copy, informational) */
+    double im_scale_f64;        /* the float64 scale NumPy divides / multiplies by (test.py:216, :123) */
+    int im_h, im_w;             /* shape of the UNSCALED image: clip bounds (test.py:229) */
+    float reg_weights[4];       /* MODEL.BBOX_REG_WEIGHTS (wx, wy, ww, wh) */
+    float xform_clip;           /* BBOX_XFORM_CLIP = log(1000/16) */
+    float score_thresh;         /* TEST.SCORE_THRESH */
+    float nms_thresh;           /* TEST.NMS */
+} dat_det_desc;
+size_t dat_box_results_workspace_bytes(int roi_cap, int num_classes, int T);
+/* rois fp32 [roi_cap, 4T+1] with *n_rois valid rows (DEVICE count), cls_prob fp32 [R, prob_ld >= K], bbox_pred fp32
+ * [R, pred_ld >= K*4T] (class-major, then frame, then xyxy).  Outputs, class-major then NMS output order (= np.vstack of the
+ * reference's cls_boxes): dets_out fp32 [out_cap, 4T+2] rows (box, score, class); keypoint_rois fp32 [out_cap, 4T+1] rows
+ * (0, box * im_scale), zero rows past the kept ones; n_out int32[2] = {rows written (<= out_cap), rows the limit rule keeps}: when
+ * n_out[1] > out_cap (exact score ties at the D-th place) the caller must take the host path to honour the reference. */
+int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob, int prob_ld,
+                    const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
+                    float* keypoint_rois, int* n_out);
+
 /* ---- keypoint head tail: ConvTranspose k4s2p1 (as 3x3 sub-pixel conv) + bilinear up (detector.py:348-380) -- */
 /* Expand kps_score_lowres_w fp32 [Cin, K, 4, 4] (Caffe2 ConvTranspose layout) into an equivalent 3x3 conv
  * weight fp32 [4*K, Cin, 1, 3, 3] whose output channel (a*2+b)*K + k is sub-pixel (a,b) of keypoint k. */

@@ -511,6 +511,43 @@ def test_rpn_proposals_with_the_reference_default_pre_nms_12000(ops):
     np.testing.assert_allclose(out[:exp.shape[0]].cpu().numpy(), exp, atol=3e-3)
 
 
+@pytest.mark.parametrize('T,K,R,D', [(1, 2, 1000, 100), (1, 5, 700, 100), (3, 2, 300, 40), (1, 2, 50, 100), (1, 3, 400, 0)])
+def test_box_results_on_device_match_the_oracle(ops, T, K, R, D):
+    """dat_box_results vs oracle/box_results.py (lib/core/test.py:211-244 decode + clip, :750-806 threshold / per-class NMS /
+    DETECTIONS_PER_IM, :78-123 keypoint rois): same detections in the same order, scores bit-equal, boxes to exp rounding
+    (NumPy's float32 exp is within 1 ulp of the correctly rounded one used on the device), keypoint rois to the same tolerance."""
+    from oracle import box_results as obr
+    rs = np.random.RandomState(100 * T + K)
+    H, W, scale = 720, 1280, 800.0 / 720.0
+    cap = R + 24                                             # the proposal blob has spare capacity rows past its count
+    xy = np.stack([rs.uniform(0, W * scale - 60, cap), rs.uniform(0, H * scale - 60, cap)], axis=1)
+    wh = rs.uniform(8, 300, (cap, 2))
+    rois = np.zeros((cap, 4 * T + 1), np.float32)
+    for t in range(T):
+        jit = rs.uniform(-4, 4, (cap, 2))
+        rois[:, 1 + 4 * t:3 + 4 * t] = xy + jit
+        rois[:, 3 + 4 * t:5 + 4 * t] = xy + jit + wh
+    logits = rs.randn(cap, K).astype(np.float32) * 2
+    prob = (np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)).astype(np.float32)
+    pred = (rs.randn(cap, K * 4 * T) * np.tile([1.0, 1.0, 2.0, 2.0], K * T)).astype(np.float32)
+    dets, kp, n_out = ops.box_results(_dev(rois), torch.tensor([R], dtype=torch.int32).cuda(), _dev(prob), _dev(pred), K, T, scale,
+                                      (H, W, 3), (10., 10., 5., 5.), float(np.float32(np.log(1000. / 16.))), 0.05, 0.5, D,
+                                      D if D > 0 else cap)
+    n = n_out.cpu().numpy()
+    scores, boxes = obr.read_bbox_outputs(rois[:R], prob[:R], pred[:R], scale, (H, W, 3))
+    ref_scores, ref_boxes, ref_cls = obr.box_results_with_nms_and_limit(scores, boxes, K, 0.05, 0.5, D)
+    assert n[1] == ref_boxes.shape[0], (n, ref_boxes.shape)
+    assert n[0] == min(n[1], D if D > 0 else cap)
+    k = int(n[0])
+    d = dets.cpu().numpy()
+    ref_cls_col = np.concatenate([np.full((len(ref_cls[j]),), j, np.float32) for j in range(1, K)])
+    np.testing.assert_array_equal(d[:k, 4 * T], ref_scores[:k])
+    np.testing.assert_array_equal(d[:k, 4 * T + 1], ref_cls_col[:k])
+    np.testing.assert_allclose(d[:k, :4 * T], ref_boxes[:k], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(kp.cpu().numpy()[:k], obr.get_rois_blob(ref_boxes[:k], scale), rtol=0, atol=3e-3)
+    assert not kp.cpu().numpy()[k:].any() and not d[k:].any()
+
+
 def _head_tensor(ops, scores, deltas, dtype, logits=True):
     """scores (1,A,H,W) probabilities, deltas (1,4AT,H,W) -> head [1,H,W,cs] holding LOGITS (or probs) + deltas."""
     A = scores.shape[1]
