@@ -11,7 +11,7 @@ from collections import defaultdict
 import numpy as np
 
 from detectandtrack_amd.core.config import cfg
-from detectandtrack_amd.core.nms_wrapper import nms
+from detectandtrack_amd.core.nms_wrapper import nms, soft_nms
 from detectandtrack_amd.utils.timer import Timer
 from detectandtrack_amd import workspace
 import detectandtrack_amd.utils.blob as blob_utils
@@ -125,10 +125,15 @@ def box_results_with_nms_and_limit(scores, boxes):
         inds = np.where(scores[:, j] > cfg.TEST.SCORE_THRESH)[0]
         dets_j = np.hstack((boxes[inds, j * 4 * time_dim:(j + 1) * 4 * time_dim],
                             scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
-        if cfg.TEST.SOFT_NMS.ENABLED or cfg.TEST.BBOX_VOTE.ENABLED:
-            raise NotImplementedError('Soft-NMS / box voting are disabled in every shipped config')
-        keep = nms(dets_j, cfg.TEST.NMS)
-        cls_boxes[j] = dets_j[keep, :]
+        if cfg.TEST.SOFT_NMS.ENABLED:    # (:766-772; not implemented for time_dim > 1)
+            nms_dets, _ = soft_nms(dets_j, sigma=cfg.TEST.SOFT_NMS.SIGMA, overlap_thresh=cfg.TEST.NMS, score_thresh=0.0001,
+                                   method=cfg.TEST.SOFT_NMS.METHOD)
+        else:
+            keep = nms(dets_j, cfg.TEST.NMS)
+            nms_dets = dets_j[keep, :]
+        if cfg.TEST.BBOX_VOTE.ENABLED:   # refine the post-NMS boxes using bounding-box voting (:776-779)
+            nms_dets = box_utils.box_voting(nms_dets, dets_j, cfg.TEST.BBOX_VOTE.VOTE_TH)
+        cls_boxes[j] = nms_dets
     if cfg.TEST.DETECTIONS_PER_IM > 0:
         image_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
         if len(image_scores) > cfg.TEST.DETECTIONS_PER_IM:

@@ -251,4 +251,59 @@ int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_
     return DAT_OK;
 }
 
+// Soft-NMS on the HOST (lib/utils/cython_nms.pyx:98-203; caller lib/core/nms_wrapper.py:29-46, lib/core/test.py:766-772): the
+// greedy in-place re-scoring loop in C float arithmetic, statement for statement what Cython emits for the reference's .pyx
+// (differences in float, `+ 1` and the area products in double, the Gaussian weight through a double exp, the
+// discard-by-swap-with-last that makes the result order-dependent).  Plain host code: the algorithm is sequential by construction and off in every shipped config.
+int dat_soft_nms_host(const float* boxes_in, int n, float sigma, float Nt, float threshold, int method, float* boxes_out,
+                      int* inds_out, int* n_out) {
+    if (!boxes_in || !boxes_out || !inds_out || !n_out || n < 0 || method < 0 || method > 2) return DAT_ERR_ARG;
+    float* b = boxes_out;
+    memcpy(b, boxes_in, (size_t)n * 5 * sizeof(float));
+    for (int i = 0; i < n; ++i) inds_out[i] = i;
+    int N = n;
+    for (int i = 0; i < N; ++i) {
+        float maxscore = b[i * 5 + 4];
+        int maxpos = i;
+        float tx1 = b[i * 5 + 0], ty1 = b[i * 5 + 1], tx2 = b[i * 5 + 2], ty2 = b[i * 5 + 3], ts = b[i * 5 + 4];
+        const int ti = inds_out[i];
+        for (int pos = i + 1; pos < N; ++pos)
+            if (maxscore < b[pos * 5 + 4]) { maxscore = b[pos * 5 + 4]; maxpos = pos; }
+        for (int c = 0; c < 5; ++c) b[i * 5 + c] = b[maxpos * 5 + c];
+        inds_out[i] = inds_out[maxpos];
+        b[maxpos * 5 + 0] = tx1; b[maxpos * 5 + 1] = ty1; b[maxpos * 5 + 2] = tx2; b[maxpos * 5 + 3] = ty2; b[maxpos * 5 + 4] = ts;
+        inds_out[maxpos] = ti;
+        tx1 = b[i * 5 + 0]; ty1 = b[i * 5 + 1]; tx2 = b[i * 5 + 2]; ty2 = b[i * 5 + 3];
+        int pos = i + 1;
+        while (pos < N) {
+            const float x1 = b[pos * 5 + 0], y1 = b[pos * 5 + 1], x2 = b[pos * 5 + 2], y2 = b[pos * 5 + 3];
+            // (`+ 1` is a DOUBLE constant in the C that Cython emits for the .pyx: sums and the area products are formed in double and
+            //  rounded once to float where the .pyx assigns a `cdef float`)
+            const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+            const float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);
+            if (iw > 0) {
+                const float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);
+                if (ih > 0) {
+                    const float ua = (float)((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0) + (double)area) - (double)(iw * ih));
+                    const float ov = iw * ih / ua;
+                    float weight;
+                    if (method == 1) weight = ov > Nt ? (float)(1.0 - (double)ov) : 1.f;
+                    else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
+                    else weight = ov > Nt ? 0.f : 1.f;
+                    b[pos * 5 + 4] = weight * b[pos * 5 + 4];
+                    if (b[pos * 5 + 4] < threshold) {   // discard: swap with the last box, shrink N, revisit this slot
+                        for (int c = 0; c < 5; ++c) b[pos * 5 + c] = b[(N - 1) * 5 + c];
+                        inds_out[pos] = inds_out[N - 1];
+                        --N;
+                        --pos;
+                    }
+                }
+            }
+            ++pos;
+        }
+    }
+    *n_out = N;
+    return DAT_OK;
+}
+
 }  // extern "C"

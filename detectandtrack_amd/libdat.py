@@ -83,6 +83,7 @@ _PROTOS = {
     '_nms': (None, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f, _i]),
     'dat_box_results_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'dat_box_results': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, C.POINTER(DetDesc), _p, _i, _p, _p, _p]),
+    'dat_soft_nms_host': (_i, [C.POINTER(_f), _i, _f, _f, _f, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_stem_conv_weight_bytes': (C.c_size_t, [_i]),

@@ -127,6 +127,18 @@ def clip_tiled_boxes(boxes, im_shape):
     return boxes
 
 
+def box_voting(top_dets, all_dets, thresh):
+    """Refine `top_dets` [N, 5] by score-weighted averaging of the `all_dets` boxes that overlap each by >= thresh (:294-310,
+    https://arxiv.org/abs/1505.01749)."""
+    out = top_dets.copy()
+    all_boxes, all_scores = all_dets[:, :4], all_dets[:, 4]
+    overlaps = bbox_overlaps(top_dets[:, :4], all_boxes)
+    for k in range(out.shape[0]):
+        vote = np.where(overlaps[k] >= thresh)[0]
+        out[k, :4] = np.average(all_boxes[vote, :], axis=0, weights=all_scores[vote])
+    return out
+
+
 def xywh_to_xyxy(boxes):
     boxes = np.asarray(boxes)
     if boxes.ndim == 1:

@@ -220,6 +220,12 @@ int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_
                     const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
                     float* keypoint_rois, int* n_out);
 
+/* Soft-NMS, HOST pointers, host arithmetic (lib/utils/cython_nms.pyx:98-203 statement for statement in C float): boxes_in
+ * [n, 5] -> boxes_out [*n_out <= n, 5] (re-scored, in the order the greedy loop leaves them) and inds_out (rows of boxes_in).
+ * method 0 = hard, 1 = linear, 2 = gaussian (nms_wrapper.py:37).  Buffers hold n rows.  Off in every shipped config. */
+int dat_soft_nms_host(const float* boxes_in, int n, float sigma, float Nt, float threshold, int method, float* boxes_out,
+                      int* inds_out, int* n_out);
+
 /* ---- keypoint head tail: ConvTranspose k4s2p1 (as 3x3 sub-pixel conv) + bilinear up (detector.py:348-380) -- */
 /* Expand kps_score_lowres_w fp32 [Cin, K, 4, 4] (Caffe2 ConvTranspose layout) into an equivalent 3x3 conv
  * weight fp32 [4*K, Cin, 1, 3, 3] whose output channel (a*2+b)*K + k is sub-pixel (a,b) of keypoint k. */

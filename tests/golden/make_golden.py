@@ -331,5 +331,55 @@ def golden_posetrack_json(cfg):
     print('wrote reference_posetrack_annorect.json', len(out['cases']), 'cases')
 
 
+def golden_postproc(cfg):
+    """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
+    compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
+    modes.  The boxes fed to box_results come from the reference's own bbox_transform / clip (utils/boxes.py)."""
+    import utils.boxes as box_utils
+    import core.test as ref_test
+    nms_mod = sys.modules['utils.cython_nms']
+    rs = np.random.RandomState(17)
+    out = {}
+    for name, (T, K, R, D, thr, nms_thr) in {'pp_boxes_k2': (1, 2, 600, 100, 0.05, 0.5), 'pp_boxes_k5': (1, 5, 400, 60, 0.05, 0.3),
+                                              'pp_tubes_k2': (3, 2, 200, 30, 0.05, 0.5), 'pp_nolimit': (1, 3, 150, 0, 0.2, 0.5)}.items():
+        H, W = 720, 1280
+        xy = np.stack([rs.uniform(0, W - 60, R), rs.uniform(0, H - 60, R)], axis=1)
+        wh = rs.uniform(8, 300, (R, 2))
+        boxes = np.zeros((R, 4 * T), np.float32)
+        for t in range(T):
+            jit = rs.uniform(-4, 4, (R, 2))
+            boxes[:, 4 * t:4 * t + 2] = xy + jit
+            boxes[:, 4 * t + 2:4 * t + 4] = xy + jit + wh
+        logits = rs.randn(R, K).astype(np.float32) * 2
+        scores = (np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)).astype(np.float32)
+        deltas = (rs.randn(R, K * 4 * T) * np.tile([1.0, 1.0, 2.0, 2.0], K * T)).astype(np.float32)
+        pred = box_utils.clip_tiled_boxes(box_utils.bbox_transform(boxes, deltas, (10., 10., 5., 5.)), (H, W, 3))
+        cfg.MODEL.NUM_CLASSES, cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, cfg.TEST.DETECTIONS_PER_IM = K, thr, nms_thr, D
+        cfg.TEST.SOFT_NMS.ENABLED = cfg.TEST.BBOX_VOTE.ENABLED = False
+        sc, bx, cls_boxes = ref_test.box_results_with_nms_and_limit(scores, pred)
+        out[name + '_cfg'] = np.array([T, K, R, D, thr, nms_thr], dtype=np.float64)
+        out[name + '_boxes'], out[name + '_scores'], out[name + '_deltas'], out[name + '_pred'] = boxes, scores, deltas, pred
+        out[name + '_out_scores'], out[name + '_out_boxes'] = sc, bx
+        out[name + '_out_counts'] = np.array([len(cls_boxes[j]) for j in range(1, K)], dtype=np.int64)
+    # soft-NMS + box voting on one class worth of detections
+    n = 300
+    b = rs.uniform(0, 250, (n, 4)).astype(np.float32)
+    b[:, 2:] = b[:, :2] + rs.uniform(5, 120, (n, 2)).astype(np.float32)
+    dets = np.hstack((b, rs.uniform(0.01, 1, (n, 1)).astype(np.float32)))
+    out['soft_dets'] = dets
+    for method, code in (('hard', 0), ('linear', 1), ('gaussian', 2)):
+        d, inds = nms_mod.soft_nms(np.ascontiguousarray(dets), np.float32(0.5), np.float32(0.3), np.float32(0.001), np.uint8(code))
+        out['soft_%s_dets' % method], out['soft_%s_inds' % method] = np.asarray(d), np.asarray(inds, dtype=np.int64)
+    keep = np.asarray(nms_mod.nms(dets, np.float32(0.5)))
+    out['vote_top'] = dets[keep]
+    out['vote_out'] = box_utils.box_voting(dets[keep], dets, 0.8)
+    np.savez_compressed(os.path.join(HERE, 'reference_postproc.npz'), **out)
+    print('wrote reference_postproc.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    main()
+    if '--only-postproc' in sys.argv:
+        golden_postproc(_install_shims())
+    else:
+        main()
+        golden_postproc(sys.modules['core.config'].cfg)

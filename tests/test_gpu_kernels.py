@@ -1,4 +1,6 @@
 """GPU parity tests: every HIP kernel, called through the C ABI, against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -546,6 +548,29 @@ def test_box_results_on_device_match_the_oracle(ops, T, K, R, D):
     np.testing.assert_allclose(d[:k, :4 * T], ref_boxes[:k], rtol=0, atol=2e-3)
     np.testing.assert_allclose(kp.cpu().numpy()[:k], obr.get_rois_blob(ref_boxes[:k], scale), rtol=0, atol=3e-3)
     assert not kp.cpu().numpy()[k:].any() and not d[k:].any()
+
+
+@pytest.mark.parametrize('name', ['pp_boxes_k2', 'pp_boxes_k5', 'pp_tubes_k2', 'pp_nolimit'])
+def test_box_results_on_device_match_the_real_reference(ops, name):
+    """dat_box_results against outputs of the reference's own box_results_with_nms_and_limit (core/test.py:750-806 run under py3
+    shims with its compiled Cython NMS; tests/golden/reference_postproc.npz): same detections, same order, scores bit-equal, boxes
+    to the 1-ulp exp difference."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_postproc.npz'))
+    T, K, R, D, thr, nms_thr = g[name + '_cfg']
+    T, K, R, D = int(T), int(K), int(R), int(D)
+    rois = np.hstack((np.zeros((R, 1), np.float32), g[name + '_boxes']))
+    out_cap = D if D > 0 else R
+    dets, kp, n_out = ops.box_results(_dev(rois), torch.tensor([R], dtype=torch.int32).cuda(), _dev(g[name + '_scores']),
+                                      _dev(g[name + '_deltas']), K, T, 1.0, (720, 1280, 3), (10., 10., 5., 5.),
+                                      float(np.float32(np.log(1000. / 16.))), float(thr), float(nms_thr), D, out_cap)
+    n = n_out.cpu().numpy()
+    ref_s, ref_b = g[name + '_out_scores'], g[name + '_out_boxes']
+    assert n[0] == n[1] == ref_s.shape[0], (n, ref_s.shape)
+    d = dets.cpu().numpy()[:n[0]]
+    np.testing.assert_array_equal(d[:, 4 * T], ref_s)
+    np.testing.assert_allclose(d[:, :4 * T], ref_b, rtol=0, atol=2e-3)
+    counts = [int((d[:, 4 * T + 1] == j).sum()) for j in range(1, K)]
+    assert counts == g[name + '_out_counts'].tolist()
 
 
 def _head_tensor(ops, scores, deltas, dtype, logits=True):

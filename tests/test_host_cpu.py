@@ -324,6 +324,26 @@ def test_host_resamplers_and_keypoint_decode_match_the_cv2_oracle():
     reset_cfg()
 
 
+def test_soft_nms_and_box_voting_match_the_real_reference():
+    """core/nms_wrapper.soft_nms (dat_soft_nms_host: the loop of lib/utils/cython_nms.pyx:98-203 in C float) and utils/boxes.box_voting
+    (lib/utils/boxes.py:294-310) against outputs of the REAL reference (its Cython compiled into oracle/_ref, its boxes.py run under
+    py3 shims; tests/golden/reference_postproc.npz): bit-identical re-scored boxes, order and indices."""
+    from detectandtrack_amd.core import nms_wrapper
+    from detectandtrack_amd.utils import boxes as bu
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_postproc.npz'))
+    dets = g['soft_dets']
+    for method in ('hard', 'linear', 'gaussian'):
+        d, inds = nms_wrapper.soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method=method)
+        np.testing.assert_array_equal(inds, g['soft_%s_inds' % method])
+        np.testing.assert_array_equal(d, g['soft_%s_dets' % method])
+    assert 0 < len(g['soft_linear_inds']) <= len(dets)
+    np.testing.assert_allclose(bu.box_voting(g['vote_top'], dets, 0.8), g['vote_out'], rtol=0, atol=1e-4)
+    with pytest.raises(ValueError):
+        nms_wrapper.nms(dets, 0.5, soft_nms=True)
+    d0, i0 = nms_wrapper.soft_nms(np.zeros((0, 5), np.float32))
+    assert d0.shape == (0, 5) and i0.shape == (0,)
+
+
 def test_tracker_hungarian_greedy_and_ids():
     from detectandtrack_amd.core.config import cfg, reset_cfg
     from detectandtrack_amd.core import tracking_engine as te

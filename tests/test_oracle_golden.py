@@ -230,3 +230,27 @@ def test_resize_oracle_scale_given_uses_the_given_scale():
     assert abs(out[700, 0] - ((700.5) * 720.0 / 750.0 - 0.5)) > 0.1      # the dsize-derived step would land elsewhere
     assert R.resize_linear(np.zeros((5, 5), np.float32), fx=0.5, fy=0.5).shape == (2, 2)      # 2.5 -> 2 (half to even)
     assert R.resize_linear(np.zeros((7, 7), np.float32), fx=0.5, fy=0.5).shape == (4, 4)      # 3.5 -> 4
+
+
+# ---- detection post-processing: the oracle's restatement against the REAL reference's functions --------------------------------
+@pytest.fixture(scope='module')
+def postproc():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_postproc.npz'))
+
+
+@pytest.mark.parametrize('name', ['pp_boxes_k2', 'pp_boxes_k5', 'pp_tubes_k2', 'pp_nolimit'])
+def test_box_results_oracle_matches_the_real_reference(postproc, name):
+    """oracle/box_results.py vs core/test.py:750-806 of the reference run under py3 shims (tests/golden/make_golden.py): identical
+    detections, order and scores; the decode (bbox_transform + clip) reproduces the reference's `pred` boxes."""
+    from oracle import box_results as obr
+    T, K, R, D, thr, nms_thr = postproc[name + '_cfg']
+    T, K, D = int(T), int(K), int(D)
+    boxes, scores, deltas = postproc[name + '_boxes'], postproc[name + '_scores'], postproc[name + '_deltas']
+    rois = np.hstack((np.zeros((boxes.shape[0], 1), np.float32), boxes))
+    sc, pred = obr.read_bbox_outputs(rois, scores, deltas, 1.0, (720, 1280, 3))
+    np.testing.assert_array_equal(pred, postproc[name + '_pred'])
+    out_s, out_b, cls_boxes = obr.box_results_with_nms_and_limit(sc, pred, K, thr, nms_thr, D)
+    np.testing.assert_array_equal(out_s, postproc[name + '_out_scores'])
+    np.testing.assert_array_equal(out_b, postproc[name + '_out_boxes'])
+    assert [len(cls_boxes[j]) for j in range(1, K)] == postproc[name + '_out_counts'].tolist()
