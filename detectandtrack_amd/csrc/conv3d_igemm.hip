@@ -550,9 +550,12 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
 // weight packing: fp32 [Cout_real, Cin_real, KT, KH, KW] -> [tap][Cout_pad][Cin] in dtype, zero padded
 // frag = 1: MFMA A-fragment order of the WD kernel variants: [tap][channel chunk of 128 B][32-row block][k-slice][lane][16 B],
 // lane = k-half * 32 + row, the 16-B slot (2 * k-slice + k-half) of the row's 128-B chunk (what swz() addresses in the LDS path)
+// dgrad = 1: pack the weights of the DATA-GRADIENT conv straight from the forward master w [CoutF = Cin_real][CinF = Cout_real][taps]:
+// logical W'[co'][ci'][tap'] = w[ci'][co'][ntap - 1 - tap'] * scale[ci']  (channels swapped, every kernel axis flipped, the fused
+// AffineChannelNd scale folded in) -- what the host used to build with flip + transpose + mul + contiguous before packing.
 template <int DT>
 __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real, int Cin_real,
-                                    int ntap, int Cout_pad, int Cin, int frag) {
+                                    int ntap, int Cout_pad, int Cin, int frag, int dgrad, const float* __restrict__ scale) {
     constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;   // channels per 128-B chunk, elements per 16-B slot
     const size_t total = (size_t)ntap * Cout_pad * Cin;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -560,7 +563,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
         const int co = (i / Cin) % Cout_pad;
         const int tap = i / ((size_t)Cin * Cout_pad);
         float v = 0.f;
-        if (co < Cout_real && ci < Cin_real) v = w[((size_t)co * Cin_real + ci) * ntap + tap];
+        if (co < Cout_real && ci < Cin_real) {
+            if (dgrad) v = w[((size_t)ci * Cout_real + co) * ntap + (ntap - 1 - tap)] * (scale ? scale[ci] : 1.f);
+            else v = w[((size_t)co * Cin_real + ci) * ntap + tap];
+        }
         size_t dst = i;
         if (frag) {
             const int cc = ci / CK, cl = ci % CK, slot = cl / EPS, e = cl % EPS;
@@ -792,11 +798,31 @@ int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, 
     const int frag = weights_direct(ctx, d) ? 1 : 0;
     if (d->dtype == DAT_BF16)
         hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin, frag);
+                           Cout_real, Cin_real, ntap, cp, d->Cin, frag, 0, (const float*)nullptr);
     else
         hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin, frag);
+                           Cout_real, Cin_real, ntap, cp, d->Cin, frag, 0, (const float*)nullptr);
     DAT_CHECK_LAUNCH(ctx, "pack_weights");
+    return DAT_OK;
+}
+
+int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w_fwd, int CoutF, int CinF,
+                                  const float* scale_fwd, void* packed) {
+    DAT_ENFORCE(ctx, d && w_fwd && packed, "conv3d_pack_weights_dgrad: null argument");
+    DAT_ENFORCE(ctx, CinF <= d->Cout && CoutF <= d->Cin, "conv3d_pack_weights_dgrad: forward dims %d x %d exceed the data-gradient descriptor (%d outputs, %d inputs)",
+                CoutF, CinF, d->Cout, d->Cin);
+    const int ntap = d->KT * d->KH * d->KW;
+    const int cp = cout_pad_of(d);
+    const size_t total = (size_t)ntap * cp * d->Cin;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    const int frag = weights_direct(ctx, d) ? 1 : 0;
+    if (d->dtype == DAT_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w_fwd, packed,
+                           CinF, CoutF, ntap, cp, d->Cin, frag, 1, scale_fwd);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w_fwd, packed,
+                           CinF, CoutF, ntap, cp, d->Cin, frag, 1, scale_fwd);
+    DAT_CHECK_LAUNCH(ctx, "pack_weights_dgrad");
     return DAT_OK;
 }
 

@@ -65,6 +65,7 @@ _PROTOS = {
     'dat_conv3d_out_shape': (_i, [C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i)]),
     'dat_conv3d_packed_weight_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'dat_conv3d_pack_weights': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p]),
+    'dat_conv3d_pack_weights_dgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p, _p]),
     'dat_conv3d_fwd': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     'dat_conv3d_tune_plan': (_i, [_p, _i, _i]),
     'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),

@@ -97,6 +97,12 @@ size_t dat_conv3d_packed_weight_bytes(const dat_conv_desc* d);
 /* w: fp32 [Cout_real, Cin_real, KT, KH, KW] (reference blob layout); rows/cols beyond are zero. */
 int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w, int Cout_real,
                             int Cin_real, void* packed);
+/* The same packed layout for the DATA-GRADIENT conv of a forward layer (training): d describes the
+ * data-gradient conv (Cin = channel stride of the output gradient, Cout = forward input channels, same kernel, stride 1, pads
+ * k-1-p); w_fwd is the forward master fp32 [CoutF, CinF, KT, KH, KW]; packs W'[ci][co][taps flipped] = w_fwd[co][ci][..] *
+ * scale_fwd[co] (scale_fwd: the layer's fused AffineChannelNd scale, or NULL) in one pass -- no flipped / transposed copy. */
+int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w_fwd, int CoutF, int CinF,
+                                  const float* scale_fwd, void* packed);
 /* y = act( conv(x, w)*scale[c] + bias[c] + residual ); scale may be NULL (=1), bias may be NULL (=0).
  * scale/bias: fp32 [Cout].  residual: same dtype/stride as y. */
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,

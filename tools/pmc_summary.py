@@ -7,6 +7,11 @@ Reads  <in>/stats/r1_kernel_stats.csv, <in>/pmc_fetch/r1_counter_collection.csv,
 Writes <out>/kernel_stats.csv (copy), <out>/pmc_hbm.csv (per kernel: launches, FETCH_SIZE, WRITE_SIZE, corrected bytes)
 and profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
 
+With <in>/pmc_mfma/r1_counter_collection.csv present (round 2: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_BF16, SQ_BUSY_CYCLES,
+GRBM_GUI_ACTIVE in one pass) also writes <out>/pmc_mfma.csv: per kernel the average duration, the shader clock during the launch
+(GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = GUI / 8 / duration) and the MFMA utilisation
+SQ_VALU_MFMA_BUSY_CYCLES / (GUI / 8 x 1024 SIMDs); SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x issued v_mfma_f32_32x32x16_bf16.
+
 Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3's FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so reads are doubled.  WRITE_SIZE is
 uncalibrated and taken as reported.
@@ -31,7 +36,7 @@ def per_kernel(path):
 
 
 def short(name):
-    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>', name)
+    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>', name)
     if m:
         tps = ',tps%s' % m.group(5) if m.group(5) not in (None, '1') else ''
         return 'conv3d_igemm_kernel<%s,%s,%s%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3), tps)
@@ -39,9 +44,39 @@ def short(name):
     return m.group(1) if m else name
 
 
+def mfma_summary(src, dst):
+    path = os.path.join(src, 'pmc_mfma', 'r1_counter_collection.csv')
+    if not os.path.exists(path):
+        return
+    agg = collections.OrderedDict()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            e = agg.setdefault(short(r['Kernel_Name']), collections.defaultdict(float))
+            e[r['Counter_Name']] += float(r['Counter_Value'])
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+                e['n'] += 1
+                e['ns'] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    with open(os.path.join(dst, 'pmc_mfma.csv'), 'w') as f:
+        f.write('kernel,launches,avg_duration_us,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,SQ_INSTS_VALU_MFMA_MOPS_BF16_per_launch,'
+                'SQ_BUSY_CYCLES_per_launch,GRBM_GUI_ACTIVE_per_launch,shader_clock_mhz,mfma_utilisation,total_ms\n')
+        for k, e in sorted(agg.items(), key=lambda kv: -kv[1]['ns']):
+            n = max(e['n'], 1)
+            cyc = e['GRBM_GUI_ACTIVE'] / 8.0          # summed over the 8 XCDs
+            util = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024.0) if cyc > 0 else 0.0
+            mhz = cyc / (e['ns'] * 1e-3) if e['ns'] > 0 else 0.0
+            f.write('%s,%d,%.1f,%.4g,%.4g,%.4g,%.4g,%.0f,%.3f,%.3f\n' % (k, n, e['ns'] / n / 1e3, e['SQ_VALU_MFMA_BUSY_CYCLES'] / n,
+                                                                        e['SQ_INSTS_VALU_MFMA_MOPS_BF16'] / n, e['SQ_BUSY_CYCLES'] / n,
+                                                                        e['GRBM_GUI_ACTIVE'] / n, mhz, util, e['ns'] / 1e6))
+    for k, e in sorted(agg.items(), key=lambda kv: -kv[1]['ns'])[:6]:
+        cyc = e['GRBM_GUI_ACTIVE'] / 8.0
+        print('%-44s n=%4d MFMA utilisation %.3f at %.0f MHz' % (k, e['n'], e['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024.0) if cyc else 0,
+                                                               cyc / (e['ns'] * 1e-3) if e['ns'] else 0))
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
+    mfma_summary(src, dst)
     shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
     fetch = per_kernel(os.path.join(src, 'pmc_fetch', 'r1_counter_collection.csv'))
     write = per_kernel(os.path.join(src, 'pmc_write', 'r1_counter_collection.csv'))
