@@ -109,9 +109,22 @@ class ConvLayer(object):
     """
 
     def __init__(self, w, scale=None, bias=None, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=BF16,
-                 cin_stride=None):
-        w = w.contiguous().float()
-        self.cout_real, self.cin_real, self.kt, self.kh, self.kw = [int(v) for v in w.shape]
+                 cin_stride=None, dgrad_of=None):
+        """dgrad_of = (w_fwd, scale_fwd): this layer is the DATA-GRADIENT conv of a forward conv with master weights w_fwd
+        [CoutF, CinF, KT, KH, KW]; `w` is then ignored and the packed weights come straight from w_fwd (channels swapped, kernel
+        flipped, AffineChannelNd scale folded in: dat_conv3d_pack_weights_dgrad)."""
+        if dgrad_of is not None:
+            w_fwd = dgrad_of[0].contiguous().float()
+            self.w_src, self.dgrad_scale = w_fwd, (None if dgrad_of[1] is None else dgrad_of[1].contiguous().float())
+            coutf, cinf = int(w_fwd.shape[0]), int(w_fwd.shape[1])
+            self.cout_real, self.cin_real = cinf, coutf
+            self.kt, self.kh, self.kw = [int(v) for v in w_fwd.shape[2:]]
+            w = w_fwd
+        else:
+            w = w.contiguous().float()
+            self.w_src, self.dgrad_scale = w, None          # kept (no copy when `w` already was a contiguous fp32 master): repack()
+            self.cout_real, self.cin_real, self.kt, self.kh, self.kw = [int(v) for v in w.shape]
+        self.is_dgrad = dgrad_of is not None
         self.dtype = dtype
         self.cin = cin_stride or round_up(self.cin_real, 64)
         self.cout = round_up(self.cout_real, 4)
@@ -125,14 +138,30 @@ class ConvLayer(object):
         if scale is not None:
             self.scale = torch.ones(self.cout, dtype=torch.float32, device=dev)
             self.scale[:self.cout_real] = scale.float()
+        self.bias_src = None
         if bias is not None:
-            self.bias = torch.zeros(self.cout, dtype=torch.float32, device=dev)
-            self.bias[:self.cout_real] = bias.float()
+            if bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == self.cout:
+                self.bias = bias            # the master itself: always current, nothing to refresh after an update
+            else:
+                self.bias = torch.zeros(self.cout, dtype=torch.float32, device=dev)
+                self.bias[:self.cout_real] = bias.float()
+                self.bias_src = bias
         d = self.desc(1, 1, 8, 8)
         nbytes = L.lib().dat_conv3d_packed_weight_bytes(C.byref(d))
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(w), self.cout_real, self.cin_real,
-                   _ptr(self.packed))
+        self.repack(weights_only=True)
+
+    def repack(self, weights_only=False):
+        """(Re-)derive the packed weights (and a padded bias copy) from the fp32 masters -- after an SGD update in place."""
+        d = self.desc(1, 1, 8, 8)
+        if self.is_dgrad:
+            ctx().call('dat_conv3d_pack_weights_dgrad', _stream(), C.byref(d), _ptr(self.w_src), self.cin_real, self.cout_real,
+                       _ptr(self.dgrad_scale), _ptr(self.packed))
+        else:
+            ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(self.w_src), self.cout_real, self.cin_real,
+                       _ptr(self.packed))
+        if not weights_only and self.bias_src is not None:
+            self.bias[:self.cout_real] = self.bias_src.float()
 
     def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None, out_t=None, in_t=None):
         d = L.ConvDesc()
@@ -218,16 +247,18 @@ class ConvGrad(object):
         d.relu, d.res_mode, d.out_t0, d.out_tn, d.in_t0, d.in_tn = 0, 0, 0, 0, 0, 0
         return d
 
-    def weight(self, x, g, T, want_dscale=False, g_frames=None):
+    def weight(self, x, g, T, want_dscale=False, g_frames=None, out=None):
         """x [frames,H,W,x_cstride], g [frames,Ho,Wo,g_cstride] -> (dW fp32 [Cout,Cin,KT,KH,KW] (already x scale),
-        dscale fp32 [Cout] | None)"""
+        dscale fp32 [Cout] | None); out: a contiguous fp32 tensor of the weight's shape to write dW into (gradient arena)"""
         frames, H, W, _ = x.shape
         d = self._fwd_desc(frames, T, H, W)
         if g_frames is not None and frames == T:      # g is zero outside frames [t0, t0 + n) of the (single) clip
             d.out_t0, d.out_tn = int(g_frames[0]), int(g_frames[1])
         nbytes = L.lib().dat_conv3d_wgrad_workspace_bytes(C.byref(d), self.cin, self.cout)
         wsb = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        dW = torch.empty(self.w.shape, dtype=torch.float32, device=x.device)
+        if out is not None:
+            assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.w.numel()
+        dW = out if out is not None else torch.empty(self.w.shape, dtype=torch.float32, device=x.device)
         ctx().call('dat_conv3d_wgrad', _stream(), C.byref(d), _ptr(x), _ptr(g), self.g_cstride, self.cin, self.cout,
                    _ptr(self.scale), _ptr(wsb), _ptr(dW))
         if self.scale is None or not want_dscale:
@@ -239,11 +270,10 @@ class ConvGrad(object):
     def data(self, g, T, H, W, accumulate_into=None, g_frames=None):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given)."""
         if self._data_layer is None:
-            w = self.w if self.scale is None else self.w * self.scale.view(-1, 1, 1, 1, 1)
-            wt = torch.flip(w, dims=(2, 3, 4)).transpose(0, 1).contiguous()          # [Cin, Cout, KT, KH, KW]
+            # flipped / transposed / scale-folded weights are packed straight from the forward master (no ATen flip, mul, copy)
             pads = (self.kt - 1 - self.pads[0], self.kh - 1 - self.pads[1], self.kw - 1 - self.pads[2])
-            self._data_layer = ConvLayer(wt, None, None, stride=(1, 1), pads=pads, relu=False, dtype=self.dtype,
-                                         cin_stride=self.g_cstride)
+            self._data_layer = ConvLayer(None, None, None, stride=(1, 1), pads=pads, relu=False, dtype=self.dtype,
+                                         cin_stride=self.g_cstride, dgrad_of=(self.w, self.scale))
         frames, Ho, Wo, cs = g.shape
         Hz, Wz = H - self.kh + 1 + 2 * self.pads[1], W - self.kw + 1 + 2 * self.pads[2]
         if self.stride[0] == 2 or (Hz, Wz) != (Ho, Wo):
@@ -259,6 +289,15 @@ class ConvGrad(object):
         if accumulate_into is not None:
             return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into, in_t=in_t)
         return lay(gz, T=T, in_t=in_t)
+
+
+def _convgrad_repack(self):
+    """after an in-place update of the forward master: refresh the packed data-gradient weights (if they were built)"""
+    if self._data_layer is not None:
+        self._data_layer.repack()
+
+
+ConvGrad.repack = _convgrad_repack
 
 
 def relu_bias_bwd(dy, y, dtype, C_real, relu=True, dy2=None, dbias=None):

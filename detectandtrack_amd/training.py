@@ -29,10 +29,13 @@ logger = logging.getLogger(__name__)
 class TrainExecutor(Executor):
     """Forward (inherits the inference handlers) + loss ops + backward + update for one net on one workspace."""
 
-    def __init__(self, ws, net):
+    def __init__(self, ws, net, arena=None):
         super(TrainExecutor, self).__init__(ws, net)
         self.grads = {}          # blob name -> list of gradient tensors (blob layout; activation dtype or fp32)
         self.param_grads = {}    # param name -> fp32 CUDA tensor (reference blob layout)
+        # Trainer's gradient arena: param name -> a zeroed fp32 view of ONE flat buffer (the all-reduce and the SGD update run on
+        # the flat buffer; weight-gradient kernels write into the views directly).  None: gradients are separate tensors.
+        self.arena = arena
         self.losses = {}         # loss blob name -> fp32 CUDA scalar tensor
         self.metrics = {}
         self._cg = {}
@@ -183,11 +186,32 @@ class TrainExecutor(Executor):
         return acc, lo
 
     def _pgrad(self, name, t):
+        """Add a parameter-gradient contribution `t` (a fresh tensor the caller does not reuse)."""
+        if self.arena is not None and name in self.arena:
+            view = self.arena[name]
+            if t.data_ptr() != view.data_ptr():      # not produced in place (see _pgrad_out)
+                view += t.reshape(view.shape)
+            self.param_grads[name] = view
+            return
         t = t.reshape(self.ws.params[name].shape) if name in self.ws.params else t
         if name in self.param_grads:
             self.param_grads[name] += t
         else:
-            self.param_grads[name] = t.clone()
+            self.param_grads[name] = t
+
+    def _pgrad_out(self, name):
+        """Where a kernel may WRITE (overwrite) the gradient of `name` directly: its arena view on the first contribution of the
+        step, else None (the kernel then returns a temporary that _pgrad adds)."""
+        if self.arena is None or name not in self.arena or name in self.param_grads:
+            return None
+        return self.arena[name]
+
+    def _conv_grad(self, i, build):
+        """ConvGrad of op i, cached across iterations in the workspace (the Trainer re-packs it after every update)."""
+        key = (self.net.name, ('grad', i))
+        if key not in self.ws._layers:
+            self.ws._layers[key] = build()
+        return self.ws._layers[key]
 
     def _master(self, name):
         """fp32 device master copy of a parameter (reference blob layout)."""
@@ -226,7 +250,10 @@ class TrainExecutor(Executor):
         assert full or xin.N == 1, 'frame-window gradients assume one clip per forward (TRAIN.IMS_PER_BATCH 1)'
         cout = a['dim_out']
         train_b = a['b'] if (a['b'] and self._trainable(a['b'])) else None
-        dbias = torch.zeros(cout, dtype=torch.float32, device=ws.device) if train_b else None
+        dbias = None
+        if train_b:     # the kernel ACCUMULATES the bias reduction: straight into the (zeroed) arena view when there is one
+            dbias = self.arena[train_b] if (self.arena is not None and train_b in self.arena) else \
+                torch.zeros(cout, dtype=torch.float32, device=ws.device)
         g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=a['relu'], dbias=dbias)
         if train_b:
             self._pgrad(train_b, dbias)
@@ -246,16 +273,29 @@ class TrainExecutor(Executor):
         else:
             g_emb = g
         Tw = (ihi - ilo) if xin.N == 1 else xin.T
-        w5 = self._master(a['w'])
-        w5 = w5 if w5.dim() == 5 else w5.unsqueeze(2)
-        scale = self._master(a['scale']) if a['scale'] else None
-        cg = ops.ConvGrad(w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
+        def build():
+            w5 = self._master(a['w'])
+            w5 = w5 if w5.dim() == 5 else w5.unsqueeze(2)
+            scale = self._master(a['scale']) if a['scale'] else None
+            return ops.ConvGrad(w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
+        cg = self._conv_grad(i, build)
         if self._trainable(a['w']):
-            dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=(lo - ilo, n) if xin.N == 1 else None)
+            dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=(lo - ilo, n) if xin.N == 1 else None, out=self._pgrad_out(a['w']))
             self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             f, H, W, _ = xin.t.shape
-            self._add_grad(op.inputs[0], cg.data(g_emb, Tw, H, W, g_frames=(lo - ilo, n) if xin.N == 1 else None), ilo)
+            # a gradient of the same frame window that already waits for this input (the block's shortcut): the data-gradient conv
+            # adds into it in its epilogue instead of producing a second tensor for an ATen add
+            into = None
+            pend = self.grads.get(op.inputs[0])
+            if pend and len(pend) == 1:
+                t0, l0 = pend[0]
+                if l0 == ilo and t0.shape[0] == ihi - ilo and t0.dtype == ops.tdtype(y.dt) and tuple(t0.shape[1:3]) == (H, W) and \
+                        t0.is_contiguous() and not getattr(t0, '_roi_acc', False) and t0.shape[3] == ops.round_up(cg.cin, 64):
+                    into = t0
+            dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None)
+            if into is None:
+                self._add_grad(op.inputs[0], dx, ilo)
 
     def _bwd_rpn_head(self, i):
         ws = self.ws
@@ -492,40 +532,79 @@ class TrainExecutor(Executor):
 
 class Trainer(object):
     """One training process (one GPU): forward + backward + gradient all-reduce + momentum SGD on device fp32 masters
-    (tools/train_net.py:120-170, model_builder.py:908-985)."""
+    (tools/train_net.py:120-170, model_builder.py:908-985).
+
+    The trainable parameters, their momentum and their gradients each live in ONE flat fp32 buffer (weights first, then biases):
+    the workspace's device masters are views into the first, the weight-gradient kernels write into views of the third, the
+    all-reduce runs over bucket-sized slices of it (no flatten / unflatten copies) and the update is two `dat_sgd_momentum`
+    launches (weights; biases with their 2x learning rate and no decay).  Packed layer weights are refreshed in place after the
+    update; layers of frozen parameters are left alone."""
 
     BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound: few, large buckets
 
     def __init__(self, model, ws, dist=None):
         self.model, self.ws, self.dist = model, ws, dist
-        self.momentum = {}
         self.trainable = list(model.TrainableParams())
         self.biases = set(model.biases)
         self.iter = 0
+        order = [n for n in self.trainable if n not in self.biases] + [n for n in self.trainable if n in self.biases]
+        sizes = [int(np.prod(ws.params[n].shape)) for n in order]
+        self.n_weights = sum(sz for n, sz in zip(order, sizes) if n not in self.biases)
+        total = sum(sizes)
+        dev = ws.device
+        self.flat_w = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.momentum, self.arena = {}, {}
+        off = 0
+        for n, sz in zip(order, sizes):
+            shape = tuple(ws.params[n].shape)
+            view = self.flat_w[off:off + sz].view(shape)
+            view.copy_(ws.dev_param(n))
+            ws._dev_params[n] = view                      # the workspace's device master IS the slice of the flat buffer
+            self.momentum[n] = self.flat_v[off:off + sz].view(shape)
+            self.arena[n] = self.flat_g[off:off + sz].view(shape)
+            off += sz
+        ws._layers.clear()                                # layers built before held the old master tensors
+        self._train_ptrs = {ws._dev_params[n].data_ptr() for n in order}
 
     def step(self, lr):
         ws = self.ws
-        ex = TrainExecutor(ws, self.model.net)
+        self.flat_g.zero_()
+        ex = TrainExecutor(ws, self.model.net, arena=self.arena)
         ex.run()
         ex.backward()
-        grads = ex.param_grads
         if self.dist is not None and self.dist.get_world_size() > 1:
-            # every rank reduces the SAME fixed list (a parameter without a gradient on this rank -- e.g. no foreground roi
-            # reached a branch -- contributes zeros), otherwise the buckets of different ranks would not line up
-            for n in self.trainable:
-                if n not in grads:
-                    grads[n] = torch.zeros_like(ws.dev_param(n))
-            self._all_reduce([grads[n] for n in self.trainable])
-        names = [n for n in self.trainable if n in grads]
-        for n in names:
-            w = ws.dev_param(n)
-            if n not in self.momentum:
-                self.momentum[n] = torch.zeros_like(w)
-            ops.sgd_momentum(w.view(-1), self.momentum[n].view(-1), grads[n].contiguous().view(-1), lr, cfg.SOLVER.MOMENTUM,
-                             cfg.SOLVER.WEIGHT_DECAY, n in self.biases)
-        ws._layers.clear()            # packed weights are re-derived from the updated device masters on the next forward
+            # every rank reduces the same flat buffer: a parameter without a gradient on this rank contributes its zeros
+            self._all_reduce()
+        nw, n = self.n_weights, self.flat_w.numel()
+        if nw > 0:
+            ops.sgd_momentum(self.flat_w[:nw], self.flat_v[:nw], self.flat_g[:nw], lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, False)
+        if n > nw:
+            ops.sgd_momentum(self.flat_w[nw:], self.flat_v[nw:], self.flat_g[nw:], lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, True)
+        self._refresh_layers()
         self.iter += 1
         return ex
+
+    def _refresh_layers(self):
+        """Packed weights follow the updated masters: layers (and cached gradient layers) packed straight from a trainable master are
+        re-packed in place, layers of frozen parameters stay, layers built from derived tensors (concatenated RPN heads, permuted FC
+        weights, the sub-pixel deconv) are dropped and rebuilt on the next forward."""
+        ws = self.ws
+        all_ptrs = {t.data_ptr() for t in ws._dev_params.values()}
+        for key in list(ws._layers.keys()):
+            layer = ws._layers[key]
+            src = getattr(layer, 'w_src', None) if isinstance(layer, ops.ConvLayer) else \
+                (layer.w if isinstance(layer, ops.ConvGrad) else None)
+            if src is None:     # anchors (tensors) stay; the fused stem holds conv1, frozen below the StopGradient marker in every config
+                if isinstance(layer, ops.StemConv) and 'conv1_w' in self.trainable:
+                    del ws._layers[key]
+                continue
+            ptr = src.data_ptr()
+            if ptr in self._train_ptrs:
+                layer.repack()
+            elif ptr not in all_ptrs:
+                del ws._layers[key]
 
     def momentum_blobs(self):
         """name -> host array of the momentum buffers (saved as `<param>_momentum`, reference utils/net.py:268-275)."""
@@ -534,22 +613,12 @@ class Trainer(object):
     def load_momentum(self, blobs):
         """Restore momentum buffers read from a checkpoint (utils.net.initialize_from_weights_file(momentum=...))."""
         for n, m in (blobs or {}).items():
-            if n in self.trainable:
-                self.momentum[n] = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(self.ws.dev_param(n).device).view_as(self.ws.dev_param(n))
+            if n in self.momentum:
+                self.momentum[n].copy_(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(self.flat_v.device).view_as(self.momentum[n]))
 
-    def _all_reduce(self, tensors):
-        """Bucketed sum all-reduce (losses are already divided by NUM_GPUS, model_builder.py:932-942)."""
-        bucket, size = [], 0
-        for t in tensors + [None]:
-            if t is None or size + t.numel() * 4 > self.BUCKET_BYTES:
-                if bucket:
-                    flat = torch.cat([b.reshape(-1) for b in bucket])
-                    self.dist.all_reduce(flat)
-                    off = 0
-                    for b in bucket:
-                        b.copy_(flat[off:off + b.numel()].view_as(b))
-                        off += b.numel()
-                bucket, size = [], 0
-            if t is not None:
-                bucket.append(t)
-                size += t.numel() * 4
+    def _all_reduce(self):
+        """Bucketed sum all-reduce over slices of the flat gradient buffer (losses are already divided by NUM_GPUS,
+        model_builder.py:932-942)."""
+        per = max(1, self.BUCKET_BYTES // 4)
+        for off in range(0, self.flat_g.numel(), per):
+            self.dist.all_reduce(self.flat_g[off:off + per])

@@ -425,9 +425,15 @@ def _allreduce_worker(rank, world, port, q):
     t.dist = dist
     t.BUCKET_BYTES = 4096          # force several buckets
     g = torch.Generator().manual_seed(100 + rank)
-    tensors = [torch.randn(n, generator=g) for n in (7, 300, 1500, 64, 2000, 5)]
+    # the Trainer's flat gradient buffer with per-parameter views into it (training.py): reduced in bucket-sized slices, in place
+    sizes = (7, 300, 1500, 64, 2000, 5)
+    t.flat_g = torch.randn(sum(sizes), generator=g)
+    tensors, off = [], 0
+    for n in sizes:
+        tensors.append(t.flat_g[off:off + n])
+        off += n
     local = [x.clone() for x in tensors]
-    t._all_reduce(tensors)
+    t._all_reduce()
     q.put((rank, [x.numpy() for x in local], [x.numpy() for x in tensors]))
     dist.destroy_process_group()
 
