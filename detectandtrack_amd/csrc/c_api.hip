@@ -45,6 +45,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_lds_pad = env_int("DAT_CONV_LDS_PAD", 0);
         c->dbg_tps3 = env_int("DAT_CONV_TPS", 3) == 3;
         c->dbg_wd = env_int("DAT_CONV_WD", 1) != 0;
+        c->dbg_ntap = env_int("DAT_CONV_NTAP", 1) != 0;
     }
     if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemset(c->zeros, 0, 512) != hipSuccess) {
         delete c;

@@ -108,8 +108,17 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + ((
 // (their ISSUE was the largest non-MFMA cost of a step), the 8 ds_read_b128 of the A fragments, the
 // 32 KB weight stage and -- because nothing a tap needs is written by another wave any more -- the per-tap barrier: the block
 // synchronises only around a patch reload (every KH*KW taps).
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvParams p) {
+//
+// NTAP > 0 (with WD): the spatial taps of a patch are a compile-time unrolled sequence (9 = dense 3x3 stride 1, 1 = 1x1), which
+// takes everything tap-dependent out of the hot loop: the swizzled LDS address of every (tap, position sub-tile) B fragment is
+// computed ONCE per block into NTAP x PT registers (one v_xor per ds_read remains), the tap tables are never read again (the
+// s_load + s_waitcnt lgkmcnt(0) they cost per tap also drained the LDS queue), the weight pointer advances by a scalar add, and the
+// per-lane source offsets of the patch LDS-DMA are kept in registers across reloads.  NTAP = 0: the generic table-driven loop
+// (strided 3x3 convs with their stride-parity planes, other kernel shapes).
+// (the unrolled 128-position variants are held to 168 registers -- three blocks per CU -- the 256-position ones to 256)
+template <int BP, int NTAP> struct MinWaves { static constexpr int value = (NTAP > 0 && BP == 128) ? 3 : 2; };
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
+__global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
     constexpr int CK = Mma<DT>::CK;
     constexpr int WAVES_P = 4 / WAVES_N;
@@ -240,6 +249,116 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
     const size_t wd_cc_stride = (size_t)(p.Cout_pad >> 5) * 4096;
     const char* const wd_lane = p.w + (size_t)((n0 + wave_n * WN) >> 5) * 4096 + lane * 16;
 #define WD_PTR(KT_, CC_, TI_) (wd_lane + ((size_t)((KT_) * ntap + p.tab_tap[(TI_)]) * p.n_cchunks + (CC_)) * wd_cc_stride)
+    if constexpr (WD && NTAP > 0) {
+      if (total > 0) {
+        static_assert(TPS == 1, "unrolled taps: one tap per step");
+        constexpr int MAXCH = BP == 256 ? 11 : 6;             // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
+        const int kt_hi_x = kt_lo + n_kt;
+        int kshift = 0;
+        if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
+        int kt = kt_lo + pi_lo / p.n_cchunks + kshift, cc = pi_lo % p.n_cchunks;
+        if (kt >= kt_hi_x) kt -= n_kt;
+        // ---- per-lane LDS address of the B fragment (k-slice 0) of every (tap, position sub-tile); k-slice ks is `^ (ks << 5)`:
+        // row * 128 + ((khalf ^ (g & 1)) << 4) + (((g >> 1) ^ ks) << 5), g = (row >> 1) & 7 -- bits 5-6 of the first two terms are 0
+        // (a patch is < 64 KiB: two 16-bit addresses per register -- NTAP x PT / 2 registers instead of NTAP x PT)
+        static_assert(PT % 2 == 0, "packed fragment addresses: even number of position sub-tiles");
+        unsigned qp[NTAP][PT / 2];
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const int row = rowbase[j] + p.tab_rowoff[tp];
+                const int g = (row >> 1) & 7;
+                const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
+                if (j & 1) qp[tp][j >> 1] |= a16 << 16; else qp[tp][j >> 1] = a16;
+            }
+        // ---- per-lane source offsets of this wave's patch pieces (relative to the frame/chunk base; -1 = halo outside the frame)
+        const int nchunks = (npatch_items + 63) >> 6;
+        int poff[MAXCH];
+#pragma unroll
+        for (int u = 0; u < MAXCH; ++u) {
+            const int c = wave + 4 * u;
+            const int it = c * 64 + lane;
+            int off = -2;                                      // -2: no such piece / item
+            if (c < nchunks && it < npatch_items) {
+                const int row = it >> 3;
+                const int slot = (it ^ (row >> 1)) & 7;
+                const int prow = p.pw_magic ? (int)__umulhi((unsigned)row, p.pw_magic) : row, pcol = row - prow * p.PW;
+                const int ih = ih0 + p.tab_dy[0] + prow * p.psh, iw = iw0 + p.tab_dx[0] + pcol * p.psw;
+                off = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? (int)((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16)) : -1;
+            }
+            poff[u] = off;
+        }
+        // ---- weights: this wave's fragment stream; tap tp of patch (kt, cc) sits tp * tap_stride bytes behind the patch's first tap
+        // (block-uniform 64-bit base in SGPRs + one 32-bit lane offset: the loads take the "SGPR base + VGPR offset + immediate" form,
+        //  no per-lane 64-bit pointer arithmetic and no pointer registers per tap)
+        const size_t tap_stride = (size_t)p.n_cchunks * wd_cc_stride;
+        const char* const wd_base = p.w + (size_t)((n0 + wave_n * WN) >> 5) * 4096;       // uniform
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const char* wcur = wd_base + ((size_t)(kt * ntap) * p.n_cchunks + cc) * wd_cc_stride;
+        uint4 wa[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wa[i][ks] = *(const uint4*)(wcur + i * 4096 + ks * 1024 + lane16);
+        const int npat = pi_hi - pi_lo;
+        for (int pi = 0; pi < npat; ++pi) {
+            if (!((p.ablate & 1) && pi > 0)) {
+                __syncthreads();                               // all waves finished reading the previous patch
+                const int fin = f_in + kt - p.pt;
+                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+#pragma unroll
+                for (int u = 0; u < MAXCH; ++u) {
+                    if (poff[u] != -2) {
+                        const char* src = poff[u] >= 0 ? xbase + (unsigned)poff[u] : p.zeros;
+                        P_DMA(src, patch + (wave + 4 * u) * 1024);
+                    }
+                }
+                W_COMMIT();
+                __syncthreads();
+            }
+            // the patch after this one (its first tap's weights are fetched during this patch's last tap)
+            int ncc = cc + 1, nkt = kt;
+            if (ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
+            const char* wnextpatch = (pi + 1 < npat) ? wd_base + ((size_t)(nkt * ntap) * p.n_cchunks + ncc) * wd_cc_stride : wcur;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tp = 0; tp < NTAP; ++tp) {
+                const char* wnext = (tp + 1 < NTAP) ? wcur + (size_t)(tp + 1) * tap_stride : wnextpatch;
+                uint4 b[2][PT];
+                // (the empty asm makes the packed addresses opaque per tap: without it the compiler hoists all NTAP x PT x 4 unpacked and
+                //  xor-ed addresses out of the patch loop as loop invariants -- 144 registers, spilled to scratch)
+                unsigned qa[PT];
+#pragma unroll
+                for (int jj = 0; jj < PT / 2; ++jj) asm volatile("" : "+v"(qp[tp][jj]));
+#pragma unroll
+                for (int j = 0; j < PT; ++j) qa[j] = (j & 1) ? (qp[tp][j >> 1] >> 16) : (qp[tp][j >> 1] & 0xffffu);
+#pragma unroll
+                for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + qa[j]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int cur = ks & 1, nxt = cur ^ 1;
+                    if (ks < 3) {
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + (qa[j] ^ (unsigned)((ks + 1) << 5)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) Mma<DT>::step(wa[i][ks], b[cur][j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) wa[i][ks] = *(const uint4*)(wnext + i * 4096 + ks * 1024 + lane16);   // a whole tap to land
+                    // keep this k-slice's reloads HERE: left alone, the scheduler sinks all eight loads of a tap behind its last MFMA and
+                    // the next tap's first MFMA then waits out a full L2 round trip
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            wcur = wnextpatch;
+            cc = ncc; kt = nkt;
+        }
+      }
+    } else
     if (total > 0) {
         // temporal taps are visited in order of the INPUT frame index mod KT, not of kt: the blocks of output frames
         // t-1, t, t+1 (queue neighbours on one XCD) then stage the same input frame during the same third of their
@@ -350,9 +469,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_igemm_kernel(const ConvPar
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < PT; ++j) Mma<DT>::step(WD ? wa[i][ks] : a[cur][i], b[cur][j], acc[i][j]);
-                    if (WD && !((p.ablate & 2) && step > 1)) {   // this k-slice's fragments of the NEXT tap: a whole tap to land
+                    if (WD) {   // this k-slice's fragments of the NEXT tap: a whole tap to land.  Unconditional (a branch around the loads made
+                                // the compiler wait with vmcnt(0) at the top of every tap) and pinned here (see the unrolled variant)
 #pragma unroll
                         for (int i = 0; i < MT; ++i) wa[i][ks] = *(const uint4*)(wnext + i * 4096 + ks * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -663,7 +784,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
     return best;
 }
 
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0>
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
 int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
     const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
     p.th_log2 = tc.th_log2;
@@ -724,7 +845,12 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     lds += ctx->dbg_lds_pad;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
-    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD>;
+    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP>;
+    if (NTAP > 0) {   // what the unrolled variant assumes (the dispatcher only picks it for these shapes)
+        DAT_ENFORCE(ctx, p.tab_n == NTAP && p.tab_new == 1u && (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (BP == 256 ? 11 : 6),
+                    "conv3d: unrolled-tap variant on an unsupported shape (%d taps, patch %dx%d)", p.tab_n, p.PH, p.PW);
+        for (int i = 0; i < p.tab_n; ++i) DAT_ENFORCE(ctx, p.tab_tap[i] == i, "conv3d: unrolled-tap variant needs taps in natural order");
+    }
     {
         const int rc = dat_ensure_lds(ctx, (const void*)kern, 160 * 1024);
         if (rc != DAT_OK) return rc;
@@ -915,10 +1041,18 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         tag += 3;   // (dtype digit + 3: the 3-taps-per-step variant)
         rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 64, 128, 1, 3>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 64, 128, 1, 3>(ctx, st, p, 7, ksplit);
     } else if (!small_n && weights_direct(ctx, d)) {   // 128-channel tiles, weights straight into the MFMA registers
-        if (d->dtype == DAT_BF16)
-            rc = big ? launch_conv<DAT_BF16, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit);
-        else
-            rc = big ? launch_conv<DAT_F32, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_F32, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit);
+        // unrolled-tap variants: dense 3x3 (stride 1) and 1x1 (any stride: one tap, one plane); the patch must fit the per-wave
+        // piece registers (tile shapes with very long rows fall back to the table-driven loop)
+        const TileChoice tc = choose_tile(p.Ho, p.Wo, big ? 8 : 7, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
+        const long long prow = ((1ll << tc.th_log2) + (p.KH - 1) / p.sh) * ((1ll << tc.tw_log2) + (p.KW - 1) / p.sw);
+        const bool fits = ((prow * 8 + 63) >> 6) <= 4 * (big ? 11 : 6);
+        const int ntapv = !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
+                          (d->KH == 1 && d->KW == 1) ? 1 : 0;
+#define DAT_WD_LAUNCH(DT_) (ntapv == 9 ? (big ? launch_conv<DT_, 128, 256, 2, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
+                            : ntapv == 1 ? (big ? launch_conv<DT_, 128, 256, 2, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
+                            : (big ? launch_conv<DT_, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit)))
+        rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16) : DAT_WD_LAUNCH(DAT_F32);
+#undef DAT_WD_LAUNCH
     } else if (d->dtype == DAT_BF16) {
         if (big)
             rc = small_n ? launch_conv<DAT_BF16, 64, 256, 1>(ctx, st, p, 8, ksplit) : launch_conv<DAT_BF16, 128, 256, 2>(ctx, st, p, 8, ksplit);
