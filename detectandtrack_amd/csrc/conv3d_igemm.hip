@@ -261,8 +261,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
         // ---- per-lane LDS address of the B fragment (k-slice 0) of every (tap, position sub-tile); k-slice ks is `^ (ks << 5)`:
         // row * 128 + ((khalf ^ (g & 1)) << 4) + (((g >> 1) ^ ks) << 5), g = (row >> 1) & 7 -- bits 5-6 of the first two terms are 0
         // (a patch is < 64 KiB: two 16-bit addresses per register -- NTAP x PT / 2 registers instead of NTAP x PT)
-        static_assert(PT % 2 == 0, "packed fragment addresses: even number of position sub-tiles");
-        unsigned qp[NTAP][PT / 2];
+        constexpr int NQ = (PT + 1) / 2;
+        unsigned qp[NTAP][NQ];
 #pragma unroll
         for (int tp = 0; tp < NTAP; ++tp)
 #pragma unroll
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                 //  xor-ed addresses out of the patch loop as loop invariants -- 144 registers, spilled to scratch)
                 unsigned qa[PT];
 #pragma unroll
-                for (int jj = 0; jj < PT / 2; ++jj) asm volatile("" : "+v"(qp[tp][jj]));
+                for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[tp][jj]));
 #pragma unroll
                 for (int j = 0; j < PT; ++j) qa[j] = (j & 1) ? (qp[tp][j >> 1] >> 16) : (qp[tp][j >> 1] & 0xffffu);
 #pragma unroll
@@ -698,6 +698,66 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
     }
 }
 
+// The same packing through LDS: one block packs a tile of 32 output rows x 16 input channels for ALL taps.  The master layout has
+// the taps innermost, the packed layout has them outermost, so the element-wise kernel above reads with a stride of ntap floats;
+// training re-packs every trainable layer (and its data-gradient twin) after every SGD step, where that gather cost ~1.3 ms per
+// iteration.  Here both sides are coalesced: the tile is read as contiguous runs (16 x ntap floats per row; in dgrad mode 32 x ntap
+// floats per source row, the source being [CoutF][CinF][taps] with the dgrad's output channels second) and written as 16-byte
+// pieces, 32 consecutive rows (= lanes of a fragment) per 512-byte run.
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real,
+                                                                 int Cin_real, int ntap, int Cout_pad, int Cin, int frag, int dgrad,
+                                                                 const float* __restrict__ scale) {
+    constexpr int CT = 32, CIT = 16;
+    constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;
+    extern __shared__ float tile[];                    // [CT co][CIT ci][ntap]
+    const int co0 = blockIdx.x * CT, ci0 = blockIdx.y * CIT;
+    const int tid = threadIdx.x;
+    const int per_co = CIT * ntap;
+    if (!dgrad) {
+        for (int L = tid; L < CT * per_co; L += 256) {
+            const int co_l = L / per_co, e = L - co_l * per_co;
+            const int co = co0 + co_l, ci = ci0 + e / ntap;
+            tile[L] = (co < Cout_real && ci < Cin_real) ? w[((size_t)co * Cin_real + ci0) * ntap + e] : 0.f;
+        }
+    } else {
+        const int per_ci = CT * ntap;
+        for (int L = tid; L < CIT * per_ci; L += 256) {
+            const int ci_l = L / per_ci, e = L - ci_l * per_ci;
+            const int co_l = e / ntap, tsrc = e - co_l * ntap;
+            const int co = co0 + co_l, ci = ci0 + ci_l;
+            float v = 0.f;
+            if (co < Cout_real && ci < Cin_real) v = w[((size_t)ci * Cout_real + co0) * ntap + e] * (scale ? scale[ci] : 1.f);
+            tile[(co_l * CIT + ci_l) * ntap + (ntap - 1 - tsrc)] = v;
+        }
+    }
+    __syncthreads();
+    constexpr int SL = CIT / EPS;                      // 16-byte pieces per row of the tile
+    const int npieces = ntap * SL * CT;
+    for (int id = tid; id < npieces; id += 256) {
+        const int co_l = id % CT, r = id / CT, sl = r % SL, tap = r / SL;
+        const int co = co0 + co_l, ci = ci0 + sl * EPS;
+        float v[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) v[e] = tile[(co_l * CIT + sl * EPS + e) * ntap + tap];
+        size_t dst;                                     // in elements
+        if (frag) {
+            const int cc = ci / CK, slot = (ci % CK) / EPS;
+            const int lane = (slot & 1) * 32 + (co & 31);
+            dst = (((((size_t)tap * (Cin / CK) + cc) * (Cout_pad >> 5) + (co >> 5)) * 4 + (slot >> 1)) * 64 + lane) * EPS;
+        } else {
+            dst = ((size_t)tap * Cout_pad + co) * Cin + ci;
+        }
+        uint4 o;
+        if (DT == DAT_BF16) {
+            o.x = f2bf2(v[0], v[1]); o.y = f2bf2(v[2], v[3]); o.z = f2bf2(v[4 % EPS], v[5 % EPS]); o.w = f2bf2(v[6 % EPS], v[7 % EPS]);
+        } else {
+            o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+        }
+        *(uint4*)((char*)out + dst * ElemOf<DT>::size) = o;
+    }
+}
+
 // stem packing (see dat_hip.h: dat_stem_pack): one thread = one 16-byte group of output channels
 template <int DT>
 __global__ void stem_pack_kernel(const float* __restrict__ data, void* __restrict__ out, int N, int T, int H, int W,
@@ -889,7 +949,7 @@ int cout_pad_of(const dat_conv_desc* d) {
 }
 
 // packed-weight layout of a layer: the 128-channel tile variants read A fragments straight from global memory (WD)
-bool weights_direct(const dat_ctx* ctx, const dat_conv_desc* d) { return ctx->dbg_wd && d->Cout > 64; }
+bool weights_direct(const dat_ctx* ctx, const dat_conv_desc* d) { return ctx->dbg_wd && (d->Cout > 64 || ctx->dbg_wd >= 2); }
 
 }  // namespace
 
@@ -913,23 +973,50 @@ double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
     return 2.0 * Cout_real * Cin_real * d->KT * d->KH * d->KW * oframes * Ho * Wo;
 }
 
+}  // extern "C"
+
+namespace {
+// rows / cols: real extents of the packed matrix (forward: Cout, Cin; dgrad: CinF, CoutF)
+int launch_pack(dat_ctx* ctx, hipStream_t st, const dat_conv_desc* d, const float* w, int rows, int cols, int dgrad, const float* scale,
+                void* packed) {
+    const int ntap = d->KT * d->KH * d->KW;
+    const int cp = cout_pad_of(d);
+    const int frag = weights_direct(ctx, d) ? 1 : 0;
+    const size_t lds = (size_t)32 * 16 * ntap * sizeof(float);
+    if (lds <= 160 * 1024 && !ctx->dbg_pack_simple) {     // coalesced on both sides (see pack_weights_tiled_kernel)
+        const dim3 grid(cp / 32, d->Cin / 16);
+        int rc;
+        if (d->dtype == DAT_BF16) {
+            if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_tiled_kernel<DAT_BF16>, 160 * 1024)) != DAT_OK) return rc;
+            hipLaunchKernelGGL(pack_weights_tiled_kernel<DAT_BF16>, grid, dim3(256), lds, st, w, packed, rows, cols, ntap, cp, d->Cin, frag,
+                               dgrad, scale);
+        } else {
+            if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_tiled_kernel<DAT_F32>, 160 * 1024)) != DAT_OK) return rc;
+            hipLaunchKernelGGL(pack_weights_tiled_kernel<DAT_F32>, grid, dim3(256), lds, st, w, packed, rows, cols, ntap, cp, d->Cin, frag,
+                               dgrad, scale);
+        }
+    } else {
+        const size_t total = (size_t)ntap * cp * d->Cin;
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+        if (d->dtype == DAT_BF16)
+            hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, st, w, packed, rows, cols, ntap, cp, d->Cin, frag,
+                               dgrad, scale);
+        else
+            hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, st, w, packed, rows, cols, ntap, cp, d->Cin, frag,
+                               dgrad, scale);
+    }
+    DAT_CHECK_LAUNCH(ctx, "pack_weights");
+    return DAT_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w, int Cout_real,
                             int Cin_real, void* packed) {
     DAT_ENFORCE(ctx, d && w && packed, "conv3d_pack_weights: null argument");
     DAT_ENFORCE(ctx, Cout_real <= d->Cout && Cin_real <= d->Cin, "conv3d_pack_weights: real dims exceed descriptor");
-    const int ntap = d->KT * d->KH * d->KW;
-    const int cp = cout_pad_of(d);
-    const size_t total = (size_t)ntap * cp * d->Cin;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    const int frag = weights_direct(ctx, d) ? 1 : 0;
-    if (d->dtype == DAT_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin, frag, 0, (const float*)nullptr);
-    else
-        hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, packed,
-                           Cout_real, Cin_real, ntap, cp, d->Cin, frag, 0, (const float*)nullptr);
-    DAT_CHECK_LAUNCH(ctx, "pack_weights");
-    return DAT_OK;
+    return launch_pack(ctx, (hipStream_t)s, d, w, Cout_real, Cin_real, 0, nullptr, packed);
 }
 
 int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w_fwd, int CoutF, int CinF,
@@ -937,19 +1024,7 @@ int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_des
     DAT_ENFORCE(ctx, d && w_fwd && packed, "conv3d_pack_weights_dgrad: null argument");
     DAT_ENFORCE(ctx, CinF <= d->Cout && CoutF <= d->Cin, "conv3d_pack_weights_dgrad: forward dims %d x %d exceed the data-gradient descriptor (%d outputs, %d inputs)",
                 CoutF, CinF, d->Cout, d->Cin);
-    const int ntap = d->KT * d->KH * d->KW;
-    const int cp = cout_pad_of(d);
-    const size_t total = (size_t)ntap * cp * d->Cin;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    const int frag = weights_direct(ctx, d) ? 1 : 0;
-    if (d->dtype == DAT_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<DAT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w_fwd, packed,
-                           CinF, CoutF, ntap, cp, d->Cin, frag, 1, scale_fwd);
-    else
-        hipLaunchKernelGGL(pack_weights_kernel<DAT_F32>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w_fwd, packed,
-                           CinF, CoutF, ntap, cp, d->Cin, frag, 1, scale_fwd);
-    DAT_CHECK_LAUNCH(ctx, "pack_weights_dgrad");
-    return DAT_OK;
+    return launch_pack(ctx, (hipStream_t)s, d, w_fwd, CinF, CoutF, 1, scale_fwd, packed);
 }
 
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
@@ -1036,22 +1111,25 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     int rc;
     const int tps3 = ctx->dbg_tps3;
     // thin layers (<= 64 output channels, dense 3x3 spatial taps): 3 taps per step
-    const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3;
+    const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3 && !weights_direct(ctx, d);
     if (thin3) {
         tag += 3;   // (dtype digit + 3: the 3-taps-per-step variant)
         rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 64, 128, 1, 3>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 64, 128, 1, 3>(ctx, st, p, 7, ksplit);
-    } else if (!small_n && weights_direct(ctx, d)) {   // 128-channel tiles, weights straight into the MFMA registers
+    } else if (weights_direct(ctx, d)) {   // weights straight into the MFMA registers (all 128-channel tiles; 64-channel ones at DAT_CONV_WD=2)
         // unrolled-tap variants: dense 3x3 (stride 1) and 1x1 (any stride: one tap, one plane); the patch must fit the per-wave
-        // piece registers (tile shapes with very long rows fall back to the table-driven loop)
+        // piece registers (tile shapes with very long rows fall back to the table-driven loop).  1x1 layers with a large output
+        // grid are bandwidth-bound and do better with the leaner table-driven loop (one block more per CU), measured.
         const TileChoice tc = choose_tile(p.Ho, p.Wo, big ? 8 : 7, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
         const long long prow = ((1ll << tc.th_log2) + (p.KH - 1) / p.sh) * ((1ll << tc.tw_log2) + (p.KW - 1) / p.sw);
         const bool fits = ((prow * 8 + 63) >> 6) <= 4 * (big ? 11 : 6);
+        const bool pw_small = (long long)p.frames * p.Ho * p.Wo <= 65536;
         const int ntapv = !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
-                          (d->KH == 1 && d->KW == 1) ? 1 : 0;
-#define DAT_WD_LAUNCH(DT_) (ntapv == 9 ? (big ? launch_conv<DT_, 128, 256, 2, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
-                            : ntapv == 1 ? (big ? launch_conv<DT_, 128, 256, 2, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
-                            : (big ? launch_conv<DT_, 128, 256, 2, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, 128, 128, 2, 1, 1>(ctx, st, p, 7, ksplit)))
-        rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16) : DAT_WD_LAUNCH(DAT_F32);
+                          (d->KH == 1 && d->KW == 1 && (pw_small || ctx->dbg_ntap >= 2)) ? 1 : 0;
+#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
+                            : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
+                            : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1>(ctx, st, p, 7, ksplit)))
+        if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);
+        else rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 128, 2) : DAT_WD_LAUNCH(DAT_F32, 128, 2);
 #undef DAT_WD_LAUNCH
     } else if (d->dtype == DAT_BF16) {
         if (big)

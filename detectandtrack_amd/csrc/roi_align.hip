@@ -7,9 +7,10 @@
 // level directly, and writes its output row in RoI order, so no transposes, concat or permutation exist.
 //
 // Sampling semantics = legacy Detectron RoIAlign (Caffe2 modules/detectron, restated in oracle/roi_align.py).
-// Work split: one 64-lane wave per (roi, frame, ph, pw) output cell; lanes stride over channels in 16-byte
-// vectors, so each of the (sampling^2 x 4) bilinear taps is a contiguous channel read — the wave-level
-// bilinear reduction the C axis of NDHWC makes natural.
+// Work split: a group of lanes per (roi, frame, ph, pw) output cell, the lanes striding over the channels in 16-byte
+// vectors, so each of the (sampling^2 x 4) bilinear taps is a contiguous channel read — the wave-level bilinear reduction the C
+// axis of NDHWC makes natural.  The group is the power of two covering C / (16 bytes) lanes, at most 64: 256 bf16 channels are 32
+// vectors, so a wave works on TWO cells at a time and all 64 lanes fetch (one cell per wave left half of them idle).
 #include "dat_common.h"
 
 namespace {
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
     const long long ncell = (long long)p.R * p.Tr * P * P;
     const int cvecs = p.C / V;
     const int roi_cols = 4 * p.Tr + 1;
-    for (long long cell = (long long)blockIdx.x * 4 + wave; cell < ncell; cell += (long long)gridDim.x * 4) {
+    int grp = 64;                                   // lanes per cell
+    while (grp > 1 && (grp >> 1) >= cvecs) grp >>= 1;
+    const int cpw = 64 / grp;                       // cells per wave
+    const int sub = lane / grp, gl = lane - sub * grp;
+    for (long long cell = ((long long)blockIdx.x * 4 + wave) * cpw + sub; cell < ncell; cell += (long long)gridDim.x * 4 * cpw) {
         const int pw = cell % P;
         long long q = cell / P;
         const int ph = q % P; q /= P;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiParams p) {
         const int gw = p.sampling > 0 ? p.sampling : (int)ceilf(rw / (float)P);
         const float inv = 1.f / (float)(gh * gw);
 
-        for (int cv = lane; cv < cvecs; cv += 64) {
+        for (int cv = gl; cv < cvecs; cv += grp) {
             float acc[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) acc[e] = 0.f;
@@ -154,7 +159,11 @@ extern "C" int dat_roi_align(dat_ctx* ctx, dat_stream s, int dtype, const dat_ro
     p.T = T; p.C = C; p.rois = rois; p.R = R; p.Tr = Tr; p.t0 = t0; p.pooled = pooled; p.sampling = sampling_ratio;
     p.out = (char*)out;
     const long long ncell = (long long)R * Tr * pooled * pooled;
-    long long blocks = (ncell + 3) / 4;
+    const int cvecs = C / (16 / dat_esize(dtype));
+    int grp = 64;
+    while (grp > 1 && (grp >> 1) >= cvecs) grp >>= 1;
+    const int cells_per_block = 4 * (64 / grp);
+    long long blocks = (ncell + cells_per_block - 1) / cells_per_block;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (dtype == DAT_BF16)
         hipLaunchKernelGGL(roi_align_kernel<DAT_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, p);
