@@ -173,12 +173,14 @@ class ClipPipeline(object):
     decodes/NMS-filters the boxes of clip i, the device already runs the body of clip i+1.  depth=1 is the strictly
     sequential reference order (im_detect_all per clip)."""
 
-    def __init__(self, model, ws, depth):
+    def __init__(self, model, ws, depth, graph=False):
         self.model, self.depth = model, depth
         self.slots = [(ws if i == 0 else ws.fork(), torch.cuda.Stream()) for i in range(depth)]
+        self.use_graph, self.graphs = bool(graph), {}
         self.pending = []
         self.n_det = 0
         self.i = 0
+        self.host_enqueue_s = 0.0
         from detectandtrack_amd.core import test as engine
         self.device_glue = engine.device_results_supported()
 
@@ -187,9 +189,26 @@ class ClipPipeline(object):
         self.i += 1
         if len(self.pending) == self.depth:
             self._finish(self.pending.pop(0))
+        t0 = time.perf_counter()
+        slot = (self.i - 1) % self.depth
+        if self.use_graph and self.device_glue:
+            # the clip as ONE hipGraph launch (core/clip_graph.py), captured per slot on first use; a failed capture falls back to eager
+            if slot not in self.graphs:
+                try:
+                    from detectandtrack_amd.core.clip_graph import ClipGraph
+                    self.graphs[slot] = ClipGraph(self.model, w, data_dev, im_info, im_shape, stream=st)
+                except Exception as e:   # noqa
+                    print('hipGraph capture failed (%r): eager launches' % (e,), file=sys.stderr)
+                    self.use_graph = False
+            if self.use_graph:
+                dev = self.graphs[slot].launch(data_dev)
+                self.host_enqueue_s += time.perf_counter() - t0
+                self.pending.append((w, st, im_info, im_shape, dev))
+                return
         with torch.cuda.stream(st):
             stage_net(self.model, w, data_dev, im_info)
             dev = stage_heads_enqueue(self.model, w, im_info, im_shape) if self.device_glue else None
+        self.host_enqueue_s += time.perf_counter() - t0       # host time to enqueue one clip's launches (no synchronisation inside)
         self.pending.append((w, st, im_info, im_shape, dev))
 
     def _finish(self, item):
@@ -351,6 +370,7 @@ def main():
     ap.add_argument('--no-accuracy', action='store_true', help='skip the bf16-vs-fp32 error report (one extra fp32 forward)')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
     ap.add_argument('--pipeline', type=int, default=3, help='clips in flight per GPU (1 = strictly sequential)')
+    ap.add_argument('--graph', type=int, default=1, help='1: every slot replays its clip as one captured hipGraph (core/clip_graph.py); 0: eager launches')
     ap.add_argument('--keyframe-dce', action='store_true',
                     help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '
                          '(identical detections; NOT the default, the default materialises every frame like the reference)')
@@ -397,7 +417,7 @@ def main():
             clips = [[synthetic_clip(1, H, W, 1000 * rank + 10 * i + f)[:, :, 0].contiguous().cuda() for f in range(T)] for i in range(2)]
         else:
             clips = [[synthetic_clip(T, H, W, 1000 * rank + i).cuda()] for i in range(2)]
-        pipe = ClipPipeline(model, ws, a.pipeline)
+        pipe = ClipPipeline(model, ws, a.pipeline, graph=a.graph)
         slots = pipe.slots
 
         def run_steps(n):
@@ -426,6 +446,8 @@ def main():
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
+    if not train:
+        pipe.host_enqueue_s = 0.0
     t0 = time.perf_counter()
     run_steps(a.steps)
     if dist is not None:
@@ -445,8 +467,10 @@ def main():
         mhz.append(getattr(pr, 'shader_mhz', 0.0))
         w.conv_log = None
     shader_mhz = float(np.mean([m for m in mhz if m > 0])) if any(m > 0 for m in mhz) else 0.0
+    host_enqueue_ms = None
     if not train:
         n_det = pipe.n_det
+        host_enqueue_ms = 1e3 * pipe.host_enqueue_s / max(a.steps, 1)
     prof_steps = a.steps
     # One clip in flight, right after the timed region: the strictly sequential rate (host glue and its syncs exposed) and the
     # per-launch durations the roofline is computed from.  With several clips in flight a launch's event pair ALSO spans the
@@ -454,12 +478,23 @@ def main():
     # starts when the hardware queue admits it), so in-region pairs over-state kernel durations ~2x; rocprofv3 (kernel begin -> end)
     # agrees with the one-stream pairs, not with those.  The in-region figures are reported next to them.
     seq_rate, conc = None, None
-    if not train and a.pipeline > 1 and rank == 0:
-        conc = (records, conv_log)
+    graph_on = (not train) and pipe.use_graph and len(pipe.graphs) > 0
+    if not train and (a.pipeline > 1 or graph_on) and rank == 0:
+        conc = (records, conv_log) if records else None     # (graph replays record nothing on the host side)
         w0, st0 = slots[0]
-        seq = ClipPipeline(model, w0, 1)
-        seq.slots = [slots[0]]
         n_seq = min(a.steps, 5)
+        if graph_on:    # the sequential rate of the graph path: slot 0's captured graph, one clip in flight
+            gseq = ClipPipeline(model, w0, 1, graph=True)
+            gseq.slots, gseq.graphs = [slots[0]], {0: pipe.graphs[0]}
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_seq):
+                for unit in clips[i % 2]:
+                    gseq.submit(unit, im_info, im_shape)
+            gseq.drain()
+            seq_rate = n_seq / (time.perf_counter() - t1)
+        seq = ClipPipeline(model, w0, 1)       # eager, per-launch events: the durations the roofline is computed from
+        seq.slots = [slots[0]]
         w0.conv_log = []
         with torch.cuda.stream(st0):
             pr = ops.ConvProfiler(capacity=cap)
@@ -470,7 +505,8 @@ def main():
             for unit in clips[i % 2]:
                 seq.submit(unit, im_info, im_shape)
         seq.drain()
-        seq_rate = n_seq / (time.perf_counter() - t1)
+        if seq_rate is None:
+            seq_rate = n_seq / (time.perf_counter() - t1)
         with torch.cuda.stream(st0):
             records = pr.stop()
         conv_log, w0.conv_log = w0.conv_log, None
@@ -538,6 +574,10 @@ def main():
                              'tflops': round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
                              },
     }
+    if conc is None and (a.pipeline > 1 or graph_on) and not train:
+        roofline['measured'] = ('HIP-event pair around every launch on its launch stream, %d clips run EAGERLY one at a time right after the timed '
+                                'region (%d launches of this kernel); the timed region replays captured hipGraphs, whose launches carry no '
+                                'host-side event pairs' % (prof_steps, dom_n))
     if conc is not None:
         c_rec, c_log = conc
         c_fl = sum(fl for (tag, _, ms), (_, fl, _b) in zip(c_rec, c_log) if tag == dom_tag)
@@ -570,10 +610,15 @@ def main():
         'config': {'workload': workload, 'mode': a.mode, 'name': a.workload,
                    'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
                    'clips_in_flight': 1 if train else a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
+                   'hip_graph': bool(graph_on),
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
         'roofline': roofline,
     }
+    if host_enqueue_ms is not None:
+        # host time spent enqueueing a step's kernel launches (Python executor + ctypes, no synchronisation): the step is
+        # host-bound when this approaches ms_per_step
+        out['host_enqueue_ms_per_step'] = round(host_enqueue_ms, 3)
     if seq_rate is not None:
         out['sequential_clips_per_s'] = round(seq_rate, 3)      # --pipeline 1 equivalent: one clip in flight, host glue exposed
     if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:

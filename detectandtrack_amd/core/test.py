@@ -205,7 +205,7 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     cols = int(rois.t.shape[1])
     T = (cols - 1) // 4
     D = int(cfg.TEST.DETECTIONS_PER_IM)
-    out_cap = D if D > 0 else int(rois.t.shape[0])
+    out_cap = D if D > 0 else int(rois.t.shape[0]) * (cfg.MODEL.NUM_CLASSES - 1)     # no limit: every roi may survive in every class
     dets, kp_rois, n_out = ops.box_results(
         rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, float(im_scale), im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,

@@ -44,7 +44,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_ablate = env_int("DAT_CONV_ABLATE", 0);
         c->dbg_lds_pad = env_int("DAT_CONV_LDS_PAD", 0);
         c->dbg_tps3 = env_int("DAT_CONV_TPS", 3) == 3;
-        c->dbg_wd = env_int("DAT_CONV_WD", 1);       // 0 off, 1 the 128-channel tiles, 2 also the 64-channel ones
+        c->dbg_wd = env_int("DAT_CONV_WD", 2);       // 0 off, 1 the 128-channel tiles only, 2 (default) also the 64-channel ones
         c->dbg_ntap = env_int("DAT_CONV_NTAP", 1);   // 0 off, 1 default rule, 2 unrolled 1x1 variant for every 1x1 layer
         c->dbg_pack_simple = env_int("DAT_PACK_SIMPLE", 0) != 0;
     }

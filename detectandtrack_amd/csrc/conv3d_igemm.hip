@@ -710,15 +710,17 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __
                                                                  const float* __restrict__ scale) {
     constexpr int CT = 32, CIT = 16;
     constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;
-    extern __shared__ float tile[];                    // [CT co][CIT ci][ntap]
+    extern __shared__ float tile[];                    // [CT co][CIT ci][ntap], rows padded by one float: the store phase reads with
+                                                       // co across the lanes, and CIT * ntap (e.g. 432) is a multiple of 16 banks
     const int co0 = blockIdx.x * CT, ci0 = blockIdx.y * CIT;
     const int tid = threadIdx.x;
     const int per_co = CIT * ntap;
+    const int pitch = per_co + 1;
     if (!dgrad) {
         for (int L = tid; L < CT * per_co; L += 256) {
             const int co_l = L / per_co, e = L - co_l * per_co;
             const int co = co0 + co_l, ci = ci0 + e / ntap;
-            tile[L] = (co < Cout_real && ci < Cin_real) ? w[((size_t)co * Cin_real + ci0) * ntap + e] : 0.f;
+            tile[co_l * pitch + e] = (co < Cout_real && ci < Cin_real) ? w[((size_t)co * Cin_real + ci0) * ntap + e] : 0.f;
         }
     } else {
         const int per_ci = CT * ntap;
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __
             const int co = co0 + co_l, ci = ci0 + ci_l;
             float v = 0.f;
             if (co < Cout_real && ci < Cin_real) v = w[((size_t)ci * Cout_real + co0) * ntap + e] * (scale ? scale[ci] : 1.f);
-            tile[(co_l * CIT + ci_l) * ntap + (ntap - 1 - tsrc)] = v;
+            tile[co_l * pitch + ci_l * ntap + (ntap - 1 - tsrc)] = v;
         }
     }
     __syncthreads();
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __
         const int co = co0 + co_l, ci = ci0 + sl * EPS;
         float v[EPS];
 #pragma unroll
-        for (int e = 0; e < EPS; ++e) v[e] = tile[(co_l * CIT + sl * EPS + e) * ntap + tap];
+        for (int e = 0; e < EPS; ++e) v[e] = tile[co_l * pitch + (sl * EPS + e) * ntap + tap];
         size_t dst;                                     // in elements
         if (frag) {
             const int cc = ci / CK, slot = (ci % CK) / EPS;
@@ -982,7 +984,7 @@ int launch_pack(dat_ctx* ctx, hipStream_t st, const dat_conv_desc* d, const floa
     const int ntap = d->KT * d->KH * d->KW;
     const int cp = cout_pad_of(d);
     const int frag = weights_direct(ctx, d) ? 1 : 0;
-    const size_t lds = (size_t)32 * 16 * ntap * sizeof(float);
+    const size_t lds = (size_t)32 * (16 * ntap + 1) * sizeof(float);
     if (lds <= 160 * 1024 && !ctx->dbg_pack_simple) {     // coalesced on both sides (see pack_weights_tiled_kernel)
         const dim3 grid(cp / 32, d->Cin / 16);
         int rc;

@@ -534,12 +534,12 @@ def test_box_results_on_device_match_the_oracle(ops, T, K, R, D):
     pred = (rs.randn(cap, K * 4 * T) * np.tile([1.0, 1.0, 2.0, 2.0], K * T)).astype(np.float32)
     dets, kp, n_out = ops.box_results(_dev(rois), torch.tensor([R], dtype=torch.int32).cuda(), _dev(prob), _dev(pred), K, T, scale,
                                       (H, W, 3), (10., 10., 5., 5.), float(np.float32(np.log(1000. / 16.))), 0.05, 0.5, D,
-                                      D if D > 0 else cap)
+                                      D if D > 0 else cap * (K - 1))
     n = n_out.cpu().numpy()
     scores, boxes = obr.read_bbox_outputs(rois[:R], prob[:R], pred[:R], scale, (H, W, 3))
     ref_scores, ref_boxes, ref_cls = obr.box_results_with_nms_and_limit(scores, boxes, K, 0.05, 0.5, D)
     assert n[1] == ref_boxes.shape[0], (n, ref_boxes.shape)
-    assert n[0] == min(n[1], D if D > 0 else cap)
+    assert n[0] == min(n[1], D if D > 0 else cap * (K - 1))
     k = int(n[0])
     d = dets.cpu().numpy()
     ref_cls_col = np.concatenate([np.full((len(ref_cls[j]),), j, np.float32) for j in range(1, K)])
@@ -559,7 +559,7 @@ def test_box_results_on_device_match_the_real_reference(ops, name):
     T, K, R, D, thr, nms_thr = g[name + '_cfg']
     T, K, R, D = int(T), int(K), int(R), int(D)
     rois = np.hstack((np.zeros((R, 1), np.float32), g[name + '_boxes']))
-    out_cap = D if D > 0 else R
+    out_cap = D if D > 0 else R * (K - 1)
     dets, kp, n_out = ops.box_results(_dev(rois), torch.tensor([R], dtype=torch.int32).cuda(), _dev(g[name + '_scores']),
                                       _dev(g[name + '_deltas']), K, T, 1.0, (720, 1280, 3), (10., 10., 5., 5.),
                                       float(np.float32(np.log(1000. / 16.))), float(thr), float(nms_thr), D, out_cap)

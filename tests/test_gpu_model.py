@@ -130,6 +130,35 @@ def test_im_detect_all_surface():
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_clip_graph_replay_equals_eager(dtype):
+    """core/clip_graph.ClipGraph: a clip captured as one hipGraph (model.net + device post-processing + keypoint net + decode) and
+    replayed on new clips gives exactly the eager results -- same kernels, same arguments."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.clip_graph import ClipGraph
+    from detectandtrack_amd.core.config import cfg
+    T, H, W = 4, 96, 128
+    model, ws, _ = build_product(fpn3d_kps_cfg('18', T=T, dtype=dtype))
+    cfg.TEST.SCORE_THRESH = 0.0
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    clips = [torch.from_numpy(synthetic_clip(T, H, W, seed=s)).cuda() for s in (3, 4, 5)]
+
+    def eager(data):
+        ws.FeedBlob('data', data)
+        ws.FeedBlob('im_info', im_info)
+        ws.RunNet(model.net.name)
+        return engine.read_results_from_device(*engine.enqueue_results_on_device(model, (H, W, 3), 1.0))
+    ref = [eager(c) for c in clips]
+    g = ClipGraph(model, ws, clips[0], im_info, (H, W, 3), stream=torch.cuda.Stream())
+    for c, (rb, rk) in zip(clips, ref):
+        g.launch(c)
+        boxes, keyps = g.results()
+        np.testing.assert_array_equal(boxes[1], rb[1])
+        assert len(keyps[1]) == len(rk[1]) > 0
+        for a, b in zip(keyps[1], rk[1]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_frame_trunk_cache_gives_identical_sliding_window_results(dtype):
     """cfg.HIP.FRAME_TRUNK_CACHE: conv1 / pool1 / res2 have no temporal extent, so a sliding window (one clip per key frame,
     stride 1, border frames replicated, reference utils/video.py:149-201) re-uses their per-frame output.  Detections and
