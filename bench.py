@@ -34,6 +34,11 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+def _dbg(msg):
+    if os.environ.get('BENCH_DEBUG'):
+        print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -427,11 +432,14 @@ def main():
             pipe.drain()
 
     torch.cuda.synchronize()
+    _dbg('built')
     if not train:   # prime every slot once (each HIP stream has its own pool in the caching allocator): not a step, not timed
         for _ in range(len(slots)):
             pipe.submit(clips[0][0], im_info, im_shape)
         pipe.drain()
+    _dbg('primed')
     run_steps(a.warmup)
+    _dbg('warmed up')
 
     # ---- timed region: EXACTLY `steps` steps, barrier + synchronize on both sides.  Every conv launch of every stream is
     # bracketed by its own HIP-event pair (recorded on the launch stream by the C ABI, dat_prof_enable) INSIDE the region ----
@@ -443,6 +451,7 @@ def main():
             pr = ops.ConvProfiler(capacity=cap)
             pr.start()
             profs.append(pr)
+    _dbg('profilers started')
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
@@ -454,6 +463,7 @@ def main():
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _dbg('timed region done')
     records, conv_log, mhz = [], [], []
     for (w, st), pr in zip(slots, profs):
         with torch.cuda.stream(st):
@@ -477,6 +487,7 @@ def main():
     # time the kernel waits behind the other streams' kernels (a HIP event completes when the stream reaches it, a kernel
     # starts when the hardware queue admits it), so in-region pairs over-state kernel durations ~2x; rocprofv3 (kernel begin -> end)
     # agrees with the one-stream pairs, not with those.  The in-region figures are reported next to them.
+    _dbg('profilers stopped')
     seq_rate, conc = None, None
     graph_on = (not train) and pipe.use_graph and len(pipe.graphs) > 0
     if not train and (a.pipeline > 1 or graph_on) and rank == 0:
@@ -493,6 +504,7 @@ def main():
                     gseq.submit(unit, im_info, im_shape)
             gseq.drain()
             seq_rate = n_seq / (time.perf_counter() - t1)
+            _dbg('graph sequential pass done')
         seq = ClipPipeline(model, w0, 1)       # eager, per-launch events: the durations the roofline is computed from
         seq.slots = [slots[0]]
         w0.conv_log = []

@@ -52,6 +52,18 @@ int dat_ctx_create(dat_ctx** out, int device) {
         delete c;
         return DAT_ERR_ALLOC;
     }
+    // a private non-blocking stream + a pinned word buffer for the context's own small device <-> host transfers: the synchronous
+    // hipMemcpy / hipMemset entry points are avoided after start-up (measured on ROCm 7.2: a synchronous device -> host hipMemcpy
+    // between two replays of a captured hipGraph made the next replay fault)
+    c->util_stream = nullptr;
+    c->pinned = nullptr;
+    if (hipStreamCreateWithFlags((hipStream_t*)&c->util_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
+        if (c->util_stream) hipStreamDestroy((hipStream_t)c->util_stream);
+        hipFree(c->zeros);
+        delete c;
+        return DAT_ERR_ALLOC;
+    }
     *out = c;
     return DAT_OK;
 }
@@ -66,6 +78,8 @@ void dat_ctx_destroy(dat_ctx* ctx) {
     }
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->zeros) hipFree(ctx->zeros);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->util_stream) hipStreamDestroy((hipStream_t)ctx->util_stream);
     delete ctx;
 }
 
@@ -92,15 +106,19 @@ int dat_prof_enable(dat_ctx* ctx, int capacity) {
     }
     ctx->prof_n = 0;
     ctx->prof_enabled = 1;
-    if (hipMemset((char*)ctx->zeros + 256, 0, 16) != hipSuccess) return DAT_ERR_LAUNCH;   // clock counters
+    // clock counters (after everything in flight: the conv kernels of earlier launches add to them)
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemsetAsync((char*)ctx->zeros + 256, 0, 16, (hipStream_t)ctx->util_stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)ctx->util_stream) != hipSuccess) return DAT_ERR_LAUNCH;
     return DAT_OK;
 }
 
 int dat_prof_clock(dat_ctx* ctx, double* shader_mhz) {
     if (!ctx || !shader_mhz) return DAT_ERR_ARG;
-    unsigned long long h[2] = {0, 0};
+    unsigned long long* h = (unsigned long long*)ctx->pinned;
     if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(h, (char*)ctx->zeros + 256, 16, hipMemcpyDeviceToHost) != hipSuccess) return DAT_ERR_LAUNCH;
+        hipMemcpyAsync(h, (char*)ctx->zeros + 256, 16, hipMemcpyDeviceToHost, (hipStream_t)ctx->util_stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)ctx->util_stream) != hipSuccess) return DAT_ERR_LAUNCH;
     *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;   // s_memrealtime ticks at 100 MHz
     return DAT_OK;
 }

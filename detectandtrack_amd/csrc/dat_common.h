@@ -24,6 +24,8 @@ struct dat_ctx {
     size_t ws_bytes;
     void* zeros;           // 512 B in HBM: [0,256) zeros (conv patch loader: source of out-of-frame halo lanes),
                            // [256,272) profiling clock counters of the conv kernel
+    void* util_stream;     // private non-blocking hipStream_t for the context's own small transfers
+    void* pinned;          // 256 B of pinned host memory (their host side)
     // Launch-plan state of THIS context (no process globals: N contexts / N devices per process are independent,
     // SURVEY.md 8b "thread-safe per dat_ctx").  The debug knobs are read from the environment once, at dat_ctx_create.
     int force_bp, force_ks;                 // dat_conv3d_tune_plan / DAT_CONV_BP, DAT_CONV_KSPLIT; 0 = makespan model

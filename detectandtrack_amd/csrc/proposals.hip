@@ -788,19 +788,24 @@ static int nms_host_impl(dat_ctx* ctx, int* keep_out, int* num_out, const float*
     const size_t bytes = (size_t)boxes_num * boxes_dim * 4;
     if (hipMalloc(&d_dets, bytes) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed");
     if (hipMalloc(&d_keep, (size_t)(boxes_num + 1) * 4) != hipSuccess) { hipFree(d_dets); DAT_FAIL(ctx, DAT_ERR_ALLOC, "_nms: hipMalloc failed"); }
+    // everything on the context's private stream with asynchronous copies + one stream synchronisation per direction (the
+    // synchronous hipMemcpy entry point is avoided: on ROCm 7.2 a synchronous device -> host hipMemcpy between two replays of a
+    // captured hipGraph made the next replay fault)
+    hipStream_t us = (hipStream_t)ctx->util_stream;
     int rc = DAT_OK;
-    if (hipMemcpy(d_dets, boxes_host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpyAsync(d_dets, boxes_host, bytes, hipMemcpyHostToDevice, us) != hipSuccess) {
         ctx->last_error = "_nms: host -> device copy failed";
         rc = DAT_ERR_LAUNCH;
     }
-    if (rc == DAT_OK) rc = nms_impl(ctx, nullptr, d_dets, boxes_num, T, thresh, strict, presorted, d_keep, d_keep + boxes_num);
+    if (rc == DAT_OK) rc = nms_impl(ctx, us, d_dets, boxes_num, T, thresh, strict, presorted, d_keep, d_keep + boxes_num);
     if (rc == DAT_OK) {
-        // blocking copies on the null stream: ordered behind the kernels above, no device-wide synchronisation
-        if (hipMemcpy(num_out, d_keep + boxes_num, 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(keep_out, d_keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpyAsync(num_out, d_keep + boxes_num, 4, hipMemcpyDeviceToHost, us) != hipSuccess || hipStreamSynchronize(us) != hipSuccess ||
+            hipMemcpyAsync(keep_out, d_keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost, us) != hipSuccess || hipStreamSynchronize(us) != hipSuccess) {
             ctx->last_error = "_nms: device -> host copy failed";
             rc = DAT_ERR_LAUNCH;
         }
+    } else {
+        hipStreamSynchronize(us);
     }
     hipFree(d_dets);
     hipFree(d_keep);
