@@ -1094,7 +1094,10 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
                 double rounds = nblk / slots;
                 if (rounds <= 3.0) rounds = ceil(rounds); else rounds += 0.5;
                 const double steps = ceil((double)npatch / ks) * ntaps;
-                const double step_us = cand_bp == 256 ? 2.15 : 1.35;
+                // (stride-2 3x3 convs run the table-driven loop with four stride-parity patches per chunk: the 256-position tile pays
+                //  more per step there -- tools/tune_plan.py, round 2: res4_0_branch2a 0.114 ms at 256 positions vs 0.089 at 128)
+                const bool strided_taps = ntaps > 1 && (d->stride_h > 1 || d->stride_w > 1);
+                const double step_us = cand_bp == 256 ? (strided_taps ? 2.8 : 2.15) : 1.35;
                 const double fixed_us = 2.0 + 0.6 * ceil((double)npatch / ks);      // epilogue + exposed patch loads
                 double t = rounds * (steps * step_us + fixed_us);
                 if (ks > 1) t += 4.0 + 2.0 * ks * (double)p.frames * p.Ho * p.Wo * d->Cout * 4.0 / 3.0e6;  // us @3 TB/s
