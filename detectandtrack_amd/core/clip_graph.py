@@ -34,7 +34,8 @@ class ClipGraph(object):
                 self._enqueue()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        # thread_local: other threads of the process (torch.distributed's RCCL watchdog polls events) may touch the runtime meanwhile
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
             self.dev = self._enqueue()
         torch.cuda.synchronize()
 

@@ -322,25 +322,36 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             if (ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
             const char* wnextpatch = (pi + 1 < npat) ? wd_base + ((size_t)(nkt * ntap) * p.n_cchunks + ncc) * wd_cc_stride : wcur;
             __builtin_amdgcn_s_setprio(1);
+            // (the empty asm makes the packed addresses opaque per tap: without it the compiler hoists all NTAP x PT x 4 unpacked and
+            //  xor-ed addresses out of the patch loop as loop invariants -- 144 registers, spilled to scratch)
+            uint4 b[2][PT];
+            unsigned qa[PT];
+#pragma unroll
+            for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[0][jj]));
+#pragma unroll
+            for (int j = 0; j < PT; ++j) qa[j] = (j & 1) ? (qp[0][j >> 1] >> 16) : (qp[0][j >> 1] & 0xffffu);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + qa[j]);
 #pragma unroll
             for (int tp = 0; tp < NTAP; ++tp) {
                 const char* wnext = (tp + 1 < NTAP) ? wcur + (size_t)(tp + 1) * tap_stride : wnextpatch;
-                uint4 b[2][PT];
-                // (the empty asm makes the packed addresses opaque per tap: without it the compiler hoists all NTAP x PT x 4 unpacked and
-                //  xor-ed addresses out of the patch loop as loop invariants -- 144 registers, spilled to scratch)
-                unsigned qa[PT];
-#pragma unroll
-                for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[tp][jj]));
-#pragma unroll
-                for (int j = 0; j < PT; ++j) qa[j] = (j & 1) ? (qp[tp][j >> 1] >> 16) : (qp[tp][j >> 1] & 0xffffu);
-#pragma unroll
-                for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + qa[j]);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int cur = ks & 1, nxt = cur ^ 1;
                     if (ks < 3) {
 #pragma unroll
                         for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + (qa[j] ^ (unsigned)((ks + 1) << 5)));
+                    } else if (tp + 1 < NTAP) {
+                        // the first fragments of the NEXT tap, behind this tap's last k-slice: no tap opens with an exposed LDS round trip
+#pragma unroll
+                        for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[tp + 1 < NTAP ? tp + 1 : tp][jj]));
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) {
+                            const unsigned w2 = qp[tp + 1 < NTAP ? tp + 1 : tp][j >> 1];
+                            qa[j] = (j & 1) ? (w2 >> 16) : (w2 & 0xffffu);
+                        }
+#pragma unroll
+                        for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + qa[j]);
                     }
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
