@@ -629,6 +629,226 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
 #endif
 }
 
+// ---- weights-stationary 3x3, 64 -> 64 channels (the res2 stage: ResNet3D.py:266-272 at 1/4 resolution) -------------------------
+// The generic kernel streams a layer's weights to every block; with 64 output channels a block has only 2 row blocks of MFMA work
+// per weight fragment, so the 72 KB of weights per 128 positions are the traffic that bounds it (each MFMA needs a fresh 1-KiB
+// fragment through the CU's 64 B/clk L1: 0.12 ms per layer in the network, 310 TFLOP/s, against a 0.03 ms HBM floor).  Here the
+// WHOLE weight tensor (9 taps x 64 x 64 bf16 = 72 fragments of 16 B per lane) lives in each wave's registers for the life of a
+// PERSISTENT block (one block per CU, one wave per SIMD, 512-register budget), and the block walks over output tiles:
+//   * a tile is 256 positions (8 x 32 or 16 x 16); its (TH+2) x (TW+2) x 128-B input patch is double-buffered in LDS by LDS-DMA
+//     -- the next tile's patch is requested before the current tile's MFMAs, so HBM latency never shows;
+//   * per tile a wave runs 9 taps x 4 k-slices x (2 B-fragment ds_read_b128 + 4 MFMAs): the only operand traffic is 72 LDS reads
+//     for 144 MFMAs (every B fragment feeds both 32-channel row blocks), no weight traffic at all, ONE barrier per tile;
+//   * the epilogue (affine, residual, ReLU, 16-byte channel-contiguous stores) goes through a per-wave LDS slice as in the
+//     generic kernel.
+struct Ws64Params {
+    const char* x;
+    const char* w;              // MFMA-fragment order (pack_weights*, frag = 1): [tap][32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    const char* zeros;
+    int frames, H, W, out_cs, relu, res_mode;
+    int tiles_h, tiles_w, ntiles;
+    int ablate;                 // DEBUG (DAT_CONV_ABLATE): 1 skip the patch loads after the first, 4 skip the stores (and residual loads)
+};
+
+template <int TWL>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c64_ws_kernel(const Ws64Params p) {
+    constexpr int TW = 1 << TWL, TH = 256 >> TWL, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIX = PH * PW, NPIECE = (NPIX * 8 + 63) / 64, PBYTES = NPIECE * 1024, UMAX = (NPIECE + 3) / 4;
+    constexpr int EPITCH = 64 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    char* const est = smem + 2 * PBYTES + wave * (32 * EPITCH);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- the layer's weights: 72 fragments, resident: taps 0-2 in VGPRs, taps 3-8 in AGPRs (with the 64 accumulators: all 256) ----
+    // The MFMAs below are inline assembly for exactly this reason: gfx950 MFMAs read their A operand from either register file, but
+    // the compiler only ever used the AGPR half as spill space (4 v_accvgpr_read per fragment and tile) and, out of VGPRs,
+    // serialised every ds_read behind an lgkmcnt(0).  The "v" / "a" constraints pin each fragment to its file.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int VT = 3;                                   // taps held in VGPRs
+    u32x4_t wv[VT][2][4], wg[9 - VT][2][4];
+    {
+        const char* wl = p.w + lane * 16;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4_t v = *(const u32x4_t*)(wl + ((tp * 2 + mb) * 4 + ks) * 1024);
+                    if (tp < VT) wv[tp][mb][ks] = v; else wg[tp - VT][mb][ks] = v;
+                }
+    }
+#define WS_MFMA0_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_A(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "a"(A_), "v"(B_) : "memory")
+    // ---- swizzled LDS address (k-slice 0) of the B fragment of every (tap, position sub-tile), two per register ----
+    // sub-tile j of this wave: 8 x 32 tiles: output row 2*wave + j, column n; 16 x 16 tiles: rows 4*wave + 2*j + (n >> 4), column n & 15
+    unsigned qp[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        unsigned q = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (n >> 4), c = TWL == 5 ? n : (n & 15);
+            const int row = (r + tp / 3) * PW + c + tp % 3;
+            const int g = (row >> 1) & 7;
+            const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
+            q |= a16 << (16 * j);
+        }
+        qp[tp] = q;
+    }
+    static_assert(PBYTES < 65536, "two 16-bit patch addresses per register");
+    // ---- epilogue constants: this lane's 8 channels in the store phase ----
+    const int sl_c = (lane & 7) * 8, sl_p = lane >> 3;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[sl_c + e] : 1.f;
+        bi[e] = p.bias ? p.bias[sl_c + e] : 0.f;
+    }
+    const int tiles_per_frame = p.tiles_h * p.tiles_w;
+
+    // patch of tile `tl` -> LDS buffer `b` (this wave's 1-KiB pieces wave, wave + 4, ...): lane-linear LDS-DMA image, the XOR swizzle
+    // applied on the source side; halo pixels outside the frame (and the tail lanes of the last piece) fetch zeros
+#define WS_DMA(TL_, B_)                                                                                                   \
+    {                                                                                                                     \
+        const int f_ = (TL_) / tiles_per_frame, r_ = (TL_) - f_ * tiles_per_frame;                                        \
+        const int th_ = r_ / p.tiles_w, tw_ = r_ - th_ * p.tiles_w;                                                       \
+        const int ih0_ = th_ * TH - 1, iw0_ = tw_ * TW - 1;                                                               \
+        const char* xf_ = p.x + (size_t)f_ * p.H * p.W * 128;                                                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < UMAX; ++u_) {                                                             \
+            const int piece_ = wave + 4 * u_;                                                                             \
+            if (piece_ < NPIECE) {                                                                                        \
+                const int it_ = piece_ * 64 + lane, row_ = it_ >> 3;                                                      \
+                const int slot_ = (it_ ^ (row_ >> 1)) & 7;                                                                \
+                const int prow_ = row_ / PW, pcol_ = row_ - prow_ * PW;                                                   \
+                const int ih_ = ih0_ + prow_, iw_ = iw0_ + pcol_;                                                         \
+                const bool ok_ = row_ < NPIX && (unsigned)ih_ < (unsigned)p.H && (unsigned)iw_ < (unsigned)p.W;           \
+                const char* src_ = ok_ ? xf_ + ((unsigned)(ih_ * p.W + iw_) * 128u + (unsigned)(slot_ * 16)) : p.zeros;   \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (B_) * PBYTES + piece_ * 1024), 16, 0, 0); \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) WS_DMA(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int buf = 0;
+    for (; tile < p.ntiles; tile += gridDim.x, buf ^= 1) {
+        // every wave has retired its DMA pieces of this tile (the vmcnt(0) before its last epilogue / above) and has left the other
+        // buffer (its reads ended before that epilogue): one barrier publishes the patch and frees the other buffer
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles && !(p.ablate & 1)) WS_DMA(next, buf ^ 1);
+        f32x16_t acc[2][2];
+        const unsigned boff = (unsigned)buf * PBYTES;
+        __builtin_amdgcn_s_setprio(1);
+        // 36 steps (tap, k-slice) of 2 B-fragment reads + 4 MFMAs; the reads run two steps ahead through a 3-slot register ring (one
+        // wave per SIMD: nothing else hides the LDS latency).  The statements are volatile asm with memory clobbers: program order.
+        u32x4_t bq[3][2];
+        unsigned a0 = 0, a1 = 0;
+#define WS_READ(S_)                                                                                  \
+        {                                                                                            \
+            if ((S_) % 4 == 0) {                                                                     \
+                unsigned q_ = qp[(S_) / 4];                                                          \
+                asm volatile("" : "+v"(q_));   /* opaque per tile: keeps the 72 unpacked / xor-ed addresses out of registers */ \
+                a0 = (q_ & 0xffffu) + boff; a1 = (q_ >> 16) + boff;                                  \
+            }                                                                                        \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 3][0]) : "v"(a0 ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 3][1]) : "v"(a1 ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+        }
+        WS_READ(0);
+        WS_READ(1);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            if (st + 2 < 36) WS_READ(st + 2);
+            // LDS returns in order: all but the reads of the (up to) two later steps have landed.  (The reads are asm too, so the
+            // compiler's own waitcnt pass -- which waited for lgkmcnt(0) before every asm use of a pending ds_read -- stays out.)
+            if (st + 2 < 36) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (st + 1 < 36) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int tp = st / 4, ks = st % 4;
+            const u32x4_t b0 = bq[st % 3][0], b1 = bq[st % 3][1];
+            if (st == 0) {
+                WS_MFMA0_V(acc[0][0], wv[0][0][0], b0); WS_MFMA0_V(acc[1][0], wv[0][1][0], b0);
+                WS_MFMA0_V(acc[0][1], wv[0][0][0], b1); WS_MFMA0_V(acc[1][1], wv[0][1][0], b1);
+            } else if (tp < VT) {
+                WS_MFMA_V(acc[0][0], wv[tp < VT ? tp : 0][0][ks], b0); WS_MFMA_V(acc[1][0], wv[tp < VT ? tp : 0][1][ks], b0);
+                WS_MFMA_V(acc[0][1], wv[tp < VT ? tp : 0][0][ks], b1); WS_MFMA_V(acc[1][1], wv[tp < VT ? tp : 0][1][ks], b1);
+            } else {
+                WS_MFMA_A(acc[0][0], wg[tp >= VT ? tp - VT : 0][0][ks], b0); WS_MFMA_A(acc[1][0], wg[tp >= VT ? tp - VT : 0][1][ks], b0);
+                WS_MFMA_A(acc[0][1], wg[tp >= VT ? tp - VT : 0][0][ks], b1); WS_MFMA_A(acc[1][1], wg[tp >= VT ? tp - VT : 0][1][ks], b1);
+            }
+        }
+#undef WS_READ
+        // (the compiler does not see MFMAs in the asm above: cover the XDL-write -> VALU-read wait states of the accumulators by hand)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's patch pieces (requested a whole tile of MFMAs ago)
+
+        // ---- epilogue: per-wave LDS transpose, affine + residual + ReLU, 16-byte channel-contiguous stores ----
+        // (interleaving it with the next tile's MFMAs was tried and dropped: vmcnt is one in-order counter, so the first residual
+        //  load consumed -- and, through the compiler's LDS-DMA alias rule, the first LDS access of the epilogue -- would wait for the
+        //  patch DMA issued just before it)
+        const int f = tile / tiles_per_frame, rr = tile - f * tiles_per_frame;
+        const int th_i = rr / p.tiles_w, tw_i = rr - th_i * p.tiles_w;
+        const int oh0 = th_i * TH, ow0 = tw_i * TW;
+        const size_t tile_pos = ((size_t)f * p.H + oh0) * p.W + ow0;
+        char* const ybase = p.y + tile_pos * p.out_cs * 2;
+        const char* const rbase = p.res + tile_pos * p.out_cs * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(est + n * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                        make_float4(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+                const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const int ohl = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                if (oh0 + ohl >= p.H || ow0 + owl >= p.W || (p.ablate & 4)) continue;
+                const unsigned lpos = (unsigned)(ohl * p.W + owl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                if (p.res_mode) {
+                    const uint4 r = *(const uint4*)(rbase + (lpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u);
+                    const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(uint4*)(ybase + (lpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#undef WS_DMA
+#undef WS_MFMA0_V
+#undef WS_MFMA_V
+#undef WS_MFMA_A
+}
+
 // split-K finish: y = act(sum_s part[s] * scale + bias + residual), 4 channels per thread
 template <int DT>
 __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit, size_t npos, int Cout, int out_cs,
@@ -1021,6 +1241,53 @@ int launch_pack(dat_ctx* ctx, hipStream_t st, const dat_conv_desc* d, const floa
     DAT_CHECK_LAUNCH(ctx, "pack_weights");
     return DAT_OK;
 }
+
+// weights-stationary persistent kernel (conv3x3_c64_ws_kernel): what it assumes, and the tile shape with the least wasted work
+bool ws64_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_ws64 && d->dtype == DAT_BF16 && d->Cin == 64 && d->Cout == 64 && d->KT == 1 && d->KH == 3 && d->KW == 3 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->pad_t == 0 && d->res_mode != 2 &&
+           d->out_tn <= 0 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
+}
+
+int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    if (ctx->num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        ctx->num_cu = n > 0 ? n : 256;
+    }
+    Ws64Params p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y; p.zeros = cp.zeros;
+    p.frames = cp.frames; p.H = cp.H; p.W = cp.W; p.out_cs = cp.out_cs; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    p.ablate = ctx->dbg_ablate;
+    DAT_ENFORCE(ctx, (long long)p.H * p.W * std::max(p.out_cs, 64) * 2 < (1ll << 31), "conv3d: frame of %dx%d exceeds 32-bit offsets", p.H, p.W);
+    // 8 x 32 or 16 x 16 positions per tile: fewest rounds of the persistent grid (ties: the smaller 16 x 16 patch)
+    int best_twl = 4;
+    long long best_rounds = -1, best_tiles = 0;
+    for (int twl = 4; twl <= 5; ++twl) {
+        if ((ctx->dbg_ws64 == 2 && twl != 5) || (ctx->dbg_ws64 == 3 && twl != 4)) continue;   // DEBUG: DAT_CONV_WS64=2 / 3 force 8x32 / 16x16
+        const int tw = 1 << twl, th = 256 >> twl;
+        const long long tiles = (long long)p.frames * cdiv_ll(p.H, th) * cdiv_ll(p.W, tw);
+        const long long rounds = cdiv_ll(tiles, ctx->num_cu);
+        if (best_rounds < 0 || rounds < best_rounds) { best_rounds = rounds; best_twl = twl; best_tiles = tiles; }
+    }
+    const int tw = 1 << best_twl, th = 256 >> best_twl;
+    p.tiles_h = (int)cdiv_ll(p.H, th); p.tiles_w = (int)cdiv_ll(p.W, tw);
+    DAT_ENFORCE(ctx, best_tiles > 0 && best_tiles < (1ll << 31), "conv3d: %lld tiles unsupported", best_tiles);
+    p.ntiles = (int)best_tiles;
+    const int npiece = ((th + 2) * (tw + 2) * 8 + 63) / 64;
+    const size_t lds = (size_t)2 * npiece * 1024 + 4 * 32 * (64 * 4 + 16);
+    const unsigned grid = (unsigned)std::min<long long>(best_tiles, ctx->num_cu);
+    if (best_twl == 5) {
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_c64_ws_kernel<5>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_c64_ws_kernel<5>, dim3(grid), dim3(NTHREADS), lds, st, p);
+    } else {
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_c64_ws_kernel<4>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_c64_ws_kernel<4>, dim3(grid), dim3(NTHREADS), lds, st, p);
+    }
+    DAT_CHECK_LAUNCH(ctx, "conv3x3_c64_ws");
+    return DAT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1128,7 +1395,10 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     const int tps3 = ctx->dbg_tps3;
     // thin layers (<= 64 output channels, dense 3x3 spatial taps): 3 taps per step
     const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3 && !weights_direct(ctx, d);
-    if (thin3) {
+    if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
+        tag = 64 * 10000 + 9990 + d->dtype;    // ("999 positions": the persistent weights-stationary kernel)
+        rc = launch_ws64(ctx, st, p);
+    } else if (thin3) {
         tag += 3;   // (dtype digit + 3: the 3-taps-per-step variant)
         rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 64, 128, 1, 3>(ctx, st, p, 7, ksplit) : launch_conv<DAT_F32, 64, 128, 1, 3>(ctx, st, p, 7, ksplit);
     } else if (weights_direct(ctx, d)) {   // weights straight into the MFMA registers (all 128-channel tiles; 64-channel ones at DAT_CONV_WD=2)

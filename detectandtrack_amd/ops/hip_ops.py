@@ -441,6 +441,18 @@ class StemConv(object):
                    int(self.relu), n, t, h, w, _ptr(out))
         return out
 
+    def pooled(self, data):
+        """conv1 + affine + ReLU + MaxPool [1,3,3]/[1,2,2]/pad 1 in one kernel (dat_stem_conv_pool): returns pool1 only."""
+        data = data.contiguous()
+        n, c, t, h, w = data.shape
+        assert c == 3 and data.dtype == torch.float32
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+        out = torch.empty((n * t, hp, wp, 64), dtype=tdtype(self.dtype), device=data.device)
+        ctx().call('dat_stem_conv_pool', _stream(), self.dtype, _ptr(data), _ptr(self.packed), _ptr(self.scale), _ptr(self.bias),
+                   int(self.relu), n, t, h, w, _ptr(out))
+        return out
+
 
 def maxpool_hw(x, dtype, k, stride, pad):
     f, h, w, c = x.shape

@@ -421,8 +421,35 @@ class Executor(object):
             return ops.StemConv(_w5d(ws.dev_param(a['w'])), scale, bias, dt, relu=a['relu'])
         layer = self._layer(i, build)
         # (the fused stem kernel is not a conv3d_igemm launch: it is not part of the bench's per-launch conv log)
+        pool = self._stem_pool_op(i, op)
+        if pool is not None:           # conv1 has one reader, pool1: one kernel, conv1 never written (cfg.HIP.FUSE_STEM_POOL)
+            pi, pop = pool
+            self._skip.add(pi)
+            ws.blobs.pop(op.outputs[0], None)
+            ws.blobs[pop.outputs[0]] = Blob(layer.pooled(data.float()), 'fmap', n, t, a['dim_out'], dt, five_d)
+            return
         y = layer(data.float())
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
+
+    def _stem_pool_op(self, i, op):
+        """(index, op) of the MaxPool [1,3,3] / [1,2,2] / pad 1 that is the ONLY reader of the stem's output (in any net of this
+        workspace), or None."""
+        if not cfg.HIP.get('FUSE_STEM_POOL', True):
+            return None
+        out, found = op.outputs[0], None
+        for net in self.ws.nets.values():
+            for j, o in enumerate(net.ops):
+                res = o.args.get('residual') if isinstance(o.args, dict) else None
+                if out in o.inputs or res == out:
+                    if found is not None or net is not self.net or o.type != 'MaxPool':
+                        return None
+                    found = (j, o)
+        if found is None or found[0] <= i:
+            return None
+        pa = found[1].args
+        if (pa['k'], pa['stride'], pa['pad']) != (3, 2, 1):
+            return None
+        return found
 
     def _rpn_head_conv(self, i):
         ws, dt = self.ws, _dt(self.ws)

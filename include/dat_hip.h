@@ -256,6 +256,12 @@ int dat_stem_conv_pack_weights(dat_ctx* ctx, dat_stream s, int dtype, const floa
 int dat_stem_conv(dat_ctx* ctx, dat_stream s, int dtype, const float* data, const void* w_packed, const float* scale,
                   const float* bias, int relu, int N, int T, int H, int W, void* out);
 
+/* conv1 + AffineChannelNd + ReLU + pool1 fused (ResNet3D.py:258-265: ... -> MaxPool [1,3,3] / [1,2,2] / pad [0,1,1]): writes
+ * only out_pool [N*T, Hp, Wp, 64]; the `conv1` blob (the largest of the network, one reader) is never materialised.
+ * Bit-identical to dat_stem_conv followed by dat_maxpool_hw(k 3, stride 2, pad 1). */
+int dat_stem_conv_pool(dat_ctx* ctx, dat_stream s, int dtype, const float* data, const void* w_packed, const float* scale,
+                       const float* bias, int relu, int N, int T, int H, int W, void* out_pool);
+
 /* ---- keypoint heatmap decoding  (lib/utils/keypoints.py:94-149 heatmaps_to_keypoints, :210-216) ---- */
 /* maps fp32 [R, T*K, M, M] (kps_score), boxes fp32 [R, 4*T] image-space tubes -> out fp32 [R, 4, T*K], rows
  * (x, y, logit, prob), column t*K + k (core/test.py:875-893 concatenates the frames along the keypoint axis):

@@ -137,6 +137,43 @@ def test_conv3d(ops, case, dtype):
     assert err < tol
 
 
+WS64_CASES = [
+    # name, frames, H, W, relu, residual, affine   (3x3, 64 -> 64, bf16: the persistent weights-stationary kernel)
+    ('ragged_16x16', 2, 37, 53, True, True, True),          # 16 x 16 tiles, ragged in both directions
+    ('tiny', 1, 3, 5, False, False, False),                 # smaller than one tile
+    ('long_rows_8x32', 1, 8, 9600, True, False, True),      # 8 x 32 tiles (fewer rounds of the persistent grid), > 256 tiles
+    ('res2_like', 8, 96, 168, True, True, True),            # many tiles per block: the double-buffered patch pipeline
+]
+
+
+@pytest.mark.parametrize('case', WS64_CASES, ids=[c[0] for c in WS64_CASES])
+def test_conv3x3_c64_weights_stationary(ops, case):
+    """conv3x3_c64_ws_kernel (3x3, 64 -> 64 channels, bf16; weights resident in registers, persistent blocks) against torch on the
+    same bf16 operands, and bit for bit against the generic kernel (forced plan: same tap / k-slice accumulation order)."""
+    name, frames, H, W, relu, with_res, affine = case
+    rs = np.random.RandomState(len(name) * 7 + H)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(1, 64, frames, H, W).astype(np.float32))
+    w = q((rs.randn(64, 64, 1, 3, 3) * np.sqrt(2.0 / (64 * 9))).astype(np.float32))
+    scale = rs.uniform(0.5, 1.5, 64).astype(np.float32) if affine else None
+    bias = (rs.randn(64) * 0.1).astype(np.float32)
+    res = q(rs.randn(1, 64, frames, H, W).astype(np.float32)) if with_res else None
+    ref = _conv_ref(x, w, scale, bias, res, (1, 1), (0, 1, 1), relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(1, 1), pads=(0, 1, 1), relu=relu, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    rd = ops.to_ndhwc(_dev(res), 1, layer.cstride) if with_res else None
+    y = layer(xd, T=frames, residual=rd, res_mode=1 if with_res else 0)
+    try:
+        assert ops.tune_plan(128, 1) == 0          # a forced plan selects the generic kernel
+        y_gen = layer(xd, T=frames, residual=rd, res_mode=1 if with_res else 0)
+    finally:
+        ops.tune_plan(0, 0)
+    assert torch.equal(y, y_gen)
+    got = ops.to_ncdhw(y, 1, 1, 64, frames).cpu().numpy()
+    err = np.abs(got - ref).max()
+    assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4), err
+
+
 PW_CASES = [
     # name, T, H, W, Cin, Cout, relu, res_mode, affine   (HBM-bound pointwise layers at a realistic number of positions)
     ('lateral_up2', 2, 126, 162, 64, 256, False, 2, False),
@@ -866,6 +903,28 @@ def test_fused_stem_and_maxpool_at_bench_size(ops):
     pool = ops.maxpool_hw(y, ops.BF16, 3, 2, 1).float().cpu().view(1, 8, 192, 336, 64).permute(0, 4, 1, 2, 3)
     ref_pool = F.max_pool3d(got, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
     assert (pool - ref_pool).abs().max().item() == 0.0
+    # dat_stem_conv_pool: the same two layers as one kernel, conv1 never written -- bit-identical pool1
+    layer = ops.StemConv(w.cuda(), scale.cuda(), bias.cuda(), ops.BF16, relu=True)
+    assert torch.equal(layer.pooled(data.cuda()), ops.maxpool_hw(y, ops.BF16, 3, 2, 1))
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('shape', [(1, 1, 7, 9), (2, 3, 45, 61), (1, 2, 64, 122), (1, 1, 130, 251), (1, 2, 23, 24)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_stem_conv_pool_fused_equals_two_kernels(ops, dtype, shape, relu):
+    """dat_stem_conv_pool == dat_stem_conv + dat_maxpool_hw bit for bit on ragged sizes (tile edges in both directions, inputs
+    smaller than one tile, no ReLU so that negative maxima exercise the clamped window)."""
+    dt = ops.BF16 if dtype == 'bf16' else ops.F32
+    n, t, h, w_ = shape
+    g = torch.Generator().manual_seed(h * 1000 + w_)
+    data = (torch.rand((n, 3, t, h, w_), generator=g) * 255 - 110).cuda()
+    w = (torch.randn((64, 3, 1, 7, 7), generator=g) * 0.025).cuda()
+    scale, bias = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) - (0.0 if relu else 3.0)).cuda()
+    layer = ops.StemConv(w, scale, bias, dt, relu=relu)
+    two = ops.maxpool_hw(layer(data), dt, 3, 2, 1)
+    one = layer.pooled(data)
+    assert one.shape == two.shape
+    assert torch.equal(one, two)
 
 
 def test_roi_align_at_bench_size_vs_oracle(ops):

@@ -59,12 +59,15 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--out', default='')
+    ap.add_argument('--only', default='', help='comma-separated layer names')
     a = ap.parse_args()
     dt = ops.BF16 if a.dtype == 'bf16' else ops.F32
     dev = torch.device('cuda:0')
     rows = []
     tot_ms = tot_fl = 0.0
     for (name, cin, cout, k, st, hi, wi, cnt) in layer_list(a.arch, a.T, a.H, a.W, a.kt):
+        if a.only and name not in a.only.split(','):
+            continue
         w = torch.randn(cout, cin, *k, device=dev) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
         pads = (k[0] // 2, k[1] // 2, k[2] // 2) if name != 'stem_k4x1' else (0, 0, 0)
         layer = ops.ConvLayer(w, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), stride=(st, st),
