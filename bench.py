@@ -134,6 +134,18 @@ def build(arch, T, dtype, keyframe_dce=False, two_d=False):
     return model, ws
 
 
+def conv_kernel_name(tag, dtype):
+    """Kernel behind a conv launch tag of the C ABI's profiler (dat_conv3d_fwd: channels-per-block * 10000 + positions-per-block * 10
+    + dtype digit; 999 / 256x256 mark the two special-cased kernels)."""
+    bn, bp = tag // 10000, (tag % 10000) // 10
+    if bn == 64 and bp == 999:
+        return 'conv3x3_c64_ws_kernel<%s>' % dtype          # weights-stationary persistent kernel (3x3, 64 -> 64)
+    if bn == 256 and bp == 256:
+        return 'conv3x3_bt_kernel<%s,256,256>' % dtype      # big-tile kernel (one wave per SIMD)
+    tps = {3: ',tps3', 4: ',tps3'}.get(tag % 10, '')
+    return 'conv3d_igemm_kernel<%s,%d,%d%s>' % (dtype, bn, bp, tps)
+
+
 def stage_net(model, ws, data_dev, im_info):
     """Stage A of a step: feed the resident clip and enqueue `model.net` (asynchronous)."""
     ws.FeedBlob('data', data_dev)
@@ -561,9 +573,8 @@ def main():
     all_ms = sum(ms for _, _, ms in records)
     peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    tps = {3: ',tps3', 4: ',tps3'}.get(dom_tag % 10, '')
-    kernel_name = 'conv3d_igemm_kernel<%s,%d,%d%s>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10, tps)
-    traffic = pmc_traffic(a, 'conv3d_igemm_kernel<%s,%d,%d>' % (a.dtype, dom_tag // 10000, (dom_tag % 10000) // 10)) if not (train or two_d) else None
+    kernel_name = conv_kernel_name(dom_tag, a.dtype)
+    traffic = pmc_traffic(a, kernel_name.replace(',tps3', '')) if not (train or two_d) else None
     streams = len(slots)
     roofline = {
         'bound': 'mfma', 'kernel': kernel_name,

@@ -27,6 +27,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "dat_common.h"
 
 namespace {
@@ -849,6 +852,265 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef WS_MFMA_A
 }
 
+// compile-time index sequence for the hand-scheduled loops (`#pragma unroll` is refused for bodies of this size, and immediates /
+// register-ring slots need constant indices)
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// ---- big-tile 3x3 kernel: 256 output channels x 256 positions per block, one block per CU, one wave per SIMD ---------------------
+// The 128 x 256 kernel above feeds 8 MFMAs per k-slice from 6 operand fragments per wave, two blocks per CU: the CU's operand
+// delivery (L1 64 B/clk for the weight fragments, LDS for the patch) is what holds it at ~55 % of the matrix peak (DESIGN.md
+// section 3).  Here a wave owns 128 channels x 128 positions -- 16 accumulators, all 256 AGPRs -- so a k-slice is 16 MFMAs
+// (512 matrix cycles) for 4 + 4 fragments: half the operand traffic per MFMA, and the CU's L1 / LDS run at 50 % / 25 % of their
+// rate.  With one wave per SIMD nothing hides latencies by itself, so the main loop is software-pipelined BY HAND in volatile asm
+// (the compiler neither re-orders it nor inserts conservative waits):
+//   * weight fragments: straight from global memory (fragment-order layout) into an R-step register ring; the slot a k-slice just
+//     consumed is re-loaded with the slice R steps ahead (R x 512 cycles for L2 latency), waited for with COUNTED vmcnt;
+//   * patch fragments: ds_read_b128 one step ahead (2-slot ring), counted lgkmcnt;
+//   * the (kt, channel-chunk) patches are double-buffered in LDS by LDS-DMA: the next patch is requested when the current one
+//     starts (36 k-slices = 18 k cycles earlier); one barrier per patch.  Every wave issues the same number of DMA pieces (the
+//     tail re-fetches the last piece), so that the vmcnt arithmetic is the same in all waves.
+// The launcher uses it for 256-channel-multiple layers whose grid fills the chip at least ~2 times (FPN P2 / P3 outputs).
+template <int TWL, int R>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_bt_kernel(const ConvParams p) {
+    constexpr int TW = 1 << TWL, TH = 256 >> TWL, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIX = PH * PW, NPIECE = (NPIX * 8 + 63) / 64, PBYTES = NPIECE * 1024, UMAX = (NPIECE + 3) / 4;
+    static_assert(36 % R == 0 && PBYTES < 65536, "ring slots are static per unrolled step; 16-bit patch addresses");
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave & 1, wave_p = wave >> 1;
+    const int khalf = lane >> 5, n = lane & 31;
+
+    // ---- XCD-aware block -> (channel block, tile, frame) map, as in conv3d_igemm_kernel ----
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nx = 8, q = p.nblocks / nx, r = p.nblocks % nx;
+        const unsigned xcd = bid % nx, k = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int nb = bid % p.nblk_n;
+    unsigned tile = bid / p.nblk_n;
+    const int fc = tile % p.otn; tile /= p.otn;
+    const int tw_i = tile % p.tiles_w; tile /= p.tiles_w;
+    const int th_i = tile % p.tiles_h;
+    const int clip = tile / p.tiles_h;
+    const int f = clip * p.otn + fc;
+    const int t = p.ot0 + fc;
+    const int f_in = clip * p.T + t;
+    const int oh0 = th_i * TH, ow0 = tw_i * TW;
+
+    // valid temporal taps of this output frame, rotated start (same order as the generic kernel: bit-identical sums)
+    int kt_lo = 0, kt_hi = p.KT - 1;
+    while (kt_lo < p.KT && (t + kt_lo - p.pt) < p.in_lo) ++kt_lo;
+    while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.in_hi) --kt_hi;
+    const int n_kt = kt_hi - kt_lo + 1;
+    const int npat = n_kt * p.n_cchunks;
+    const int kt_hi_x = kt_lo + n_kt;
+    int kshift = 0;
+    if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
+    int kt = kt_lo + kshift, cc = 0;
+    if (kt >= kt_hi_x) kt -= n_kt;
+
+    // ---- swizzled LDS address (k-slice 0) of the B fragment of every (tap, position sub-tile j), two per register ----
+    // sub-tile j of this wave: 16 x 16 tiles: rows 8*wave_p + 2*j + (n >> 4), column n & 15; 8 x 32 tiles: row 4*wave_p + j, column n
+    unsigned qp[9][2];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (n >> 4), c = TWL == 5 ? n : (n & 15);
+            const int row = (r + tp / 3) * PW + c + tp % 3;
+            const int g = (row >> 1) & 7;
+            const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
+            if (j & 1) qp[tp][j >> 1] |= a16 << 16; else qp[tp][j >> 1] = a16;
+        }
+    // ---- weights: fragment (tap, chunk, 32-row block, k-slice) = 1 KiB at (((tap * ncc + chunk) * MB + block) * 4 + k-slice) * 1024 ----
+    const size_t wd_cc_stride = (size_t)(p.Cout_pad >> 5) * 4096;
+    const size_t tap_stride = (size_t)p.n_cchunks * wd_cc_stride;
+    const char* const wd_base = p.w + (size_t)(nb * 8 + wave_n * 4) * 4096;        // this wave's four 32-row blocks
+    unsigned aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)lane * 16u + (unsigned)i * 4096u;
+
+    // patch (KT_, CC_) of this tile -> LDS buffer B_: every wave issues exactly UMAX pieces (wave, wave + 4, ...; indices past the
+    // last piece re-fetch it); lane-linear LDS-DMA image, XOR swizzle on the source side, halo / tail lanes fetch zeros
+#define BT_DMA(KT_, CC_, B_)                                                                                              \
+    {                                                                                                                     \
+        const int fin_ = f_in + (KT_) - p.pt;                                                                             \
+        const char* xf_ = p.x + ((size_t)fin_ * p.H * p.W) * p.Cin * 2 + (size_t)(CC_) * 128;                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < UMAX; ++u_) {                                                             \
+            const int piece_ = min(wave + 4 * u_, NPIECE - 1);                                                            \
+            const int it_ = piece_ * 64 + lane, row_ = it_ >> 3;                                                          \
+            const int slot_ = (it_ ^ (row_ >> 1)) & 7;                                                                    \
+            const int prow_ = row_ / PW, pcol_ = row_ - prow_ * PW;                                                       \
+            const int ih_ = oh0 - 1 + prow_, iw_ = ow0 - 1 + pcol_;                                                       \
+            const bool ok_ = row_ < NPIX && (unsigned)ih_ < (unsigned)p.H && (unsigned)iw_ < (unsigned)p.W;               \
+            const char* src_ = ok_ ? xf_ + ((size_t)(unsigned)(ih_ * p.W + iw_) * (unsigned)(p.Cin * 2) + (unsigned)(slot_ * 16)) : p.zeros; \
+            __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (B_) * PBYTES + piece_ * 1024), 16, 0, 0);     \
+        }                                                                                                                 \
+    }
+#define BT_WPATCH(KT_, CC_) (wd_base + ((size_t)((KT_) * 9) * p.n_cchunks + (CC_)) * wd_cc_stride)
+    // A fragments of step S_ (tap S_ / 4, k-slice S_ % 4) of the patch whose first tap sits at WP_ -> ring slot SLOT_
+#define BT_ALOAD(WP_, S_, SLOT_)                                                                                          \
+    {                                                                                                                     \
+        const char* wt_ = (WP_) + (size_t)((S_) / 4) * tap_stride;                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                  \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(aq[SLOT_][i_]) : "v"(aoff[i_]), "s"(wt_), "n"(((S_) % 4) * 1024) : "memory"); \
+    }
+    // B fragments of step S_ from buffer offset BOFF_ -> ring slot S_ % 2
+#define BT_BREAD(S_, BOFF_)                                                                                               \
+    {                                                                                                                     \
+        if ((S_) % 4 == 0) {                                                                                              \
+            unsigned q0_ = qp[(S_) / 4][0], q1_ = qp[(S_) / 4][1];                                                        \
+            asm volatile("" : "+v"(q0_), "+v"(q1_));   /* opaque: keeps the unpacked / xor-ed addresses out of registers */ \
+            ba[0] = (q0_ & 0xffffu) + (BOFF_); ba[1] = (q0_ >> 16) + (BOFF_);                                             \
+            ba[2] = (q1_ & 0xffffu) + (BOFF_); ba[3] = (q1_ >> 16) + (BOFF_);                                             \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 2][j_]) : "v"(ba[j_] ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+    }
+#define BT_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4_t aq[R][4], bq[2][4];
+    unsigned ba[4] = {0, 0, 0, 0};
+
+    if (npat > 0) {
+        // ---- prologue: first patch, first R steps of weights ----
+        BT_DMA(kt, cc, 0);
+        const char* wcur = BT_WPATCH(kt, cc);
+        static_for(std::make_integer_sequence<int, R>{}, [&](auto ic_) __attribute__((always_inline)) {
+            constexpr int s0 = decltype(ic_)::value;
+            (void)&aq; (void)&aoff;                            // (operands of asm statements alone do not capture)
+            BT_ALOAD(wcur, s0, s0);
+        });
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * R) : "memory");      // the DMA pieces (older than the R x 4 weight loads)
+        __syncthreads();
+        int buf = 0;
+        for (int pi = 0; pi < npat; ++pi, buf ^= 1) {
+            // the patch after this one
+            int ncc = cc + 1, nkt = kt;
+            if (ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
+            const bool has_next = pi + 1 < npat;
+            if (has_next) BT_DMA(nkt, ncc, buf ^ 1);
+            const char* wnxt = has_next ? BT_WPATCH(nkt, ncc) : wcur;       // (past the last patch: harmless re-loads keep the counts fixed)
+            const unsigned boff = (unsigned)buf * PBYTES;
+            __builtin_amdgcn_s_setprio(1);
+            BT_BREAD(0, boff);
+            static_for(std::make_integer_sequence<int, 36>{}, [&](auto ic_) __attribute__((always_inline)) {
+                constexpr int st = decltype(ic_)::value;
+                (void)&aq; (void)&aoff; (void)&bq; (void)&ba; (void)&acc; (void)&qp;   // (asm operands alone do not capture)
+                if (st + 1 < 36) BT_BREAD(st + 1, boff);
+                // LDS returns in order: all but the 4 reads of the next step have landed
+                if (st + 1 < 36) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // vector memory returns in order: younger than this step's weight loads are the loads of the R - 1 later steps and,
+                // while those loads still date from the previous patch (st < R), this patch's UMAX DMA pieces
+                if constexpr (st < R) {
+                    if (has_next) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1) + UMAX) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1)) : "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) BT_MFMA(acc[i][j], aq[st % R][i], bq[st % 2][j]);
+                // re-load the consumed slot with the step R ahead (this patch, or the first steps of the next one)
+                if constexpr (st + R < 36) { BT_ALOAD(wcur, st + R, st % R); } else { BT_ALOAD(wnxt, st + R - 36, st % R); }
+            });
+            __builtin_amdgcn_s_setprio(0);
+            // every wave's pieces of the next patch have landed (its vmcnt waits from step R on cover them) and it has left this buffer
+            __syncthreads();
+            kt = nkt; cc = ncc; wcur = wnxt;
+        }
+    }
+    // (the asm MFMAs / loads are invisible to the compiler: drain them and cover the XDL-write -> VALU-read wait states by hand)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef BT_MFMA
+#undef BT_BREAD
+#undef BT_ALOAD
+#undef BT_WPATCH
+#undef BT_DMA
+
+    // ---- epilogue: per-wave LDS transpose of 32 positions x 64 channels at a time, affine + residual + ReLU, 16-byte stores ----
+    constexpr int EPITCH = 64 * 4 + 16;
+    char* const est = smem + wave * (32 * EPITCH);             // (the patch buffers are free: the loop ended with a barrier)
+    const int sl_c = (lane & 7) * 8, sl_p = lane >> 3;
+    const size_t tile_pos = ((size_t)f * p.Ho + oh0) * p.Wo + ow0;
+    char* const ybase = p.y + tile_pos * p.out_cs * 2;
+    const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * 2 : p.res + tile_pos * p.out_cs * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                              // 64-channel half of this wave's 128
+        const int c_st = nb * 256 + wave_n * 128 + h * 64 + sl_c;
+        float sc[8], bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = (c_st + e) < p.Cout;
+            sc[e] = (p.scale && ok) ? p.scale[c_st + e] : 1.f;
+            bi[e] = (p.bias && ok) ? p.bias[c_st + e] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(est + n * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                        make_float4(acc[2 * h + i][j][g * 4 + 0], acc[2 * h + i][j][g * 4 + 1], acc[2 * h + i][j][g * 4 + 2], acc[2 * h + i][j][g * 4 + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+                const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const int ohl = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const int oh = oh0 + ohl, ow = ow0 + owl;
+                if (oh >= p.Ho || ow >= p.Wo || c_st >= p.Cout || (p.ablate & 4)) continue;
+                const unsigned lpos = (unsigned)(ohl * p.Wo + owl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                if (p.res_mode) {
+                    unsigned rpos = lpos;
+                    if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
+                    const uint4 r = *(const uint4*)(rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u);
+                    const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(uint4*)(ybase + (lpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.clk && threadIdx.x == 0) {
+        atomicAdd(&p.clk[0], __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(&p.clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
+}
+
 // split-K finish: y = act(sum_s part[s] * scale + bias + residual), 4 channels per thread
 template <int DT>
 __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit, size_t npos, int Cout, int out_cs,
@@ -1249,12 +1511,62 @@ bool ws64_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
            d->out_tn <= 0 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
 }
 
-int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+int ctx_num_cu(dat_ctx* ctx) {
     if (ctx->num_cu == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
         ctx->num_cu = n > 0 ? n : 256;
     }
+    return ctx->num_cu;
+}
+
+// big-tile kernel (conv3x3_bt_kernel): what it assumes; the grid must fill the chip about twice (one block per CU at a time)
+bool bt_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_bt && d->dtype == DAT_BF16 && d->Cin % 64 == 0 && cout_pad_of(d) % 256 == 0 && d->KH == 3 && d->KW == 3 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
+}
+
+int bt_tile_twl(const ConvParams& p, long long* nblocks) {
+    int best = 4;
+    long long best_tiles = -1;
+    for (int twl = 4; twl <= 5; ++twl) {
+        const long long tiles = cdiv_ll(p.Ho, 256 >> twl) * cdiv_ll(p.Wo, 1 << twl);
+        if (best_tiles < 0 || tiles < best_tiles) { best_tiles = tiles; best = twl; }
+    }
+    *nblocks = best_tiles * p.frames * (p.Cout_pad / 256);
+    return best;
+}
+
+int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p) {
+    long long nblocks = 0;
+    const int twl = bt_tile_twl(p, &nblocks);
+    const int tw = 1 << twl, th = 256 >> twl;
+    p.th_log2 = 8 - twl; p.tw_log2 = twl;
+    p.tiles_h = (int)cdiv_ll(p.Ho, th); p.tiles_w = (int)cdiv_ll(p.Wo, tw);
+    p.n_cchunks = p.Cin / 64;
+    p.nblk_n = p.Cout_pad / 256;
+    p.ksplit = 1; p.part = nullptr;
+    p.ablate = ctx->dbg_ablate;
+    DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
+    DAT_ENFORCE(ctx, (long long)p.Ho * p.Wo * std::max(p.out_cs, p.Cout) * 4 < (1ll << 31) && (long long)p.H * p.W * p.Cin * 2 < (1ll << 32),
+                "conv3d: one frame of %dx%d exceeds the 32-bit offsets of the big-tile kernel", p.H, p.W);
+    p.nblocks = (unsigned)nblocks;
+    const int npiece = ((th + 2) * (tw + 2) * 8 + 63) / 64;
+    const size_t lds = (size_t)2 * npiece * 1024;
+#define BT_LAUNCH(TWL_, R_)                                                                                            \
+    {                                                                                                                  \
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_bt_kernel<TWL_, R_>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((conv3x3_bt_kernel<TWL_, R_>), dim3(p.nblocks), dim3(NTHREADS), lds, st, p);                \
+    }
+    // (a 9-step weight ring was tried: 256 VGPRs, spills -- and a scratch access in the loop would break the counted vmcnt waits)
+    if (twl == 5) BT_LAUNCH(5, 6) else BT_LAUNCH(4, 6)
+#undef BT_LAUNCH
+    DAT_CHECK_LAUNCH(ctx, "conv3x3_bt");
+    return DAT_OK;
+}
+
+int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    ctx_num_cu(ctx);
     Ws64Params p;
     p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y; p.zeros = cp.zeros;
     p.frames = cp.frames; p.H = cp.H; p.W = cp.W; p.out_cs = cp.out_cs; p.relu = cp.relu; p.res_mode = cp.res_mode;
@@ -1395,7 +1707,16 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     const int tps3 = ctx->dbg_tps3;
     // thin layers (<= 64 output channels, dense 3x3 spatial taps): 3 taps per step
     const bool thin3 = tps3 && small_n && !big && d->stride_h == 1 && d->stride_w == 1 && d->KH == 3 && d->KW == 3 && !weights_direct(ctx, d);
-    if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
+    // big-tile kernel: one block per CU at a time, so the grid has to fill the chip several times and evenly (FPN P2: 2016 blocks on
+    // 256 CUs = 7.9 rounds; P3's 528 blocks would run 3 rounds for 2.06 of work: 0.45 ms against 0.34 ms with the generic kernel)
+    long long bt_blocks = 0;
+    if (bt_eligible(ctx, d)) bt_tile_twl(p, &bt_blocks);
+    const long long ncu = ctx_num_cu(ctx), bt_rounds = cdiv_ll(bt_blocks, ncu);
+    const bool bt_fits = ctx->dbg_bt >= 2 ? bt_blocks * 2 >= 3 * ncu : (bt_blocks >= 4 * ncu && bt_blocks * 100 >= bt_rounds * ncu * 95);
+    if (bt_fits && ksplit == 1 && !force_bp && !force_ks) {
+        tag = 256 * 10000 + 2560 + d->dtype;
+        rc = launch_bt(ctx, st, p);
+    } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
         tag = 64 * 10000 + 9990 + d->dtype;    // ("999 positions": the persistent weights-stationary kernel)
         rc = launch_ws64(ctx, st, p);
     } else if (thin3) {

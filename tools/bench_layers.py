@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--out', default='')
     ap.add_argument('--only', default='', help='comma-separated layer names')
+    ap.add_argument('--clock', action='store_true', help='also report the shader clock under each layer (dat_prof_clock)')
     a = ap.parse_args()
     dt = ops.BF16 if a.dtype == 'bf16' else ops.F32
     dev = torch.device('cuda:0')
@@ -84,11 +85,20 @@ def main():
         ms = e0.elapsed_time(e1) / a.iters
         fl = layer.flops(a.T, hi, wi)
         tf = fl / ms / 1e9
+        mhz = 0.0
+        if a.clock:
+            prof = ops.ConvProfiler(64)
+            prof.start()
+            for _ in range(a.iters):
+                layer(x, T=a.T, out=y)
+            torch.cuda.synchronize()
+            prof.stop()
+            mhz = prof.shader_mhz
         rows.append(dict(layer=name, cin=cin, cout=cout, k=k, stride=st, hw=(hi, wi), count=cnt, ms=ms, tflops=tf))
         tot_ms += ms * cnt
         tot_fl += fl * cnt
-        print('%-18s cin %4d cout %4d k %s s%d in %4dx%-4d x%d : %8.3f ms  %7.1f TFLOP/s' %
-              (name, cin, cout, k, st, hi, wi, cnt, ms, tf), flush=True)
+        print('%-18s cin %4d cout %4d k %s s%d in %4dx%-4d x%d : %8.3f ms  %7.1f TFLOP/s%s' %
+              (name, cin, cout, k, st, hi, wi, cnt, ms, tf, '  %.0f MHz' % mhz if a.clock else ''), flush=True)
         del x, y, layer, w
     print('TOTAL conv: %.3f ms, %.3f TFLOP -> %.1f TFLOP/s (%.1f%% of 2500)' %
           (tot_ms, tot_fl / 1e12, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 25.0))
