@@ -545,8 +545,28 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * ES
                                               : p.res + tile_pos * p.out_cs * ES;
     float* const pbase = part_mode ? p.part + ((size_t)split * npos_all + tile_pos) * p.Cout : nullptr;
+    // Residual rows (Sum shortcuts, the top-down map of the FPN laterals) are fetched one position group AHEAD of their use: a load
+    // issued where its value is added costs a full memory round trip per store group -- with a top-down map the 64 -> 256 lateral
+    // took 0.188 ms (cold caches) against 0.108 ms without one, for 66 MB of extra reads.
+    constexpr int NQ = 32 / PPI;
+    const bool res_pre = p.res_mode && !part_mode && (p.out_cs & 7) == 0 && c_st + CPL <= p.Cout;   // whole 16-byte pieces
+    uint4 rq[2][NQ];
+    auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pos = wave_p * WP + j * 32 + q * PPI + sl_p;
+            const int ohl = pos >> p.tw_log2, owl = pos & (TW - 1);
+            const int oh = oh0 + ohl, ow = ow0 + owl;
+            const bool live = oh < p.Ho && ow < p.Wo && !(p.ablate & 4);
+            unsigned rpos = (unsigned)(ohl * p.Wo + owl);
+            if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
+            dst[q] = *(const uint4*)(rbase + (live ? (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES : 0u));
+        }
+    };
+    if (res_pre) res_fetch(0, rq[0]);
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
+        if (res_pre && j + 1 < PT) res_fetch(j + 1, rq[(j + 1) & 1]);
         // phase 1: accumulators -> LDS [position][channel] fp32
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
         __builtin_amdgcn_wave_barrier();
         // phase 2: position-major read back, fused epilogue, 16-byte stores
 #pragma unroll
-        for (int q = 0; q < 32 / PPI; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int pl = q * PPI + sl_p;                       // position inside this 32-position group
             float v[CPL];
 #pragma unroll
@@ -580,7 +600,19 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             }
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + bi[e];
-            if (p.res_mode) {
+            if (res_pre) {
+                const uint4 r = rq[j & 1][q];
+                if (DT == DAT_BF16) {
+                    const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < CPL / 2; ++e2) {
+                        v[2 * e2] += bf2f((uint16_t)(ru[e2 % 4] & 0xffff));
+                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2 % 4] >> 16));
+                    }
+                } else {
+                    v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y); v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
+                }
+            } else if (p.res_mode) {
                 unsigned rpos = lpos;
                 if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
                 const char* rp = rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES;
@@ -807,8 +839,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         const size_t tile_pos = ((size_t)f * p.H + oh0) * p.W + ow0;
         char* const ybase = p.y + tile_pos * p.out_cs * 2;
         const char* const rbase = p.res + tile_pos * p.out_cs * 2;
+        // residual rows one sub-tile ahead of their use (a load issued where it is consumed costs a memory round trip per store group)
+        uint4 rq[2][4];
+        auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const int ohl = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const bool live = oh0 + ohl < p.H && ow0 + owl < p.W && !(p.ablate & 4);
+                dst[q] = *(const uint4*)(rbase + (live ? ((unsigned)(ohl * p.W + owl) * (unsigned)p.out_cs + (unsigned)sl_c) * 2u : 0u));
+            }
+        };
+        if (p.res_mode) res_fetch(0, rq[0]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (p.res_mode && j == 0) res_fetch(1, rq[1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -828,7 +873,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
                 if (p.res_mode) {
-                    const uint4 r = *(const uint4*)(rbase + (lpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u);
+                    const uint4 r = rq[j][q];
                     const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) {
@@ -850,6 +895,133 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef WS_MFMA0_V
 #undef WS_MFMA_V
 #undef WS_MFMA_A
+}
+
+// ---- weights-stationary 1x1, 64 -> 256 channels (the FPN P2 lateral: FPN3D.py:111-134 on res2, 1/4 resolution) ------------------
+// An HBM-bound layer: 66 MB in, 264 MB out (+ 66 MB of top-down map).  The generic kernel's 128-channel x 128-position blocks write
+// every output position as four 128-byte pieces from different waves and blocks, at different times; measured with cold caches that
+// costs 0.117 of the layer's 0.188 ms -- 2.3 TB/s of stores on a part that fills memory at 5.8 TB/s (tools/hbm_probe.py).  Here a
+// wave owns ALL 256 channels of its 32 positions: the whole weight matrix (32 fragments, 128 VGPRs) stays in its registers, the
+// input fragments come straight from global memory (32 contiguous bytes per lane pair; prefetched one tile ahead), and after a
+// per-wave LDS transpose every store instruction writes two complete 512-byte output rows.  Waves never synchronise; the grid is
+// persistent (one block per CU: the fp32 transpose slice is 33 KB per wave).
+struct Pw256Params {
+    const char* x;
+    const char* w;              // MFMA-fragment order: [32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    long long npos;             // frames * H * W
+    int H, W, out_cs, relu, res_mode;
+    int ntiles;                 // wave tiles of 32 positions
+    unsigned hw, w_magic;       // H * W; ceil(2^32 / W): row = umulhi(position in frame, w_magic)
+};
+
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_k64_c256_ws_kernel(const Pw256Params p) {
+    constexpr int EPITCH = 256 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    char* const est = smem + wave * (32 * EPITCH);
+    uint4 wa[8][4];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wa[mb][ks] = *(const uint4*)(p.w + (mb * 4 + ks) * 1024 + lane * 16);
+    // store phase: lane = 8 channels of one of two positions
+    const int sl_c = (lane & 31) * 8, sl_p = lane >> 5;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[sl_c + e] : 1.f;
+        bi[e] = p.bias ? p.bias[sl_c + e] : 0.f;
+    }
+    const int nwaves = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    // B fragment (k-slice ks) of position pos: bytes [ks * 32 + khalf * 16, +16) of its 128-byte channel row
+    uint4 bcur[4], bnext[4];
+#define PW_LOAD(DST_, TILE_)                                                                                   \
+    {                                                                                                          \
+        const unsigned pos_ = min((unsigned)(TILE_) * 32u + (unsigned)n, (unsigned)p.npos - 1u);               \
+        const char* src_ = p.x + (size_t)(pos_ * 128u + (unsigned)khalf * 16u);                                                   \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) DST_[ks_] = *(const uint4*)(src_ + ks_ * 32);      \
+    }
+    if (tile < p.ntiles) PW_LOAD(bcur, tile);
+    for (; tile < p.ntiles; tile += nwaves) {
+        const int next = tile + nwaves;
+        if (next < p.ntiles) PW_LOAD(bnext, next);
+        // 32-bit position arithmetic (the launcher checks the ranges); the frame / row split of the tile's first position is
+        // wave-uniform, a lane only adds its offset (one conditional frame wrap: a frame has >= 32 positions)
+        const unsigned pos0 = (unsigned)tile * 32u;
+        const unsigned f0 = pos0 / p.hw, rem0 = pos0 - f0 * p.hw;
+        // the residual rows of this tile (16 store groups of 2 positions) are requested NOW: one wave per SIMD has nothing else to
+        // hide their latency behind than its own MFMA and transpose phases
+        uint4 rr[16];
+        if (p.res_mode) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned pl = (unsigned)(q * 2 + sl_p);
+                const unsigned pos = min(pos0 + pl, (unsigned)p.npos - 1u);
+                unsigned rpos = pos;
+                if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map
+                    unsigned fr = f0, rem = pos - f0 * p.hw;
+                    if (rem >= p.hw) { rem -= p.hw; ++fr; }
+                    const unsigned oh = __umulhi(rem, p.w_magic), ow = rem - oh * (unsigned)p.W;
+                    rpos = (fr * (unsigned)(p.H >> 1) + (oh >> 1)) * (unsigned)(p.W >> 1) + (ow >> 1);
+                }
+                rr[q] = *(const uint4*)(p.res + (size_t)((rpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u));
+            }
+        }
+        (void)rem0;
+        f32x16_t acc[8];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) Mma<DAT_BF16>::step(wa[mb][ks], bcur[ks], acc[mb]);
+        // ---- epilogue: transpose through this wave's LDS slice, then two complete output rows per store instruction ----
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(est + n * EPITCH + (mb * 32 + g * 8 + khalf * 4) * 4) =
+                    make_float4(acc[mb][g * 4 + 0], acc[mb][g * 4 + 1], acc[mb][g * 4 + 2], acc[mb][g * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pl = q * 2 + sl_p;
+            const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+            const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const unsigned pos = pos0 + (unsigned)pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+            if (p.res_mode) {
+                const uint32_t ru[4] = {rr[q].x, rr[q].y, rr[q].z, rr[q].w};
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                    v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (pos < (unsigned)p.npos)
+                *(uint4*)(p.y + (size_t)((pos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u)) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
+    }
+#undef PW_LOAD
 }
 
 // compile-time index sequence for the hand-scheduled loops (`#pragma unroll` is refused for bodies of this size, and immediates /
@@ -1063,8 +1235,25 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
             sc[e] = (p.scale && ok) ? p.scale[c_st + e] : 1.f;
             bi[e] = (p.bias && ok) ? p.bias[c_st + e] : 0.f;
         }
+        // residual rows one sub-tile ahead of their use
+        uint4 rq[2][4];
+        const bool res_on = p.res_mode && c_st < p.Cout;
+        auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const int ohl = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const int oh = oh0 + ohl, ow = ow0 + owl;
+                const bool live = oh < p.Ho && ow < p.Wo && !(p.ablate & 4);
+                unsigned rpos = (unsigned)(ohl * p.Wo + owl);
+                if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
+                dst[q] = *(const uint4*)(rbase + (live ? (rpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u : 0u));
+            }
+        };
+        if (res_on) res_fetch(0, rq[0]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (res_on && j + 1 < 4) res_fetch(j + 1, rq[(j + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1085,9 +1274,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
                 if (p.res_mode) {
-                    unsigned rpos = lpos;
-                    if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
-                    const uint4 r = *(const uint4*)(rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u);
+                    const uint4 r = rq[j & 1][q];
                     const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) {
@@ -1522,7 +1709,7 @@ int ctx_num_cu(dat_ctx* ctx) {
 
 // big-tile kernel (conv3x3_bt_kernel): what it assumes; the grid must fill the chip about twice (one block per CU at a time)
 bool bt_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
-    return ctx->dbg_bt && d->dtype == DAT_BF16 && d->Cin % 64 == 0 && cout_pad_of(d) % 256 == 0 && d->KH == 3 && d->KW == 3 &&
+    return ctx->dbg_bt && d->dtype == DAT_BF16 && d->Cin % 64 == 0 && cout_pad_of(d) % 256 == 0 && d->Cout % 8 == 0 && d->KH == 3 && d->KW == 3 &&
            d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
 }
 
@@ -1562,6 +1749,34 @@ int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p) {
     if (twl == 5) BT_LAUNCH(5, 6) else BT_LAUNCH(4, 6)
 #undef BT_LAUNCH
     DAT_CHECK_LAUNCH(ctx, "conv3x3_bt");
+    return DAT_OK;
+}
+
+// weights-stationary 1x1 64 -> 256 kernel (conv1x1_k64_c256_ws_kernel)
+bool pw256_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_ws64 && d->dtype == DAT_BF16 && d->Cin == 64 && d->Cout == 256 && d->KT == 1 && d->KH == 1 && d->KW == 1 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->pad_t == 0 && d->out_tn <= 0 &&
+           d->out_cstride % 8 == 0 && weights_direct(ctx, d) &&
+           // the kernel's 32-bit position / byte arithmetic and its row split by multiplication
+           (long long)d->H * d->W >= 32 && (long long)d->H * d->W * d->W < (1ll << 32) &&
+           (long long)d->frames * d->H * d->W * std::max(d->out_cstride, 64) * 2 < (1ll << 32);
+}
+
+int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    Pw256Params p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.npos = (long long)cp.frames * cp.H * cp.W;
+    p.H = cp.H; p.W = cp.W; p.out_cs = cp.out_cs; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    const long long ntiles = cdiv_ll(p.npos, 32);
+    DAT_ENFORCE(ctx, ntiles > 0 && ntiles < (1ll << 31), "conv3d: %lld wave tiles unsupported", ntiles);
+    p.ntiles = (int)ntiles;
+    p.hw = (unsigned)(cp.H * cp.W);
+    p.w_magic = cp.W == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.W - 1) / (unsigned)cp.W);
+    const unsigned grid = (unsigned)std::min<long long>(cdiv_ll(ntiles, 4), ctx_num_cu(ctx));
+    const size_t lds = (size_t)4 * 32 * (256 * 4 + 16);
+    if (dat_ensure_lds(ctx, (const void*)conv1x1_k64_c256_ws_kernel, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv1x1_k64_c256_ws_kernel, dim3(grid), dim3(NTHREADS), lds, st, p);
+    DAT_CHECK_LAUNCH(ctx, "conv1x1_k64_c256_ws");
     return DAT_OK;
 }
 
@@ -1716,6 +1931,9 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     if (bt_fits && ksplit == 1 && !force_bp && !force_ks) {
         tag = 256 * 10000 + 2560 + d->dtype;
         rc = launch_bt(ctx, st, p);
+    } else if (pw256_eligible(ctx, d) && !force_bp && !force_ks) {
+        tag = 256 * 10000 + 320 + d->dtype;     // (256 channels x 32 positions per wave: the weights-stationary 1x1 kernel)
+        rc = launch_pw256(ctx, st, p);
     } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
         tag = 64 * 10000 + 9990 + d->dtype;    // ("999 positions": the persistent weights-stationary kernel)
         rc = launch_ws64(ctx, st, p);

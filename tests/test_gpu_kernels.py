@@ -174,6 +174,46 @@ def test_conv3x3_c64_weights_stationary(ops, case):
     assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4), err
 
 
+PW256_CASES = [
+    # name, T, H, W, relu, res_mode, affine   (1x1, 64 -> 256, bf16: the weights-stationary lateral kernel)
+    ('up2_ragged', 2, 26, 38, False, 2, False),       # 1976 positions: the last wave tile is partial
+    ('sum_relu', 3, 17, 19, True, 1, True),
+    ('plain_tiny', 1, 3, 5, False, 0, True),           # fewer positions than one wave tile
+    ('many_tiles', 4, 96, 168, False, 2, False),       # > 1 tile per wave of the persistent grid
+]
+
+
+@pytest.mark.parametrize('case', PW256_CASES, ids=[c[0] for c in PW256_CASES])
+def test_conv1x1_k64_c256_weights_stationary(ops, case):
+    """conv1x1_k64_c256_ws_kernel against torch on the same bf16 operands and bit for bit against the generic kernel (forced plan)."""
+    name, T, H, W, relu, res_mode, affine = case
+    rs = np.random.RandomState(len(name) * 5 + W)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(1, 64, T, H, W).astype(np.float32))
+    w = q((rs.randn(256, 64, 1, 1, 1) * np.sqrt(2.0 / 64)).astype(np.float32))
+    scale = rs.uniform(0.5, 1.5, 256).astype(np.float32) if affine else None
+    bias = (rs.randn(256) * 0.1).astype(np.float32)
+    res = res_small = None
+    if res_mode == 1:
+        res = q(rs.randn(1, 256, T, H, W).astype(np.float32))
+    elif res_mode == 2:
+        res_small = q(rs.randn(1, 256, T, H // 2, W // 2).astype(np.float32))
+        res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    ref = _conv_ref(x, w, scale, bias, res, (1, 1), (0, 0, 0), relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(1, 1), pads=(0, 0, 0), relu=relu, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    rd = ops.to_ndhwc(_dev(res if res_mode == 1 else res_small), 1, layer.cstride) if res_mode else None
+    y = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    try:
+        assert ops.tune_plan(128, 1) == 0          # a forced plan selects the generic kernel
+        y_gen = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    finally:
+        ops.tune_plan(0, 0)
+    assert torch.equal(y, y_gen)
+    got = ops.to_ncdhw(y, 1, 1, 256, T).cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+
+
 BT_CASES = [
     # name, T, H, W, Cin, Cout, kt, relu, res_mode, affine   (3x3 bf16 layers with >= 384 tiles of 256 x 256: the big-tile kernel)
     ('3x3x3_ragged_16x16', 3, 120, 250, 128, 256, 3, True, 1, True),

@@ -60,6 +60,8 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--out', default='')
     ap.add_argument('--only', default='', help='comma-separated layer names')
+    ap.add_argument('--cold', action='store_true', help='flush the caches (a 1-GB fill) before every timed launch: the in-network condition of HBM-bound layers')
+    ap.add_argument('--topdown', action='store_true', help='fpn_lat_* layers add the nearest-2x up-sampled coarser map (res_mode 2), as in the network')
     ap.add_argument('--clock', action='store_true', help='also report the shader clock under each layer (dat_prof_clock)')
     a = ap.parse_args()
     dt = ops.BF16 if a.dtype == 'bf16' else ops.F32
@@ -74,15 +76,30 @@ def main():
         layer = ops.ConvLayer(w, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), stride=(st, st),
                               pads=pads, relu=True, dtype=dt)
         x = torch.randn(a.T, hi, wi, layer.cin, device=dev).to(ops.tdtype(dt))
-        y = layer(x, T=a.T)
+        kw = {}
+        if a.topdown and name.startswith('fpn_lat_') and hi % 2 == 0 and wi % 2 == 0:
+            kw = dict(residual=torch.randn(a.T, hi // 2, wi // 2, layer.cstride, device=dev).to(ops.tdtype(dt)), res_mode=2)
+        y = layer(x, T=a.T, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            layer(x, T=a.T, out=y)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
+        if a.cold:
+            junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            ms = 0.0
+            for it in range(a.iters):
+                junk.fill_(float(it))
+                e0.record()
+                layer(x, T=a.T, out=y, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ms += e0.elapsed_time(e1) / a.iters
+            del junk
+        else:
+            e0.record()
+            for _ in range(a.iters):
+                layer(x, T=a.T, out=y, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
         fl = layer.flops(a.T, hi, wi)
         tf = fl / ms / 1e9
         mhz = 0.0
