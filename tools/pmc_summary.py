@@ -36,10 +36,14 @@ def per_kernel(path):
 
 
 def short(name):
-    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?>', name)
-    if m:
-        tps = ',tps%s' % m.group(5) if m.group(5) not in (None, '1') else ''
+    m = re.search(r'conv3d_igemm_kernel<(\d+), (\d+), (\d+), (\d+)((?:, \d+)*)>', name)
+    if m:       # <dtype, channels per block, positions per block, waves over channels, taps per step, weights direct, unrolled taps>
+        rest = [int(x) for x in m.group(5).replace(',', ' ').split()]
+        tps = ',tps%d' % rest[0] if rest and rest[0] != 1 else ''
         return 'conv3d_igemm_kernel<%s,%s,%s%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3), tps)
+    m = re.search(r'(conv3x3_c64_ws_kernel|conv3x3_bt_kernel|conv1x1_k64_c256_ws_kernel|stem_pool_kernel|stem_conv_kernel)', name)
+    if m:
+        return m.group(1) + ('<bf16,256,256>' if m.group(1) == 'conv3x3_bt_kernel' else '<bf16>')
     m = re.search(r'([A-Za-z_0-9]+)(<[^(]*>)?\(', name)
     return m.group(1) if m else name
 
@@ -78,8 +82,15 @@ def main():
     os.makedirs(dst, exist_ok=True)
     mfma_summary(src, dst)
     shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
-    fetch = per_kernel(os.path.join(src, 'pmc_fetch', 'r1_counter_collection.csv'))
-    write = per_kernel(os.path.join(src, 'pmc_write', 'r1_counter_collection.csv'))
+    def by_short(agg):      # template variants of one tile shape (table-driven / unrolled-tap loops) are one bench bucket
+        out = collections.OrderedDict()
+        for name, (n, v) in agg.items():
+            e = out.setdefault(short(name), [0, 0.0])
+            e[0] += n
+            e[1] += v
+        return out
+    fetch = by_short(per_kernel(os.path.join(src, 'pmc_fetch', 'r1_counter_collection.csv')))
+    write = by_short(per_kernel(os.path.join(src, 'pmc_write', 'r1_counter_collection.csv')))
     kernels = {}
     rows = []
     for name, (n, fk) in sorted(fetch.items(), key=lambda kv: -kv[1][1]):
