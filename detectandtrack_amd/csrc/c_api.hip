@@ -45,7 +45,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_lds_pad = env_int("DAT_CONV_LDS_PAD", 0);
         c->dbg_tps3 = env_int("DAT_CONV_TPS", 3) == 3;
         c->dbg_wd = env_int("DAT_CONV_WD", 2);       // 0 off, 1 the 128-channel tiles only, 2 (default) also the 64-channel ones
-        c->dbg_ntap = env_int("DAT_CONV_NTAP", 1);   // 0 off, 1 default rule, 2 unrolled 1x1 variant for every 1x1 layer
+        c->dbg_ntap = env_int("DAT_CONV_NTAP", 1);   // 0 off, 1 default rule; bit 1 (2/3): unrolled 1x1 variant for every 1x1 layer; bit 2 (5): no dense stride-2 patches
         c->dbg_pack_simple = env_int("DAT_PACK_SIMPLE", 0) != 0;
         c->dbg_ws64 = env_int("DAT_CONV_WS64", 1);
         c->dbg_bt = env_int("DAT_CONV_BT", 0);   // opt-in: measured neutral on the full network (the part is power-limited)

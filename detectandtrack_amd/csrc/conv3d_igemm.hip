@@ -60,7 +60,8 @@ struct ConvParams {
     int th_log2, tw_log2;     // output tile = 2^th x 2^tw positions
     int tiles_h, tiles_w;
     int PH, PW;               // patch rows/cols (LDS rows = PH*PW)
-    int psh, psw;             // patch sampling step in the input (= conv stride)
+    int psh, psw;             // patch sampling step in the input (= conv stride; 1 for the dense stride-2 patch of the NTAP = 10 variant)
+    int rsh, rsw;             // patch rows / columns between neighbouring output positions (1; 2 for the dense stride-2 patch)
     // spatial tap schedule of one (kt, channel chunk): taps grouped by stride-parity plane, so that every plane is a
     // dense (tile + halo/stride) patch whose rows are read consecutively (stride-2 convs: 4 small patches)
     int tab_n;
@@ -119,7 +120,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + ((
 // per-lane source offsets of the patch LDS-DMA are kept in registers across reloads.  NTAP = 0: the generic table-driven loop
 // (strided 3x3 convs with their stride-parity planes, other kernel shapes).
 // (the unrolled 128-position variants are held to 168 registers -- three blocks per CU -- the 256-position ones to 256)
-template <int BP, int NTAP> struct MinWaves { static constexpr int value = (NTAP > 0 && BP == 128) ? 3 : 2; };
+template <int BP, int NTAP> struct MinWaves { static constexpr int value = (NTAP > 0 && NTAP != 10 && BP == 128) ? 3 : 2; };
 template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     for (int j = 0; j < PT; ++j) {
         const int pos = wave_p * WP + j * 32 + (lane & 31);
         const int ohl = pos >> p.tw_log2, owl = pos & (TW - 1);
-        rowbase[j] = ohl * p.PW + owl;
+        rowbase[j] = ohl * p.rsh * p.PW + owl * p.rsw;
     }
     const int khalf = lane >> 5;
 
@@ -253,9 +254,10 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     const char* const wd_lane = p.w + (size_t)((n0 + wave_n * WN) >> 5) * 4096 + lane * 16;
 #define WD_PTR(KT_, CC_, TI_) (wd_lane + ((size_t)((KT_) * ntap + p.tab_tap[(TI_)]) * p.n_cchunks + (CC_)) * wd_cc_stride)
     if constexpr (WD && NTAP > 0) {
+      constexpr int NT = NTAP == 10 ? 9 : NTAP;   // NTAP = 10: the 9 taps of a 3x3 stride-2 conv on ONE dense (2*TH+1) x (2*TW+1) patch
       if (total > 0) {
         static_assert(TPS == 1, "unrolled taps: one tap per step");
-        constexpr int MAXCH = BP == 256 ? 11 : 6;             // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
+        constexpr int MAXCH = NTAP == 10 ? 19 : BP == 256 ? 11 : 6;   // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
         const int kt_hi_x = kt_lo + n_kt;
         int kshift = 0;
         if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
@@ -264,16 +266,19 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
         // ---- per-lane LDS address of the B fragment (k-slice 0) of every (tap, position sub-tile); k-slice ks is `^ (ks << 5)`:
         // row * 128 + ((khalf ^ (g & 1)) << 4) + (((g >> 1) ^ ks) << 5), g = (row >> 1) & 7 -- bits 5-6 of the first two terms are 0
         // (a patch is < 64 KiB: two 16-bit addresses per register -- NTAP x PT / 2 registers instead of NTAP x PT)
-        constexpr int NQ = (PT + 1) / 2;
-        unsigned qp[NTAP][NQ];
+        constexpr bool PACK16 = NTAP != 10;                    // (the dense stride-2 patch is 70 KiB: one address per register there)
+        constexpr int NQ = PACK16 ? (PT + 1) / 2 : PT;
+        unsigned qp[NT][NQ];
 #pragma unroll
-        for (int tp = 0; tp < NTAP; ++tp)
+        for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
                 const int row = rowbase[j] + p.tab_rowoff[tp];
                 const int g = (row >> 1) & 7;
                 const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
-                if (j & 1) qp[tp][j >> 1] |= a16 << 16; else qp[tp][j >> 1] = a16;
+                if (!PACK16) qp[tp][j] = a16;
+                else if (j & 1) qp[tp][j >> 1] |= a16 << 16;
+                else qp[tp][j >> 1] = a16;
             }
         // ---- per-lane source offsets of this wave's patch pieces (relative to the frame/chunk base; -1 = halo outside the frame)
         const int nchunks = (npatch_items + 63) >> 6;
@@ -332,26 +337,26 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
 #pragma unroll
             for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[0][jj]));
 #pragma unroll
-            for (int j = 0; j < PT; ++j) qa[j] = (j & 1) ? (qp[0][j >> 1] >> 16) : (qp[0][j >> 1] & 0xffffu);
+            for (int j = 0; j < PT; ++j) qa[j] = !PACK16 ? qp[0][j % NQ] : (j & 1) ? (qp[0][(j >> 1) % NQ] >> 16) : (qp[0][(j >> 1) % NQ] & 0xffffu);
 #pragma unroll
             for (int j = 0; j < PT; ++j) b[0][j] = *(const uint4*)(patch + qa[j]);
 #pragma unroll
-            for (int tp = 0; tp < NTAP; ++tp) {
-                const char* wnext = (tp + 1 < NTAP) ? wcur + (size_t)(tp + 1) * tap_stride : wnextpatch;
+            for (int tp = 0; tp < NT; ++tp) {
+                const char* wnext = (tp + 1 < NT) ? wcur + (size_t)(tp + 1) * tap_stride : wnextpatch;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int cur = ks & 1, nxt = cur ^ 1;
                     if (ks < 3) {
 #pragma unroll
                         for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + (qa[j] ^ (unsigned)((ks + 1) << 5)));
-                    } else if (tp + 1 < NTAP) {
+                    } else if (tp + 1 < NT) {
                         // the first fragments of the NEXT tap, behind this tap's last k-slice: no tap opens with an exposed LDS round trip
 #pragma unroll
-                        for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[tp + 1 < NTAP ? tp + 1 : tp][jj]));
+                        for (int jj = 0; jj < NQ; ++jj) asm volatile("" : "+v"(qp[tp + 1 < NT ? tp + 1 : tp][jj]));
 #pragma unroll
                         for (int j = 0; j < PT; ++j) {
-                            const unsigned w2 = qp[tp + 1 < NTAP ? tp + 1 : tp][j >> 1];
-                            qa[j] = (j & 1) ? (w2 >> 16) : (w2 & 0xffffu);
+                            const unsigned w2 = qp[tp + 1 < NT ? tp + 1 : tp][(PACK16 ? j >> 1 : j) % NQ];
+                            qa[j] = !PACK16 ? w2 : (j & 1) ? (w2 >> 16) : (w2 & 0xffffu);
                         }
 #pragma unroll
                         for (int j = 0; j < PT; ++j) b[nxt][j] = *(const uint4*)(patch + qa[j]);
@@ -1536,9 +1541,22 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     p.tiles_w = (p.Wo + tw - 1) / tw;
     p.psh = p.sh;
     p.psw = p.sw;
+    p.rsh = p.rsw = 1;
     p.PH = th + (p.KH - 1) / p.sh;
     p.PW = tw + (p.KW - 1) / p.sw;
-    {   // tap table in stride-parity plane order
+    if (NTAP == 10) {   // one DENSE patch for all 9 taps of a strided 3x3: neighbouring outputs are `stride` patch cells apart
+        p.psh = p.psw = 1;
+        p.rsh = p.sh; p.rsw = p.sw;
+        p.PH = (th - 1) * p.sh + p.KH;
+        p.PW = (tw - 1) * p.sw + p.KW;
+        p.tab_new = 1u;
+        p.tab_n = p.KH * p.KW;
+        for (int i = 0; i < p.tab_n; ++i) {
+            p.tab_tap[i] = i;
+            p.tab_rowoff[i] = (i / p.KW) * p.PW + i % p.KW;
+            p.tab_dy[i] = p.tab_dx[i] = 0;
+        }
+    } else {   // tap table in stride-parity plane order
         int n = 0;
         p.tab_new = 0;
         DAT_ENFORCE(ctx, p.KH * p.KW <= 32, "conv3d: %dx%d spatial kernel exceeds the 32-entry tap table", p.KH, p.KW);
@@ -1589,7 +1607,8 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
                 th, tw, p.sh, p.sw);
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP>;
     if (NTAP > 0) {   // what the unrolled variant assumes (the dispatcher only picks it for these shapes)
-        DAT_ENFORCE(ctx, p.tab_n == NTAP && p.tab_new == 1u && (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (BP == 256 ? 11 : 6),
+        DAT_ENFORCE(ctx, p.tab_n == (NTAP == 10 ? 9 : NTAP) && p.tab_new == 1u &&
+                             (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (NTAP == 10 ? 19 : BP == 256 ? 11 : 6) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
                     "conv3d: unrolled-tap variant on an unsupported shape (%d taps, patch %dx%d)", p.tab_n, p.PH, p.PW);
         for (int i = 0; i < p.tab_n; ++i) DAT_ENFORCE(ctx, p.tab_tap[i] == i, "conv3d: unrolled-tap variant needs taps in natural order");
     }
@@ -1887,6 +1906,9 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         const bool deep_1x1 = (ntaps == 1 && ncc >= 16);
         for (int cand_bp = 128; cand_bp <= 256; cand_bp += 128) {
             if (cand_bp == 256 && (small_n || ntaps == 1)) continue;   // the 64-channel and 1x1 variants do not profit
+            // strided 3x3: the dense-patch variant exists for 128-position tiles only and beats the 256-position table-driven loop
+            // (res4_0_branch2a 0.128 -> 0.081 ms, res3_0_branch2a 0.086 -> 0.081, cold caches)
+            if (cand_bp == 256 && !force_bp && ctx->dbg_ntap && !(ctx->dbg_ntap & 4) && d->KH == 3 && d->KW == 3 && d->stride_h == 2 && d->stride_w == 2) continue;
             if (force_bp && cand_bp != force_bp && !(force_bp == 256 && (small_n || ntaps == 1))) continue;
             const int lg = cand_bp == 256 ? 8 : 7;
             const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
@@ -1948,9 +1970,14 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         const long long prow = ((1ll << tc.th_log2) + (p.KH - 1) / p.sh) * ((1ll << tc.tw_log2) + (p.KW - 1) / p.sw);
         const bool fits = ((prow * 8 + 63) >> 6) <= 4 * (big ? 11 : 6);
         const bool pw_small = (long long)p.frames * p.Ho * p.Wo <= 65536;
-        const int ntapv = !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
-                          (d->KH == 1 && d->KW == 1 && (pw_small || ctx->dbg_ntap >= 2)) ? 1 : 0;
-#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
+        // strided 3x3: ONE dense patch of (2*TH+1) x (2*TW+1) cells serves all 9 taps (the table-driven loop stages four stride-parity
+        // patches per channel chunk and synchronises around each); 128-position tiles only (the patch is 70 KiB: two blocks per CU)
+        const long long drow = (((1ll << tc.th_log2) - 1) * p.sh + p.KH) * (((1ll << tc.tw_log2) - 1) * p.sw + p.KW);
+        const bool dense2 = ctx->dbg_ntap && !big && d->KH == 3 && d->KW == 3 && d->stride_h == 2 && d->stride_w == 2 && !(ctx->dbg_ntap & 4) &&
+                            ((drow * 8 + 63) >> 6) <= 4 * 19;
+        const int ntapv = dense2 ? 10 : !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
+                          (d->KH == 1 && d->KW == 1 && (pw_small || (ctx->dbg_ntap & 2))) ? 1 : 0;
+#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
                             : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
                             : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1>(ctx, st, p, 7, ksplit)))
         if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);
