@@ -389,7 +389,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the bf16-vs-fp32 error report (one extra fp32 forward)')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
-    ap.add_argument('--pipeline', type=int, default=3, help='clips in flight per GPU (1 = strictly sequential)')
+    ap.add_argument('--pipeline', type=int, default=4, help='clips in flight per GPU (1 = strictly sequential; 2 / 3 / 4 / 5 measured 206.9 / 214.7 / 217.9 / 208.9 clips/s)')
     ap.add_argument('--graph', type=int, default=1, help='1: every slot replays its clip as one captured hipGraph (core/clip_graph.py); 0: eager launches')
     ap.add_argument('--keyframe-dce', action='store_true',
                     help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '

@@ -62,6 +62,8 @@ struct ConvParams {
     int PH, PW;               // patch rows/cols (LDS rows = PH*PW)
     int psh, psw;             // patch sampling step in the input (= conv stride; 1 for the dense stride-2 patch of the NTAP = 10 variant)
     int rsh, rsw;             // patch rows / columns between neighbouring output positions (1; 2 for the dense stride-2 patch)
+    int lin_h, lin_w;         // > 0: LINEAR position tiling of small maps (see launch_conv): the real map size; H / W / Ho / Wo then describe a 1 x N strip
+    int lin_zero_row;         // patch row that is all zeros (-1: none): the B fragments of taps that fall outside a map read it
     // spatial tap schedule of one (kt, channel chunk): taps grouped by stride-parity plane, so that every plane is a
     // dense (tile + halo/stride) patch whose rows are read consecutively (stride-2 convs: 4 small patches)
     int tab_n;
@@ -273,7 +275,14 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
         for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
-                const int row = rowbase[j] + p.tab_rowoff[tp];
+                int row = rowbase[j] + p.tab_rowoff[tp];
+                if (p.lin_w > 0) {   // linear tiling: a tap that leaves the lane's map (row / column / map border) reads the zero row
+                    const int gpos = ow0 + wave_p * WP + j * 32 + (lane & 31);
+                    const int rem = gpos % (p.lin_h * p.lin_w);
+                    const int y = rem / p.lin_w, x = rem - y * p.lin_w;
+                    const int yy = y + tp / p.KW - p.KH / 2, xx = x + tp % p.KW - p.KW / 2;
+                    if ((unsigned)yy >= (unsigned)p.lin_h || (unsigned)xx >= (unsigned)p.lin_w) row = p.lin_zero_row;
+                }
                 const int g = (row >> 1) & 7;
                 const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
                 if (!PACK16) qp[tp][j] = a16;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                 const int slot = (it ^ (row >> 1)) & 7;
                 const int prow = p.pw_magic ? (int)__umulhi((unsigned)row, p.pw_magic) : row, pcol = row - prow * p.PW;
                 const int ih = ih0 + p.tab_dy[0] + prow * p.psh, iw = iw0 + p.tab_dx[0] + pcol * p.psw;
-                off = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) ? (int)((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16)) : -1;
+                off = (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && row != p.lin_zero_row) ? (int)((unsigned)(ih * p.W + iw) * (unsigned)(p.Cin * ES) + (unsigned)(slot * 16)) : -1;
             }
             poff[u] = off;
         }
@@ -1532,11 +1541,39 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
 }
 
 template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
-int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit) {
-    const TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
+int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit, bool linear = false) {
+    TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
+    p.lin_h = p.lin_w = 0;
+    p.lin_zero_row = -1;
+    if (linear) {
+        // LINEAR position tiling of small maps (RoI heads: 100 x 14 x 14): a power-of-two 2-D tile wastes 23 % of a 16 x 16 tile on a
+        // 14 x 14 map.  The maps are contiguous in memory (NDHWC, frame-major), so a tile is BP CONSECUTIVE positions of the
+        // frames x H x W sequence, its patch the same range widened by W + 1 positions on either side (one contiguous DMA image), and
+        // tap (kh, kw) of position i reads patch row i + kh*W + kw.  Where that neighbour is not the lane's own map any more (row, column
+        // or map border) the precomputed fragment address points at an all-zero patch row instead: masking costs nothing in the loop.
+        // The kernel sees the whole thing as a 1 x N strip with 1 x BP tiles (its epilogue and patch loader need nothing else).
+        const long long total = (long long)p.frames * p.Ho * p.Wo;
+        DAT_ENFORCE(ctx, NTAP == 9 && p.KT == 1 && p.pt == 0 && p.sh == 1 && p.sw == 1 && p.H == p.Ho && p.W == p.Wo && p.res_mode != 2 &&
+                             total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31),
+                    "conv3d: linear tiling on an unsupported layer");
+        p.lin_h = p.H; p.lin_w = p.W;
+        const int wr = p.W, nr = (1 << bp_log2) + 2 * (wr + 1) + 1;
+        tc = TileChoice{0, bp_log2};
+        p.H = p.Ho = 1; p.W = p.Wo = (int)total;
+        p.frames = 1; p.T = 1; p.ot0 = 0; p.otn = 1; p.in_lo = 0; p.in_hi = 1;
+        p.ph = 0; p.pw = wr + 1;
+        p.lin_zero_row = nr - 1;
+        p.th_log2 = 0; p.tw_log2 = bp_log2;
+        p.tiles_h = 1; p.tiles_w = (int)cdiv_ll(total, 1ll << bp_log2);
+        p.psh = p.psw = 1; p.rsh = p.rsw = 1;
+        p.PH = 1; p.PW = nr;
+        p.tab_new = 1u; p.tab_n = 9;
+        for (int i = 0; i < 9; ++i) { p.tab_tap[i] = i; p.tab_rowoff[i] = (i / 3) * wr + i % 3; p.tab_dy[i] = p.tab_dx[i] = 0; }
+    }
+    const int th = 1 << tc.th_log2, tw = 1 << tc.tw_log2;
+    if (!linear) {
     p.th_log2 = tc.th_log2;
     p.tw_log2 = tc.tw_log2;
-    const int th = 1 << tc.th_log2, tw = 1 << tc.tw_log2;
     p.tiles_h = (p.Ho + th - 1) / th;
     p.tiles_w = (p.Wo + tw - 1) / tw;
     p.psh = p.sh;
@@ -1544,7 +1581,9 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     p.rsh = p.rsw = 1;
     p.PH = th + (p.KH - 1) / p.sh;
     p.PW = tw + (p.KW - 1) / p.sw;
-    if (NTAP == 10) {   // one DENSE patch for all 9 taps of a strided 3x3: neighbouring outputs are `stride` patch cells apart
+    }
+    if (linear) {
+    } else if (NTAP == 10) {   // one DENSE patch for all 9 taps of a strided 3x3: neighbouring outputs are `stride` patch cells apart
         p.psh = p.psw = 1;
         p.rsh = p.sh; p.rsw = p.sw;
         p.PH = (th - 1) * p.sh + p.KH;
@@ -1977,7 +2016,15 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
                             ((drow * 8 + 63) >> 6) <= 4 * 19;
         const int ntapv = dense2 ? 10 : !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
                           (d->KH == 1 && d->KW == 1 && (pw_small || (ctx->dbg_ntap & 2))) ? 1 : 0;
-#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit)) \
+        // small maps (RoI heads): linear position tiling when it saves >= 10 % of the tiles (see launch_conv)
+        bool lin = false;
+        if (ntapv == 9 && ctx->dbg_linear && d->KT == 1 && d->pad_t == 0 && d->res_mode != 2 && d->out_tn <= 0 && p.H == p.Ho && p.W == p.Wo) {
+            const long long bpv = big ? 256 : 128, total = (long long)p.frames * p.Ho * p.Wo;
+            const long long t2d = (long long)p.frames * cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2), tlin = cdiv_ll(total, bpv);
+            const long long nr = bpv + 2 * (p.Wo + 1) + 1;
+            lin = tlin * 10 <= t2d * 9 && ((nr * 8 + 63) >> 6) <= 4 * (big ? 11 : 6) && total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31);
+        }
+#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit, lin) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit, lin)) \
                             : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
                             : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1>(ctx, st, p, 7, ksplit)))
         if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);

@@ -81,6 +81,11 @@ CONV_CASES = [
     ('cout12', 1, 1, 10, 14, 64, 12, (1, 1, 1), (1, 1), False, 0, False),
     ('fc_like', 1, 1, 1, 37, 448, 96, (1, 1, 1), (1, 1), True, 0, False),
     ('wide', 1, 1, 6, 150, 64, 64, (1, 3, 3), (1, 1), False, 0, True),
+    # RoI-head maps: linear position tiling (tiles of consecutive positions across rows and maps, border taps read a zero row)
+    ('heads_14x14', 7, 1, 14, 14, 128, 256, (1, 3, 3), (1, 1), True, 1, True),
+    ('heads_7x7', 9, 1, 7, 7, 64, 128, (1, 3, 3), (1, 1), True, 0, False),
+    ('heads_14x14_many', 40, 1, 14, 14, 64, 128, (1, 3, 3), (1, 1), False, 0, True),
+    ('heads_5x9_odd', 11, 1, 5, 9, 64, 192, (1, 3, 3), (1, 1), True, 1, False),
 ]
 
 
