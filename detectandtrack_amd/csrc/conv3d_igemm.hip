@@ -63,6 +63,7 @@ struct ConvParams {
     int psh, psw;             // patch sampling step in the input (= conv stride; 1 for the dense stride-2 patch of the NTAP = 10 variant)
     int rsh, rsw;             // patch rows / columns between neighbouring output positions (1; 2 for the dense stride-2 patch)
     int lin_h, lin_w;         // > 0: LINEAR position tiling of small maps (see launch_conv): the real map size; H / W / Ho / Wo then describe a 1 x N strip
+    int tile_w;               // output columns between neighbouring tiles
     int lin_zero_row;         // patch row that is all zeros (-1: none): the B fragments of taps that fall outside a map read it
     // spatial tap schedule of one (kt, channel chunk): taps grouped by stride-parity plane, so that every plane is a
     // dense (tile + halo/stride) patch whose rows are read consecutively (stride-2 convs: 4 small patches)
@@ -122,7 +123,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + ((
 // per-lane source offsets of the patch LDS-DMA are kept in registers across reloads.  NTAP = 0: the generic table-driven loop
 // (strided 3x3 convs with their stride-parity planes, other kernel shapes).
 // (the unrolled 128-position variants are held to 168 registers -- three blocks per CU -- the 256-position ones to 256)
-template <int BP, int NTAP> struct MinWaves { static constexpr int value = (NTAP > 0 && NTAP != 10 && BP == 128) ? 3 : 2; };
+template <int BP, int NTAP> struct MinWaves { static constexpr int value = BP == 320 ? 1 : (NTAP > 0 && NTAP != 10 && BP == 128) ? 3 : 2; };
 template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     const int n0 = nb * BN;
     const int TW = 1 << p.tw_log2;
     const int oh0 = th_i << p.th_log2;
-    const int ow0 = tw_i << p.tw_log2;
+    const int ow0 = tw_i * p.tile_w;         // (1 << tw_log2, except for the 320-position linear tiles)
     // input coordinate of patch cell (0,0)
     const int ih0 = oh0 * p.sh - p.ph;
     const int iw0 = ow0 * p.sw - p.pw;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
       constexpr int NT = NTAP == 10 ? 9 : NTAP;   // NTAP = 10: the 9 taps of a 3x3 stride-2 conv on ONE dense (2*TH+1) x (2*TW+1) patch
       if (total > 0) {
         static_assert(TPS == 1, "unrolled taps: one tap per step");
-        constexpr int MAXCH = NTAP == 10 ? 19 : BP == 256 ? 11 : 6;   // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
+        constexpr int MAXCH = NTAP == 10 ? 19 : BP >= 256 ? 11 : 6;   // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
         const int kt_hi_x = kt_lo + n_kt;
         int kshift = 0;
         if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
@@ -1557,14 +1558,15 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
                              total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31),
                     "conv3d: linear tiling on an unsupported layer");
         p.lin_h = p.H; p.lin_w = p.W;
-        const int wr = p.W, nr = (1 << bp_log2) + 2 * (wr + 1) + 1;
+        const int wr = p.W, nr = BP + 2 * (wr + 1) + 1;
         tc = TileChoice{0, bp_log2};
         p.H = p.Ho = 1; p.W = p.Wo = (int)total;
         p.frames = 1; p.T = 1; p.ot0 = 0; p.otn = 1; p.in_lo = 0; p.in_hi = 1;
         p.ph = 0; p.pw = wr + 1;
         p.lin_zero_row = nr - 1;
-        p.th_log2 = 0; p.tw_log2 = bp_log2;
-        p.tiles_h = 1; p.tiles_w = (int)cdiv_ll(total, 1ll << bp_log2);
+        p.th_log2 = 0; p.tw_log2 = bp_log2;      // (bp_log2 = 9 for the 320-position tiles: pos >> tw_log2 == 0, pos & (TW - 1) == pos)
+        p.tile_w = BP;
+        p.tiles_h = 1; p.tiles_w = (int)cdiv_ll(total, BP);
         p.psh = p.psw = 1; p.rsh = p.rsw = 1;
         p.PH = 1; p.PW = nr;
         p.tab_new = 1u; p.tab_n = 9;
@@ -1574,6 +1576,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     if (!linear) {
     p.th_log2 = tc.th_log2;
     p.tw_log2 = tc.tw_log2;
+    p.tile_w = tw;
     p.tiles_h = (p.Ho + th - 1) / th;
     p.tiles_w = (p.Wo + tw - 1) / tw;
     p.psh = p.sh;
@@ -1647,7 +1650,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP>;
     if (NTAP > 0) {   // what the unrolled variant assumes (the dispatcher only picks it for these shapes)
         DAT_ENFORCE(ctx, p.tab_n == (NTAP == 10 ? 9 : NTAP) && p.tab_new == 1u &&
-                             (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (NTAP == 10 ? 19 : BP == 256 ? 11 : 6) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
+                             (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (NTAP == 10 ? 19 : BP >= 256 ? 11 : 6) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
                     "conv3d: unrolled-tap variant on an unsupported shape (%d taps, patch %dx%d)", p.tab_n, p.PH, p.PW);
         for (int i = 0; i < p.tab_n; ++i) DAT_ENFORCE(ctx, p.tab_tap[i] == i, "conv3d: unrolled-tap variant needs taps in natural order");
     }
@@ -1786,7 +1789,7 @@ int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p) {
     long long nblocks = 0;
     const int twl = bt_tile_twl(p, &nblocks);
     const int tw = 1 << twl, th = 256 >> twl;
-    p.th_log2 = 8 - twl; p.tw_log2 = twl;
+    p.th_log2 = 8 - twl; p.tw_log2 = twl; p.tile_w = tw;
     p.tiles_h = (int)cdiv_ll(p.Ho, th); p.tiles_w = (int)cdiv_ll(p.Wo, tw);
     p.n_cchunks = p.Cin / 64;
     p.nblk_n = p.Cout_pad / 256;
@@ -2017,17 +2020,27 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         const int ntapv = dense2 ? 10 : !ctx->dbg_ntap || !fits ? 0 : (d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1) ? 9 :
                           (d->KH == 1 && d->KW == 1 && (pw_small || (ctx->dbg_ntap & 2))) ? 1 : 0;
         // small maps (RoI heads): linear position tiling when it saves >= 10 % of the tiles (see launch_conv)
-        bool lin = false;
+        bool lin = false, lin320 = false;
         if (ntapv == 9 && ctx->dbg_linear && d->KT == 1 && d->pad_t == 0 && d->res_mode != 2 && d->out_tn <= 0 && p.H == p.Ho && p.W == p.Wo) {
             const long long bpv = big ? 256 : 128, total = (long long)p.frames * p.Ho * p.Wo;
             const long long t2d = (long long)p.frames * cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2), tlin = cdiv_ll(total, bpv);
             const long long nr = bpv + 2 * (p.Wo + 1) + 1;
             lin = tlin * 10 <= t2d * 9 && ((nr * 8 + 63) >> 6) <= 4 * (big ? 11 : 6) && total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31);
+            // One block per CU runs a tap step in ~1.1 us, two co-resident ones in ~2.15 us each, so a grid just above the CU count
+            // costs a whole second block lifetime (keypoint head, 100 x 14 x 14 maps: 83 maps = 256 blocks 0.081 ms, 84 maps = 260
+            // blocks 0.119 ms).  320-position tiles bring such a grid back under one block per CU.
+            const long long ncu320 = ctx_num_cu(ctx), blk256 = tlin * nbn * ksplit, blk320 = cdiv_ll(total, 320) * nbn * ksplit;
+            // (opt-in, DAT_CONV_LINEAR=5: one clip at a time +2.9 % (170.6 -> 175.5 clips/s), but with four clips in flight -2 % (221.8 -> 217.5):
+            //  a 293-register block per CU on 248 CUs leaves no room for the other clips' kernels to run beside it)
+            lin320 = lin && big && !small_n && (ctx->dbg_linear & 4) && blk256 > ncu320 && blk320 <= ncu320 &&
+                     ((((320 + 2 * (p.Wo + 1) + 1) * 8 + 63) >> 6) <= 44);
         }
 #define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit, lin) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit, lin)) \
                             : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
                             : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1>(ctx, st, p, 7, ksplit)))
-        if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);
+        if (lin320) rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 128, 320, 2, 1, 1, 9>(ctx, st, p, 9, ksplit, true)
+                                              : launch_conv<DAT_F32, 128, 320, 2, 1, 1, 9>(ctx, st, p, 9, ksplit, true);
+        else if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);
         else rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 128, 2) : DAT_WD_LAUNCH(DAT_F32, 128, 2);
 #undef DAT_WD_LAUNCH
     } else if (d->dtype == DAT_BF16) {

@@ -86,6 +86,8 @@ CONV_CASES = [
     ('heads_7x7', 9, 1, 7, 7, 64, 128, (1, 3, 3), (1, 1), True, 0, False),
     ('heads_14x14_many', 40, 1, 14, 14, 64, 128, (1, 3, 3), (1, 1), False, 0, True),
     ('heads_5x9_odd', 11, 1, 5, 9, 64, 192, (1, 3, 3), (1, 1), True, 1, False),
+    # 308 blocks of 256 positions > 256 CUs, 248 blocks of 320 positions: the one-block-per-CU 320-position linear tiles
+    ('heads_100x14x14_c512', 100, 1, 14, 14, 64, 512, (1, 3, 3), (1, 1), True, 1, True),
 ]
 
 
@@ -219,6 +221,46 @@ def test_conv1x1_k64_c256_weights_stationary(ops, case):
     assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
 
 
+def _in_fresh_context(env, fn):
+    """Runs fn() on a new HIP stream -- i.e. on a NEW C-ABI context, which reads the library's environment switches when it is
+    created -- with `env` set; restores the environment."""
+    torch.cuda.synchronize()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out = fn()
+            torch.cuda.synchronize()
+        return out
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_conv3x3_linear_320_position_tiles(ops):
+    """The opt-in 320-position linear tiles (DAT_CONV_LINEAR=5; a grid just above one block per CU: 100 maps of 14 x 14, 512 output
+    channels = 308 blocks of 256 positions, 248 of 320) against torch and bit for bit against the 2-D tiling (DAT_CONV_LINEAR=0)."""
+    rs = np.random.RandomState(5)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    N, H, W, Cin, Cout = 100, 14, 14, 64, 512
+    x = q(rs.randn(N, Cin, 1, H, W).astype(np.float32))
+    w = q((rs.randn(Cout, Cin, 1, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32))
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    res = q(rs.randn(N, Cout, 1, H, W).astype(np.float32))
+    ref = _conv_ref(x, w, None, bias, res, (1, 1), (0, 1, 1), True)
+    layer = ops.ConvLayer(_dev(w), None, _dev(bias), stride=(1, 1), pads=(0, 1, 1), relu=True, dtype=1)
+    xd, rd = ops.to_ndhwc(_dev(x), 1), ops.to_ndhwc(_dev(res), 1, layer.cstride)
+    run = lambda: layer(xd, T=1, residual=rd, res_mode=1)
+    y320 = _in_fresh_context({'DAT_CONV_LINEAR': '5'}, run)
+    y2d = _in_fresh_context({'DAT_CONV_LINEAR': '0'}, run)
+    assert torch.equal(y320, y2d)
+    got = ops.to_ncdhw(y320, 1, N, Cout, 1).cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+
+
 BT_CASES = [
     # name, T, H, W, Cin, Cout, kt, relu, res_mode, affine   (3x3 bf16 layers with >= 384 tiles of 256 x 256: the big-tile kernel)
     ('3x3x3_ragged_16x16', 3, 120, 250, 128, 256, 3, True, 1, True),
@@ -250,25 +292,16 @@ def test_conv3x3_big_tile(ops, case):
     rd = None
     if res_mode:
         rd = ops.to_ndhwc(_dev(res if res_mode == 1 else res_small), 1, layer.cstride)
-    # The dispatcher keeps this kernel for grids that fill the chip >= 4 times; DAT_CONV_BT=2 (read when a context is created, and
-    # a new stream gets a new context) selects it for these test-sized grids too.
-    torch.cuda.synchronize()
-    old = os.environ.get('DAT_CONV_BT')
-    os.environ['DAT_CONV_BT'] = '2'
-    try:
-        with torch.cuda.stream(torch.cuda.Stream()):
-            y = layer(xd, T=T, residual=rd, res_mode=res_mode)
-            try:
-                assert ops.tune_plan(256, 1) == 0          # a forced plan selects the generic kernel
-                y_gen = layer(xd, T=T, residual=rd, res_mode=res_mode)
-            finally:
-                ops.tune_plan(0, 0)
-            torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ['DAT_CONV_BT']
-        else:
-            os.environ['DAT_CONV_BT'] = old
+    # The dispatcher keeps this kernel for grids that fill the chip >= 4 times; DAT_CONV_BT=2 selects it for these test-sized grids too.
+    def both():
+        y_ = layer(xd, T=T, residual=rd, res_mode=res_mode)
+        try:
+            assert ops.tune_plan(256, 1) == 0          # a forced plan selects the generic kernel
+            g_ = layer(xd, T=T, residual=rd, res_mode=res_mode)
+        finally:
+            ops.tune_plan(0, 0)
+        return y_, g_
+    y, y_gen = _in_fresh_context({'DAT_CONV_BT': '2'}, both)
     assert torch.equal(y, y_gen)
     got = ops.to_ncdhw(y, 1, 1, Cout, T).cpu().numpy()
     err = np.abs(got - ref).max()
