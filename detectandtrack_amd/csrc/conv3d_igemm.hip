@@ -1400,14 +1400,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
 // floats per source row, the source being [CoutF][CinF][taps] with the dgrad's output channels second) and written as 16-byte
 // pieces, 32 consecutive rows (= lanes of a fragment) per 512-byte run.
 template <int DT>
-__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real,
-                                                                 int Cin_real, int ntap, int Cout_pad, int Cin, int frag, int dgrad,
-                                                                 const float* __restrict__ scale) {
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, void* __restrict__ out, int Cout_real, int Cin_real, int ntap,
+                                          int Cout_pad, int Cin, int frag, int dgrad, const float* __restrict__ scale, int co0, int ci0) {
     constexpr int CT = 32, CIT = 16;
+    (void)CT;
     constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;
     extern __shared__ float tile[];                    // [CT co][CIT ci][ntap], rows padded by one float: the store phase reads with
                                                        // co across the lanes, and CIT * ntap (e.g. 432) is a multiple of 16 banks
-    const int co0 = blockIdx.x * CT, ci0 = blockIdx.y * CIT;
     const int tid = threadIdx.x;
     const int per_co = CIT * ntap;
     const int pitch = per_co + 1;
@@ -1453,6 +1452,30 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __
         }
         *(uint4*)((char*)out + dst * ElemOf<DT>::size) = o;
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real,
+                                                                 int Cin_real, int ntap, int Cout_pad, int Cin, int frag, int dgrad,
+                                                                 const float* __restrict__ scale) {
+    pack_tile<DT>(w, out, Cout_real, Cin_real, ntap, Cout_pad, Cin, frag, dgrad, scale, blockIdx.x * 32, blockIdx.y * 16);
+}
+
+// Batched re-pack (training): after an SGD step every trainable layer and its data-gradient twin is re-packed from the fp32 masters --
+// ~100 launches of 3-20 us each, 1.75 ms of a 23 ms iteration.  One launch over a table of entries: block b belongs to the entry whose
+// [tile0, tile0 + tiles) range holds it (binary search over <= a few hundred entries of uniform loads).
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const dat_pack_item* __restrict__ items, int n) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const dat_pack_item it = items[lo];
+    const int local = b - it.tile0;
+    const int bx = local % it.tiles_x, by = local / it.tiles_x;
+    pack_tile<DT>(it.w, it.packed, it.rows, it.cols, it.ntap, it.cout_pad, it.cin, it.frag, it.dgrad, it.scale, bx * 32, by * 16);
 }
 
 // stem packing (see dat_hip.h: dat_stem_pack): one thread = one 16-byte group of output channels
@@ -1893,6 +1916,41 @@ int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_des
     DAT_ENFORCE(ctx, CinF <= d->Cout && CoutF <= d->Cin, "conv3d_pack_weights_dgrad: forward dims %d x %d exceed the data-gradient descriptor (%d outputs, %d inputs)",
                 CoutF, CinF, d->Cout, d->Cin);
     return launch_pack(ctx, (hipStream_t)s, d, w_fwd, CinF, CoutF, 1, scale_fwd, packed);
+}
+
+int dat_conv3d_pack_item(dat_ctx* ctx, const dat_conv_desc* d, const float* w, int rows_real, int cols_real, int dgrad, const float* scale,
+                         void* packed, dat_pack_item* item) {
+    DAT_ENFORCE(ctx, d && w && packed && item, "conv3d_pack_item: null argument");
+    DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_pack_item: bad dtype %d", d->dtype);
+    if (dgrad) DAT_ENFORCE(ctx, rows_real <= d->Cout && cols_real <= d->Cin, "conv3d_pack_item: forward dims exceed the data-gradient descriptor");
+    else DAT_ENFORCE(ctx, rows_real <= d->Cout && cols_real <= d->Cin, "conv3d_pack_item: real dims exceed descriptor");
+    const int ntap = d->KT * d->KH * d->KW;
+    DAT_ENFORCE(ctx, (size_t)32 * (16 * ntap + 1) * sizeof(float) <= 160 * 1024, "conv3d_pack_item: %d taps exceed the LDS tile", ntap);
+    item->w = w; item->packed = packed; item->scale = scale;
+    item->rows = rows_real; item->cols = cols_real; item->ntap = ntap;
+    item->cout_pad = cout_pad_of(d); item->cin = d->Cin;
+    item->frag = weights_direct(ctx, d) ? 1 : 0;
+    item->dgrad = dgrad ? 1 : 0; item->dtype = d->dtype;
+    item->tile0 = 0; item->tiles_x = item->cout_pad / 32;
+    return item->tiles_x * (d->Cin / 16);
+}
+
+int dat_conv3d_pack_weights_batch(dat_ctx* ctx, dat_stream s, const dat_pack_item* items_dev, int n, int total_blocks, int max_ntap,
+                                  int dtype) {
+    DAT_ENFORCE(ctx, items_dev && n > 0 && total_blocks > 0 && max_ntap > 0, "conv3d_pack_weights_batch: empty batch");
+    DAT_ENFORCE(ctx, dtype == DAT_F32 || dtype == DAT_BF16, "conv3d_pack_weights_batch: bad dtype %d", dtype);
+    const size_t lds = (size_t)32 * (16 * max_ntap + 1) * sizeof(float);
+    DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d_pack_weights_batch: %d taps exceed the LDS tile", max_ntap);
+    int rc;
+    if (dtype == DAT_BF16) {
+        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_BF16>, 160 * 1024)) != DAT_OK) return rc;
+        hipLaunchKernelGGL(pack_weights_batch_kernel<DAT_BF16>, dim3(total_blocks), dim3(256), lds, (hipStream_t)s, items_dev, n);
+    } else {
+        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_F32>, 160 * 1024)) != DAT_OK) return rc;
+        hipLaunchKernelGGL(pack_weights_batch_kernel<DAT_F32>, dim3(total_blocks), dim3(256), lds, (hipStream_t)s, items_dev, n);
+    }
+    DAT_CHECK_LAUNCH(ctx, "pack_weights_batch");
+    return DAT_OK;
 }
 
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,

@@ -28,6 +28,11 @@ class ConvDesc(C.Structure):
         'stride_h', 'stride_w', 'pad_t', 'pad_h', 'pad_w', 'relu', 'res_mode', 'out_t0', 'out_tn', 'in_t0', 'in_tn')]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('packed', C.c_void_p), ('scale', C.c_void_p)] + \
+               [(n, C.c_int) for n in ('rows', 'cols', 'ntap', 'cout_pad', 'cin', 'frag', 'dgrad', 'dtype', 'tile0', 'tiles_x')]
+
+
 class RoiLevel(C.Structure):
     _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
 
@@ -66,6 +71,8 @@ _PROTOS = {
     'dat_conv3d_packed_weight_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'dat_conv3d_pack_weights': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p]),
     'dat_conv3d_pack_weights_dgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p, _p]),
+    'dat_conv3d_pack_item': (_i, [_p, C.POINTER(ConvDesc), _p, _i, _i, _i, _p, _p, C.POINTER(PackItem)]),
+    'dat_conv3d_pack_weights_batch': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'dat_conv3d_fwd': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),
     'dat_conv3d_tune_plan': (_i, [_p, _i, _i]),
     'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),

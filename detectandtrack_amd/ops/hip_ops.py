@@ -291,6 +291,36 @@ class ConvGrad(object):
         return lay(gz, T=T, in_t=in_t)
 
 
+class PackBatch(object):
+    """One-launch re-pack of many ConvLayers from their fp32 masters (dat_conv3d_pack_weights_batch): the table of entries lives on
+    the device and is valid as long as the layers' master / packed buffers are (training: flat parameter buffer, persistent layers)."""
+
+    def __init__(self, layers):
+        assert layers and len({l.dtype for l in layers}) == 1
+        self.layers = list(layers)
+        self.dtype = layers[0].dtype
+        items = (L.PackItem * len(layers))()
+        total, self.max_ntap = 0, 0
+        for i, l in enumerate(layers):
+            d = l.desc(1, 1, 8, 8)
+            n = L.lib().dat_conv3d_pack_item(ctx().h, C.byref(d), _ptr(l.w_src), l.cout_real, l.cin_real, int(l.is_dgrad),
+                                             _ptr(l.dgrad_scale) if l.is_dgrad else None, _ptr(l.packed), C.byref(items[i]))
+            if n <= 0:
+                ctx().check(n if n < 0 else -1)
+            items[i].tile0 = total
+            total += n
+            self.max_ntap = max(self.max_ntap, items[i].ntap)
+        self.total = total
+        raw = np.frombuffer(items, dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(layers[0].packed.device)
+
+    def run(self):
+        ctx().call('dat_conv3d_pack_weights_batch', _stream(), _ptr(self.table), len(self.layers), self.total, self.max_ntap, self.dtype)
+        for l in self.layers:
+            if l.bias_src is not None:
+                l.bias[:l.cout_real] = l.bias_src.float()
+
+
 def _convgrad_repack(self):
     """after an in-place update of the forward master: refresh the packed data-gradient weights (if they were built)"""
     if self._data_layer is not None:

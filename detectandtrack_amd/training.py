@@ -592,6 +592,7 @@ class Trainer(object):
         weights, the sub-pixel deconv) are dropped and rebuilt on the next forward."""
         ws = self.ws
         all_ptrs = {t.data_ptr() for t in ws._dev_params.values()}
+        todo = []               # ConvLayers to re-pack: ONE batched launch (they were ~100 launches, 1.75 ms of a 23 ms iteration)
         for key in list(ws._layers.keys()):
             layer = ws._layers[key]
             src = getattr(layer, 'w_src', None) if isinstance(layer, ops.ConvLayer) else \
@@ -602,9 +603,17 @@ class Trainer(object):
                 continue
             ptr = src.data_ptr()
             if ptr in self._train_ptrs:
-                layer.repack()
+                if isinstance(layer, ops.ConvLayer):
+                    todo.append(layer)
+                elif layer._data_layer is not None:
+                    todo.append(layer._data_layer)
             elif ptr not in all_ptrs:
                 del ws._layers[key]
+        if todo:
+            sig = tuple(id(l) for l in todo)
+            if getattr(self, '_pack_sig', None) != sig:
+                self._pack_sig, self._pack_batch = sig, ops.PackBatch(todo)
+            self._pack_batch.run()
 
     def momentum_blobs(self):
         """name -> host array of the momentum buffers (saved as `<param>_momentum`, reference utils/net.py:268-275)."""

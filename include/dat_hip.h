@@ -103,6 +103,22 @@ int dat_conv3d_pack_weights(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, 
  * scale_fwd[co] (scale_fwd: the layer's fused AffineChannelNd scale, or NULL) in one pass -- no flipped / transposed copy. */
 int dat_conv3d_pack_weights_dgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const float* w_fwd, int CoutF, int CinF,
                                   const float* scale_fwd, void* packed);
+/* Batched re-pack (training: every trainable layer and its data-gradient twin after each SGD step, model_builder.py:953-985 updates the
+ * blobs the next forward reads): dat_conv3d_pack_item fills one table entry with the arguments of dat_conv3d_pack_weights (dgrad 0:
+ * rows = Cout_real, cols = Cin_real) or dat_conv3d_pack_weights_dgrad (dgrad 1: rows = CinF, cols = CoutF, scale = scale_fwd) and returns
+ * the number of thread blocks the entry takes (< 0: error); the caller sets tile0 to the running sum, copies the table to the device
+ * and packs all entries (one dtype) with ONE launch of dat_conv3d_pack_weights_batch. */
+typedef struct dat_pack_item {
+    const float* w;
+    void* packed;
+    const float* scale;
+    int rows, cols, ntap, cout_pad, cin, frag, dgrad, dtype;
+    int tile0, tiles_x;
+} dat_pack_item;
+int dat_conv3d_pack_item(dat_ctx* ctx, const dat_conv_desc* d, const float* w, int rows_real, int cols_real, int dgrad, const float* scale,
+                         void* packed, dat_pack_item* item);
+int dat_conv3d_pack_weights_batch(dat_ctx* ctx, dat_stream s, const dat_pack_item* items_dev, int n, int total_blocks, int max_ntap,
+                                  int dtype);
 /* y = act( conv(x, w)*scale[c] + bias[c] + residual ); scale may be NULL (=1), bias may be NULL (=0).
  * scale/bias: fp32 [Cout].  residual: same dtype/stride as y. */
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,

@@ -181,6 +181,37 @@ def test_conv3x3_c64_weights_stationary(ops, case):
     assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4), err
 
 
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_batched_weight_repack_equals_per_layer_packing(ops, dtype):
+    """dat_conv3d_pack_weights_batch (one launch over a device table of layers: forward and data-gradient packings, different tap
+    counts and channel paddings) leaves every packed buffer bit-identical to the per-layer dat_conv3d_pack_weights[_dgrad]."""
+    g = torch.Generator().manual_seed(7)
+    specs = [((128, 64, 3, 3, 3), False), ((256, 128, 1, 1, 1), False), ((64, 64, 1, 3, 3), False), ((12, 200, 1, 1, 1), False),
+             ((128, 64, 3, 3, 3), True), ((96, 256, 1, 3, 3), True)]
+    layers, masters = [], []
+    for shape, dgrad in specs:
+        w = (torch.randn(shape, generator=g) * 0.1).cuda()
+        masters.append(w)
+        if dgrad:
+            scale = (torch.rand(shape[0], generator=g) + 0.5).cuda()
+            pads = tuple(k - 1 - k // 2 for k in shape[2:])
+            layers.append(ops.ConvLayer(None, None, None, stride=(1, 1), pads=pads, relu=False, dtype=dtype, dgrad_of=(w, scale)))
+        else:
+            layers.append(ops.ConvLayer(w, None, None, stride=(1, 1), pads=tuple(k // 2 for k in shape[2:]), relu=False, dtype=dtype))
+    batch = ops.PackBatch(layers)
+    for w in masters:                       # an "SGD step" in place
+        w.mul_(0.9).add_(0.01)
+    for l in layers:
+        l.packed.zero_()
+    batch.run()
+    got = [l.packed.clone() for l in layers]
+    for l in layers:
+        l.packed.zero_()
+        l.repack(weights_only=True)
+    for l, gpk in zip(layers, got):
+        assert torch.equal(l.packed, gpk)
+
+
 PW256_CASES = [
     # name, T, H, W, relu, res_mode, affine   (1x1, 64 -> 256, bf16: the weights-stationary lateral kernel)
     ('up2_ragged', 2, 26, 38, False, 2, False),       # 1976 positions: the last wave tile is partial
