@@ -437,7 +437,10 @@ class Executor(object):
         if not cfg.HIP.get('FUSE_STEM_POOL', True):
             return None
         out, found = op.outputs[0], None
-        for net in self.ws.nets.values():
+        nets = list(self.ws.nets.values())
+        if not any(net is self.net for net in nets):     # (a training executor runs a net the workspace never registered)
+            nets.append(self.net)
+        for net in nets:
             for j, o in enumerate(net.ops):
                 res = o.args.get('residual') if isinstance(o.args, dict) else None
                 if out in o.inputs or res == out:
