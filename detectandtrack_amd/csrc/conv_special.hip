@@ -1,0 +1,765 @@
+// The special-cased conv kernels of round 2 ("Round 2") and their launchers: weights-stationary persistent
+// kernels for the 64-channel layers (res2's 3x3 convs, the FPN P2 lateral) and the big-tile 3x3 kernel.  The dispatcher that
+// chooses between them and the generic kernel is dat_conv3d_fwd (conv3d_igemm.hip).
+#include "conv_internal.h"
+
+using namespace dat_conv;
+
+namespace {
+
+// ---- weights-stationary 3x3, 64 -> 64 channels (the res2 stage: ResNet3D.py:266-272 at 1/4 resolution) -------------------------
+// The generic kernel streams a layer's weights to every block; with 64 output channels a block has only 2 row blocks of MFMA work
+// per weight fragment, so the 72 KB of weights per 128 positions are the traffic that bounds it (each MFMA needs a fresh 1-KiB
+// fragment through the CU's 64 B/clk L1: 0.12 ms per layer in the network, 310 TFLOP/s, against a 0.03 ms HBM floor).  Here the
+// WHOLE weight tensor (9 taps x 64 x 64 bf16 = 72 fragments of 16 B per lane) lives in each wave's registers for the life of a
+// PERSISTENT block (one block per CU, one wave per SIMD, 512-register budget), and the block walks over output tiles:
+//   * a tile is 256 positions (8 x 32 or 16 x 16); its (TH+2) x (TW+2) x 128-B input patch is double-buffered in LDS by LDS-DMA
+//     -- the next tile's patch is requested before the current tile's MFMAs, so HBM latency never shows;
+//   * per tile a wave runs 9 taps x 4 k-slices x (2 B-fragment ds_read_b128 + 4 MFMAs): the only operand traffic is 72 LDS reads
+//     for 144 MFMAs (every B fragment feeds both 32-channel row blocks), no weight traffic at all, ONE barrier per tile;
+//   * the epilogue (affine, residual, ReLU, 16-byte channel-contiguous stores) goes through a per-wave LDS slice as in the
+//     generic kernel.
+struct Ws64Params {
+    const char* x;
+    const char* w;              // MFMA-fragment order (pack_weights*, frag = 1): [tap][32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    const char* zeros;
+    int frames, H, W, out_cs, relu, res_mode;
+    int tiles_h, tiles_w, ntiles;
+    int ablate;                 // DEBUG (DAT_CONV_ABLATE): 1 skip the patch loads after the first, 4 skip the stores (and residual loads)
+};
+
+template <int TWL>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c64_ws_kernel(const Ws64Params p) {
+    constexpr int TW = 1 << TWL, TH = 256 >> TWL, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIX = PH * PW, NPIECE = (NPIX * 8 + 63) / 64, PBYTES = NPIECE * 1024, UMAX = (NPIECE + 3) / 4;
+    constexpr int EPITCH = 64 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    char* const est = smem + 2 * PBYTES + wave * (32 * EPITCH);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- the layer's weights: 72 fragments, resident: taps 0-2 in VGPRs, taps 3-8 in AGPRs (with the 64 accumulators: all 256) ----
+    // The MFMAs below are inline assembly for exactly this reason: gfx950 MFMAs read their A operand from either register file, but
+    // the compiler only ever used the AGPR half as spill space (4 v_accvgpr_read per fragment and tile) and, out of VGPRs,
+    // serialised every ds_read behind an lgkmcnt(0).  The "v" / "a" constraints pin each fragment to its file.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int VT = 3;                                   // taps held in VGPRs
+    u32x4_t wv[VT][2][4], wg[9 - VT][2][4];
+    {
+        const char* wl = p.w + lane * 16;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4_t v = *(const u32x4_t*)(wl + ((tp * 2 + mb) * 4 + ks) * 1024);
+                    if (tp < VT) wv[tp][mb][ks] = v; else wg[tp - VT][mb][ks] = v;
+                }
+    }
+#define WS_MFMA0_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_A(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "a"(A_), "v"(B_) : "memory")
+    // ---- swizzled LDS address (k-slice 0) of the B fragment of every (tap, position sub-tile), two per register ----
+    // sub-tile j of this wave: 8 x 32 tiles: output row 2*wave + j, column n; 16 x 16 tiles: rows 4*wave + 2*j + (n >> 4), column n & 15
+    unsigned qp[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        unsigned q = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (n >> 4), c = TWL == 5 ? n : (n & 15);
+            const int row = (r + tp / 3) * PW + c + tp % 3;
+            const int g = (row >> 1) & 7;
+            const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
+            q |= a16 << (16 * j);
+        }
+        qp[tp] = q;
+    }
+    static_assert(PBYTES < 65536, "two 16-bit patch addresses per register");
+    // ---- epilogue constants: this lane's 8 channels in the store phase ----
+    const int sl_c = (lane & 7) * 8, sl_p = lane >> 3;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[sl_c + e] : 1.f;
+        bi[e] = p.bias ? p.bias[sl_c + e] : 0.f;
+    }
+    const int tiles_per_frame = p.tiles_h * p.tiles_w;
+
+    // patch of tile `tl` -> LDS buffer `b` (this wave's 1-KiB pieces wave, wave + 4, ...): lane-linear LDS-DMA image, the XOR swizzle
+    // applied on the source side; halo pixels outside the frame (and the tail lanes of the last piece) fetch zeros
+#define WS_DMA(TL_, B_)                                                                                                   \
+    {                                                                                                                     \
+        const int f_ = (TL_) / tiles_per_frame, r_ = (TL_) - f_ * tiles_per_frame;                                        \
+        const int th_ = r_ / p.tiles_w, tw_ = r_ - th_ * p.tiles_w;                                                       \
+        const int ih0_ = th_ * TH - 1, iw0_ = tw_ * TW - 1;                                                               \
+        const char* xf_ = p.x + (size_t)f_ * p.H * p.W * 128;                                                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < UMAX; ++u_) {                                                             \
+            const int piece_ = wave + 4 * u_;                                                                             \
+            if (piece_ < NPIECE) {                                                                                        \
+                const int it_ = piece_ * 64 + lane, row_ = it_ >> 3;                                                      \
+                const int slot_ = (it_ ^ (row_ >> 1)) & 7;                                                                \
+                const int prow_ = row_ / PW, pcol_ = row_ - prow_ * PW;                                                   \
+                const int ih_ = ih0_ + prow_, iw_ = iw0_ + pcol_;                                                         \
+                const bool ok_ = row_ < NPIX && (unsigned)ih_ < (unsigned)p.H && (unsigned)iw_ < (unsigned)p.W;           \
+                const char* src_ = ok_ ? xf_ + ((unsigned)(ih_ * p.W + iw_) * 128u + (unsigned)(slot_ * 16)) : p.zeros;   \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (B_) * PBYTES + piece_ * 1024), 16, 0, 0); \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) WS_DMA(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int buf = 0;
+    for (; tile < p.ntiles; tile += gridDim.x, buf ^= 1) {
+        // every wave has retired its DMA pieces of this tile (the vmcnt(0) before its last epilogue / above) and has left the other
+        // buffer (its reads ended before that epilogue): one barrier publishes the patch and frees the other buffer
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles && !(p.ablate & 1)) WS_DMA(next, buf ^ 1);
+        f32x16_t acc[2][2];
+        const unsigned boff = (unsigned)buf * PBYTES;
+        __builtin_amdgcn_s_setprio(1);
+        // 36 steps (tap, k-slice) of 2 B-fragment reads + 4 MFMAs; the reads run two steps ahead through a 3-slot register ring (one
+        // wave per SIMD: nothing else hides the LDS latency).  The statements are volatile asm with memory clobbers: program order.
+        u32x4_t bq[3][2];
+        unsigned a0 = 0, a1 = 0;
+#define WS_READ(S_)                                                                                  \
+        {                                                                                            \
+            if ((S_) % 4 == 0) {                                                                     \
+                unsigned q_ = qp[(S_) / 4];                                                          \
+                asm volatile("" : "+v"(q_));   /* opaque per tile: keeps the 72 unpacked / xor-ed addresses out of registers */ \
+                a0 = (q_ & 0xffffu) + boff; a1 = (q_ >> 16) + boff;                                  \
+            }                                                                                        \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 3][0]) : "v"(a0 ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 3][1]) : "v"(a1 ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+        }
+        WS_READ(0);
+        WS_READ(1);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            if (st + 2 < 36) WS_READ(st + 2);
+            // LDS returns in order: all but the reads of the (up to) two later steps have landed.  (The reads are asm too, so the
+            // compiler's own waitcnt pass -- which waited for lgkmcnt(0) before every asm use of a pending ds_read -- stays out.)
+            if (st + 2 < 36) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (st + 1 < 36) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int tp = st / 4, ks = st % 4;
+            const u32x4_t b0 = bq[st % 3][0], b1 = bq[st % 3][1];
+            if (st == 0) {
+                WS_MFMA0_V(acc[0][0], wv[0][0][0], b0); WS_MFMA0_V(acc[1][0], wv[0][1][0], b0);
+                WS_MFMA0_V(acc[0][1], wv[0][0][0], b1); WS_MFMA0_V(acc[1][1], wv[0][1][0], b1);
+            } else if (tp < VT) {
+                WS_MFMA_V(acc[0][0], wv[tp < VT ? tp : 0][0][ks], b0); WS_MFMA_V(acc[1][0], wv[tp < VT ? tp : 0][1][ks], b0);
+                WS_MFMA_V(acc[0][1], wv[tp < VT ? tp : 0][0][ks], b1); WS_MFMA_V(acc[1][1], wv[tp < VT ? tp : 0][1][ks], b1);
+            } else {
+                WS_MFMA_A(acc[0][0], wg[tp >= VT ? tp - VT : 0][0][ks], b0); WS_MFMA_A(acc[1][0], wg[tp >= VT ? tp - VT : 0][1][ks], b0);
+                WS_MFMA_A(acc[0][1], wg[tp >= VT ? tp - VT : 0][0][ks], b1); WS_MFMA_A(acc[1][1], wg[tp >= VT ? tp - VT : 0][1][ks], b1);
+            }
+        }
+#undef WS_READ
+        // (the compiler does not see MFMAs in the asm above: cover the XDL-write -> VALU-read wait states of the accumulators by hand)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's patch pieces (requested a whole tile of MFMAs ago)
+
+        // ---- epilogue: per-wave LDS transpose, affine + residual + ReLU, 16-byte channel-contiguous stores ----
+        // (interleaving it with the next tile's MFMAs was tried and dropped: vmcnt is one in-order counter, so the first residual
+        //  load consumed -- and, through the compiler's LDS-DMA alias rule, the first LDS access of the epilogue -- would wait for the
+        //  patch DMA issued just before it)
+        const int f = tile / tiles_per_frame, rr = tile - f * tiles_per_frame;
+        const int th_i = rr / p.tiles_w, tw_i = rr - th_i * p.tiles_w;
+        const int oh0 = th_i * TH, ow0 = tw_i * TW;
+        const size_t tile_pos = ((size_t)f * p.H + oh0) * p.W + ow0;
+        char* const ybase = p.y + tile_pos * p.out_cs * 2;
+        const char* const rbase = p.res + tile_pos * p.out_cs * 2;
+        // residual rows one sub-tile ahead of their use (a load issued where it is consumed costs a memory round trip per store group)
+        uint4 rq[2][4];
+        auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const int ohl = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const bool live = oh0 + ohl < p.H && ow0 + owl < p.W && !(p.ablate & 4);
+                dst[q] = *(const uint4*)(rbase + (live ? ((unsigned)(ohl * p.W + owl) * (unsigned)p.out_cs + (unsigned)sl_c) * 2u : 0u));
+            }
+        };
+        if (p.res_mode) res_fetch(0, rq[0]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (p.res_mode && j == 0) res_fetch(1, rq[1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(est + n * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                        make_float4(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+                const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const int ohl = TWL == 5 ? 2 * wave + j : 4 * wave + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                if (oh0 + ohl >= p.H || ow0 + owl >= p.W || (p.ablate & 4)) continue;
+                const unsigned lpos = (unsigned)(ohl * p.W + owl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                if (p.res_mode) {
+                    const uint4 r = rq[j][q];
+                    const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(uint4*)(ybase + (lpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#undef WS_DMA
+#undef WS_MFMA0_V
+#undef WS_MFMA_V
+#undef WS_MFMA_A
+}
+
+// ---- weights-stationary 1x1, 64 -> 256 channels (the FPN P2 lateral: FPN3D.py:111-134 on res2, 1/4 resolution) ------------------
+// An HBM-bound layer: 66 MB in, 264 MB out (+ 66 MB of top-down map).  The generic kernel's 128-channel x 128-position blocks write
+// every output position as four 128-byte pieces from different waves and blocks, at different times; measured with cold caches that
+// costs 0.117 of the layer's 0.188 ms -- 2.3 TB/s of stores on a part that fills memory at 5.8 TB/s (tools/hbm_probe.py).  Here a
+// wave owns ALL 256 channels of its 32 positions: the whole weight matrix (32 fragments, 128 VGPRs) stays in its registers, the
+// input fragments come straight from global memory (32 contiguous bytes per lane pair; prefetched one tile ahead), and after a
+// per-wave LDS transpose every store instruction writes two complete 512-byte output rows.  Waves never synchronise; the grid is
+// persistent (one block per CU: the fp32 transpose slice is 33 KB per wave).
+struct Pw256Params {
+    const char* x;
+    const char* w;              // MFMA-fragment order: [32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    long long npos;             // frames * H * W
+    int H, W, out_cs, relu, res_mode;
+    int ntiles;                 // wave tiles of 32 positions
+    unsigned hw, w_magic;       // H * W; ceil(2^32 / W): row = umulhi(position in frame, w_magic)
+};
+
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_k64_c256_ws_kernel(const Pw256Params p) {
+    constexpr int EPITCH = 256 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    char* const est = smem + wave * (32 * EPITCH);
+    uint4 wa[8][4];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wa[mb][ks] = *(const uint4*)(p.w + (mb * 4 + ks) * 1024 + lane * 16);
+    // store phase: lane = 8 channels of one of two positions
+    const int sl_c = (lane & 31) * 8, sl_p = lane >> 5;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[sl_c + e] : 1.f;
+        bi[e] = p.bias ? p.bias[sl_c + e] : 0.f;
+    }
+    const int nwaves = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    // B fragment (k-slice ks) of position pos: bytes [ks * 32 + khalf * 16, +16) of its 128-byte channel row
+    uint4 bcur[4], bnext[4];
+#define PW_LOAD(DST_, TILE_)                                                                                   \
+    {                                                                                                          \
+        const unsigned pos_ = min((unsigned)(TILE_) * 32u + (unsigned)n, (unsigned)p.npos - 1u);               \
+        const char* src_ = p.x + (size_t)(pos_ * 128u + (unsigned)khalf * 16u);                                                   \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) DST_[ks_] = *(const uint4*)(src_ + ks_ * 32);      \
+    }
+    if (tile < p.ntiles) PW_LOAD(bcur, tile);
+    for (; tile < p.ntiles; tile += nwaves) {
+        const int next = tile + nwaves;
+        if (next < p.ntiles) PW_LOAD(bnext, next);
+        // 32-bit position arithmetic (the launcher checks the ranges); the frame / row split of the tile's first position is
+        // wave-uniform, a lane only adds its offset (one conditional frame wrap: a frame has >= 32 positions)
+        const unsigned pos0 = (unsigned)tile * 32u;
+        const unsigned f0 = pos0 / p.hw, rem0 = pos0 - f0 * p.hw;
+        // the residual rows of this tile (16 store groups of 2 positions) are requested NOW: one wave per SIMD has nothing else to
+        // hide their latency behind than its own MFMA and transpose phases
+        uint4 rr[16];
+        if (p.res_mode) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned pl = (unsigned)(q * 2 + sl_p);
+                const unsigned pos = min(pos0 + pl, (unsigned)p.npos - 1u);
+                unsigned rpos = pos;
+                if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map
+                    unsigned fr = f0, rem = pos - f0 * p.hw;
+                    if (rem >= p.hw) { rem -= p.hw; ++fr; }
+                    const unsigned oh = __umulhi(rem, p.w_magic), ow = rem - oh * (unsigned)p.W;
+                    rpos = (fr * (unsigned)(p.H >> 1) + (oh >> 1)) * (unsigned)(p.W >> 1) + (ow >> 1);
+                }
+                rr[q] = *(const uint4*)(p.res + (size_t)((rpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u));
+            }
+        }
+        (void)rem0;
+        f32x16_t acc[8];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) Mma<DAT_BF16>::step(wa[mb][ks], bcur[ks], acc[mb]);
+        // ---- epilogue: transpose through this wave's LDS slice, then two complete output rows per store instruction ----
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(est + n * EPITCH + (mb * 32 + g * 8 + khalf * 4) * 4) =
+                    make_float4(acc[mb][g * 4 + 0], acc[mb][g * 4 + 1], acc[mb][g * 4 + 2], acc[mb][g * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pl = q * 2 + sl_p;
+            const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+            const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const unsigned pos = pos0 + (unsigned)pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+            if (p.res_mode) {
+                const uint32_t ru[4] = {rr[q].x, rr[q].y, rr[q].z, rr[q].w};
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                    v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (pos < (unsigned)p.npos)
+                *(uint4*)(p.y + (size_t)((pos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u)) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
+    }
+#undef PW_LOAD
+}
+
+// ---- big-tile 3x3 kernel: 256 output channels x 256 positions per block, one block per CU, one wave per SIMD ---------------------
+// The 128 x 256 kernel above feeds 8 MFMAs per k-slice from 6 operand fragments per wave, two blocks per CU: the CU's operand
+// delivery (L1 64 B/clk for the weight fragments, LDS for the patch) is what holds it at ~55 % of the matrix peak (DESIGN.md
+// section 3).  Here a wave owns 128 channels x 128 positions -- 16 accumulators, all 256 AGPRs -- so a k-slice is 16 MFMAs
+// (512 matrix cycles) for 4 + 4 fragments: half the operand traffic per MFMA, and the CU's L1 / LDS run at 50 % / 25 % of their
+// rate.  With one wave per SIMD nothing hides latencies by itself, so the main loop is software-pipelined BY HAND in volatile asm
+// (the compiler neither re-orders it nor inserts conservative waits):
+//   * weight fragments: straight from global memory (fragment-order layout) into an R-step register ring; the slot a k-slice just
+//     consumed is re-loaded with the slice R steps ahead (R x 512 cycles for L2 latency), waited for with COUNTED vmcnt;
+//   * patch fragments: ds_read_b128 one step ahead (2-slot ring), counted lgkmcnt;
+//   * the (kt, channel-chunk) patches are double-buffered in LDS by LDS-DMA: the next patch is requested when the current one
+//     starts (36 k-slices = 18 k cycles earlier); one barrier per patch.  Every wave issues the same number of DMA pieces (the
+//     tail re-fetches the last piece), so that the vmcnt arithmetic is the same in all waves.
+// The launcher uses it for 256-channel-multiple layers whose grid fills the chip at least ~2 times (FPN P2 / P3 outputs).
+template <int TWL, int R>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_bt_kernel(const ConvParams p) {
+    constexpr int TW = 1 << TWL, TH = 256 >> TWL, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIX = PH * PW, NPIECE = (NPIX * 8 + 63) / 64, PBYTES = NPIECE * 1024, UMAX = (NPIECE + 3) / 4;
+    static_assert(36 % R == 0 && PBYTES < 65536, "ring slots are static per unrolled step; 16-bit patch addresses");
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_n = wave & 1, wave_p = wave >> 1;
+    const int khalf = lane >> 5, n = lane & 31;
+
+    // ---- XCD-aware block -> (channel block, tile, frame) map, as in conv3d_igemm_kernel ----
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nx = 8, q = p.nblocks / nx, r = p.nblocks % nx;
+        const unsigned xcd = bid % nx, k = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int nb = bid % p.nblk_n;
+    unsigned tile = bid / p.nblk_n;
+    const int fc = tile % p.otn; tile /= p.otn;
+    const int tw_i = tile % p.tiles_w; tile /= p.tiles_w;
+    const int th_i = tile % p.tiles_h;
+    const int clip = tile / p.tiles_h;
+    const int f = clip * p.otn + fc;
+    const int t = p.ot0 + fc;
+    const int f_in = clip * p.T + t;
+    const int oh0 = th_i * TH, ow0 = tw_i * TW;
+
+    // valid temporal taps of this output frame, rotated start (same order as the generic kernel: bit-identical sums)
+    int kt_lo = 0, kt_hi = p.KT - 1;
+    while (kt_lo < p.KT && (t + kt_lo - p.pt) < p.in_lo) ++kt_lo;
+    while (kt_hi >= 0 && (t + kt_hi - p.pt) >= p.in_hi) --kt_hi;
+    const int n_kt = kt_hi - kt_lo + 1;
+    const int npat = n_kt * p.n_cchunks;
+    const int kt_hi_x = kt_lo + n_kt;
+    int kshift = 0;
+    if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
+    int kt = kt_lo + kshift, cc = 0;
+    if (kt >= kt_hi_x) kt -= n_kt;
+
+    // ---- swizzled LDS address (k-slice 0) of the B fragment of every (tap, position sub-tile j), two per register ----
+    // sub-tile j of this wave: 16 x 16 tiles: rows 8*wave_p + 2*j + (n >> 4), column n & 15; 8 x 32 tiles: row 4*wave_p + j, column n
+    unsigned qp[9][2];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (n >> 4), c = TWL == 5 ? n : (n & 15);
+            const int row = (r + tp / 3) * PW + c + tp % 3;
+            const int g = (row >> 1) & 7;
+            const unsigned a16 = (unsigned)(row * PPITCH) + (unsigned)(((khalf ^ (g & 1)) << 4) | ((g >> 1) << 5));
+            if (j & 1) qp[tp][j >> 1] |= a16 << 16; else qp[tp][j >> 1] = a16;
+        }
+    // ---- weights: fragment (tap, chunk, 32-row block, k-slice) = 1 KiB at (((tap * ncc + chunk) * MB + block) * 4 + k-slice) * 1024 ----
+    const size_t wd_cc_stride = (size_t)(p.Cout_pad >> 5) * 4096;
+    const size_t tap_stride = (size_t)p.n_cchunks * wd_cc_stride;
+    const char* const wd_base = p.w + (size_t)(nb * 8 + wave_n * 4) * 4096;        // this wave's four 32-row blocks
+    unsigned aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)lane * 16u + (unsigned)i * 4096u;
+
+    // patch (KT_, CC_) of this tile -> LDS buffer B_: every wave issues exactly UMAX pieces (wave, wave + 4, ...; indices past the
+    // last piece re-fetch it); lane-linear LDS-DMA image, XOR swizzle on the source side, halo / tail lanes fetch zeros
+#define BT_DMA(KT_, CC_, B_)                                                                                              \
+    {                                                                                                                     \
+        const int fin_ = f_in + (KT_) - p.pt;                                                                             \
+        const char* xf_ = p.x + ((size_t)fin_ * p.H * p.W) * p.Cin * 2 + (size_t)(CC_) * 128;                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < UMAX; ++u_) {                                                             \
+            const int piece_ = min(wave + 4 * u_, NPIECE - 1);                                                            \
+            const int it_ = piece_ * 64 + lane, row_ = it_ >> 3;                                                          \
+            const int slot_ = (it_ ^ (row_ >> 1)) & 7;                                                                    \
+            const int prow_ = row_ / PW, pcol_ = row_ - prow_ * PW;                                                       \
+            const int ih_ = oh0 - 1 + prow_, iw_ = ow0 - 1 + pcol_;                                                       \
+            const bool ok_ = row_ < NPIX && (unsigned)ih_ < (unsigned)p.H && (unsigned)iw_ < (unsigned)p.W;               \
+            const char* src_ = ok_ ? xf_ + ((size_t)(unsigned)(ih_ * p.W + iw_) * (unsigned)(p.Cin * 2) + (unsigned)(slot_ * 16)) : p.zeros; \
+            __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(smem + (B_) * PBYTES + piece_ * 1024), 16, 0, 0);     \
+        }                                                                                                                 \
+    }
+#define BT_WPATCH(KT_, CC_) (wd_base + ((size_t)((KT_) * 9) * p.n_cchunks + (CC_)) * wd_cc_stride)
+    // A fragments of step S_ (tap S_ / 4, k-slice S_ % 4) of the patch whose first tap sits at WP_ -> ring slot SLOT_
+#define BT_ALOAD(WP_, S_, SLOT_)                                                                                          \
+    {                                                                                                                     \
+        const char* wt_ = (WP_) + (size_t)((S_) / 4) * tap_stride;                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                  \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(aq[SLOT_][i_]) : "v"(aoff[i_]), "s"(wt_), "n"(((S_) % 4) * 1024) : "memory"); \
+    }
+    // B fragments of step S_ from buffer offset BOFF_ -> ring slot S_ % 2
+#define BT_BREAD(S_, BOFF_)                                                                                               \
+    {                                                                                                                     \
+        if ((S_) % 4 == 0) {                                                                                              \
+            unsigned q0_ = qp[(S_) / 4][0], q1_ = qp[(S_) / 4][1];                                                        \
+            asm volatile("" : "+v"(q0_), "+v"(q1_));   /* opaque: keeps the unpacked / xor-ed addresses out of registers */ \
+            ba[0] = (q0_ & 0xffffu) + (BOFF_); ba[1] = (q0_ >> 16) + (BOFF_);                                             \
+            ba[2] = (q1_ & 0xffffu) + (BOFF_); ba[3] = (q1_ >> 16) + (BOFF_);                                             \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 2][j_]) : "v"(ba[j_] ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
+    }
+#define BT_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4_t aq[R][4], bq[2][4];
+    unsigned ba[4] = {0, 0, 0, 0};
+
+    if (npat > 0) {
+        // ---- prologue: first patch, first R steps of weights ----
+        BT_DMA(kt, cc, 0);
+        const char* wcur = BT_WPATCH(kt, cc);
+        static_for(std::make_integer_sequence<int, R>{}, [&](auto ic_) __attribute__((always_inline)) {
+            constexpr int s0 = decltype(ic_)::value;
+            (void)&aq; (void)&aoff;                            // (operands of asm statements alone do not capture)
+            BT_ALOAD(wcur, s0, s0);
+        });
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * R) : "memory");      // the DMA pieces (older than the R x 4 weight loads)
+        __syncthreads();
+        int buf = 0;
+        for (int pi = 0; pi < npat; ++pi, buf ^= 1) {
+            // the patch after this one
+            int ncc = cc + 1, nkt = kt;
+            if (ncc == p.n_cchunks) { ncc = 0; if (++nkt == kt_hi_x) nkt = kt_lo; }
+            const bool has_next = pi + 1 < npat;
+            if (has_next) BT_DMA(nkt, ncc, buf ^ 1);
+            const char* wnxt = has_next ? BT_WPATCH(nkt, ncc) : wcur;       // (past the last patch: harmless re-loads keep the counts fixed)
+            const unsigned boff = (unsigned)buf * PBYTES;
+            __builtin_amdgcn_s_setprio(1);
+            BT_BREAD(0, boff);
+            static_for(std::make_integer_sequence<int, 36>{}, [&](auto ic_) __attribute__((always_inline)) {
+                constexpr int st = decltype(ic_)::value;
+                (void)&aq; (void)&aoff; (void)&bq; (void)&ba; (void)&acc; (void)&qp;   // (asm operands alone do not capture)
+                if (st + 1 < 36) BT_BREAD(st + 1, boff);
+                // LDS returns in order: all but the 4 reads of the next step have landed
+                if (st + 1 < 36) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // vector memory returns in order: younger than this step's weight loads are the loads of the R - 1 later steps and,
+                // while those loads still date from the previous patch (st < R), this patch's UMAX DMA pieces
+                if constexpr (st < R) {
+                    if (has_next) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1) + UMAX) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (R - 1)) : "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) BT_MFMA(acc[i][j], aq[st % R][i], bq[st % 2][j]);
+                // re-load the consumed slot with the step R ahead (this patch, or the first steps of the next one)
+                if constexpr (st + R < 36) { BT_ALOAD(wcur, st + R, st % R); } else { BT_ALOAD(wnxt, st + R - 36, st % R); }
+            });
+            __builtin_amdgcn_s_setprio(0);
+            // every wave's pieces of the next patch have landed (its vmcnt waits from step R on cover them) and it has left this buffer
+            __syncthreads();
+            kt = nkt; cc = ncc; wcur = wnxt;
+        }
+    }
+    // (the asm MFMAs / loads are invisible to the compiler: drain them and cover the XDL-write -> VALU-read wait states by hand)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#undef BT_MFMA
+#undef BT_BREAD
+#undef BT_ALOAD
+#undef BT_WPATCH
+#undef BT_DMA
+
+    // ---- epilogue: per-wave LDS transpose of 32 positions x 64 channels at a time, affine + residual + ReLU, 16-byte stores ----
+    constexpr int EPITCH = 64 * 4 + 16;
+    char* const est = smem + wave * (32 * EPITCH);             // (the patch buffers are free: the loop ended with a barrier)
+    const int sl_c = (lane & 7) * 8, sl_p = lane >> 3;
+    const size_t tile_pos = ((size_t)f * p.Ho + oh0) * p.Wo + ow0;
+    char* const ybase = p.y + tile_pos * p.out_cs * 2;
+    const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * 2 : p.res + tile_pos * p.out_cs * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                              // 64-channel half of this wave's 128
+        const int c_st = nb * 256 + wave_n * 128 + h * 64 + sl_c;
+        float sc[8], bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = (c_st + e) < p.Cout;
+            sc[e] = (p.scale && ok) ? p.scale[c_st + e] : 1.f;
+            bi[e] = (p.bias && ok) ? p.bias[c_st + e] : 0.f;
+        }
+        // residual rows one sub-tile ahead of their use
+        uint4 rq[2][4];
+        const bool res_on = p.res_mode && c_st < p.Cout;
+        auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const int ohl = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const int oh = oh0 + ohl, ow = ow0 + owl;
+                const bool live = oh < p.Ho && ow < p.Wo && !(p.ablate & 4);
+                unsigned rpos = (unsigned)(ohl * p.Wo + owl);
+                if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
+                dst[q] = *(const uint4*)(rbase + (live ? (rpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u : 0u));
+            }
+        };
+        if (res_on) res_fetch(0, rq[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (res_on && j + 1 < 4) res_fetch(j + 1, rq[(j + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(est + n * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                        make_float4(acc[2 * h + i][j][g * 4 + 0], acc[2 * h + i][j][g * 4 + 1], acc[2 * h + i][j][g * 4 + 2], acc[2 * h + i][j][g * 4 + 3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pl = q * 8 + sl_p;
+                const float4 t0 = *(const float4*)(est + pl * EPITCH + sl_c * 4);
+                const float4 t1 = *(const float4*)(est + pl * EPITCH + sl_c * 4 + 16);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const int ohl = TWL == 5 ? 4 * wave_p + j : 8 * wave_p + 2 * j + (pl >> 4), owl = TWL == 5 ? pl : (pl & 15);
+                const int oh = oh0 + ohl, ow = ow0 + owl;
+                if (oh >= p.Ho || ow >= p.Wo || c_st >= p.Cout || (p.ablate & 4)) continue;
+                const unsigned lpos = (unsigned)(ohl * p.Wo + owl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                if (p.res_mode) {
+                    const uint4 r = rq[j & 1][q];
+                    const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(uint4*)(ybase + (lpos * (unsigned)p.out_cs + (unsigned)c_st) * 2u) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.clk && threadIdx.x == 0) {
+        atomicAdd(&p.clk[0], __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(&p.clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
+}
+
+}  // namespace
+
+namespace dat_conv {
+
+// weights-stationary persistent kernel (conv3x3_c64_ws_kernel): what it assumes, and the tile shape with the least wasted work
+bool ws64_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_ws64 && d->dtype == DAT_BF16 && d->Cin == 64 && d->Cout == 64 && d->KT == 1 && d->KH == 3 && d->KW == 3 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->pad_t == 0 && d->res_mode != 2 &&
+           d->out_tn <= 0 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
+}
+
+int ctx_num_cu(dat_ctx* ctx) {
+    if (ctx->num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        ctx->num_cu = n > 0 ? n : 256;
+    }
+    return ctx->num_cu;
+}
+
+// big-tile kernel (conv3x3_bt_kernel): what it assumes; the grid must fill the chip about twice (one block per CU at a time)
+bool bt_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_bt && d->dtype == DAT_BF16 && d->Cin % 64 == 0 && cout_pad_of(d) % 256 == 0 && d->Cout % 8 == 0 && d->KH == 3 && d->KW == 3 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
+}
+
+int bt_tile_twl(const ConvParams& p, long long* nblocks) {
+    int best = 4;
+    long long best_tiles = -1;
+    for (int twl = 4; twl <= 5; ++twl) {
+        const long long tiles = cdiv_ll(p.Ho, 256 >> twl) * cdiv_ll(p.Wo, 1 << twl);
+        if (best_tiles < 0 || tiles < best_tiles) { best_tiles = tiles; best = twl; }
+    }
+    *nblocks = best_tiles * p.frames * (p.Cout_pad / 256);
+    return best;
+}
+
+int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p) {
+    long long nblocks = 0;
+    const int twl = bt_tile_twl(p, &nblocks);
+    const int tw = 1 << twl, th = 256 >> twl;
+    p.th_log2 = 8 - twl; p.tw_log2 = twl; p.tile_w = tw;
+    p.tiles_h = (int)cdiv_ll(p.Ho, th); p.tiles_w = (int)cdiv_ll(p.Wo, tw);
+    p.n_cchunks = p.Cin / 64;
+    p.nblk_n = p.Cout_pad / 256;
+    p.ksplit = 1; p.part = nullptr;
+    p.ablate = ctx->dbg_ablate;
+    DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "conv3d: grid of %lld blocks unsupported", nblocks);
+    DAT_ENFORCE(ctx, (long long)p.Ho * p.Wo * std::max(p.out_cs, p.Cout) * 4 < (1ll << 31) && (long long)p.H * p.W * p.Cin * 2 < (1ll << 32),
+                "conv3d: one frame of %dx%d exceeds the 32-bit offsets of the big-tile kernel", p.H, p.W);
+    p.nblocks = (unsigned)nblocks;
+    const int npiece = ((th + 2) * (tw + 2) * 8 + 63) / 64;
+    const size_t lds = (size_t)2 * npiece * 1024;
+#define BT_LAUNCH(TWL_, R_)                                                                                            \
+    {                                                                                                                  \
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_bt_kernel<TWL_, R_>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((conv3x3_bt_kernel<TWL_, R_>), dim3(p.nblocks), dim3(NTHREADS), lds, st, p);                \
+    }
+    // (a 9-step weight ring was tried: 256 VGPRs, spills -- and a scratch access in the loop would break the counted vmcnt waits)
+    if (twl == 5) BT_LAUNCH(5, 6) else BT_LAUNCH(4, 6)
+#undef BT_LAUNCH
+    DAT_CHECK_LAUNCH(ctx, "conv3x3_bt");
+    return DAT_OK;
+}
+
+// weights-stationary 1x1 64 -> 256 kernel (conv1x1_k64_c256_ws_kernel)
+bool pw256_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return ctx->dbg_ws64 && d->dtype == DAT_BF16 && d->Cin == 64 && d->Cout == 256 && d->KT == 1 && d->KH == 1 && d->KW == 1 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->pad_t == 0 && d->out_tn <= 0 &&
+           d->out_cstride % 8 == 0 && weights_direct(ctx, d) &&
+           // the kernel's 32-bit position / byte arithmetic and its row split by multiplication
+           (long long)d->H * d->W >= 32 && (long long)d->H * d->W * d->W < (1ll << 32) &&
+           (long long)d->frames * d->H * d->W * std::max(d->out_cstride, 64) * 2 < (1ll << 32);
+}
+
+int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    Pw256Params p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.npos = (long long)cp.frames * cp.H * cp.W;
+    p.H = cp.H; p.W = cp.W; p.out_cs = cp.out_cs; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    const long long ntiles = cdiv_ll(p.npos, 32);
+    DAT_ENFORCE(ctx, ntiles > 0 && ntiles < (1ll << 31), "conv3d: %lld wave tiles unsupported", ntiles);
+    p.ntiles = (int)ntiles;
+    p.hw = (unsigned)(cp.H * cp.W);
+    p.w_magic = cp.W == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.W - 1) / (unsigned)cp.W);
+    const unsigned grid = (unsigned)std::min<long long>(cdiv_ll(ntiles, 4), ctx_num_cu(ctx));
+    const size_t lds = (size_t)4 * 32 * (256 * 4 + 16);
+    if (dat_ensure_lds(ctx, (const void*)conv1x1_k64_c256_ws_kernel, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv1x1_k64_c256_ws_kernel, dim3(grid), dim3(NTHREADS), lds, st, p);
+    DAT_CHECK_LAUNCH(ctx, "conv1x1_k64_c256_ws");
+    return DAT_OK;
+}
+
+int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    ctx_num_cu(ctx);
+    Ws64Params p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y; p.zeros = cp.zeros;
+    p.frames = cp.frames; p.H = cp.H; p.W = cp.W; p.out_cs = cp.out_cs; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    p.ablate = ctx->dbg_ablate;
+    DAT_ENFORCE(ctx, (long long)p.H * p.W * std::max(p.out_cs, 64) * 2 < (1ll << 31), "conv3d: frame of %dx%d exceeds 32-bit offsets", p.H, p.W);
+    // 8 x 32 or 16 x 16 positions per tile: fewest rounds of the persistent grid (ties: the smaller 16 x 16 patch)
+    int best_twl = 4;
+    long long best_rounds = -1, best_tiles = 0;
+    for (int twl = 4; twl <= 5; ++twl) {
+        if ((ctx->dbg_ws64 == 2 && twl != 5) || (ctx->dbg_ws64 == 3 && twl != 4)) continue;   // DEBUG: DAT_CONV_WS64=2 / 3 force 8x32 / 16x16
+        const int tw = 1 << twl, th = 256 >> twl;
+        const long long tiles = (long long)p.frames * cdiv_ll(p.H, th) * cdiv_ll(p.W, tw);
+        const long long rounds = cdiv_ll(tiles, ctx->num_cu);
+        if (best_rounds < 0 || rounds < best_rounds) { best_rounds = rounds; best_twl = twl; best_tiles = tiles; }
+    }
+    const int tw = 1 << best_twl, th = 256 >> best_twl;
+    p.tiles_h = (int)cdiv_ll(p.H, th); p.tiles_w = (int)cdiv_ll(p.W, tw);
+    DAT_ENFORCE(ctx, best_tiles > 0 && best_tiles < (1ll << 31), "conv3d: %lld tiles unsupported", best_tiles);
+    p.ntiles = (int)best_tiles;
+    const int npiece = ((th + 2) * (tw + 2) * 8 + 63) / 64;
+    const size_t lds = (size_t)2 * npiece * 1024 + 4 * 32 * (64 * 4 + 16);
+    const unsigned grid = (unsigned)std::min<long long>(best_tiles, ctx->num_cu);
+    if (best_twl == 5) {
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_c64_ws_kernel<5>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_c64_ws_kernel<5>, dim3(grid), dim3(NTHREADS), lds, st, p);
+    } else {
+        if (dat_ensure_lds(ctx, (const void*)conv3x3_c64_ws_kernel<4>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_c64_ws_kernel<4>, dim3(grid), dim3(NTHREADS), lds, st, p);
+    }
+    DAT_CHECK_LAUNCH(ctx, "conv3x3_c64_ws");
+    return DAT_OK;
+}
+
+}  // namespace dat_conv
