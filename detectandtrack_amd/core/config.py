@@ -243,10 +243,12 @@ def _build_defaults():
     # stride 1, utils/video.py:149-201) re-uses it instead of recomputing (and re-uploading) T-1 of T frames per clip
     # DEVICE_BOX_RESULTS: the glue between model.net and model.keypoint_net (core/test.py:215-252 box decode, :750-806 score
     # threshold / per-class NMS / DETECTIONS_PER_IM) runs on the GPU -- no host synchronisation inside a clip; False = the host path
+    # RCCL_DIRECT (training): the gradient all-reduce goes through the C ABI's dat_allreduce_bucket (RCCL called directly) instead of
+    # torch.distributed.all_reduce; the process group is then only used to hand the communicator id to the ranks
     # FUSE_STEM_POOL: conv1 + affine + ReLU + pool1 (ResNet3D.py:258-265) as one kernel; the `conv1` blob is then not available
     # to FetchBlob (bit-identical pool1; False = two kernels)
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
-                      'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True})
+                      'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False})
     return c
 
 

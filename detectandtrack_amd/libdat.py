@@ -71,6 +71,10 @@ _PROTOS = {
     'dat_conv3d_packed_weight_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'dat_conv3d_pack_weights': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p]),
     'dat_conv3d_pack_weights_dgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _i, _i, _p, _p]),
+    'dat_comm_unique_id': (_i, [_p, _p]),
+    'dat_comm_init_rank': (_i, [_p, _p, _i, _i, C.POINTER(C.c_void_p)]),
+    'dat_allreduce_bucket': (_i, [_p, _p, _p, _p, C.c_size_t]),
+    'dat_comm_destroy': (_i, [_p]),
     'dat_conv3d_pack_item': (_i, [_p, C.POINTER(ConvDesc), _p, _i, _i, _i, _p, _p, C.POINTER(PackItem)]),
     'dat_conv3d_pack_weights_batch': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'dat_conv3d_fwd': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p]),

@@ -291,6 +291,44 @@ class ConvGrad(object):
         return lay(gz, T=T, in_t=in_t)
 
 
+class BucketAllReduce(object):
+    """Gradient exchange through the C ABI (dat_allreduce_bucket = ncclAllReduce of RCCL, in place, on the current stream).  The
+    128-byte communicator id is made on rank 0 and handed to the other ranks by `share_id` (default: a torch.distributed object
+    broadcast, whatever backend that group uses); world size 1 needs no rendezvous."""
+
+    def __init__(self, rank=0, world=1, share_id=None):
+        self.rank, self.world = int(rank), int(world)
+        idbuf = (C.c_char * 128)()
+        if self.rank == 0:
+            ctx().call('dat_comm_unique_id', C.cast(idbuf, C.c_void_p))
+        raw = bytes(idbuf.raw)
+        if self.world > 1:
+            if share_id is None:
+                import torch.distributed as dist
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = share_id(raw)
+        idbuf = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        ctx().call('dat_comm_init_rank', C.cast(idbuf, C.c_void_p), self.world, self.rank, C.byref(h))
+        self.h = h
+
+    def all_reduce(self, flat, bucket_elems):
+        """Sum `flat` (contiguous fp32 CUDA tensor) over the ranks, one call per bucket."""
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        n = flat.numel()
+        for off in range(0, n, bucket_elems):
+            cnt = min(bucket_elems, n - off)
+            ctx().call('dat_allreduce_bucket', _stream(), self.h, C.c_void_p(flat.data_ptr() + 4 * off), C.c_size_t(cnt))
+
+    def close(self):
+        if self.h:
+            L.lib().dat_comm_destroy(self.h)
+            self.h = None
+
+
 class PackBatch(object):
     """One-launch re-pack of many ConvLayers from their fp32 masters (dat_conv3d_pack_weights_batch): the table of entries lives on
     the device and is valid as long as the layers' master / packed buffers are (training: flat parameter buffer, persistent layers)."""

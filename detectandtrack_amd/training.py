@@ -629,5 +629,11 @@ class Trainer(object):
         """Bucketed sum all-reduce over slices of the flat gradient buffer (losses are already divided by NUM_GPUS,
         model_builder.py:932-942)."""
         per = max(1, self.BUCKET_BYTES // 4)
+        if cfg.HIP.get('RCCL_DIRECT', False) and self.flat_g.is_cuda:
+            # the same exchange through the C ABI (dat_allreduce_bucket); torch.distributed only carries the 128-byte communicator id
+            if getattr(self, '_bucket_reducer', None) is None:
+                self._bucket_reducer = ops.BucketAllReduce(self.dist.get_rank(), self.dist.get_world_size())
+            self._bucket_reducer.all_reduce(self.flat_g, per)
+            return
         for off in range(0, self.flat_g.numel(), per):
             self.dist.all_reduce(self.flat_g[off:off + per])

@@ -278,6 +278,17 @@ int dat_stem_conv(dat_ctx* ctx, dat_stream s, int dtype, const float* data, cons
 int dat_stem_conv_pool(dat_ctx* ctx, dat_stream s, int dtype, const float* data, const void* w_packed, const float* scale,
                        const float* bias, int relu, int N, int T, int H, int W, void* out_pool);
 
+/* ---- gradient exchange of data-parallel training (lib/modeling/model_builder.py:938-942: NCCLAllreduce / muji.Allreduce over the
+ * parameter gradients; losses are pre-divided by NUM_GPUS, so the reduction is a plain sum).  Thin wrappers over RCCL (loaded on first
+ * use).  The host owns the rendezvous: rank 0 calls dat_comm_unique_id and ships the 128 bytes to the other ranks; every rank calls
+ * dat_comm_init_rank on its own device; dat_allreduce_bucket sums `count` floats in place on stream s (one call per bucket of the flat
+ * gradient buffer). ---- */
+typedef struct dat_comm dat_comm;
+int dat_comm_unique_id(dat_ctx* ctx, void* id128);
+int dat_comm_init_rank(dat_ctx* ctx, const void* id128, int nranks, int rank, dat_comm** out);
+int dat_allreduce_bucket(dat_ctx* ctx, dat_stream s, dat_comm* comm, float* buf, size_t count);
+int dat_comm_destroy(dat_comm* comm);
+
 /* ---- keypoint heatmap decoding  (lib/utils/keypoints.py:94-149 heatmaps_to_keypoints, :210-216) ---- */
 /* maps fp32 [R, T*K, M, M] (kps_score), boxes fp32 [R, 4*T] image-space tubes -> out fp32 [R, 4, T*K], rows
  * (x, y, logit, prob), column t*K + k (core/test.py:875-893 concatenates the frames along the keypoint axis):

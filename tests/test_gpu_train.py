@@ -628,3 +628,21 @@ def test_fpn_tube_train_step_gradients_match_oracle_autograd(ops):
     print('largest:', ['%s %.1e' % (n, e) for e, n in sorted(errs, reverse=True)[:6]])
     assert checked > 40 and np.median([e for e, _ in errs]) < 1e-3
     reset_cfg()
+
+
+
+def test_allreduce_bucket_through_the_c_abi_world1():
+    """dat_comm_unique_id / dat_comm_init_rank / dat_allreduce_bucket / dat_comm_destroy (RCCL loaded on first use): a one-rank
+    communicator on the test GPU -- the sum over one rank is the identity, bucket by bucket, on the current stream.  (More ranks need
+    more GPUs than a test box has; the bucketing protocol itself is covered by the gloo world-2 test on the CPU.)"""
+    from detectandtrack_amd.ops import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    flat = torch.randn(1000003, generator=g).cuda()
+    want = flat.clone()
+    red = ops.BucketAllReduce(0, 1)
+    try:
+        red.all_reduce(flat, 262144)
+        torch.cuda.synchronize()
+    finally:
+        red.close()
+    assert torch.equal(flat, want)
