@@ -387,6 +387,8 @@ def main():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short runs of the other BASELINE configs (2, 4, 5) appended to the default single-GPU line')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the bf16-vs-fp32 error report (one extra fp32 forward)')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
     ap.add_argument('--pipeline', type=int, default=4, help='clips in flight per GPU (1 = strictly sequential; 2 / 3 / 4 / 5 measured 206.9 / 214.7 / 217.9 / 208.9 clips/s)')
@@ -656,9 +658,36 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.arch, T, H, W, two_d, T)
             out['cpu_proposal_path'] = cpu_proposal_path(H, W)
         out['cpu_tracker'] = cpu_tracker_baseline()
+    if (not a.no_other_configs and not a.no_cpu_baseline and a.gpus == 1 and not train and not two_d and a.workload in (None, '3d_r18_fpn3d')
+            and a.dtype == 'bf16' and not a.keyframe_dce):
+        out['other_configs'] = other_configs()
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_configs():
+    """BASELINE configs 2, 4 and 5 on the same box, as short runs of this very script in child processes (own model, own
+    workspace): the driver's default line then carries a number for every config, not only for config 3.  Each entry is the child's
+    own `value` / `unit` / `ms_per_step` (10 steps after 3 warm-up steps, same contract), or the error that prevented it."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                              'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
+    runs = [('config2_2d_r50_fpn_inference', ['--workload', '2d_r50_fpn']),
+            ('config4_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
+            ('config5_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']),
+            ('config3_3d_r18_fpn3d_training', ['--mode', 'train'])]
+    res = {}
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline',
+               '--no-accuracy', '--no-other-configs'] + extra
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+            d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            res[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'workload': d['config']['workload']}
+        except Exception as e:   # noqa: BLE001  (a failed side run must not take the headline line with it)
+            res[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return res
 
 
 if __name__ == '__main__':
