@@ -81,6 +81,7 @@ CONV_CASES = [
     ('cout12', 1, 1, 10, 14, 64, 12, (1, 1, 1), (1, 1), False, 0, False),
     ('fc_like', 1, 1, 1, 37, 448, 96, (1, 1, 1), (1, 1), True, 0, False),
     ('wide', 1, 1, 6, 150, 64, 64, (1, 3, 3), (1, 1), False, 0, True),
+    ('1x1_s2_big', 1, 2, 400, 384, 128, 256, (1, 1, 1), (2, 2), False, 0, True),       # 76800 outputs: strided 1x1 on a large grid
     # RoI-head maps: linear position tiling (tiles of consecutive positions across rows and maps, border taps read a zero row)
     ('heads_14x14', 7, 1, 14, 14, 128, 256, (1, 3, 3), (1, 1), True, 1, True),
     ('heads_7x7', 9, 1, 7, 7, 64, 128, (1, 3, 3), (1, 1), True, 0, False),
@@ -347,6 +348,9 @@ PW_CASES = [
     ('expander_sum', 3, 100, 140, 128, 512, True, 1, True),
     ('cout_200', 2, 128, 160, 256, 200, True, 0, True),
     ('cin_192', 2, 130, 160, 192, 256, False, 0, False),
+    # > 65536 positions and several channel chunks (the table-driven loop of the bandwidth-bound 1x1 layers; 5 chunks)
+    ('group4_k256_sum', 2, 192, 200, 256, 128, True, 1, True),
+    ('group4_k320', 2, 192, 200, 320, 64, False, 0, False),
 ]
 
 
