@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         // 32-bit position arithmetic (the launcher checks the ranges); the frame / row split of the tile's first position is
         // wave-uniform, a lane only adds its offset (one conditional frame wrap: a frame has >= 32 positions)
         const unsigned pos0 = (unsigned)tile * 32u;
-        const unsigned f0 = pos0 / p.hw, rem0 = pos0 - f0 * p.hw;
+        const unsigned f0 = pos0 / p.hw;
         // the residual rows of this tile (16 store groups of 2 positions) are requested NOW: one wave per SIMD has nothing else to
         // hide their latency behind than its own MFMA and transpose phases
         uint4 rr[16];
@@ -317,7 +317,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                 rr[q] = *(const uint4*)(p.res + (size_t)((rpos * (unsigned)p.out_cs + (unsigned)sl_c) * 2u));
             }
         }
-        (void)rem0;
         f32x16_t acc[8];
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
