@@ -704,7 +704,7 @@ def other_configs():
         cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline',
                '--no-accuracy', '--no-other-configs'] + extra
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
             d = json.loads(p.stdout.decode().strip().splitlines()[-1])
             res[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'workload': d['config']['workload']}
         except Exception as e:   # noqa: BLE001  (a failed side run must not take the headline line with it)
