@@ -720,3 +720,19 @@ def test_own_configs_load_and_build():
         assert len(m.net.ops) > 40 and (train or m.keypoint_net is not None), f
         assert cfg.TEST.RPN_PRE_NMS_TOP_N <= 4096 or train
     reset_cfg()
+
+
+
+def test_bench_kernel_names_and_side_run_table():
+    """bench.py host logic: the conv launch tags of the C ABI's profiler map to the kernel that ran, and the side runs appended to
+    the default line name existing workloads / modes."""
+    import bench
+    assert bench.conv_kernel_name(1282561, 'bf16') == 'conv3d_igemm_kernel<bf16,128,256>'
+    assert bench.conv_kernel_name(641284, 'bf16') == 'conv3d_igemm_kernel<bf16,64,128,tps3>'
+    assert bench.conv_kernel_name(649991, 'bf16') == 'conv3x3_c64_ws_kernel<bf16>'
+    assert bench.conv_kernel_name(2560321, 'bf16') == 'conv1x1_k64_c256_ws_kernel<bf16>'
+    assert bench.conv_kernel_name(2562561, 'bf16') == 'conv3x3_bt_kernel<bf16,256,256>'
+    import inspect
+    src = inspect.getsource(bench.other_configs)
+    for w in ('2d_r50_fpn', '3d_r50_fpn3d', "'--mode', 'train'"):
+        assert w in src
