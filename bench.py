@@ -68,6 +68,74 @@ def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False):
     }
 
 
+def launcher_argv(n_gpus, argv, port=None):
+    """The command line `python bench.py --gpus N` turns itself into when it is started WITHOUT a launcher: one rank per GPU
+    under torch.distributed.run on this node (the driver's own protocol; the reference spawns one process per GPU range the same
+    way, lib/utils/subprocess.py:38-63)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def ensure_ranks(n_gpus, world, argv, device_count=None, do_exec=True):
+    """A line with `n_gpus: N` may only ever come from N ranks on N distinct devices.  world == N: fine.  N > 1 with no launcher
+    environment: re-exec under torch.distributed.run with N ranks (needs N visible devices, otherwise exit 2).  Any other
+    combination (launcher with a different rank count): exit 2.  Returns the launcher argv when do_exec is False (tests)."""
+    if n_gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if world == n_gpus:
+        need = int(os.environ.get('LOCAL_RANK', '0')) + 1 if world > 1 else 1
+        if have < need:
+            sys.stderr.write('bench.py: rank needs device %d but only %d GPU(s) visible\n' % (need - 1, have))
+            sys.exit(2)
+        return None
+    if world != 1 or 'RANK' in os.environ or 'LOCAL_RANK' in os.environ:
+        sys.stderr.write('bench.py: --gpus %d under a launcher with WORLD_SIZE=%d: launch with --nproc-per-node == --gpus\n' % (n_gpus, world))
+        sys.exit(2)
+    if have < n_gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible: refusing to print an n_gpus=%d line from fewer devices\n'
+                         % (n_gpus, have, n_gpus))
+        sys.exit(2)
+    cmd = launcher_argv(n_gpus, argv)
+    if not do_exec:
+        return cmd
+    sys.stderr.write('bench.py: --gpus %d without a launcher: re-executing as %s\n' % (n_gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.execv(cmd[0], cmd)
+
+
+def device_identity(rank, local_rank):
+    """What this rank computes on: reported in the JSON line (`ranks_seen`) so that an N-GPU number shows N distinct devices."""
+    ident = {'rank': rank, 'local_rank': local_rank, 'pid': os.getpid()}
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        uuid = getattr(p, 'uuid', None)
+        ident['device'] = str(uuid) if uuid is not None else None
+        ident['pci'] = '%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', 0), getattr(p, 'pci_device_id', 0))
+        ident['name'] = p.name
+    except Exception as e:   # noqa: BLE001
+        ident['device'] = 'unknown (%s)' % type(e).__name__
+    return ident
+
+
+def check_ranks_seen(seen, n_gpus):
+    """N ranks, N distinct (local) devices, N distinct processes -- otherwise no line."""
+    ok = (len(seen) == n_gpus and len({s['rank'] for s in seen}) == n_gpus and len({s['pid'] for s in seen}) == n_gpus and
+          len({s['local_rank'] for s in seen}) == n_gpus)
+    keys = [(s.get('device'), s.get('pci')) for s in seen]
+    if all(k[0] or k[1] for k in keys):
+        ok = ok and len(set(keys)) == n_gpus
+    if not ok:
+        sys.stderr.write('bench.py: %d ranks do not cover %d distinct devices: %r\n' % (len(seen), n_gpus, seen))
+        sys.exit(2)
+
+
 def vendor_gemm_tflops(n=8192, dtype=torch.bfloat16):
     """What the vendor's tuned dense GEMM (torch.matmul -> hipBLASLt) reaches on THIS box right now: the practical MFMA
     ceiling of the power-capped part, reported next to the nominal 2.5 PFLOP/s (SURVEY.md §8d asks for both).  Measurement
@@ -397,8 +465,8 @@ def build_train(arch, T, H, W, dtype, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn'],
                     help='default 3d_r18_fpn3d (BASELINE config 3); 2d_r50_fpn = config 2 (a step = 8 frames, one forward per frame)')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help='train: one training iteration per step (config 4)')
@@ -429,13 +497,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == a.gpus or world == 1, 'launch with --nproc-per-node == --gpus'
+    ensure_ranks(a.gpus, world, sys.argv[1:])          # N > 1 without a launcher: re-exec under one, or exit non-zero
     torch.cuda.set_device(local_rank)
     dist = None
+    ranks_seen = [device_identity(rank, local_rank)]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')
+        seen = [None] * world
+        dist.all_gather_object(seen, ranks_seen[0])
+        ranks_seen = seen
+        check_ranks_seen(ranks_seen, a.gpus)
 
     from detectandtrack_amd.ops import hip_ops as ops
     T, H, W = a.frames, a.height, a.width
@@ -663,6 +736,7 @@ def main():
                    'hip_graph': bool(graph_on),
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
+        'ranks_seen': ranks_seen,
         'roofline': roofline,
     }
     if host_enqueue_ms is not None:
@@ -696,8 +770,8 @@ def other_configs():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
                                                               'GROUP_RANK', 'ROLE_RANK', 'LOCAL_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
     runs = [('config2_2d_r50_fpn_inference', ['--workload', '2d_r50_fpn']),
-            ('config4_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
-            ('config5_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']),
+            ('config4_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']),
+            ('config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
             ('config3_3d_r18_fpn3d_training', ['--mode', 'train'])]
     res = {}
     for name, extra in runs:

@@ -568,8 +568,22 @@ class Trainer(object):
         ws._layers.clear()                                # layers built before held the old master tensors
         self._train_ptrs = {ws._dev_params[n].data_ptr() for n in order}
 
+    def _check_aliases(self):
+        """The workspace's device masters of the trainable parameters must still BE the slices of `flat_w` (Workspace.set_param copies
+        in place; anything that replaced a master would make the update silently train a buffer nobody reads)."""
+        lo, hi = self.flat_w.data_ptr(), self.flat_w.data_ptr() + 4 * self.flat_w.numel()
+        for n in self.trainable:
+            t = self.ws._dev_params.get(n)
+            if t is None or not (lo <= t.data_ptr() < hi):
+                raise RuntimeError('device master of %r no longer aliases the Trainer\'s flat weight buffer (parameter replaced after '
+                                   'the Trainer was built): rebuild the Trainer' % n)
+
     def step(self, lr):
         ws = self.ws
+        self._check_aliases()
+        if getattr(ws, 'param_epoch', 0) != getattr(self, '_param_epoch', None):
+            self._pack_sig = None        # layers were rebuilt since the last step: the cached pack table holds stale pointers
+            self._param_epoch = getattr(ws, 'param_epoch', 0)
         self.flat_g.zero_()
         ex = TrainExecutor(ws, self.model.net, arena=self.arena)
         ex.run()

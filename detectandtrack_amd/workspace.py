@@ -132,8 +132,15 @@ class Workspace(object):
 
     def set_param(self, name, arr):
         self.params[name] = np.asarray(arr, dtype=np.float32)
-        self._dev_params.pop(name, None)
+        dev = self._dev_params.get(name)
+        if dev is not None and tuple(dev.shape) == tuple(self.params[name].shape):
+            # a device master exists (it may be a slice of a Trainer's flat buffer that the SGD update and the packed layers alias):
+            # overwrite it IN PLACE so that every alias keeps pointing at the live weights
+            dev.copy_(torch.from_numpy(self.params[name]).to(dev.device))
+        else:
+            self._dev_params.pop(name, None)
         self._layers.clear()
+        self.param_epoch = getattr(self, 'param_epoch', 0) + 1      # bumped whenever packed layers were invalidated
 
     def params_from_device(self, names=None):
         """Copy the device fp32 masters (updated in place by training) back into the host parameter dict (checkpoints)."""
@@ -432,19 +439,31 @@ class Executor(object):
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
 
     def _stem_pool_op(self, i, op):
-        """(index, op) of the MaxPool [1,3,3] / [1,2,2] / pad 1 that is the ONLY reader of the stem's output (in any net of this
-        workspace), or None."""
+        """(index, op) of the MaxPool [1,3,3] / [1,2,2] / pad 1 that is the ONLY reader of the stem's output (in this net, and in
+        any other net of this workspace that does not produce the blob itself before reading it), or None."""
         if not cfg.HIP.get('FUSE_STEM_POOL', True):
             return None
         out, found = op.outputs[0], None
+        no_grad = getattr(self, 'no_grad', None)
+        if no_grad is not None and out not in no_grad:
+            # a training executor whose stem is NOT below a StopGradient marker (RESNETS.FREEZE_AT 0): the fused kernel has no
+            # backward (bwd_MaxPool would never see the gradient), so the two layers run separately
+            return None
         nets = list(self.ws.nets.values())
         if not any(net is self.net for net in nets):     # (a training executor runs a net the workspace never registered)
             nets.append(self.net)
         for net in nets:
-            for j, o in enumerate(net.ops):
+            produced = False        # a net that computes `out` itself (conv_body_net is a clone of the body with its own stem conv)
+            for j, o in enumerate(net.ops):           # reads ITS OWN copy: not a reader of this net's blob
+                if net is not self.net and out in o.outputs:
+                    produced = True
                 res = o.args.get('residual') if isinstance(o.args, dict) else None
                 if out in o.inputs or res == out:
-                    if found is not None or net is not self.net or o.type != 'MaxPool':
+                    if net is not self.net:
+                        if produced:
+                            continue
+                        return None
+                    if found is not None or o.type != 'MaxPool':
                         return None
                     found = (j, o)
         if found is None or found[0] <= i:

@@ -352,3 +352,38 @@ def test_bf16_forward_at_bench_size_close_to_oracle():
     rois = ws.FetchBlob('rois')
     assert rois.shape == (1000, 5) and np.isfinite(rois).all()
     assert (rois[:, 3] >= rois[:, 1]).all() and rois[:, 1:].min() >= 0 and rois[:, 3].max() <= W - 1 and rois[:, 4].max() <= H - 1
+
+
+def test_fused_stem_pool_is_taken_through_runnet_and_is_bit_identical():
+    """with the nets registered the way core/test_engine.initialize_model_from_cfg registers them (net, conv_body_net,
+    keypoint_net) the fused conv1+pool1 kernel must be the one that runs (conv_body_net is a clone that produces its own conv1),
+    and `pool1` must equal the two-kernel path bit for bit."""
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.ops import hip_ops
+    T, H, W = 2, 96, 160
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, 1.0]], dtype=np.float32)
+    pools = {}
+    for dtype in ('bf16', 'fp32'):
+        for fuse in (True, False):
+            c = fpn3d_kps_cfg('18', T=T, dtype=dtype)
+            c['HIP']['FUSE_STEM_POOL'] = fuse
+            model, ws, _ = build_product(c)
+            assert model.conv_body_net.name in ws.nets and cfg.HIP.FUSE_STEM_POOL == fuse
+            calls = []
+            orig = hip_ops.StemConv.pooled
+
+            def counting(self, x, _orig=orig, _calls=calls):
+                _calls.append(1)
+                return _orig(self, x)
+            hip_ops.StemConv.pooled = counting
+            try:
+                ws.FeedBlob('data', data)
+                ws.FeedBlob('im_info', im_info)
+                ws.RunNet(model.net.name)
+            finally:
+                hip_ops.StemConv.pooled = orig
+            assert len(calls) == (1 if fuse else 0), (dtype, fuse, calls)
+            assert ('conv1' in ws.blobs) == (not fuse)
+            pools[(dtype, fuse)] = ws.FetchBlob('pool1')
+        np.testing.assert_array_equal(pools[(dtype, True)], pools[(dtype, False)])

@@ -3,6 +3,7 @@ import ast
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -736,3 +737,42 @@ def test_bench_kernel_names_and_side_run_table():
     src = inspect.getsource(bench.other_configs)
     for w in ('2d_r50_fpn', '3d_r50_fpn3d', "'--mode', 'train'"):
         assert w in src
+
+
+def test_bench_gpus_n_without_n_ranks_never_prints_an_n_gpu_line():
+    """`python bench.py --gpus 2` started WITHOUT a launcher must not print a line with n_gpus 2 from one
+    process.  It re-executes itself under torch.distributed.run with 2 ranks when 2 devices are visible and exits non-zero
+    otherwise (here: no GPU at all); under a launcher with the wrong rank count it exits non-zero too.  The other_configs
+    labels follow BASELINE.json (config 4 = R-50 training, config 5 = R-50 inference)."""
+    import subprocess
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b'n_gpus' not in p.stdout, p.stdout
+    assert b'only 0 GPU(s) visible' in p.stderr, p.stderr
+    # with enough devices the process would turn into the launcher: N ranks on 127.0.0.1, same arguments
+    cmd = bench.ensure_ranks(4, 1, ['--gpus', '4', '--steps', '7'], device_count=8, do_exec=False)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '7']
+    assert cmd[-5].endswith('bench.py')
+    assert bench.ensure_ranks(4, 4, [], device_count=8, do_exec=False) is None         # launched correctly: nothing to do
+    for n, world, have in ((4, 1, 2), (4, 2, 8), (2, 8, 8)):                            # too few devices / wrong launcher size
+        with pytest.raises(SystemExit) as e:
+            bench.ensure_ranks(n, world, [], device_count=have, do_exec=False)
+        assert e.value.code not in (0, None)
+    # ranks_seen must cover N distinct processes / devices
+    seen = [{'rank': r, 'local_rank': r, 'pid': 100 + r, 'device': 'GPU-%d' % r, 'pci': '0000:0%d:00' % r} for r in range(4)]
+    bench.check_ranks_seen(seen, 4)
+    dup = [dict(s) for s in seen]
+    dup[3]['device'], dup[3]['pci'] = dup[2]['device'], dup[2]['pci']
+    for bad in (seen[:3], dup):
+        with pytest.raises(SystemExit):
+            bench.check_ranks_seen(bad, 4)
+    import inspect
+    src = inspect.getsource(bench.other_configs)
+    assert "'config4_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']" in src
+    assert "'config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']" in src
+    ap_src = inspect.getsource(bench.main)
+    assert "'--steps', type=int, default=100" in ap_src
