@@ -195,25 +195,29 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     """Everything between `model.net` and the final read-back, enqueued on the current HIP stream WITHOUT a host sync:
     dat_box_results (test.py:215-252 decode + clip, :750-806 score threshold / per-class NMS / DETECTIONS_PER_IM, :78-123 keypoint
     rois), then -- with MODEL.KEYPOINTS_ON -- `model.keypoint_net` on the device-resident rois and the heatmap decode
-    (:584-627, :865-894).  Returns device tensors (dets [cap, 4T+2], n_out int32[2], keypoint rows [cap, 4, 17T] | None)."""
+    (:584-627, :865-894).  Returns device tensors (dets [cap, 4T+2], n_out int32[2], keypoint rows [cap, 4, 17T] | None).
+
+    Several images per forward (the `rois` blob carries one count per image): `im_shape` / `im_scale` may be per-image sequences;
+    dets / keypoint rows then hold `cap` rows per image and n_out is int32[n_images, 2] (read_batch_results_from_device)."""
     from detectandtrack_amd.ops import hip_ops as ops
     ws = workspace.GlobalWorkspace()
     rois = ws.blobs['rois']
     assert rois.kind == 'rois' and rois.count is not None, 'device post-processing expects the on-device proposal blob'
+    ni = int(rois.count.numel())
     prob = workspace.blob_as_matrix(ws.blobs['cls_prob'])
     pred = workspace.blob_as_matrix(ws.blobs['bbox_pred'])
     cols = int(rois.t.shape[1])
     T = (cols - 1) // 4
     D = int(cfg.TEST.DETECTIONS_PER_IM)
-    out_cap = D if D > 0 else int(rois.t.shape[0]) * (cfg.MODEL.NUM_CLASSES - 1)     # no limit: every roi may survive in every class
+    out_cap = D if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)     # no limit: every roi may survive in every class
     dets, kp_rois, n_out = ops.box_results(
-        rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, float(im_scale), im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
+        rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,
-        cls_agnostic=cfg.MODEL.CLS_AGNOSTIC_BBOX_REG)
+        cls_agnostic=cfg.MODEL.CLS_AGNOSTIC_BBOX_REG, n_images=ni)
     xy = None
     if cfg.MODEL.KEYPOINTS_ON:
         b = workspace.Blob(kp_rois, 'mat')
-        b.count = n_out[0:1]
+        b.count = n_out[0:1] if ni == 1 else n_out[:, 0]
         ws.blobs['keypoint_rois'] = b
         workspace.RunNet(model.keypoint_net.Proto().name)
         heat = ws.blobs['kps_score'].t                       # fp32 [cap, 17 T, M, M] on the device
@@ -223,24 +227,87 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     return dets, n_out, xy
 
 
-def read_results_from_device(dets, n_out, xy):
-    """The ONE device -> host transfer of a clip: (cls_boxes, cls_keyps) in the reference's layout, or None when exact score ties
-    at the DETECTIONS_PER_IM cut keep more rows than the device buffers hold (the caller then takes the host path)."""
-    num_classes = cfg.MODEL.NUM_CLASSES
-    n = n_out.cpu().numpy()
-    if int(n[1]) > int(n[0]):
-        return None
-    k = int(n[0])
-    d = dets[:k].cpu().numpy()
+def _split_results(d, keyps, num_classes):
     cls_boxes = [[] for _ in range(num_classes)]
-    cls_keyps = [[] for _ in range(num_classes)] if xy is not None else None
-    keyps = xy[:k].cpu().numpy() if xy is not None else None
+    cls_keyps = [[] for _ in range(num_classes)] if keyps is not None else None
     for j in range(1, num_classes):
         sel = np.where(d[:, -1] == j)[0]
         cls_boxes[j] = d[sel, :-1]
         if keyps is not None and j == keypoint_utils.get_person_class_index():
             cls_keyps[j] = [keyps[i] for i in sel]
     return cls_boxes, cls_keyps
+
+
+def read_results_from_device(dets, n_out, xy):
+    """The ONE device -> host transfer of a clip: (cls_boxes, cls_keyps) in the reference's layout, or None when exact score ties
+    at the DETECTIONS_PER_IM cut keep more rows than the device buffers hold (the caller then takes the host path)."""
+    n = n_out.cpu().numpy()
+    assert n.ndim == 1, 'several images per forward: read_batch_results_from_device'
+    if int(n[1]) > int(n[0]):
+        return None
+    k = int(n[0])
+    d = dets[:k].cpu().numpy()
+    keyps = xy[:k].cpu().numpy() if xy is not None else None
+    return _split_results(d, keyps, cfg.MODEL.NUM_CLASSES)
+
+
+def read_batch_results_from_device(dets, n_out, xy):
+    """Several images per forward: the list of per-image (cls_boxes, cls_keyps) -- or None for an image with the exact-tie
+    overflow -- from ONE read-back of the batch (dets / keypoint rows hold `cap` rows per image)."""
+    n = n_out.cpu().numpy().reshape(-1, 2)
+    ni = n.shape[0]
+    cap = int(dets.shape[0]) // ni
+    d_all = dets.cpu().numpy()
+    k_all = xy.cpu().numpy() if xy is not None else None
+    out = []
+    for i in range(ni):
+        if int(n[i, 1]) > int(n[i, 0]):
+            out.append(None)
+            continue
+        k = int(n[i, 0])
+        d = d_all[i * cap:i * cap + k]
+        keyps = k_all[i * cap:i * cap + k] if k_all is not None else None
+        out.append(_split_results(d, keyps, cfg.MODEL.NUM_CLASSES))
+    return out
+
+
+def im_detect_all_batch(model, ims, timers=None):
+    """Several independent images (2D models) or clips (3D models) in ONE forward: `ims` is a list of B entries, each what
+    im_detect_all takes (a list of T frames).  The reference runs its inference one image per forward (lib/core/test.py:212-214,
+    `assert len(im_scales) == 1`); here the batch shares every kernel launch -- the N axis of the NC[T]HW blobs -- and each image
+    keeps exactly the proposals / detections / keypoints it gets alone (per-image proposal NMS and top-N, per-image detection NMS
+    and limit).  Returns a list of B (cls_boxes, cls_segms, cls_keyps) tuples in input order.  All entries must pre-process to
+    the same blob size (same frame size and scale), as the frames of one video do."""
+    if timers is None:
+        timers = defaultdict(Timer)
+    assert device_results_supported() and not cfg.MODEL.MASK_ON and not cfg.TEST.COMPETITION_MODE, \
+        'batched inference runs the device post-processing path (cfg.HIP.DEVICE_BOX_RESULTS, hard NMS)'
+    B = len(ims)
+    if B == 1:
+        return [im_detect_all(model, ims[0], None, timers)]
+    timers['im_detect_bbox'].tic()
+    frames = [f for clip in ims for f in clip]
+    T = len(ims[0])
+    assert all(len(clip) == T for clip in ims)
+    data, im_scales = _get_image_blob(frames, num_frames=T if cfg.MODEL.VIDEO_ON else None)
+    assert data.shape[0] == B, (data.shape, B)
+    im_info = np.tile(np.array([[data.shape[-2], data.shape[-1], im_scales[0]]], dtype=np.float32), (B, 1))
+    workspace.FeedBlob('data', data)
+    workspace.FeedBlob('im_info', im_info)
+    workspace.RunNet(model.net.Proto().name)
+    dev = enqueue_results_on_device(model, [clip[0].shape for clip in ims], [im_scales[0]] * B)
+    res = read_batch_results_from_device(*dev)
+    timers['im_detect_bbox'].toc()
+    out = []
+    for i, r in enumerate(res):
+        if r is None:        # exact ties at the detection limit: this image alone through the reference's host path
+            out.append(im_detect_all(model, ims[i], None, timers))
+            continue
+        cls_boxes, cls_keyps = r
+        if cfg.MODEL.KEYPOINTS_ON and sum(len(b) for b in cls_boxes[1:]) == 0:
+            cls_keyps = None
+        out.append((cls_boxes, None, cls_keyps))
+    return out
 
 
 def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes):

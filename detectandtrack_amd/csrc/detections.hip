@@ -22,25 +22,31 @@ namespace {
 constexpr int DET_MAX_T = 16;
 constexpr int SEL_THREADS = 1024;
 
+constexpr int MAX_IMAGES = DAT_MAX_IMAGES;
+
+// One block per image (blockIdx.x): image i owns rows [i * roi_cap, (i + 1) * roi_cap) of rois / prob / pred, the count n_rois[i]
+// and the scratch at + i * img_ws bytes.
 struct DetParams {
-    const float* rois;      // [roi_cap, 4T+1]
-    const int* n_rois;      // device count
+    const float* rois;      // [n_images * roi_cap, 4T+1]
+    const int* n_rois;      // device counts [n_images]
     const float* prob;      // [R, prob_ld]
     const float* pred;      // [R, pred_ld]
     int prob_ld, pred_ld, roi_cap, T, K, cls_agnostic;
     float wx, wy, ww, wh, xform_clip, score_thresh;
-    double im_scale;
-    float im_h, im_w;       // the UNSCALED image (clip bounds, test.py:229)
+    size_t img_ws;
+    double im_scale[MAX_IMAGES];
+    float im_h[MAX_IMAGES], im_w[MAX_IMAGES];       // the UNSCALED image (clip bounds, test.py:229)
 };
 
 // one tube of class j for roi r: boxes.py:141-183 per frame, then clip (:243-253)
-__device__ void decode_tube(const DetParams& p, int r, int j, float* out) {
+__device__ void decode_tube(const DetParams& p, int img, int r, int j, float* out) {
     const int cols = 4 * p.T + 1;
+    const float im_w = p.im_w[img], im_h = p.im_h[img];
     const int dcls = p.cls_agnostic ? (p.K - 1) : j;       // CLS_AGNOSTIC_BBOX_REG: the last 4T columns (test.py:224-225)
     for (int t = 0; t < p.T; ++t) {
         const float* rb = p.rois + (size_t)r * cols + 1 + 4 * t;
         // `rois[:, 1:] / im_scales[0]`: float32 / float32(scale) under the reference environment's NumPy 1.14 casting
-        const float sc = (float)p.im_scale;
+        const float sc = (float)p.im_scale[img];
         const float x1 = rb[0] / sc, y1 = rb[1] / sc, x2 = rb[2] / sc, y2 = rb[3] / sc;
         const float* d = p.pred + (size_t)r * p.pred_ld + ((size_t)dcls * p.T + t) * 4;
         const float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
@@ -50,10 +56,10 @@ __device__ void decode_tube(const DetParams& p, int r, int j, float* out) {
         const float pcx = dx * w + cx, pcy = dy * h + cy;
         const float pw = (float)exp((double)dw) * w, ph = (float)exp((double)dh) * h;
         float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
-        ox1 = fmaxf(fminf(ox1, p.im_w - 1.f), 0.f);
-        oy1 = fmaxf(fminf(oy1, p.im_h - 1.f), 0.f);
-        ox2 = fmaxf(fminf(ox2, p.im_w - 1.f), 0.f);
-        oy2 = fmaxf(fminf(oy2, p.im_h - 1.f), 0.f);
+        ox1 = fmaxf(fminf(ox1, im_w - 1.f), 0.f);
+        oy1 = fmaxf(fminf(oy1, im_h - 1.f), 0.f);
+        ox2 = fmaxf(fminf(ox2, im_w - 1.f), 0.f);
+        oy2 = fmaxf(fminf(oy2, im_h - 1.f), 0.f);
         out[4 * t + 0] = ox1; out[4 * t + 1] = oy1; out[4 * t + 2] = ox2; out[4 * t + 3] = oy2;
     }
 }
@@ -78,10 +84,14 @@ __device__ unsigned block_scan(unsigned v, unsigned* scan, unsigned* total) {
 // ---- per class: inds = where(scores[:, j] > thresh); dets_j = [decoded boxes[inds], scores[inds]]  (test.py:759-762), in roi order
 __global__ __launch_bounds__(SEL_THREADS) void det_select_kernel(const DetParams p, int j, float* dets, int* n_sel) {
     __shared__ unsigned scan[SEL_THREADS];
-    const int n = min(*p.n_rois, p.roi_cap);
+    const int img = blockIdx.x;
+    const int n = min(p.n_rois[img], p.roi_cap);
     const int cols = 4 * p.T + 1;
     const int per = (n + SEL_THREADS - 1) / SEL_THREADS;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    const int r0 = img * p.roi_cap;              // this image's first row
+    const int lo = r0 + threadIdx.x * per, hi = min(r0 + n, lo + per);
+    dets = (float*)((char*)dets + (size_t)img * p.img_ws);
+    n_sel = (int*)((char*)n_sel + (size_t)img * p.img_ws);
     unsigned local = 0;
     for (int r = lo; r < hi; ++r) local += p.prob[(size_t)r * p.prob_ld + j] > p.score_thresh ? 1u : 0u;
     unsigned total;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(SEL_THREADS) void det_select_kernel(const DetParams
     for (int r = lo; r < hi; ++r) {
         const float sc = p.prob[(size_t)r * p.prob_ld + j];
         if (sc > p.score_thresh) {
-            decode_tube(p, r, j, tube);
+            decode_tube(p, img, r, j, tube);
             float* o = dets + (size_t)pos * cols;
             for (int c = 0; c < 4 * p.T; ++c) o[c] = tube[c];
             o[4 * p.T] = sc;
@@ -105,16 +115,29 @@ struct EmitParams {
     const int* keep;       // [K-1][cap] kept rows (NMS output order)
     const int* n_keep;     // [K-1]
     int K, T, cap, D, out_cap;
-    double im_scale;
-    float* dets_out;       // [out_cap][4T+2]: box, score, class
-    float* kp_rois;        // [out_cap][4T+1]: level 0, box * im_scale
-    int* n_out;            // [2]: rows written (<= out_cap), rows the limit rule keeps
+    size_t img_ws;         // image i (blockIdx.x): dets / keep / n_keep at + i * img_ws bytes, outputs at slot i
+    double im_scale[MAX_IMAGES];
+    float* dets_out;       // [n_images][out_cap][4T+2]: box, score, class
+    float* kp_rois;        // [n_images][out_cap][4T+1]: batch index (image i), box * im_scale
+    int* n_out;            // [n_images][2]: rows written (<= out_cap), rows the limit rule keeps
 };
 
 // ---- DETECTIONS_PER_IM (test.py:790-800): thresh = the D-th best kept score over all classes, keep score >= thresh; then the
 // class-major stack (test.py:802) and its keypoint rois.  One block; the D-th best score comes from an exact radix select on the
 // float bits (scores are probabilities > 0: the bit pattern is monotonic).
-__global__ __launch_bounds__(SEL_THREADS) void det_limit_emit_kernel(const EmitParams p) {
+__global__ __launch_bounds__(SEL_THREADS) void det_limit_emit_kernel(const EmitParams pin) {
+    EmitParams p = pin;
+    const int img = blockIdx.x;
+    {
+        const size_t o = (size_t)img * p.img_ws;
+        p.dets = (const float*)((const char*)p.dets + o);
+        p.keep = (const int*)((const char*)p.keep + o);
+        p.n_keep = (const int*)((const char*)p.n_keep + o);
+        p.dets_out += (size_t)img * p.out_cap * (4 * p.T + 2);
+        p.kp_rois += (size_t)img * p.out_cap * (4 * p.T + 1);
+        p.n_out += 2 * img;
+    }
+    const double im_scale = p.im_scale[img];
     __shared__ unsigned scan[SEL_THREADS];
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
@@ -176,10 +199,10 @@ __global__ __launch_bounds__(SEL_THREADS) void det_limit_emit_kernel(const EmitP
                 if ((int)pos < p.out_cap) {
                     float* o = p.dets_out + (size_t)pos * (cols + 1);
                     float* k = p.kp_rois + (size_t)pos * cols;
-                    k[0] = 0.f;      // single scale: pyramid level 0 (test.py:106-123)
+                    k[0] = (float)img;   // single scale: pyramid level 0 (test.py:106-123) of image `img` of the batch
                     for (int q = 0; q < 4 * p.T; ++q) {
                         o[q] = src[q];
-                        k[1 + q] = (float)((double)src[q] * p.im_scale);
+                        k[1 + q] = (float)((double)src[q] * im_scale);
                     }
                     o[4 * p.T] = src[4 * p.T];
                     o[4 * p.T + 1] = (float)(c + 1);
@@ -210,18 +233,19 @@ size_t dat_box_results_workspace_bytes(int roi_cap, int num_classes, int T) {
            dat_nms_ws_bytes(roi_cap, T);
 }
 
-int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob, int prob_ld,
-                    const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
-                    float* keypoint_rois, int* n_out) {
+int dat_box_results_batch(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob,
+                          int prob_ld, const float* bbox_pred, int pred_ld, const dat_det_desc* d, int n_images, void* workspace,
+                          int out_cap, float* dets_out, float* keypoint_rois, int* n_out) {
     DAT_ENFORCE(ctx, rois && n_rois && cls_prob && bbox_pred && d && workspace && dets_out && keypoint_rois && n_out,
                 "box_results: null argument");
+    DAT_ENFORCE(ctx, n_images >= 1 && n_images <= MAX_IMAGES, "box_results: %d images per launch (1..%d)", n_images, MAX_IMAGES);
     DAT_ENFORCE(ctx, d->num_classes >= 2 && d->T >= 1 && d->T <= DET_MAX_T, "box_results: %d classes / T %d unsupported", d->num_classes, d->T);
     DAT_ENFORCE(ctx, roi_cap > 0 && roi_cap <= 16384 && out_cap > 0, "box_results: roi capacity %d / output capacity %d out of range", roi_cap, out_cap);
     DAT_ENFORCE(ctx, prob_ld >= d->num_classes && pred_ld >= (d->cls_agnostic_bbox_reg ? 4 * d->T : d->num_classes * 4 * d->T),
                 "box_results: row strides %d / %d too small for %d classes x T %d", prob_ld, pred_ld, d->num_classes, d->T);
-    DAT_ENFORCE(ctx, d->im_scale > 0.f && d->nms_thresh > 0.f, "box_results: im_scale and TEST.NMS must be > 0");
     hipStream_t st = (hipStream_t)s;
     const int nc = d->num_classes - 1, T = d->T, cols = 4 * T + 1;
+    const size_t img_ws = dat_box_results_workspace_bytes(roi_cap, d->num_classes, T);
     char* ws = (char*)workspace;
     size_t off = 0;
     float* dets = (float*)(ws + off); off += align_up((size_t)nc * roi_cap * cols * 4);
@@ -230,25 +254,40 @@ int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_
     int* n_keep = (int*)(ws + off); off += align_up((size_t)nc * 4);
     char* nms_ws = ws + off;
     DetParams p;
+    memset(&p, 0, sizeof(p));
     p.rois = rois; p.n_rois = n_rois; p.prob = cls_prob; p.pred = bbox_pred;
     p.prob_ld = prob_ld; p.pred_ld = pred_ld; p.roi_cap = roi_cap; p.T = T; p.K = d->num_classes;
     p.cls_agnostic = d->cls_agnostic_bbox_reg;
     p.wx = d->reg_weights[0]; p.wy = d->reg_weights[1]; p.ww = d->reg_weights[2]; p.wh = d->reg_weights[3];
     p.xform_clip = d->xform_clip; p.score_thresh = d->score_thresh;
-    p.im_scale = (double)d->im_scale_f64;
-    p.im_h = (float)d->im_h; p.im_w = (float)d->im_w;
+    p.img_ws = img_ws;
+    EmitParams e;
+    memset(&e, 0, sizeof(e));
+    for (int i = 0; i < n_images; ++i) {
+        DAT_ENFORCE(ctx, d[i].im_scale > 0.f && d[i].nms_thresh > 0.f, "box_results: im_scale and TEST.NMS must be > 0");
+        p.im_scale[i] = e.im_scale[i] = (double)d[i].im_scale_f64;
+        p.im_h[i] = (float)d[i].im_h; p.im_w[i] = (float)d[i].im_w;
+    }
+    const unsigned ni = (unsigned)n_images;
     for (int c = 0; c < nc; ++c) {
         float* dets_c = dets + (size_t)c * roi_cap * cols;
-        hipLaunchKernelGGL(det_select_kernel, dim3(1), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
-        int rc = dat_nms_impl(ctx, st, nms_ws, dets_c, 0, n_sel + c, roi_cap, T, d->nms_thresh, 0, 0, keep + (size_t)c * roi_cap, n_keep + c);
+        hipLaunchKernelGGL(det_select_kernel, dim3(ni), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
+        int rc = dat_nms_impl_batch(ctx, st, nms_ws, img_ws, dets_c, img_ws / 4, 0, n_sel + c, (int)(img_ws / 4), roi_cap, T, d->nms_thresh,
+                                    0, 0, keep + (size_t)c * roi_cap, (int)(img_ws / 4), n_keep + c, (int)(img_ws / 4), n_images);
         if (rc != DAT_OK) return rc;
     }
-    EmitParams e;
     e.dets = dets; e.keep = keep; e.n_keep = n_keep; e.K = d->num_classes; e.T = T; e.cap = roi_cap; e.D = d->detections_per_im;
-    e.out_cap = out_cap; e.im_scale = (double)d->im_scale_f64; e.dets_out = dets_out; e.kp_rois = keypoint_rois; e.n_out = n_out;
-    hipLaunchKernelGGL(det_limit_emit_kernel, dim3(1), dim3(SEL_THREADS), 0, st, e);
+    e.out_cap = out_cap; e.img_ws = img_ws; e.dets_out = dets_out; e.kp_rois = keypoint_rois; e.n_out = n_out;
+    hipLaunchKernelGGL(det_limit_emit_kernel, dim3(ni), dim3(SEL_THREADS), 0, st, e);
     DAT_CHECK_LAUNCH(ctx, "box_results");
     return DAT_OK;
+}
+
+int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob, int prob_ld,
+                    const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
+                    float* keypoint_rois, int* n_out) {
+    return dat_box_results_batch(ctx, s, rois, n_rois, roi_cap, cls_prob, prob_ld, bbox_pred, pred_ld, d, 1, workspace, out_cap, dets_out,
+                                 keypoint_rois, n_out);
 }
 
 // Soft-NMS on the HOST (lib/utils/cython_nms.pyx:98-203; caller lib/core/nms_wrapper.py:29-46, lib/core/test.py:766-772): the

@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int MAX_LEVELS = 8;
+constexpr int MAX_IMAGES = DAT_MAX_IMAGES;   // images per launch (round 3: several frames / clips per forward)
 constexpr int MAX_SORT = 16384;  // pre_nms cap per level (LDS bitonic sort capacity of K3: 16384 u64 = 128 KiB of the 160 KiB);
                                  // covers the reference's defaults RPN_PRE_NMS_TOP_N 12000 (lib/core/config.py:110,183)
 constexpr int MAX_WORDS = MAX_SORT / 64;
@@ -61,16 +62,39 @@ struct LevelDev {
     LevelState* state;
 };
 
+// The level table describes image 0; image i of a launch reads head frame `frame + i * frame_stride`, owns the scratch arrays at
+// `+ i * img_ws_bytes`, the histograms / states of slot i and writes rois_out[i][level] (all images share the level geometry).
 struct RpnParams {
     LevelDev lv[MAX_LEVELS];
     int n_levels;
     int dtype;
     int pre_nms, post_nms, cap, cap_pad;   // cap_pad = pre_nms rounded up to a power of two (K3's LDS sort buffer)
-    float nms_thresh, min_size_scaled, im_h, im_w, batch_idx;
+    int n_images, frame_stride;
+    size_t img_ws_bytes;
+    float nms_thresh, batch_idx;
+    float min_size_scaled[MAX_IMAGES], im_h[MAX_IMAGES], im_w[MAX_IMAGES];
     float* rois_out;
     float* probs_out;
     int* counts_out;
 };
+
+__device__ __forceinline__ LevelDev level_of(const RpnParams& p, int l, int img) {
+    LevelDev L = p.lv[l];
+    if (img > 0) {
+        const size_t o = (size_t)img * p.img_ws_bytes;
+        L.frame += img * p.frame_stride;
+        L.keys = (unsigned*)((char*)L.keys + o);
+        L.sel = (unsigned long long*)((char*)L.sel + o);
+        L.bnd = (unsigned long long*)((char*)L.bnd + o);
+        L.boxes = (float*)((char*)L.boxes + o);
+        L.scores = (float*)((char*)L.scores + o);
+        L.mask = (unsigned long long*)((char*)L.mask + o);
+        L.kept = (int*)((char*)L.kept + o);
+        L.hist += (size_t)img * p.n_levels * 65536;
+        L.state += (size_t)img * MAX_LEVELS;
+    }
+    return L;
+}
 
 __device__ __forceinline__ float head_ld(const char* p, int dtype, size_t i) {
     return dtype == DAT_BF16 ? bf2f(((const uint16_t*)p)[i]) : ((const float*)p)[i];
@@ -89,7 +113,7 @@ constexpr int K0_CHUNK = 32768;
 constexpr int K0_THREADS = 1024;
 __global__ __launch_bounds__(K0_THREADS) void rpn_keys_hist_kernel(const RpnParams p) {
     __shared__ unsigned lh[32768];
-    const LevelDev& L = p.lv[blockIdx.y];
+    const LevelDev L = level_of(p, blockIdx.y, blockIdx.z);
     const int lo = blockIdx.x * K0_CHUNK;
     if (lo >= L.N) return;
     const int hi = min(L.N, lo + K0_CHUNK);
@@ -119,7 +143,7 @@ __global__ __launch_bounds__(K0_THREADS) void rpn_keys_hist_kernel(const RpnPara
 
 // ---- K1 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void rpn_find_bin_kernel(const RpnParams p) {
-    const LevelDev& L = p.lv[blockIdx.x];
+    const LevelDev L = level_of(p, blockIdx.x, blockIdx.y);
     __shared__ unsigned part[1024];
     __shared__ unsigned found_bin, found_gt;
     const int tid = threadIdx.x;
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(1024) void rpn_find_bin_kernel(const RpnParams p) {
 
 // ---- K2 ------------------------------------------------------------------------------------------
 __global__ void rpn_compact_kernel(const RpnParams p) {
-    const LevelDev& L = p.lv[blockIdx.y];
+    const LevelDev L = level_of(p, blockIdx.y, blockIdx.z);
     const unsigned tb = L.state->tb16;
     if (L.state->k_eff == 0) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.N; i += gridDim.x * blockDim.x) {
@@ -194,7 +218,8 @@ __device__ void bitonic_desc(unsigned long long* buf, int n) {
 
 // decode one sorted entry into a tube (4T floats); returns validity under the min-size filter.
 // Operation order follows utils/boxes.py:141-183 (weights 1), :243-253, generate_proposals.py:184-196.
-__device__ bool decode_tube(const RpnParams& p, const LevelDev& L, unsigned idx, float* out /*4T*/) {
+__device__ bool decode_tube(const RpnParams& p, const LevelDev& L, int img, unsigned idx, float* out /*4T*/) {
+    const float im_w = p.im_w[img], im_h = p.im_h[img], min_size_scaled = p.min_size_scaled[img];
     const int pos = idx / L.A, a = idx - pos * L.A;
     const int h = pos / L.W, w = pos - h * L.W;
     const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
@@ -218,21 +243,22 @@ __device__ bool decode_tube(const RpnParams& p, const LevelDev& L, unsigned idx,
         // np.exp(float32): evaluate in double and round once (correctly rounded result)
         const float pw = (float)exp((double)dw) * width, phh = (float)exp((double)dh) * height;
         float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * phh, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * phh;
-        x1 = fmaxf(fminf(x1, p.im_w - 1.f), 0.f);
-        y1 = fmaxf(fminf(y1, p.im_h - 1.f), 0.f);
-        x2 = fmaxf(fminf(x2, p.im_w - 1.f), 0.f);
-        y2 = fmaxf(fminf(y2, p.im_h - 1.f), 0.f);
+        x1 = fmaxf(fminf(x1, im_w - 1.f), 0.f);
+        y1 = fmaxf(fminf(y1, im_h - 1.f), 0.f);
+        x2 = fmaxf(fminf(x2, im_w - 1.f), 0.f);
+        y2 = fmaxf(fminf(y2, im_h - 1.f), 0.f);
         out[4 * t + 0] = x1; out[4 * t + 1] = y1; out[4 * t + 2] = x2; out[4 * t + 3] = y2;
         const float ws = x2 - x1 + 1.f, hs = y2 - y1 + 1.f;
         const float xc = x1 + ws / 2.f, yc = y1 + hs / 2.f;
-        ok = ok && (ws >= p.min_size_scaled) && (hs >= p.min_size_scaled) && (xc < p.im_w) && (yc < p.im_h);
+        ok = ok && (ws >= min_size_scaled) && (hs >= min_size_scaled) && (xc < im_w) && (yc < im_h);
     }
     return ok;
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnParams p) {
-    const LevelDev& L = p.lv[blockIdx.x];
+    const int img = blockIdx.y;
+    const LevelDev L = level_of(p, blockIdx.x, img);
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // cap_pad entries
     __shared__ unsigned hist[256];
     __shared__ unsigned cnt;
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnP
         const int j = tid * per + e;
         if (j < (int)k_eff) {
             const unsigned idx = ~(unsigned)(buf[j] & 0xFFFFFFFFull);
-            if (decode_tube(p, L, idx, tube)) { flags |= 1u << e; ++local; }
+            if (decode_tube(p, L, img, idx, tube)) { flags |= 1u << e; ++local; }
         }
     }
     scan[tid] = local;
@@ -323,7 +349,7 @@ __global__ __launch_bounds__(1024) void rpn_select_sort_decode_kernel(const RpnP
             const int j = tid * per + e;
             const unsigned long long v = buf[j];
             const unsigned idx = ~(unsigned)(v & 0xFFFFFFFFull);
-            decode_tube(p, L, idx, tube);
+            decode_tube(p, L, img, idx, tube);
             for (int c = 0; c < 4 * L.T; ++c) L.boxes[(size_t)outpos * 4 * L.T + c] = tube[c];
             L.scores[outpos] = __uint_as_float((unsigned)(v >> 32));
             ++outpos;
@@ -364,14 +390,29 @@ struct NmsLevel {
     unsigned* n_keep_ptr;
 };
 struct NmsParams {
-    NmsLevel lv[MAX_LEVELS];
+    NmsLevel lv[MAX_LEVELS];   // image 0; image i: array pointers + i * img_bytes, counter pointers + i * img_state_bytes
+    int n_levels;
     int T, cap;
     float thr;
     int strict;      // boxes only: suppress at IoU > thr (the `_nms` CUDA kernel) instead of >= thr (cython_nms)
+    size_t img_bytes, img_state_bytes;
 };
 
+__device__ __forceinline__ NmsLevel nms_level_of(const NmsParams& p, int l, int img) {
+    NmsLevel L = p.lv[l];
+    if (img > 0) {
+        const size_t o = (size_t)img * p.img_bytes, so = (size_t)img * p.img_state_bytes;
+        L.boxes = (const float*)((const char*)L.boxes + o);
+        L.mask = (unsigned long long*)((char*)L.mask + o);
+        L.kept = (int*)((char*)L.kept + o);
+        L.n_ptr = (const unsigned*)((const char*)L.n_ptr + so);
+        L.n_keep_ptr = (unsigned*)((char*)L.n_keep_ptr + so);
+    }
+    return L;
+}
+
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsParams p) {
-    const NmsLevel& L = p.lv[blockIdx.z];
+    const NmsLevel L = nms_level_of(p, blockIdx.z % p.n_levels, blockIdx.z / p.n_levels);
     const int n = (int)*L.n_ptr;
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
@@ -411,7 +452,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsParams p) {
 // mask row), each wave takes 16 of the 64 rows, loads unconditional with a fixed trip count so that they pipeline.
 constexpr int SCAN_THREADS = 256;
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const NmsParams p) {
-    const NmsLevel& L = p.lv[blockIdx.x];
+    const NmsLevel L = nms_level_of(p, blockIdx.x, blockIdx.y);
     const int n = (int)*L.n_ptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -465,18 +506,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const NmsParams 
 
 // ---- K6: emit rois of every level ---------------------------------------------------------------------------
 __global__ void rpn_emit_kernel(const RpnParams p) {
-    const LevelDev& L = p.lv[blockIdx.x];
+    const int img = blockIdx.y;
+    const LevelDev L = level_of(p, blockIdx.x, img);
     const int nkeep = min((int)L.state->n_keep, p.post_nms);
     const int cols = 4 * L.T + 1;
-    float* rois = p.rois_out + (size_t)blockIdx.x * p.post_nms * cols;
-    float* probs = p.probs_out + (size_t)blockIdx.x * p.post_nms;
+    const size_t slot = (size_t)img * p.n_levels + blockIdx.x;
+    float* rois = p.rois_out + slot * p.post_nms * cols;
+    float* probs = p.probs_out + slot * p.post_nms;
+    const float bidx = p.batch_idx + (float)img;
     for (int j = threadIdx.x; j < nkeep; j += blockDim.x) {
         const int src = L.kept[j];
-        rois[(size_t)j * cols] = p.batch_idx;
+        rois[(size_t)j * cols] = bidx;
         for (int c = 0; c < 4 * L.T; ++c) rois[(size_t)j * cols + 1 + c] = L.boxes[(size_t)src * 4 * L.T + c];
         probs[j] = L.scores[src];
     }
-    if (threadIdx.x == 0) p.counts_out[blockIdx.x] = nkeep;
+    if (threadIdx.x == 0) p.counts_out[slot] = nkeep;
 }
 
 // ---- collect: global top post_nms over the concatenated levels -------------------------------------------------
@@ -486,6 +530,14 @@ __global__ __launch_bounds__(1024) void collect_rois_kernel(const float* rois_lv
     extern __shared__ __attribute__((aligned(16))) unsigned long long cbuf[];
     __shared__ int offs[MAX_LEVELS + 1];
     const int tid = threadIdx.x;
+    {   // one block per image: its levels in, its post_nms rows out
+        const size_t img = blockIdx.x;
+        rois_lvls += img * n_levels * level_cap * roi_cols;
+        probs_lvls += img * n_levels * level_cap;
+        counts += img * n_levels;
+        rois += img * post_nms * roi_cols;
+        n_out += img;
+    }
     if (tid == 0) {
         int o = 0;
         for (int l = 0; l < n_levels; ++l) { offs[l] = o; o += counts[l]; }
@@ -517,10 +569,25 @@ __global__ __launch_bounds__(1024) void collect_rois_kernel(const float* rois_lv
 }
 
 // ---- generic NMS entry: sort any-order dets ---------------------------------------------------------------------
+// Batched calls (one block per image, dat_nms_impl_batch): image i reads dets + i * dets_stride floats and the count n_in[i * n_in_stride],
+// owns the scratch at + i * ws_stride bytes and writes keep + i * keep_stride / num_keep[i * num_stride].
+struct NmsBatch {
+    size_t dets_stride, ws_stride;
+    int n_in_stride, keep_stride, num_stride;
+};
+
 __global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, int n_host, const int* n_in, int T, int presorted,
-                                                             float* boxes, int* orig, unsigned* n_dev) {
+                                                             float* boxes, int* orig, unsigned* n_dev, const NmsBatch nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sbuf[];
     const int cols = 4 * T + 1;
+    if (blockIdx.x > 0) {
+        const size_t img = blockIdx.x;
+        dets += img * nb.dets_stride;
+        if (n_in) n_in += img * nb.n_in_stride;
+        boxes = (float*)((char*)boxes + img * nb.ws_stride);
+        orig = (int*)((char*)orig + img * nb.ws_stride);
+        n_dev = (unsigned*)((char*)n_dev + img * nb.ws_stride);
+    }
     const int n = n_in ? *n_in : n_host;       // the box count may live on the device (dat_box_results: no host round trip)
     if (n <= 0) {
         if (threadIdx.x == 0) *n_dev = 0u;
@@ -559,9 +626,18 @@ __global__ __launch_bounds__(1024) void nms_sort_dets_kernel(const float* dets, 
 
 // kept sorted positions -> reference output convention
 __global__ __launch_bounds__(1024) void nms_finish_kernel(const int* kept, const unsigned* n_keep_ptr, const int* orig, const unsigned* n_ptr,
-                                                          int T, int* keep_out, int* num_out) {
+                                                          int T, int* keep_out, int* num_out, const NmsBatch nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned fl[];
     __shared__ unsigned scan[1024];
+    if (blockIdx.x > 0) {
+        const size_t img = blockIdx.x;
+        kept = (const int*)((const char*)kept + img * nb.ws_stride);
+        n_keep_ptr = (const unsigned*)((const char*)n_keep_ptr + img * nb.ws_stride);
+        orig = (const int*)((const char*)orig + img * nb.ws_stride);
+        n_ptr = (const unsigned*)((const char*)n_ptr + img * nb.ws_stride);
+        keep_out += img * nb.keep_stride;
+        num_out += img * nb.num_stride;
+    }
     const int n = (int)*n_ptr;
     const int nk = n > 0 ? (int)*n_keep_ptr : 0;
     const int tid = threadIdx.x;
@@ -605,11 +681,13 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
-                      const float* const* anchors, int n_levels, const float* im_info, int pre_nms, int post_nms,
-                      float nms_thresh, float min_size, float batch_idx, float* rois_out, float* probs_out, int* counts_out) {
+int dat_rpn_proposals_batch(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
+                            const float* const* anchors, int n_levels, int n_images, int frame_stride, const float* im_info,
+                            int pre_nms, int post_nms, float nms_thresh, float min_size, float batch_idx, float* rois_out,
+                            float* probs_out, int* counts_out) {
     DAT_ENFORCE(ctx, heads && levels && anchors && im_info && rois_out && probs_out && counts_out, "rpn_proposals: null argument");
     DAT_ENFORCE(ctx, n_levels >= 1 && n_levels <= MAX_LEVELS, "rpn_proposals: n_levels %d out of range", n_levels);
+    DAT_ENFORCE(ctx, n_images >= 1 && n_images <= MAX_IMAGES, "rpn_proposals: %d images per launch (1..%d)", n_images, MAX_IMAGES);
     DAT_ENFORCE(ctx, pre_nms > 0 && pre_nms <= MAX_SORT, "rpn_proposals: RPN_PRE_NMS_TOP_N %d must be in 1..%d", pre_nms, MAX_SORT);
     DAT_ENFORCE(ctx, post_nms > 0, "rpn_proposals: RPN_POST_NMS_TOP_N must be > 0");
     DAT_ENFORCE(ctx, nms_thresh > 0.f, "rpn_proposals: RPN_NMS_THRESH must be > 0 (NMS is always applied)");
@@ -619,11 +697,12 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
     const int cap = pre_nms;
     const int nwords_cap = (cap + 63) / 64;
     int T = levels[0].T;
-    // workspace layout
+    // workspace layout: [states of all images | histograms of all images] (zeroed every call), then one array region per image
     size_t off = 0, state_off = 0, hist_off = 0;
-    state_off = off; off += align_up(sizeof(LevelState) * MAX_LEVELS);
-    hist_off = off; off += align_up((size_t)n_levels * 65536 * 4);
-    const size_t zero_bytes = off;  // states + histograms are zeroed every call
+    state_off = off; off += align_up(sizeof(LevelState) * MAX_LEVELS * n_images);
+    hist_off = off; off += align_up((size_t)n_images * n_levels * 65536 * 4);
+    const size_t zero_bytes = off;
+    const size_t img0 = off;
     size_t per_level_off[MAX_LEVELS][7];
     for (int l = 0; l < n_levels; ++l) {
         DAT_ENFORCE(ctx, levels[l].T == T && T >= 1 && T <= MAX_T, "rpn_proposals: tube length %d unsupported", levels[l].T);
@@ -637,7 +716,8 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
         per_level_off[l][5] = off; off += align_up((size_t)cap * nwords_cap * 8);// mask
         per_level_off[l][6] = off; off += align_up((size_t)cap * 4);             // kept
     }
-    int rc = ensure_ws(ctx, off);
+    const size_t img_bytes = off - img0;
+    int rc = ensure_ws(ctx, img0 + img_bytes * n_images);
     if (rc != DAT_OK) return rc;
     char* ws = (char*)ctx->ws;
     hipMemsetAsync(ws, 0, zero_bytes, st);
@@ -671,31 +751,45 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
     p.n_levels = n_levels; p.dtype = dtype; p.pre_nms = pre_nms; p.post_nms = post_nms; p.cap = cap;
     p.cap_pad = 1;
     while (p.cap_pad < cap) p.cap_pad <<= 1;
+    p.n_images = n_images; p.frame_stride = frame_stride; p.img_ws_bytes = img_bytes;
     p.nms_thresh = nms_thresh;
-    p.min_size_scaled = (float)((double)min_size * (double)im_info[2]);
-    p.im_h = im_info[0]; p.im_w = im_info[1]; p.batch_idx = batch_idx;
+    for (int i = 0; i < n_images; ++i) {
+        p.min_size_scaled[i] = (float)((double)min_size * (double)im_info[3 * i + 2]);
+        p.im_h[i] = im_info[3 * i + 0]; p.im_w[i] = im_info[3 * i + 1];
+    }
+    p.batch_idx = batch_idx;
     p.rois_out = rois_out; p.probs_out = probs_out; p.counts_out = counts_out;
-    np.T = T; np.cap = cap; np.thr = nms_thresh;
+    np.n_levels = n_levels; np.T = T; np.cap = cap; np.thr = nms_thresh;
+    np.img_bytes = img_bytes; np.img_state_bytes = sizeof(LevelState) * MAX_LEVELS;
 
     int bx = (maxN + 255) / 256;
     if (bx > 512) bx = 512;
-    hipLaunchKernelGGL(rpn_keys_hist_kernel, dim3((maxN + K0_CHUNK - 1) / K0_CHUNK, n_levels), dim3(K0_THREADS), 0, st, p);
-    hipLaunchKernelGGL(rpn_find_bin_kernel, dim3(n_levels), dim3(1024), 0, st, p);
-    hipLaunchKernelGGL(rpn_compact_kernel, dim3(bx, n_levels), dim3(256), 0, st, p);
+    const unsigned ni = (unsigned)n_images;
+    hipLaunchKernelGGL(rpn_keys_hist_kernel, dim3((maxN + K0_CHUNK - 1) / K0_CHUNK, n_levels, ni), dim3(K0_THREADS), 0, st, p);
+    hipLaunchKernelGGL(rpn_find_bin_kernel, dim3(n_levels, ni), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(rpn_compact_kernel, dim3(bx, n_levels, ni), dim3(256), 0, st, p);
     rc = dat_ensure_lds(ctx, (const void*)rpn_select_sort_decode_kernel, MAX_SORT * 8);
     if (rc != DAT_OK) return rc;
-    hipLaunchKernelGGL(rpn_select_sort_decode_kernel, dim3(n_levels), dim3(1024), (size_t)p.cap_pad * 8, st, p);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords_cap, nwords_cap, n_levels), dim3(64), 0, st, np);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_levels), dim3(SCAN_THREADS), 0, st, np);
-    hipLaunchKernelGGL(rpn_emit_kernel, dim3(n_levels), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(rpn_select_sort_decode_kernel, dim3(n_levels, ni), dim3(1024), (size_t)p.cap_pad * 8, st, p);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords_cap, nwords_cap, n_levels * ni), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_levels, ni), dim3(SCAN_THREADS), 0, st, np);
+    hipLaunchKernelGGL(rpn_emit_kernel, dim3(n_levels, ni), dim3(256), 0, st, p);
     DAT_CHECK_LAUNCH(ctx, "rpn_proposals");
     return DAT_OK;
 }
 
-int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
-                     int n_levels, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out) {
+int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
+                      const float* const* anchors, int n_levels, const float* im_info, int pre_nms, int post_nms,
+                      float nms_thresh, float min_size, float batch_idx, float* rois_out, float* probs_out, int* counts_out) {
+    return dat_rpn_proposals_batch(ctx, s, dtype, heads, levels, anchors, n_levels, 1, 0, im_info, pre_nms, post_nms, nms_thresh,
+                                   min_size, batch_idx, rois_out, probs_out, counts_out);
+}
+
+int dat_collect_rois_batch(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
+                           int n_levels, int n_images, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out) {
     DAT_ENFORCE(ctx, rois_lvls && probs_lvls && counts && rois && n_out, "collect_rois: null argument");
     DAT_ENFORCE(ctx, n_levels >= 1 && n_levels <= MAX_LEVELS, "collect_rois: n_levels %d out of range", n_levels);
+    DAT_ENFORCE(ctx, n_images >= 1 && n_images <= MAX_IMAGES, "collect_rois: %d images per launch (1..%d)", n_images, MAX_IMAGES);
     int npad = 1;
     while (npad < n_levels * level_cap) npad <<= 1;
     DAT_ENFORCE(ctx, (size_t)npad * 8 <= 128 * 1024, "collect_rois: %d candidate rois exceed the 16384-entry LDS sort", n_levels * level_cap);
@@ -703,10 +797,15 @@ int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const f
         const int rc = dat_ensure_lds(ctx, (const void*)collect_rois_kernel, 128 * 1024);
         if (rc != DAT_OK) return rc;
     }
-    hipLaunchKernelGGL(collect_rois_kernel, dim3(1), dim3(1024), (size_t)npad * 8, (hipStream_t)s, rois_lvls, probs_lvls, counts,
-                       n_levels, level_cap, roi_cols, post_nms, rois, n_out);
+    hipLaunchKernelGGL(collect_rois_kernel, dim3((unsigned)n_images), dim3(1024), (size_t)npad * 8, (hipStream_t)s, rois_lvls, probs_lvls,
+                       counts, n_levels, level_cap, roi_cols, post_nms, rois, n_out);
     DAT_CHECK_LAUNCH(ctx, "collect_rois");
     return DAT_OK;
+}
+
+int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
+                     int n_levels, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out) {
+    return dat_collect_rois_batch(ctx, s, rois_lvls, probs_lvls, counts, n_levels, 1, level_cap, roi_cols, post_nms, rois, n_out);
 }
 
 // strict / presorted select the `_nms` (lib/nms/nms_kernel.cu) convention instead of cython_nms / py_cpu_nms_tubes.
@@ -720,13 +819,15 @@ size_t dat_nms_ws_bytes(int cap, int T) {
            align_up((size_t)cap * 4);
 }
 
-int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int n, const int* n_dev, int cap, int T, float thresh,
-                 int strict, int presorted, int* keep, int* num_keep) {
+int dat_nms_impl_batch(dat_ctx* ctx, hipStream_t st, char* ws, size_t ws_stride, const float* dets, size_t dets_stride, int n,
+                       const int* n_dev, int n_dev_stride, int cap, int T, float thresh, int strict, int presorted, int* keep,
+                       int keep_stride, int* num_keep, int num_stride, int n_images) {
     DAT_ENFORCE(ctx, keep && num_keep, "nms: null output");
     DAT_ENFORCE(ctx, T >= 1 && T <= MAX_T, "nms: tube length %d unsupported", T);
+    DAT_ENFORCE(ctx, n_images >= 1 && n_images <= MAX_IMAGES, "nms: %d images per launch (1..%d)", n_images, MAX_IMAGES);
     if (!n_dev) cap = n;
     if (cap == 0) {
-        hipMemsetAsync(num_keep, 0, sizeof(int), st);
+        for (int i = 0; i < n_images; ++i) hipMemsetAsync(num_keep + (size_t)i * num_stride, 0, sizeof(int), st);
         return DAT_OK;
     }
     DAT_ENFORCE(ctx, dets, "nms: null dets");
@@ -734,9 +835,11 @@ int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int 
     const int nwords = (cap + 63) / 64;
     int rc;
     if (!ws) {
-        if ((rc = ensure_ws(ctx, dat_nms_ws_bytes(cap, T))) != DAT_OK) return rc;
+        ws_stride = dat_nms_ws_bytes(cap, T);
+        if ((rc = ensure_ws(ctx, ws_stride * n_images)) != DAT_OK) return rc;
         ws = (char*)ctx->ws;
     }
+    DAT_ENFORCE(ctx, n_images == 1 || ws_stride >= dat_nms_ws_bytes(cap, T), "nms: per-image scratch stride too small");
     size_t off = 0;
     const size_t o_state = off; off += align_up(16);
     const size_t o_boxes = off; off += align_up((size_t)cap * 4 * T * 4);
@@ -749,8 +852,12 @@ int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int 
     while (npad < cap) npad <<= 1;
     if ((rc = dat_ensure_lds(ctx, (const void*)nms_sort_dets_kernel, MAX_SORT * 8)) != DAT_OK) return rc;
     if ((rc = dat_ensure_lds(ctx, (const void*)nms_finish_kernel, MAX_SORT * 4)) != DAT_OK) return rc;
-    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(1), dim3(1024), presorted ? 0 : (size_t)npad * 8, st, dets, n, n_dev, T, presorted,
-                       (float*)(ws + o_boxes), (int*)(ws + o_orig), st_n);
+    NmsBatch nb;
+    nb.dets_stride = dets_stride; nb.ws_stride = ws_stride; nb.n_in_stride = n_dev_stride; nb.keep_stride = keep_stride;
+    nb.num_stride = num_stride;
+    const unsigned ni = (unsigned)n_images;
+    hipLaunchKernelGGL(nms_sort_dets_kernel, dim3(ni), dim3(1024), presorted ? 0 : (size_t)npad * 8, st, dets, n, n_dev, T, presorted,
+                       (float*)(ws + o_boxes), (int*)(ws + o_orig), st_n, nb);
     NmsParams np;
     memset(&np, 0, sizeof(np));
     np.lv[0].boxes = (const float*)(ws + o_boxes);
@@ -758,13 +865,19 @@ int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int 
     np.lv[0].n_ptr = st_n;
     np.lv[0].kept = (int*)(ws + o_kept);
     np.lv[0].n_keep_ptr = st_keep;
-    np.T = T; np.cap = cap; np.thr = thresh; np.strict = strict;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, 1), dim3(64), 0, st, np);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, np);
-    hipLaunchKernelGGL(nms_finish_kernel, dim3(1), dim3(1024), (size_t)cap * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
-                       (const int*)(ws + o_orig), (const unsigned*)st_n, T, keep, num_keep);
+    np.n_levels = 1; np.T = T; np.cap = cap; np.thr = thresh; np.strict = strict;
+    np.img_bytes = ws_stride; np.img_state_bytes = ws_stride;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, ni), dim3(64), 0, st, np);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1, ni), dim3(SCAN_THREADS), 0, st, np);
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(ni), dim3(1024), (size_t)cap * 4, st, (const int*)(ws + o_kept), (const unsigned*)st_keep,
+                       (const int*)(ws + o_orig), (const unsigned*)st_n, T, keep, num_keep, nb);
     DAT_CHECK_LAUNCH(ctx, "nms");
     return DAT_OK;
+}
+
+int dat_nms_impl(dat_ctx* ctx, hipStream_t st, char* ws, const float* dets, int n, const int* n_dev, int cap, int T, float thresh,
+                 int strict, int presorted, int* keep, int* num_keep) {
+    return dat_nms_impl_batch(ctx, st, ws, 0, dets, 0, n, n_dev, 0, cap, T, thresh, strict, presorted, keep, 0, num_keep, 0, 1);
 }
 
 extern "C" {

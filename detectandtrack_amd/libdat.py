@@ -90,11 +90,15 @@ _PROTOS = {
     'dat_rpn_proposals': (_i, [_p, _p, _i, C.POINTER(_p), C.POINTER(RpnLevel), C.POINTER(_p), _i, C.POINTER(_f),
                                _i, _i, _f, _f, _f, _p, _p, _p]),
     'dat_collect_rois': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'dat_rpn_proposals_batch': (_i, [_p, _p, _i, C.POINTER(_p), C.POINTER(RpnLevel), C.POINTER(_p), _i, _i, _i, C.POINTER(_f),
+                                     _i, _i, _f, _f, _f, _p, _p, _p]),
+    'dat_collect_rois_batch': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     'dat_nms': (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
     'dat_nms_host': (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f]),
     '_nms': (None, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), _i, _i, _f, _i]),
     'dat_box_results_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'dat_box_results': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, C.POINTER(DetDesc), _p, _i, _p, _p, _p]),
+    'dat_box_results_batch': (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, C.POINTER(DetDesc), _i, _p, _i, _p, _p, _p]),
     'dat_soft_nms_host': (_i, [C.POINTER(_f), _i, _f, _f, _f, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)]),
     'dat_deconv_k4s2_weights': (_i, [_p, _p, _p, _i, _i, _p]),
     'dat_kps_finalize': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -579,8 +579,11 @@ class RpnLevelSpec(object):
         self.per_frame = per_frame
 
 
-def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_size, batch_idx=0.):
-    """Returns (rois [nl, post_nms, 4T+1], probs [nl, post_nms], counts int32 [nl]) CUDA tensors."""
+def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_size, batch_idx=0., n_images=1, frame_stride=0):
+    """One image: returns (rois [nl, post_nms, 4T+1], probs [nl, post_nms], counts int32 [nl]) CUDA tensors.  n_images > 1
+    (dat_rpn_proposals_batch): image i reads frame `level.frame + i * frame_stride` of every head tensor and is clipped with
+    im_info[i]; returns rois [n_images, nl, post_nms, 4T+1] (col 0 = batch_idx + i), probs [n_images, nl, post_nms], counts
+    [n_images, nl] -- per image exactly what the one-image call returns."""
     nl = len(levels)
     T = levels[0].T
     dev = levels[0].head.device
@@ -593,20 +596,28 @@ def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_siz
         lv[i].cstride, lv[i].logit_off, lv[i].delta_off, lv[i].frame = l.cstride, l.logit_off, l.delta_off, l.frame
         lv[i].apply_sigmoid = int(l.apply_sigmoid)
         lv[i].per_frame = int(l.per_frame)
-    info = (C.c_float * 3)(*[float(v) for v in im_info])
-    rois = torch.zeros((nl, post_nms, 4 * T + 1), dtype=torch.float32, device=dev)
-    probs = torch.zeros((nl, post_nms), dtype=torch.float32, device=dev)
-    counts = torch.zeros((nl,), dtype=torch.int32, device=dev)
-    ctx().call('dat_rpn_proposals', _stream(), dtype, heads, lv, anchors, nl, info, pre_nms, post_nms,
-               C.c_float(nms_thresh), C.c_float(min_size), C.c_float(batch_idx), _ptr(rois), _ptr(probs), _ptr(counts))
+    im_info = np.asarray(im_info, dtype=np.float32).reshape(-1, 3)
+    assert im_info.shape[0] == n_images, (im_info.shape, n_images)
+    info = (C.c_float * (3 * n_images))(*[float(v) for v in im_info.reshape(-1)])
+    lead = (n_images, nl) if n_images > 1 else (nl,)
+    rois = torch.zeros(lead + (post_nms, 4 * T + 1), dtype=torch.float32, device=dev)
+    probs = torch.zeros(lead + (post_nms,), dtype=torch.float32, device=dev)
+    counts = torch.zeros(lead, dtype=torch.int32, device=dev)
+    ctx().call('dat_rpn_proposals_batch', _stream(), dtype, heads, lv, anchors, nl, int(n_images), int(frame_stride), info, pre_nms,
+               post_nms, C.c_float(nms_thresh), C.c_float(min_size), C.c_float(batch_idx), _ptr(rois), _ptr(probs), _ptr(counts))
     return rois, probs, counts
 
 
 def collect_rois(rois, probs, counts, post_nms):
-    nl, cap, cols = rois.shape
-    out = torch.zeros((post_nms, cols), dtype=torch.float32, device=rois.device)
-    n_out = torch.zeros((1,), dtype=torch.int32, device=rois.device)
-    ctx().call('dat_collect_rois', _stream(), _ptr(rois), _ptr(probs), _ptr(counts), nl, cap, cols, post_nms,
+    """rois [nl, cap, cols] -> (out [post_nms, cols], n_out int32[1]); batched rois [n_images, nl, cap, cols] ->
+    (out [n_images * post_nms, cols] with image i in rows [i * post_nms, ...), n_out int32[n_images]): PER IMAGE top post_nms."""
+    if rois.dim() == 4:
+        ni, nl, cap, cols = rois.shape
+    else:
+        ni, (nl, cap, cols) = 1, rois.shape
+    out = torch.zeros((ni * post_nms, cols), dtype=torch.float32, device=rois.device)
+    n_out = torch.zeros((ni,), dtype=torch.int32, device=rois.device)
+    ctx().call('dat_collect_rois_batch', _stream(), _ptr(rois), _ptr(probs), _ptr(counts), nl, ni, cap, cols, post_nms,
                _ptr(out), _ptr(n_out))
     return out, n_out
 
@@ -633,26 +644,38 @@ def nms_host(dets_np, thresh):
 
 
 def box_results(rois, n_rois, cls_prob, bbox_pred, num_classes, T, im_scale, im_shape, reg_weights, xform_clip, score_thresh,
-                nms_thresh, detections_per_im, out_cap, cls_agnostic=False):
+                nms_thresh, detections_per_im, out_cap, cls_agnostic=False, n_images=1):
     """dat_box_results (lib/core/test.py:215-252, 750-806, 78-123 on the device).  rois CUDA fp32 [cap, 4T+1] with the DEVICE count
     n_rois (int32[1]); cls_prob [R, K], bbox_pred [R, K*4T] CUDA fp32.  Returns (dets [out_cap, 4T+2], keypoint_rois [out_cap, 4T+1],
-    n_out int32[2]) on the device -- no host synchronisation."""
-    cap = int(rois.shape[0])
-    d = L.DetDesc()
-    d.num_classes, d.T, d.cls_agnostic_bbox_reg, d.detections_per_im = int(num_classes), int(T), int(bool(cls_agnostic)), int(detections_per_im)
-    d.im_scale, d.im_scale_f64 = float(im_scale), float(im_scale)
-    d.im_h, d.im_w = int(im_shape[0]), int(im_shape[1])
-    for i in range(4):
-        d.reg_weights[i] = float(reg_weights[i])
-    d.xform_clip, d.score_thresh, d.nms_thresh = float(xform_clip), float(score_thresh), float(nms_thresh)
+    n_out int32[2]) on the device -- no host synchronisation.  n_images > 1 (dat_box_results_batch): rois [n_images * cap, ...] with
+    counts n_rois[n_images], im_scale / im_shape sequences per image; returns dets [n_images * out_cap, 4T+2], keypoint_rois
+    [n_images * out_cap, 4T+1] (col 0 = image index) and n_out int32[n_images, 2]."""
+    ni = int(n_images)
+    cap = int(rois.shape[0]) // ni
+    assert cap * ni == int(rois.shape[0])
+    scales = [float(v) for v in np.asarray(im_scale, dtype=np.float64).reshape(-1)]
+    shapes = [tuple(im_shape)] * ni if not isinstance(im_shape[0], (tuple, list, np.ndarray)) else [tuple(sh) for sh in im_shape]
+    if len(scales) == 1:
+        scales = scales * ni
+    assert len(scales) == ni and len(shapes) == ni
+    ds = (L.DetDesc * ni)()
+    for i in range(ni):
+        d = ds[i]
+        d.num_classes, d.T, d.cls_agnostic_bbox_reg, d.detections_per_im = int(num_classes), int(T), int(bool(cls_agnostic)), int(detections_per_im)
+        d.im_scale, d.im_scale_f64 = scales[i], scales[i]
+        d.im_h, d.im_w = int(shapes[i][0]), int(shapes[i][1])
+        for k in range(4):
+            d.reg_weights[k] = float(reg_weights[k])
+        d.xform_clip, d.score_thresh, d.nms_thresh = float(xform_clip), float(score_thresh), float(nms_thresh)
     cols = 4 * T + 1
-    wsb = torch.empty(L.lib().dat_box_results_workspace_bytes(cap, int(num_classes), int(T)), dtype=torch.uint8, device=rois.device)
-    dets = torch.empty((out_cap, cols + 1), dtype=torch.float32, device=rois.device)
-    kp = torch.empty((out_cap, cols), dtype=torch.float32, device=rois.device)
-    n_out = torch.empty((2,), dtype=torch.int32, device=rois.device)
+    wsb = torch.empty(ni * L.lib().dat_box_results_workspace_bytes(cap, int(num_classes), int(T)), dtype=torch.uint8, device=rois.device)
+    dets = torch.empty((ni * out_cap, cols + 1), dtype=torch.float32, device=rois.device)
+    kp = torch.empty((ni * out_cap, cols), dtype=torch.float32, device=rois.device)
+    n_out = torch.empty((2,) if ni == 1 else (ni, 2), dtype=torch.int32, device=rois.device)
     assert rois.dtype == cls_prob.dtype == bbox_pred.dtype == torch.float32 and rois.is_contiguous()
-    ctx().call('dat_box_results', _stream(), _ptr(rois), _ptr(n_rois), cap, _ptr(cls_prob), int(cls_prob.stride(0)), _ptr(bbox_pred),
-               int(bbox_pred.stride(0)), C.byref(d), _ptr(wsb), int(out_cap), _ptr(dets), _ptr(kp), _ptr(n_out))
+    assert n_rois.numel() == ni
+    ctx().call('dat_box_results_batch', _stream(), _ptr(rois), _ptr(n_rois), cap, _ptr(cls_prob), int(cls_prob.stride(0)), _ptr(bbox_pred),
+               int(bbox_pred.stride(0)), ds, ni, _ptr(wsb), int(out_cap), _ptr(dets), _ptr(kp), _ptr(n_out))
     return dets, kp, n_out
 
 

@@ -72,13 +72,13 @@ class Workspace(object):
         if b.kind == 'rows':
             r = b.t.shape[2]
             m = ops.to_ncdhw(b.t.view(r, 1, 1, b.t.shape[3]), b.dt, r, b.C, 1).cpu().numpy().reshape(r, b.C)
-            return m[:_count(b)] if b.count is not None else m
+            return _valid_rows(b, m)
         if b.kind == 'rois':
-            return b.t[:_count(b)].cpu().numpy()
+            return _valid_rows(b, b.t.cpu().numpy())
         arr = b.t.cpu().numpy()
         if b.sigmoid_of is not None:
             arr = 1.0 / (1.0 + np.exp(-arr))
-        return arr[:_count(b)] if b.count is not None else arr
+        return _valid_rows(b, arr)
 
     def HasBlob(self, name):
         return _unscoped(name) in self.blobs or _unscoped(name) in self.params
@@ -166,6 +166,21 @@ def _unscoped(name):
 
 def _count(b):
     return int(b.count.item()) if isinstance(b.count, torch.Tensor) else int(b.count)
+
+
+def _valid_rows(b, arr):
+    """The live rows of a row-counted blob: arr[:count], or -- several images per forward, count = one entry per image over equal
+    row segments -- the images' live rows concatenated in image order (what the reference's batched blobs hold, col 0 = image)."""
+    if b.count is None:
+        return arr
+    if isinstance(b.count, torch.Tensor) and b.count.numel() > 1:
+        cnt = b.count.cpu().numpy().reshape(-1)
+        if arr.ndim == 3 and arr.shape[0] == len(cnt):      # [n_images, rows, cols] view of a per-level proposal blob
+            arr = arr.reshape(-1, arr.shape[-1])
+        seg = arr.shape[0] // len(cnt)
+        assert seg * len(cnt) == arr.shape[0], (arr.shape, len(cnt))
+        return np.concatenate([arr[i * seg:i * seg + int(c)] for i, c in enumerate(cnt)], axis=0)
+    return arr[:_count(b)]
 
 
 def _dt(ws=None):
@@ -592,6 +607,8 @@ class Executor(object):
             'tube RPN head with %d frames for %d-frame anchors (per_frame %s)' % (head.T, T, per_frame)
         spec = ops.RpnLevelSpec(head.t, h, w, A, T, 1. / op.args['spatial_scale'], cs, 0, A, 0, an, apply_sigmoid=True,
                                 per_frame=per_frame)
+        self._rpn_images, self._rpn_frame_stride = head.N, head.T      # image i of the batch: frames [i * head.T, (i + 1) * head.T)
+        assert f == head.N * head.T, (f, head.N, head.T)
         self.pending_rpn.append((spec, op))
         if not self.has_collect:
             self._run_rpn(single=True)
@@ -601,15 +618,24 @@ class Executor(object):
         key = 'TRAIN' if self.net._helper is not None and self.net._helper.train else 'TEST'
         im_info = ws.blobs['im_info']
         info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
-        assert info.shape[0] == 1, 'one clip per forward (reference inference is batch 1, core/test.py:212-214)'
         specs = [s for s, _ in self.pending_rpn]
-        rois, probs, counts = ops.rpn_proposals(specs, _dt(self.ws), info[0], cfg[key].RPN_PRE_NMS_TOP_N,
+        # several images per forward (the reference's op loops over them, generate_proposals.py:133-147; its inference is batch 1,
+        # core/test.py:212-214): the image is a grid dimension of the same kernels, every image keeps what it keeps alone
+        ni = int(info.shape[0])
+        assert ni == self._rpn_images, 'im_info has %d rows for %d images in the RPN head blobs' % (ni, self._rpn_images)
+        assert ni == 1 or key == 'TEST', 'several images per forward: inference only (TRAIN.IMS_PER_BATCH 1 per GPU)'
+        rois, probs, counts = ops.rpn_proposals(specs, _dt(self.ws), info, cfg[key].RPN_PRE_NMS_TOP_N,
                                                 cfg[key].RPN_POST_NMS_TOP_N, cfg[key].RPN_NMS_THRESH,
-                                                cfg[key].RPN_MIN_SIZE)
+                                                cfg[key].RPN_MIN_SIZE, n_images=ni, frame_stride=self._rpn_frame_stride)
         for li, (_, op) in enumerate(self.pending_rpn):
-            ws.blobs[op.outputs[0]] = Blob(rois[li], 'rois', count=counts[li:li + 1])
-            if len(op.outputs) > 1:
-                ws.blobs[op.outputs[1]] = Blob(probs[li].view(-1, 1), 'mat', count=counts[li:li + 1])
+            if ni == 1:
+                ws.blobs[op.outputs[0]] = Blob(rois[li], 'rois', count=counts[li:li + 1])
+                if len(op.outputs) > 1:
+                    ws.blobs[op.outputs[1]] = Blob(probs[li].view(-1, 1), 'mat', count=counts[li:li + 1])
+            else:       # strided views [n_images, post_nms, ...] (no copy; only read when somebody fetches a per-level blob)
+                ws.blobs[op.outputs[0]] = Blob(rois[:, li], 'rois', count=counts[:, li])
+                if len(op.outputs) > 1:
+                    ws.blobs[op.outputs[1]] = Blob(probs[:, li].unsqueeze(-1), 'mat', count=counts[:, li])
         self._rpn_out = (rois, probs, counts)
         self.pending_rpn = []
 

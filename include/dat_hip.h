@@ -197,6 +197,23 @@ int dat_rpn_proposals(dat_ctx* ctx, dat_stream s, int dtype, const void* const* 
 int dat_collect_rois(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
                      int n_levels, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out);
 
+/* Several images per forward (round 3; the reference's GenerateProposalsOp loops `for im_i in range(num_images)`,
+ * lib/ops/generate_proposals.py:133-147, and runs inference with one image per batch, lib/core/test.py:212-214).  All images share
+ * the level geometry; image i reads frame `levels[l].frame + i * frame_stride` of every head tensor, is clipped / filtered with
+ * im_info[3*i .. 3*i+2] (HOST, n_images x 3) and writes rois_out [n_images, n_levels, post_nms, 4T+1] (col 0 = batch_idx + i),
+ * probs_out [n_images, n_levels, post_nms], counts_out [n_images, n_levels].  Every image's result is what dat_rpn_proposals
+ * returns for it alone (same kernels, the image is a grid dimension).  n_images <= DAT_MAX_IMAGES. */
+#define DAT_MAX_IMAGES 16
+int dat_rpn_proposals_batch(dat_ctx* ctx, dat_stream s, int dtype, const void* const* heads, const dat_rpn_level* levels,
+                            const float* const* anchors, int n_levels, int n_images, int frame_stride, const float* im_info,
+                            int pre_nms, int post_nms, float nms_thresh, float min_size, float batch_idx, float* rois_out,
+                            float* probs_out, int* counts_out);
+/* collect PER IMAGE (inference keeps RPN_POST_NMS_TOP_N proposals per image, exactly what a one-image forward keeps): in
+ * [n_images, n_levels, level_cap, ...] as written by dat_rpn_proposals_batch, out rois [n_images, post_nms, roi_cols] (rows past
+ * n_out[i] of image i are not written), n_out int32[n_images]. */
+int dat_collect_rois_batch(dat_ctx* ctx, dat_stream s, const float* rois_lvls, const float* probs_lvls, const int* counts,
+                           int n_levels, int n_images, int level_cap, int roi_cols, int post_nms, float* rois, int* n_out);
+
 /* ---- NMS (lib/utils/cython_nms.pyx:37-87, lib/nms/py_cpu_nms_tubes.py:17-53) ---------------------- */
 /* dets: dev fp32 [n, 4T+1], ANY order.  keep: dev int32[n]; boxes (T==1): ascending original indices
  * (cython_nms semantics, suppress at IoU >= thresh); tubes (T>1): score order, suppress at mean IoU > thresh.
@@ -241,6 +258,15 @@ size_t dat_box_results_workspace_bytes(int roi_cap, int num_classes, int T);
 int dat_box_results(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob, int prob_ld,
                     const float* bbox_pred, int pred_ld, const dat_det_desc* d, void* workspace, int out_cap, float* dets_out,
                     float* keypoint_rois, int* n_out);
+/* The same for n_images images of one forward (each image's rows are what dat_box_results returns for it alone): image i owns rois
+ * rows [i*roi_cap, (i+1)*roi_cap) with n_rois[i] valid ones (and the same rows of cls_prob / bbox_pred), is decoded with d[i]
+ * (im_scale / im_h / im_w per image; classes, T, weights and thresholds from d[0]) and writes dets_out [n_images, out_cap, 4T+2],
+ * keypoint_rois [n_images, out_cap, 4T+1] (col 0 = i: the image's index in the batch, what RoIAlign reads as the batch index;
+ * zero rows -- col 0 included -- past the kept ones) and n_out int32[n_images, 2].  workspace: n_images x
+ * dat_box_results_workspace_bytes. */
+int dat_box_results_batch(dat_ctx* ctx, dat_stream s, const float* rois, const int* n_rois, int roi_cap, const float* cls_prob,
+                          int prob_ld, const float* bbox_pred, int pred_ld, const dat_det_desc* d, int n_images, void* workspace,
+                          int out_cap, float* dets_out, float* keypoint_rois, int* n_out);
 
 /* Soft-NMS, HOST pointers, host arithmetic (lib/utils/cython_nms.pyx:98-203 statement for statement in C float): boxes_in
  * [n, 5] -> boxes_out [*n_out <= n, 5] (re-scored, in the order the greedy loop leaves them) and inds_out (rows of boxes_in).

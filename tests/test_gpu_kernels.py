@@ -1120,3 +1120,66 @@ def test_roi_align_at_bench_size_vs_oracle(ops):
             l = int(lvls[i])
             ref = roi_align_2d(feats[l - 2][:, :, 0], rois[i:i + 1], pooled, 1. / 2 ** l, 2)[0]
             assert np.abs(out[i] - ref).max() < 1e-4, (pooled, i, l)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_batched_proposals_collect_and_box_results_equal_the_one_image_calls(ops, dtype):
+    """Round 3: several images per forward.  dat_rpn_proposals_batch / dat_collect_rois_batch / dat_box_results_batch run the image
+    as a grid dimension of the same kernels: every image's rois, scores, counts, detections and keypoint rois must be BIT-identical
+    to the one-image calls (reference loop: lib/ops/generate_proposals.py:133-147; per-image post-processing
+    lib/core/test.py:750-806).  Images differ in content AND in im_info (clip bounds / min-size scale)."""
+    from oracle.anchors import generate_anchors
+    rs = np.random.RandomState(5)
+    NI = 5
+    shapes = {2: (40, 56), 3: (20, 28), 4: (10, 14), 5: (5, 7), 6: (3, 4)}
+    im_info = np.array([[160., 224., 1.0], [150., 200., 1.2], [160., 224., 0.9], [120., 224., 1.0], [160., 180., 1.1]], np.float32)
+    heads, anchors = [], []
+    for lvl in range(2, 7):
+        H, W = shapes[lvl]
+        an = generate_anchors(2. ** lvl, (32 * 2. ** (lvl - 2),), (0.5, 1, 2)).astype(np.float32)
+        scores = rs.uniform(0.01, 0.99, (NI, 3, H, W)).astype(np.float32)
+        deltas = (rs.randn(NI, 12, H, W) * 0.3).astype(np.float32)
+        lg = np.log(scores / (1 - scores)).astype(np.float32)
+        cat = np.concatenate([lg, deltas], axis=1)[:, :, None]                        # (NI, 15, 1, H, W)
+        heads.append(ops.to_ndhwc(_dev(cat), dtype, 64))                              # [NI, H, W, 64]
+        anchors.append(_dev(an))
+
+    def specs(frame):
+        return [ops.RpnLevelSpec(heads[i], shapes[l][0], shapes[l][1], 3, 1, float(2 ** l), 64, 0, 3, frame, anchors[i])
+                for i, l in enumerate(range(2, 7))]
+    pre, post = 600, 200
+    rois_b, probs_b, counts_b = ops.rpn_proposals(specs(0), dtype, im_info, pre, post, 0.7, 4., n_images=NI, frame_stride=1)
+    out_b, n_b = ops.collect_rois(rois_b, probs_b, counts_b, post)
+    assert rois_b.shape == (NI, 5, post, 5) and out_b.shape == (NI * post, 5) and n_b.shape == (NI,)
+    singles = []
+    for i in range(NI):
+        r, p, c = ops.rpn_proposals(specs(i), dtype, im_info[i], pre, post, 0.7, 4., batch_idx=float(i))
+        assert torch.equal(c, counts_b[i]), (i, c, counts_b[i])
+        assert torch.equal(r, rois_b[i]) and torch.equal(p, probs_b[i]), i
+        o, n = ops.collect_rois(r, p, c, post)
+        k = int(n.item())
+        assert k == int(n_b[i].item()) and k > 20
+        assert torch.equal(o[:k], out_b[i * post:i * post + k])
+        assert (o[:k, 0] == i).all()
+        singles.append((o, n))
+    # detection post-processing over the batch: rows of image i = [i * post, (i + 1) * post)
+    K = 3
+    R = NI * post
+    logits = rs.randn(R, K).astype(np.float32) * 2
+    prob = _dev((np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)).astype(np.float32))
+    pred = _dev((rs.randn(R, K * 4) * np.tile([1.0, 1.0, 2.0, 2.0], K)).astype(np.float32))
+    scales = [float(s) for s in im_info[:, 2]]
+    shapes_im = [(int(round(h / s)), int(round(w / s)), 3) for h, w, s in im_info]
+    args = ((10., 10., 5., 5.), float(np.float32(np.log(1000. / 16.))), 0.05, 0.5, 30, 30)
+    dets_b, kp_b, nout_b = ops.box_results(out_b, n_b, prob, pred, K, 1, scales, shapes_im, *args, n_images=NI)
+    assert dets_b.shape == (NI * 30, 6) and kp_b.shape == (NI * 30, 5) and nout_b.shape == (NI, 2)
+    for i in range(NI):
+        o, n = singles[i]
+        d1, k1, n1 = ops.box_results(o, n, prob[i * post:(i + 1) * post], pred[i * post:(i + 1) * post], K, 1, scales[i],
+                                     shapes_im[i], *args)
+        assert torch.equal(n1, nout_b[i]), (i, n1, nout_b[i])
+        k = int(n1[0].item())
+        assert k > 0
+        assert torch.equal(d1, dets_b[i * 30:(i + 1) * 30])
+        assert torch.equal(k1[:, 1:], kp_b[i * 30:(i + 1) * 30, 1:])
+        assert (kp_b[i * 30:i * 30 + k, 0] == i).all() and not kp_b[i * 30 + k:(i + 1) * 30].any()

@@ -387,3 +387,60 @@ def test_fused_stem_pool_is_taken_through_runnet_and_is_bit_identical():
             assert ('conv1' in ws.blobs) == (not fuse)
             pools[(dtype, fuse)] = ws.FetchBlob('pool1')
         np.testing.assert_array_equal(pools[(dtype, True)], pools[(dtype, False)])
+
+
+def _boxes_agree(a, b, tol):
+    """fraction of rows of `a` that have a row of `b` within `tol` (max-abs over the columns)"""
+    if len(a) == 0 or len(b) == 0:
+        return 1.0 if len(a) == len(b) else 0.0
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(axis=2).min(axis=1)
+    return float((d < tol).mean())
+
+
+@pytest.mark.parametrize('kind,B,T,H,W', [('2d', 4, 1, 128, 192), ('3d', 2, 4, 96, 128)])
+def test_several_images_per_forward_give_each_image_its_own_results(kind, B, T, H, W):
+    """Round 3 (SURVEY §8d config 2 'new build may batch N=8'): B frames (2D R-50-FPN) / B clips (3D R-18 FPN3D)
+    through ONE forward -- the N axis of the blobs, the image as a grid dimension of the proposal / detection kernels -- must give
+    every image what it gets alone through im_detect_all (reference order of results, lib/core/test.py:897-957): the same
+    proposals (`rois` rows of image i, col 0 = i), detections and keypoints.  fp32 parity mode; the conv plans of the two batch
+    sizes may sum in a different order, hence a 1e-2 px tolerance on boxes instead of bit equality."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.config import cfg
+    from tests.model_util import fpn2d_kps_cfg
+    c = fpn2d_kps_cfg('50', dtype='fp32', pre=400, post=150) if kind == '2d' else fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=400, post=150)
+    c['TEST'].update(SCALES=(H,), MAX_SIZE=max(H, W), SCORE_THRESH=0.0, DETECTIONS_PER_IM=20)
+    model, ws, _ = build_product(c)
+    rs = np.random.RandomState(11)
+    ims = [[rs.randint(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(T)] for _ in range(B)]
+    singles = []
+    for i in range(B):
+        cls_boxes, _, cls_keyps = engine.im_detect_all(model, ims[i], None)
+        singles.append((cls_boxes, cls_keyps, ws.FetchBlob('rois').copy()))
+    batch = engine.im_detect_all_batch(model, ims)
+    assert ws.blobs['data'].t.shape[0] == B and len(batch) == B
+    rois = ws.FetchBlob('rois')                         # images concatenated, col 0 = image index
+    off = 0
+    for i in range(B):
+        r1 = singles[i][2]
+        rb = rois[rois[:, 0] == i]
+        assert np.all(rois[off:off + len(rb), 0] == i)              # image-major order
+        off += len(rb)
+        assert abs(len(rb) - len(r1)) <= 2, (i, len(rb), len(r1))
+        assert _boxes_agree(rb[:, 1:], r1[:, 1:], 1e-2) > 0.97, i
+        b1, k1 = singles[i][0][1], singles[i][1][1]
+        bb, _, kb = batch[i]
+        assert len(bb[1]) == len(b1) == 20 and len(kb[1]) == 20
+        assert _boxes_agree(bb[1], b1, 2e-2) > 0.9, (i, bb[1][:3], b1[:3])
+        # keypoints of the detections present in both: the decoded (x, y) agree (an arg-max over a 56 x 56 map upsampled to the box may
+        # flip between near-equal cells under a 1e-6 logit difference: 95 % within one pixel)
+        hit, diffs = 0, []
+        for j, row in enumerate(bb[1]):
+            d = np.abs(b1 - row[None]).max(axis=1)
+            m = int(d.argmin())
+            if d[m] < 2e-2:
+                hit += 1
+                diffs.append(np.abs(kb[1][j][:2] - k1[m][:2]).max(axis=0))
+        assert hit >= 18
+        assert (np.concatenate(diffs) < 1.0).mean() > 0.95
+    # different images really are different results (the batch is not image 0 repeated)
+    assert _boxes_agree(batch[0][0][1], batch[1][0][1], 1.0) < 0.5
