@@ -216,121 +216,6 @@ def conv_kernel_name(tag, dtype):
     return 'conv3d_igemm_kernel<%s,%d,%d%s>' % (dtype, bn, bp, tps)
 
 
-def stage_net(model, ws, data_dev, im_info):
-    """Stage A of a step: feed the resident clip and enqueue `model.net` (asynchronous)."""
-    ws.FeedBlob('data', data_dev)
-    ws.FeedBlob('im_info', im_info)
-    ws.RunNet(model.net.name)
-
-
-def stage_heads_enqueue(model, ws, im_info, im_shape):
-    """Stage B, device part (no host synchronisation): the reference's glue between the nets (core/test.py:215-252, 750-806) as
-    dat_box_results, `keypoint_net` on the device-resident rois, the heatmap decode -- all enqueued behind `model.net`."""
-    from detectandtrack_amd.core import test as engine
-    from detectandtrack_amd import workspace as wsmod
-    prev, wsmod._GLOBAL = wsmod._GLOBAL, ws          # the engine functions talk to the global workspace
-    try:
-        return engine.enqueue_results_on_device(model, im_shape, float(im_info[0, 2]))
-    finally:
-        wsmod._GLOBAL = prev
-
-
-def stage_heads(model, ws, im_info, im_shape, dev=None):
-    """Stage B, the read-back: the step ends with the per-detection boxes and 4 x 17 keypoint rows on the host.  Falls back to the
-    reference's host glue (device NMS) when the device path is off or hit an exact-tie overflow."""
-    from detectandtrack_amd.core import test as engine
-    from detectandtrack_amd import workspace as wsmod
-    prev, wsmod._GLOBAL = wsmod._GLOBAL, ws
-    try:
-        if dev is not None:
-            res = engine.read_results_from_device(*dev)
-            if res is not None:
-                return sum(len(b) for b in res[0][1:])
-        scores, boxes, _ = engine._read_bbox_outputs([np.zeros(im_shape, np.uint8)], np.array([im_info[0, 2]]))
-        scores, boxes, cls_boxes = engine.box_results_with_nms_and_limit(scores, boxes)
-        n_det = boxes.shape[0]
-        if n_det > 0:   # keypoint net on the detections + on-device heatmap decode (core/test.py:584-627, 865-894)
-            engine.keypoint_results_on_device(model, cls_boxes, boxes, np.array([im_info[0, 2]]))
-    finally:
-        wsmod._GLOBAL = prev
-    return n_det
-
-
-class ClipPipeline(object):
-    """Runs steps with up to `depth` clips in flight, each on its own HIP stream + blob namespace, serviced in COMPLETION order: a
-    slot is read back and re-used as soon as its clip is done, whichever slot that is (the hardware queues do not drain in
-    submission order).  On the bench's equal clips this measures the same as round-robin servicing (`--fifo`: 217.5-219.4 vs
-    216.8-217.0 clips/s); it matters when clips differ in cost.  depth=1 is the strictly sequential reference order."""
-
-    def __init__(self, model, ws, depth, graph=False, fifo=False):
-        self.model, self.depth = model, depth
-        self.slots = [(ws if i == 0 else ws.fork(), torch.cuda.Stream()) for i in range(depth)]
-        self.events = [torch.cuda.Event() for _ in range(depth)]
-        self.free = list(range(depth))
-        self.use_graph, self.graphs = bool(graph), {}
-        self.pending = []          # (slot, im_info, im_shape, dev) in submission order
-        self.n_det = 0
-        self.fifo = bool(fifo)
-        self.host_enqueue_s = 0.0
-        from detectandtrack_amd.core import test as engine
-        self.device_glue = engine.device_results_supported()
-
-    def _acquire(self):
-        """A free slot; with all slots busy: the first pending clip found complete (the oldest one with fifo=True)."""
-        if self.free:
-            return self.free.pop(0)
-        k = 0
-        if not self.fifo and len(self.pending) > 1:
-            while True:
-                done = [j for j, it in enumerate(self.pending) if self.events[it[0]].query()]
-                if done:
-                    k = done[0]
-                    break
-                time.sleep(2e-5)
-        item = self.pending.pop(k)
-        self._finish(item)
-        return item[0]
-
-    def submit(self, data_dev, im_info, im_shape):
-        slot = self._acquire()
-        w, st = self.slots[slot]
-        t0 = time.perf_counter()
-        dev = None
-        launched = False
-        if self.use_graph and self.device_glue:
-            # the clip as ONE hipGraph launch (core/clip_graph.py), captured per slot on first use; a failed capture falls back to eager
-            if slot not in self.graphs:
-                try:
-                    from detectandtrack_amd.core.clip_graph import ClipGraph
-                    self.graphs[slot] = ClipGraph(self.model, w, data_dev, im_info, im_shape, stream=st)
-                except Exception as e:   # noqa
-                    print('hipGraph capture failed (%r): eager launches' % (e,), file=sys.stderr)
-                    self.use_graph = False
-            if self.use_graph:
-                dev = self.graphs[slot].launch(data_dev)
-                launched = True
-        if not launched:
-            with torch.cuda.stream(st):
-                stage_net(self.model, w, data_dev, im_info)
-                dev = stage_heads_enqueue(self.model, w, im_info, im_shape) if self.device_glue else None
-        self.events[slot].record(st)
-        self.host_enqueue_s += time.perf_counter() - t0       # host time to enqueue one clip's launches (no synchronisation inside)
-        self.pending.append((slot, im_info, im_shape, dev))
-
-    def _finish(self, item):
-        slot, im_info, im_shape, dev = item
-        w, st = self.slots[slot]
-        with torch.cuda.stream(st):
-            self.n_det = stage_heads(self.model, w, im_info, im_shape, dev)
-
-    def drain(self):
-        while self.pending:
-            item = self.pending.pop(0)
-            self._finish(item)
-            self.free.append(item[0])
-        torch.cuda.synchronize()
-
-
 def cpu_oracle_forward(net, data, im_info, n_box, n_kp):
     from oracle import proposals as op
     net.body(data)
@@ -480,6 +365,12 @@ def main():
                     help='skip the short runs of the other BASELINE configs (2, 4, 5) appended to the default single-GPU line')
     ap.add_argument('--no-accuracy', action='store_true', help='skip the bf16-vs-fp32 error report (one extra fp32 forward)')
     ap.add_argument('--dump-convs', action='store_true', help='per-layer conv timing to stderr')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='clips (3D) / frames (2D) per forward: the N axis of the blobs, every image keeps the results it gets alone '
+                         '(default: 1 clip for the 3D workloads, all --frames frames of a step for 2d_r50_fpn)')
+    ap.add_argument('--h2d', type=int, default=1,
+                    help='1: also time the same pipeline fed from HOST uint8 720 x 1280 frames (pinned staging, uint8 upload on a copy stream, '
+                         'dat_preprocess_frames) and report it as value_including_upload next to value (which is the resident-input rate)')
     ap.add_argument('--pipeline', type=int, default=4, help='clips in flight per GPU (1 = strictly sequential; 2 / 3 / 4 / 5 measured 206.9 / 214.7 / 217.9 / 208.9 clips/s)')
     ap.add_argument('--fifo', action='store_true', help='service the clips in flight in submission order (A/B switch; default: completion order)')
     ap.add_argument('--graph', type=int, default=1, help='1: every slot replays its clip as one captured hipGraph (core/clip_graph.py); 0: eager launches')
@@ -512,9 +403,16 @@ def main():
 
     from detectandtrack_amd.ops import hip_ops as ops
     T, H, W = a.frames, a.height, a.width
-    units_per_step = T if two_d else 1          # 2D: one forward per frame, T frames per step
-    im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
-    im_shape = (int(round(H / im_info[0, 2])), int(round(W / im_info[0, 2])), 3)
+    # images per forward B; a step = ONE forward of B clips (3D) or the T frames of a 2D step in T / B forwards
+    B = a.batch if a.batch else (T if two_d else 1)
+    assert B >= 1 and (not two_d or T % B == 0), '--batch must divide --frames for the 2D workload'
+    fwd_per_step = T // B if two_d else 1
+    clips_per_step = 1 if two_d else B          # what `value` counts per step: a 2D step is one 8-frame clip, a 3D step B clips
+    units_per_step = fwd_per_step
+    src_h, src_w = 720, 1280                    # PoseTrack frames: min(800/720, 1333/1280) = 1.0414 -> 750 x 1333 -> pad 32 -> 768 x 1344
+    im_scale = min(800.0 / src_h, 1333.0 / src_w)
+    im_info = np.tile(np.array([[H, W, im_scale]], dtype=np.float32), (B, 1))
+    im_shape = (src_h, src_w, 3)
 
     if train:
         from detectandtrack_amd.training import Trainer
@@ -530,12 +428,14 @@ def main():
     else:
         model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d)
         # every rank gets its own clips (weak scaling): seed by rank.  2D: the frames of a clip are fed one by one.
-        if two_d:
-            clips = [[synthetic_clip(1, H, W, 1000 * rank + 10 * i + f)[:, :, 0].contiguous().cuda() for f in range(T)] for i in range(2)]
+        from detectandtrack_amd.core.pipeline import ClipPipeline
+        if two_d:   # a step = T frames in T / B forwards of B frames
+            clips = [[torch.cat([synthetic_clip(1, H, W, 1000 * rank + 10 * i + g * B + f)[:, :, 0] for f in range(B)]).contiguous().cuda()
+                      for g in range(fwd_per_step)] for i in range(2)]
         else:
-            clips = [[synthetic_clip(T, H, W, 1000 * rank + i).cuda()] for i in range(2)]
-        pipe = ClipPipeline(model, ws, a.pipeline, graph=a.graph, fifo=a.fifo)
-        slots = pipe.slots
+            clips = [[torch.cat([synthetic_clip(T, H, W, 1000 * rank + 10 * i + f) for f in range(B)]).contiguous().cuda()] for i in range(2)]
+        pipe = ClipPipeline(model, ws, a.pipeline, graph=a.graph, fifo=a.fifo, keep_results=False)
+        slots = [(sl.ws, sl.stream) for sl in pipe.slots]
 
         def run_steps(n):
             for i in range(n):
@@ -576,6 +476,43 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _dbg('timed region done')
+    # ---- the same pipeline fed from HOST frames: uint8 720 x 1280 BGR frames -> pinned staging -> uint8 H2D on
+    # a copy stream -> dat_preprocess_frames (resize + mean + pad on the device) -> the same graphs.  Same step count, same
+    # barrier / synchronize bracket; reported NEXT TO `value`, never as `value` ----
+    h2d = None
+    if not train and a.h2d:
+        rs_h = np.random.RandomState(1000 * rank + 7)
+        base = [rs_h.randint(0, 256, (src_h, src_w, 3)).astype(np.uint8) for _ in range(4)]     # (frame content does not change the work)
+        n_per = 1 if two_d else T
+        hclips = [[[base[(i + b + t) % 4] for t in range(n_per)] for b in range(B)] for i in range(2)]
+
+        def run_h2d(n):
+            for i in range(n):
+                for _ in range(fwd_per_step):
+                    pipe.submit_frames(hclips[i % 2])
+            pipe.drain()
+        run_h2d(max(a.warmup, a.pipeline + 1))
+        pipe.host_enqueue_s, pipe.upload_bytes = 0.0, 0
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_h2d(a.steps)
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        el_h = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([el_h], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_h = float(t.item())
+        h2d = {'value_including_upload': round(a.gpus * a.steps * clips_per_step / el_h, 4), 'unit': 'clips/s',
+               'ms_per_step': round(1e3 * el_h / a.steps, 3),
+               'upload_mb_per_step': round(pipe.upload_bytes / 1e6 / max(a.steps, 1), 2),
+               'host_ms_per_step': round(1e3 * pipe.host_enqueue_s / max(a.steps, 1), 3),
+               'path': 'uint8 %dx%dx3 frames in host memory -> pinned buffer (memcpy) -> hipMemcpyAsync on a copy stream -> '
+                       'dat_preprocess_frames (bilinear resize x%.4f, mean subtraction, pad to 32) -> the same hipGraphs' % (src_h, src_w, im_scale)}
+        _dbg('h2d region done')
     records, conv_log, mhz = [], [], []
     for (w, st), pr in zip(slots, profs):
         with torch.cuda.stream(st):
@@ -601,24 +538,24 @@ def main():
     # agrees with the one-stream pairs, not with those.  The in-region figures are reported next to them.
     _dbg('profilers stopped')
     seq_rate, conc = None, None
-    graph_on = (not train) and pipe.use_graph and len(pipe.graphs) > 0
+    graph_on = (not train) and pipe.use_graph and len(pipe.slots[0].graphs) > 0
     if not train and (a.pipeline > 1 or graph_on) and rank == 0:
         conc = (records, conv_log) if records else None     # (graph replays record nothing on the host side)
         w0, st0 = slots[0]
         n_seq = min(a.steps, 5)
         if graph_on:    # the sequential rate of the graph path: slot 0's captured graph, one clip in flight
-            gseq = ClipPipeline(model, w0, 1, graph=True)
-            gseq.slots, gseq.graphs = [slots[0]], {0: pipe.graphs[0]}
+            gseq = ClipPipeline(model, w0, 1, graph=True, keep_results=False)
+            gseq.slots = [pipe.slots[0]]          # slot 0 with its captured graph
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(n_seq):
                 for unit in clips[i % 2]:
                     gseq.submit(unit, im_info, im_shape)
             gseq.drain()
-            seq_rate = n_seq / (time.perf_counter() - t1)
+            seq_rate = n_seq * clips_per_step / (time.perf_counter() - t1)
             _dbg('graph sequential pass done')
-        seq = ClipPipeline(model, w0, 1)       # eager, per-launch events: the durations the roofline is computed from
-        seq.slots = [slots[0]]
+        seq = ClipPipeline(model, w0, 1, graph=False, keep_results=False)   # eager, per-launch events: the durations the roofline is computed from
+        seq.slots = [pipe.slots[0]]
         w0.conv_log = []
         with torch.cuda.stream(st0):
             pr = ops.ConvProfiler(capacity=cap)
@@ -630,7 +567,7 @@ def main():
                 seq.submit(unit, im_info, im_shape)
         seq.drain()
         if seq_rate is None:
-            seq_rate = n_seq / (time.perf_counter() - t1)
+            seq_rate = n_seq * clips_per_step / (time.perf_counter() - t1)
         with torch.cuda.stream(st0):
             records = pr.stop()
         conv_log, w0.conv_log = w0.conv_log, None
@@ -715,23 +652,25 @@ def main():
             'all_conv_event_pair_ms_per_step': round(sum(ms for _, _, ms in c_rec) / max(a.steps, 1), 3),
             'note': 'event pairs of different streams overlap in time: their sum exceeds the wall-clock ms_per_step; they bound a launch\'s '
                     'queueing + execution, not its execution'}
-    value = a.gpus * a.steps / elapsed
+    value = a.gpus * a.steps * (1 if train else clips_per_step) / elapsed
     if train:
         workload = ('3D R-%s FPN3D keypoint R-CNN TRAINING iteration, 1x3x%dx%dx%d clip per step per GPU (forward + 13 losses + backward + '
                     'gradient all-reduce + momentum SGD; 2000 proposals, 512 sampled rois; labels resident)' % (a.arch, T, H, W))
     elif two_d:
-        workload = ('2D R-%s-FPN keypoint R-CNN inference, a step = %d frames of 1x3x%dx%d run one forward per frame '
-                    '(1000 proposals, %d detections in the last frame -> kps_score -> decoded keypoints)' % (a.arch, T, H, W, n_det))
+        workload = ('2D R-%s-FPN keypoint R-CNN inference, a step = %d frames of 1x3x%dx%d run as %d forward(s) of %d frame(s) '
+                    '(per frame: 1000 proposals, %d detections in the last frame -> kps_score -> decoded keypoints)'
+                    % (a.arch, T, H, W, fwd_per_step, B, n_det))
     else:
-        workload = ('3D R-%s FPN3D keypoint R-CNN inference, 1x3x%dx%dx%d clip per step per GPU '
-                    '(kT=3 body+FPN, slice-center 2D heads, 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
-                    % (a.arch, T, H, W, n_det))
+        workload = ('3D R-%s FPN3D keypoint R-CNN inference, %d clip(s) of 1x3x%dx%dx%d per step (= per forward) per GPU '
+                    '(kT=3 body+FPN, slice-center 2D heads, per clip: 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
+                    % (a.arch, B, T, H, W, n_det))
     out = {
         'metric': 'clips/sec (8-frame 800px)', 'value': round(value, 4), 'unit': 'clips/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': workload, 'mode': a.mode, 'name': a.workload,
-                   'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1,
+                   'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1 if train else clips_per_step,
+                   'images_per_forward': 1 if train else B,
                    'clips_in_flight': 1 if train else a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
                    'hip_graph': bool(graph_on),
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
@@ -744,11 +683,13 @@ def main():
         # host-bound when this approaches ms_per_step
         out['host_enqueue_ms_per_step'] = round(host_enqueue_ms, 3)
     if seq_rate is not None:
-        out['sequential_clips_per_s'] = round(seq_rate, 3)      # --pipeline 1 equivalent: one clip in flight, host glue exposed
+        out['sequential_clips_per_s'] = round(seq_rate, 3)      # --pipeline 1 equivalent: one forward in flight, host glue exposed
+    if h2d is not None:
+        out['host_frames'] = h2d
     if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:
         # what the benched arithmetic costs: bf16 vs the fp32 parity mode of the same model on the benched clip
         from detectandtrack_amd.utils import precision
-        out['accuracy_vs_fp32'] = precision.bf16_vs_fp32(model, slots[0][0], clips[0][0], im_info, n_kp=100)
+        out['accuracy_vs_fp32'] = precision.bf16_vs_fp32(model, slots[0][0], clips[0][0][:1].contiguous(), im_info[:1], n_kp=100)
     if not a.no_cpu_baseline and a.gpus == 1:     # CPU baselines are timed on rank 0 of the single-GPU run only
         if not train:
             out['cpu_baseline'] = cpu_baseline(a.arch, T, H, W, two_d, T)

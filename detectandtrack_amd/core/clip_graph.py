@@ -18,16 +18,24 @@ from detectandtrack_amd.core import test as engine
 
 
 class ClipGraph(object):
-    """model.net + device post-processing (+ keypoint net + decode) for one input geometry on one workspace / HIP stream."""
+    """model.net + device post-processing (+ keypoint net + decode) for ONE input geometry on one workspace / HIP stream.  The
+    geometry -- blob shape, im_info rows (blob height / width / scale per image) and the unscaled image shapes -- is baked into the
+    captured launches (`rpn_proposals` / `dat_box_results` take them by value): `launch` refuses anything else."""
 
-    def __init__(self, model, ws, data_like, im_info, im_shape, stream=None, warmup=2):
+    def __init__(self, model, ws, data_like, im_info, im_shape, stream=None, warmup=2, static_data=None):
         assert engine.device_results_supported(), 'graph capture needs the device-side post-processing (cfg.HIP.DEVICE_BOX_RESULTS)'
         self.model, self.ws = model, ws
-        self.im_info = np.asarray(im_info, dtype=np.float32)
-        self.im_shape = tuple(im_shape)
+        B = int(data_like.shape[0])
+        self.im_info = np.asarray(im_info, dtype=np.float32).reshape(-1, 3)
+        assert self.im_info.shape[0] == B, 'im_info has %d rows for a blob of %d images' % (self.im_info.shape[0], B)
+        self.im_shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
+        assert len(self.im_shapes) == B
         self.stream = stream or torch.cuda.current_stream()
-        self.static_data = torch.empty_like(data_like)
-        self.static_data.copy_(data_like)
+        if static_data is not None:         # the caller's own input buffer (filled in place before every launch)
+            self.static_data = static_data
+        else:
+            self.static_data = torch.empty_like(data_like)
+            self.static_data.copy_(data_like)
         ws.FeedBlob('im_info', self.im_info)            # host -> device copy OUTSIDE the capture (the kernels read the host copy)
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):                     # builds the layers, sizes every workspace, primes the allocator
@@ -44,12 +52,21 @@ class ClipGraph(object):
         try:
             self.ws.FeedBlob('data', self.static_data)
             self.ws.RunNet(self.model.net.name)
-            return engine.enqueue_results_on_device(self.model, self.im_shape, float(self.im_info.reshape(-1)[2]))
+            return engine.enqueue_results_on_device(self.model, self.im_shapes, [float(v) for v in self.im_info[:, 2]])
         finally:
             wsmod._GLOBAL = prev
 
-    def launch(self, data_dev):
-        """Enqueue one clip (asynchronous): the resident clip is copied into the graph's input buffer on the graph's stream."""
+    def launch(self, data_dev, im_info=None, im_shape=None):
+        """Enqueue one forward (asynchronous): the resident input is copied into the graph's input buffer on the graph's stream
+        (unless it IS that buffer).  im_info / im_shape, when given, must be the captured ones."""
+        assert tuple(data_dev.shape) == tuple(self.static_data.shape), \
+            'graph captured for a %s blob, launched with %s' % (tuple(self.static_data.shape), tuple(data_dev.shape))
+        if im_info is not None:
+            assert np.array_equal(np.asarray(im_info, np.float32).reshape(-1, 3), self.im_info), \
+                'graph captured for im_info %s, launched with %s' % (self.im_info.tolist(), np.asarray(im_info).tolist())
+        if im_shape is not None:
+            shapes = [tuple(im_shape)] * len(self.im_shapes) if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
+            assert [sh[:2] for sh in shapes] == [sh[:2] for sh in self.im_shapes], (shapes, self.im_shapes)
         with torch.cuda.stream(self.stream):
             if data_dev.data_ptr() != self.static_data.data_ptr():
                 self.static_data.copy_(data_dev, non_blocking=True)
@@ -57,10 +74,12 @@ class ClipGraph(object):
         return self.dev
 
     def results(self):
-        """(cls_boxes, cls_keyps) of the last launched clip, or None on the exact-tie overflow (see read_results_from_device)."""
+        """Per-image (cls_boxes, cls_keyps) list of the last launched forward (None entries: exact-tie overflow, see
+        read_results_from_device); a one-image graph returns its single entry."""
         prev, wsmod._GLOBAL = wsmod._GLOBAL, self.ws
         try:
             with torch.cuda.stream(self.stream):
-                return engine.read_results_from_device(*self.dev)
+                res = engine.read_batch_results_from_device(*self.dev)
+                return res[0] if len(res) == 1 else res
         finally:
             wsmod._GLOBAL = prev

@@ -247,8 +247,14 @@ def _build_defaults():
     # torch.distributed.all_reduce; the process group is then only used to hand the communicator id to the ranks
     # FUSE_STEM_POOL: conv1 + affine + ReLU + pool1 (ResNet3D.py:258-265) as one kernel; the `conv1` blob is then not available
     # to FetchBlob (bit-identical pool1; False = two kernels)
+    # PIPELINE_DEPTH: forwards in flight in core/test_engine.test_net (core/pipeline.ClipPipeline: own HIP stream + blob namespace per
+    # slot, completion-order read-back, uint8 frame upload on a copy stream, dat_preprocess_frames); 1 = strictly sequential;
+    # 0 = the reference's eager loop through im_detect_all (host pre-processing, fp32 upload).  CLIP_GRAPH: every slot replays its
+    # forward as one captured hipGraph.  IMS_PER_FORWARD: independent images (2D models) / clips (3D models) per forward -- the N
+    # axis of the blobs; every image keeps the results it gets alone (the reference runs one image per forward, core/test.py:212-214)
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
-                      'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False})
+                      'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
+                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1})
     return c
 
 

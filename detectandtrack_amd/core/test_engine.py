@@ -64,24 +64,86 @@ def load_clip(entry):
     return out
 
 
+def _pipelined(part):
+    """Can this clip list run on the pipelined engine?  It needs the device post-processing path, frames given as uint8 arrays and
+    no per-frame trunk cache (the sliding-window reuse of cfg.HIP.FRAME_TRUNK_CACHE feeds partial clips: eager path)."""
+    from detectandtrack_amd.core import test as engine
+    if int(cfg.HIP.get('PIPELINE_DEPTH', 0)) < 1 or not engine.device_results_supported() or cfg.MODEL.MASK_ON:
+        return False
+    if cfg.TEST.COMPETITION_MODE or cfg.HIP.FRAME_TRUNK_CACHE > 0 or cfg.HIP.KEYFRAME_DCE:
+        return False
+    for entry in part[:1] + part[-1:]:
+        for f in load_clip(entry):
+            if f.dtype != np.uint8:
+                return False
+    return True
+
+
+def _test_net_pipelined(model, part, all_boxes, all_keyps, timers):
+    """The clip loop on core/pipeline.ClipPipeline: cfg.HIP.IMS_PER_FORWARD clips of equal frame size per forward,
+    cfg.HIP.PIPELINE_DEPTH forwards in flight, results placed by clip index (the detections.pkl order never depends on the
+    completion order)."""
+    from detectandtrack_amd.core.pipeline import ClipPipeline
+    pipe = ClipPipeline(model, workspace.GlobalWorkspace(), depth=int(cfg.HIP.PIPELINE_DEPTH), graph=bool(cfg.HIP.CLIP_GRAPH))
+    per = max(1, int(cfg.HIP.IMS_PER_FORWARD))
+
+    def place(done):
+        for tags, res in done:
+            for i, (cls_boxes_i, _, cls_keyps_i) in zip(tags, res):
+                extend_results(i, all_boxes, cls_boxes_i)
+                if cls_keyps_i is not None:
+                    extend_results(i, all_keyps, cls_keyps_i)
+    timers['im_detect_bbox'].tic()
+    group, gshape = [], None
+    for i, entry in enumerate(part):
+        clip = load_clip(entry)
+        shape = (len(clip),) + tuple(clip[0].shape)
+        if group and (shape != gshape or len(group) == per):
+            pipe.submit_frames([c for _, c in group], tag=[j for j, _ in group])
+            group = []
+        group.append((i, clip))
+        gshape = shape
+        if len(pipe.results) > 64:
+            done, pipe.results = pipe.results, []
+            place(done)
+    if group:
+        pipe.submit_frames([c for _, c in group], tag=[j for j, _ in group])
+    place(pipe.drain())
+    timers['im_detect_bbox'].toc()
+    return pipe
+
+
 def test_net(roidb, ind_range=None, output_dir=None):
-    """Run the detector over roidb[start:end] (one clip per step) and dump detection_range_s_e.pkl (:124-204)."""
+    """Run the detector over roidb[start:end] and dump detection_range_s_e.pkl (:124-204).  Execution mode: the pipelined engine
+    (core/pipeline.py; cfg.HIP.PIPELINE_DEPTH >= 1, default) or the reference's one-clip-at-a-time loop through im_detect_all."""
     model = initialize_model_from_cfg()
     start, end = (0, len(roidb)) if ind_range is None else ind_range
     part = roidb[start:end]
     num_classes = cfg.MODEL.NUM_CLASSES
     all_boxes, all_segms, all_keyps = empty_results(num_classes, len(part))
     timers = defaultdict(Timer)
-    for i, entry in enumerate(part):
-        cls_boxes_i, cls_segms_i, cls_keyps_i = im_detect_all(model, load_clip(entry), None, timers, frame_ids=entry.get('frame_ids'))
-        extend_results(i, all_boxes, cls_boxes_i)
-        if cls_keyps_i is not None:
-            extend_results(i, all_keyps, cls_keyps_i)
-        if i % 10 == 0:
-            logger.info('im_detect: range [%d, %d] of %d: %d/%d  bbox %.3fs misc_bbox %.3fs kps %.3fs misc_kps %.3fs',
-                        start + 1, end, len(roidb), i + 1, len(part), timers['im_detect_bbox'].average_time,
-                        timers['misc_bbox'].average_time, timers['im_detect_keypoints'].average_time,
-                        timers['misc_keypoints'].average_time)
+    test_net.last_stats = None
+    if part and _pipelined(part):
+        pipe = _test_net_pipelined(model, part, all_boxes, all_keyps, timers)
+        rate = pipe.rate()
+        test_net.last_stats = {'clips': len(part), 'seconds': timers['im_detect_bbox'].total_time, 'steady_clips_per_s': rate,
+                               'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
+                               'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH)}
+        logger.info('im_detect: range [%d, %d] of %d: %d clips in %.3fs incl. warm-up%s (pipelined: %d in flight, %d per forward, '
+                    'hipGraph %s, %.1f MB uploaded per clip)', start + 1, end, len(roidb), len(part), timers['im_detect_bbox'].total_time,
+                    ', steady state %.1f clips/s' % rate if rate else '', int(cfg.HIP.PIPELINE_DEPTH), int(cfg.HIP.IMS_PER_FORWARD),
+                    bool(cfg.HIP.CLIP_GRAPH), pipe.upload_bytes / 1e6 / len(part))
+    else:
+        for i, entry in enumerate(part):
+            cls_boxes_i, cls_segms_i, cls_keyps_i = im_detect_all(model, load_clip(entry), None, timers, frame_ids=entry.get('frame_ids'))
+            extend_results(i, all_boxes, cls_boxes_i)
+            if cls_keyps_i is not None:
+                extend_results(i, all_keyps, cls_keyps_i)
+            if i % 10 == 0:
+                logger.info('im_detect: range [%d, %d] of %d: %d/%d  bbox %.3fs misc_bbox %.3fs kps %.3fs misc_kps %.3fs',
+                            start + 1, end, len(roidb), i + 1, len(part), timers['im_detect_bbox'].average_time,
+                            timers['misc_bbox'].average_time, timers['im_detect_keypoints'].average_time,
+                            timers['misc_keypoints'].average_time)
     res = dict(all_boxes=all_boxes, all_segms=all_segms, all_keyps=all_keyps, cfg=yaml.safe_dump(net_utils._plain(cfg)))   # (:199-204)
     if output_dir is not None:
         name = 'detection_range_%s_%s.pkl' % (start, end) if ind_range is not None else 'detections.pkl'

@@ -696,6 +696,23 @@ def kps_finalize(sub, dtype, R, Tr, K, up):
     return out
 
 
+def preprocess_frames(frames, T, scale, pixel_means, pad_stride=0, out=None):
+    """frames: CUDA uint8 [F, h, w, 3] (BGR, HWC) -> the `data` blob fp32 [F / T, 3, T, H, W] (dat_preprocess_frames: mean
+    subtraction, cv2.INTER_LINEAR resize by `scale`, zero padding to a multiple of pad_stride), bit-identical to
+    utils.blob.prep_im_for_blob + im_list_to_blob.  Returns (data, (out_h, out_w))."""
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+    F, h, w, _ = [int(v) for v in frames.shape]
+    oh, ow = int(np.rint(h * scale)), int(np.rint(w * scale))          # cvRound(src * fx): half to even
+    ph, pw = (oh, ow) if not pad_stride else (int(np.ceil(oh / float(pad_stride)) * pad_stride), int(np.ceil(ow / float(pad_stride)) * pad_stride))
+    if out is None:
+        out = torch.empty((F // T, 3, T, ph, pw), dtype=torch.float32, device=frames.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == F * 3 * ph * pw
+    means = (C.c_double * 3)(*[float(v) for v in np.asarray(pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    ctx().call('dat_preprocess_frames', _stream(), _ptr(frames), F, int(T), h, w, C.c_double(scale), C.c_double(scale), oh, ow, ph, pw,
+               means, _ptr(out))
+    return out, (oh, ow)
+
+
 def heatmaps_to_keypoints(maps, boxes, T, K, min_size=0):
     """maps fp32 CUDA [R, T*K, M, M], boxes fp32 CUDA [R, 4T] -> fp32 CUDA [R, 4, T*K] rows (x, y, logit, prob)."""
     R, TK, M, M2 = maps.shape

@@ -38,3 +38,29 @@ def prep_im_for_blob(im, pixel_means, target_sizes, max_size):
         ims.append(image_utils.resize_bilinear(im, fx=scale, fy=scale))
         scales.append(scale)
     return ims, scales
+
+
+def test_scale(frame_shape, target_size, max_size):
+    """The scale prep_im_for_blob applies (:78-85): short side -> target_size, capped so that the long side <= max_size."""
+    short, long_ = min(frame_shape[0:2]), max(frame_shape[0:2])
+    scale = float(target_size) / float(short)
+    if np.round(scale * long_) > max_size:
+        scale = float(max_size) / float(long_)
+    return scale
+
+
+def frames_to_blob_on_device(frames_u8, num_frames, out=None):
+    """prep_im_for_blob + im_list_to_blob for frames that are already on the GPU as a uint8 [F, h, w, 3] tensor (round 3: a clip is
+    uploaded as 3 bytes per source pixel and prepared by dat_preprocess_frames, bit-identical to the host path).
+    Returns (data blob fp32 [F / num_frames, 3, num_frames, H, W] -- or [F, 3, H, W] for 2D models --, scale, im_info rows)."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    assert len(cfg.TEST.SCALES) == 1, 'single-scale inference (TTA is out of the hot-path scope)'
+    h, w = int(frames_u8.shape[1]), int(frames_u8.shape[2])
+    scale = test_scale((h, w), cfg.TEST.SCALES[0], cfg.TEST.MAX_SIZE)
+    T = int(num_frames) if cfg.MODEL.VIDEO_ON else 1
+    data, _ = ops.preprocess_frames(frames_u8, T, scale, cfg.PIXEL_MEANS, int(cfg.FPN.COARSEST_STRIDE) if cfg.FPN.FPN_ON else 0, out=out)
+    n = data.shape[0]
+    im_info = np.tile(np.array([[data.shape[-2], data.shape[-1], scale]], dtype=np.float32), (n, 1))
+    if not cfg.MODEL.VIDEO_ON:
+        data = data.view(n, 3, data.shape[-2], data.shape[-1])
+    return data, scale, im_info

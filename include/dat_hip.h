@@ -159,6 +159,15 @@ int dat_roi_align(dat_ctx* ctx, dat_stream s, int dtype, const dat_roi_level* le
                   float canon_scale, int canon_level, int T, int C, const float* rois, int R, int Tr, int t0,
                   int pooled, int sampling_ratio, void* out);
 
+/* ---- network input on the device (lib/utils/blob.py:40-90, lib/utils/image.py:82-93) -------------- */
+/* frames: DEVICE uint8 [n_frames, h, w, 3] (BGR, HWC: decoded video frames as they are).  data: fp32 [n_frames / T, 3, T, pad_h,
+ * pad_w] = im_list_to_blob(prep_im_for_blob(frame)): float32(frame - pixel_means) resized by (fx, fy) with cv2.INTER_LINEAR
+ * semantics to out_h x out_w (= rint(h * fy) x rint(w * fx), computed by the caller like the reference does), zero-padded to
+ * pad_h x pad_w (a multiple of FPN.COARSEST_STRIDE), channels-first, frames of a clip along T (T = 1, n_frames = N: the 2D
+ * blob [N, 3, pad_h, pad_w]).  pixel_means: HOST double[3] (cfg.PIXEL_MEANS, BGR).  Bit-identical to the host path. */
+int dat_preprocess_frames(dat_ctx* ctx, dat_stream s, const unsigned char* frames, int n_frames, int T, int h, int w, double fx,
+                          double fy, int out_h, int out_w, int pad_h, int pad_w, const double* pixel_means, float* data);
+
 /* ---- small head maths ------------------------------------------------------------------------- */
 /* mean over H,W of [frames,H,W,C] -> [frames,C] fp32 (ReduceBackMean x2, ResNet3D.py:318-319) */
 int dat_spatial_mean(dat_ctx* ctx, dat_stream s, int dtype, const void* x, float* y, int frames, int HW, int C,

@@ -1183,3 +1183,32 @@ def test_batched_proposals_collect_and_box_results_equal_the_one_image_calls(ops
         assert torch.equal(d1, dets_b[i * 30:(i + 1) * 30])
         assert torch.equal(k1[:, 1:], kp_b[i * 30:(i + 1) * 30, 1:])
         assert (kp_b[i * 30:i * 30 + k, 0] == i).all() and not kp_b[i * 30 + k:(i + 1) * 30].any()
+
+
+@pytest.mark.parametrize('h,w,target,max_size,T,stride', [(72, 128, 80, 133, 2, 32), (60, 80, 80, 1333, 1, 32), (97, 53, 64, 100, 3, 0),
+                                                          (720, 1280, 800, 1333, 1, 32)])
+def test_device_preprocessing_is_bit_identical_to_the_host_path(ops, h, w, target, max_size, T, stride):
+    """dat_preprocess_frames (uint8 BGR frames on the device -> `data`) vs the host path it replaces, utils.blob.prep_im_for_blob +
+    im_list_to_blob (reference lib/utils/blob.py:40-90), and vs the independent oracle/resize.py restatement of cv2.INTER_LINEAR:
+    bit-identical fp32 blobs, up- and down-scaling, padded and unpadded, clips and single frames."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import blob as blob_utils
+    from oracle import resize as oresize
+    reset_cfg()
+    rs = np.random.RandomState(h + w)
+    frames = rs.randint(0, 256, (2 * T, h, w, 3)).astype(np.uint8)
+    scale = blob_utils.test_scale((h, w), target, max_size)
+    data, (oh, ow) = ops.preprocess_frames(torch.from_numpy(frames).cuda(), T, scale, cfg.PIXEL_MEANS, stride)
+    got = data.cpu().numpy()
+    assert got.shape[:3] == (2, 3, T)
+    for f in range(2 * T):
+        ims, scales = blob_utils.prep_im_for_blob(frames[f], cfg.PIXEL_MEANS, (target,), max_size)
+        assert scales[0] == scale and ims[0].shape[:2] == (oh, ow)
+        ref = ims[0]
+        ora = oresize.resize_linear((frames[f].astype(np.float32) - cfg.PIXEL_MEANS).astype(np.float32), fx=scale, fy=scale)
+        np.testing.assert_array_equal(ref, ora)
+        mine = got[f // T, :, f % T]
+        np.testing.assert_array_equal(mine[:, :oh, :ow], ref.transpose(2, 0, 1))
+        assert not mine[:, oh:].any() and not mine[:, :, ow:].any()
+    if stride:
+        assert got.shape[3] % stride == 0 and got.shape[4] % stride == 0 and got.shape[3] - oh < stride

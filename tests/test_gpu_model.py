@@ -1,5 +1,7 @@
 """End-to-end GPU parity: the recorded graph executed through the C ABI vs the oracle graph (fp32 parity mode,
 north-star bar: kps_score within 1e-3 max-abs) plus the bf16 performance mode with its own (looser) bound."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -444,3 +446,49 @@ def test_several_images_per_forward_give_each_image_its_own_results(kind, B, T, 
         assert (np.concatenate(diffs) < 1.0).mean() > 0.95
     # different images really are different results (the batch is not image 0 repeated)
     assert _boxes_agree(batch[0][0][1], batch[1][0][1], 1.0) < 0.5
+
+
+def test_pipelined_engine_writes_the_same_detections_as_the_eager_loop(tmp_path):
+    """core/test_engine.test_net on core/pipeline.ClipPipeline (uint8 upload, device pre-processing, several forwards in flight,
+    hipGraph replay, completion-order read-back) must produce the detections.pkl of the reference's one-clip-at-a-time loop
+    (lib/core/test_engine.py:124-204): bit-identical with one clip per forward -- the same kernels on a bit-identical `data` blob --
+    and, with two clips per forward, the same detections up to the summation order of the larger conv grids."""
+    import pickle
+    from detectandtrack_amd.core import test_engine
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd import workspace
+    T, H, W = 2, 96, 128
+    rs = np.random.RandomState(5)
+    roidb = [{'image': [rs.randint(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(T)], 'height': H, 'width': W} for _ in range(7)]
+
+    def run(depth, per, graph, out):
+        c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)     # (fp32: no exactly tied scores at the detection limit)
+        c['TEST'].update(SCALES=(H,), MAX_SIZE=max(H, W), SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+        c['HIP'].update(PIPELINE_DEPTH=depth, IMS_PER_FORWARD=per, CLIP_GRAPH=graph)
+        c['RNG_SEED'] = 3
+        reset_cfg()
+        cfg_from_cfg(c)
+        assert_and_infer_cfg()
+        workspace.ResetWorkspace()
+        os.makedirs(out, exist_ok=True)
+        res = test_engine.test_net(roidb, None, out)
+        with open(os.path.join(out, 'detections.pkl'), 'rb') as f:
+            disk = pickle.load(f)
+        assert sorted(disk) == ['all_boxes', 'all_keyps', 'all_segms', 'cfg']
+        return res, test_engine.test_net.last_stats
+    eager, st0 = run(0, 1, False, str(tmp_path / 'eager'))
+    assert st0 is None
+    for depth, per, graph in ((3, 1, True), (2, 1, False)):
+        got, st = run(depth, per, graph, str(tmp_path / ('p%d%d' % (depth, int(graph)))))
+        assert st['clips'] == 7 and st['per_forward'] == 1 and st['upload_bytes_per_clip'] == T * H * W * 3
+        for i in range(7):
+            np.testing.assert_array_equal(got['all_boxes'][1][i], eager['all_boxes'][1][i])
+            assert len(got['all_keyps'][1][i]) == len(eager['all_keyps'][1][i]) == 15
+            for a, b in zip(got['all_keyps'][1][i], eager['all_keyps'][1][i]):
+                np.testing.assert_array_equal(a, b)
+    got, st = run(2, 2, True, str(tmp_path / 'p22'))           # 7 clips = 3 forwards of two + a forward of one
+    assert st['per_forward'] == 2
+    for i in range(7):
+        a, b = got['all_boxes'][1][i], eager['all_boxes'][1][i]
+        assert a.shape == b.shape == (15, 5)
+        assert _boxes_agree(a, b, 0.5) > 0.85, (i, a[:3], b[:3])
