@@ -686,6 +686,8 @@ def main():
         out['sequential_clips_per_s'] = round(seq_rate, 3)      # --pipeline 1 equivalent: one forward in flight, host glue exposed
     if h2d is not None:
         out['host_frames'] = h2d
+    if not train:    # images whose detections went through the host glue (exact score ties beyond the device buffers' spare rows)
+        out['host_path_images'] = pipe.host_path_images
     if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:
         # what the benched arithmetic costs: bf16 vs the fp32 parity mode of the same model on the benched clip
         from detectandtrack_amd.utils import precision

@@ -58,6 +58,7 @@ class ClipPipeline(object):
         self.fifo = bool(fifo)
         self.host_enqueue_s = 0.0
         self.upload_bytes = 0
+        self.host_path_images = 0   # images that took the host glue (exact score ties beyond the device buffers' spare rows)
         self.finish_times = []      # perf_counter() at every completed forward (steady-state rate of a run: see rate())
         self.device_glue = engine.device_results_supported()
         assert self.device_glue, 'the pipelined engine runs the device post-processing path (cfg.HIP.DEVICE_BOX_RESULTS, hard NMS)'
@@ -189,20 +190,16 @@ class ClipPipeline(object):
 
     def _host_path(self, s, i, im_info, shapes, clips):
         """The reference's host glue for ONE image of a finished forward (box_results_with_nms_and_limit keeps every row tied at the
-        DETECTIONS_PER_IM cut, more than the device buffers hold): its own eager forward, then the host post-processing."""
-        if clips is not None:
-            return engine.im_detect_all(self.model, clips[i], None)
-        # resident `data` blob: re-run this image alone (eager) and take the host glue on its blobs
-        data = s.ws.blobs['data'].t[i:i + 1]
-        s.ws.FeedBlob('data', data)
-        s.ws.FeedBlob('im_info', np.asarray(im_info[i:i + 1], np.float32))
-        s.ws.RunNet(self.model.net.name)
+        DETECTIONS_PER_IM cut -- more than the device buffers hold): its rows of the slot's `rois` / `cls_prob` / `bbox_pred` blobs
+        go through the host post-processing, its boxes through the keypoint net and the device decode."""
         scales = np.array([im_info[i, 2]])
-        scores, boxes, _ = engine._read_bbox_outputs([np.zeros(shapes[i], np.uint8)], scales)
+        ni = int(im_info.shape[0])
+        scores, boxes, _ = engine._read_bbox_outputs([np.zeros(shapes[i], np.uint8)], scales, image=i if ni > 1 else None)
         scores, boxes, cls_boxes = engine.box_results_with_nms_and_limit(scores, boxes)
         cls_keyps = None
         if cfg.MODEL.KEYPOINTS_ON and boxes.shape[0] > 0:
-            cls_keyps = engine.keypoint_results_on_device(self.model, cls_boxes, boxes, scales)
+            cls_keyps = engine.keypoint_results_on_device(self.model, cls_boxes, boxes, scales, image=i)
+        self.host_path_images += 1
         return cls_boxes, None, cls_keyps
 
     def rate(self, skip=None):

@@ -94,17 +94,20 @@ def im_detect_bbox(model, im, boxes=None, frame_ids=None, fetch=True):
     return _read_bbox_outputs(im, im_scales) if fetch else im_scales    # fetch=False: nothing read back (device post-processing)
 
 
-def _read_bbox_outputs(im, im_scales):
+def _read_bbox_outputs(im, im_scales, image=None):
+    """image: with several images per forward, the index of the ONE image whose rows are read (rois col 0 == image)."""
     assert cfg.MODEL.FASTER_RCNN and len(im_scales) == 1, 'Only single-image / single-scale batch implemented'
     rois = workspace.FetchBlob('rois')
+    sel = slice(None) if image is None else np.where(rois[:, 0] == image)[0]
+    rois = rois[sel]
     # float32 / float32(scale): what the reference environment's NumPy 1.14 value-based casting computes (NumPy 2 would promote)
     boxes = rois[:, 1:] / np.float32(im_scales[0])
     scores = workspace.FetchBlob('cls_prob')
-    scores = scores.reshape([-1, scores.shape[-1]])
+    scores = scores.reshape([-1, scores.shape[-1]])[sel]
     time_dim = boxes.shape[-1] // 4
     if cfg.TEST.BBOX_REG:
         box_deltas = workspace.FetchBlob('bbox_pred')
-        box_deltas = box_deltas.reshape([-1, box_deltas.shape[-1]])
+        box_deltas = box_deltas.reshape([-1, box_deltas.shape[-1]])[sel]
         if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG:
             box_deltas = box_deltas[:, -4 * time_dim:]
         pred_boxes = box_utils.bbox_transform(boxes, box_deltas, cfg.MODEL.BBOX_REG_WEIGHTS)
@@ -159,10 +162,11 @@ def im_detect_keypoints(model, im_scales, boxes):
     return heat
 
 
-def keypoint_results_on_device(model, cls_boxes, ref_boxes, im_scales):
+def keypoint_results_on_device(model, cls_boxes, ref_boxes, im_scales, image=0):
     """im_detect_keypoints (:584-627) + keypoint_results (:865-894) without the heatmaps ever leaving the GPU
     (SURVEY.md §8 f-2): run the keypoint net on `ref_boxes`, decode `kps_score` with dat_heatmaps_to_keypoints and
-    fetch only the R x 4 x (17 T) rows.  Same return value as keypoint_results."""
+    fetch only the R x 4 x (17 T) rows.  Same return value as keypoint_results.  image: the batch index of the image the boxes
+    belong to (several images per forward)."""
     from detectandtrack_amd.ops import hip_ops as ops
     import torch
     num_classes = cfg.MODEL.NUM_CLASSES
@@ -173,7 +177,9 @@ def keypoint_results_on_device(model, cls_boxes, ref_boxes, im_scales):
     time_dim = ref_boxes.shape[-1] // 4
     if cfg.KRCNN.NMS_OKS:
         raise NotImplementedError('Handle tubes')
-    workspace.FeedBlob('keypoint_rois', _get_rois_blob(ref_boxes, im_scales))
+    kp_rois = _get_rois_blob(ref_boxes, im_scales)
+    kp_rois[:, 0] = image                               # (column 0 = the image's index in the batch: what RoIAlign reads)
+    workspace.FeedBlob('keypoint_rois', kp_rois)
     workspace.RunNet(model.keypoint_net.Proto().name)
     ws = workspace.GlobalWorkspace()
     heat = ws.blobs['kps_score'].t                      # fp32 [R, 17 T, M, M] on the device
@@ -209,7 +215,10 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     cols = int(rois.t.shape[1])
     T = (cols - 1) // 4
     D = int(cfg.TEST.DETECTIONS_PER_IM)
-    out_cap = D if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)     # no limit: every roi may survive in every class
+    # rows per image: the limit rule keeps EVERY score tied with the D-th best (test.py:795-800), so D rows are not always enough --
+    # frequent with bf16 logits; D/8 spare rows make the overflow (host path for that image) rare.  No limit: every roi may survive
+    # in every class.
+    out_cap = D + max(4, D // 8) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
     dets, kp_rois, n_out = ops.box_results(
         rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,
