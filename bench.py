@@ -210,6 +210,8 @@ def conv_kernel_name(tag, dtype):
         return 'conv3x3_c64_ws_kernel<%s>' % dtype          # weights-stationary persistent kernel (3x3, 64 -> 64)
     if bn == 256 and bp == 32:
         return 'conv1x1_k64_c256_ws_kernel<%s>' % dtype     # weights-stationary 1x1 kernel (64 -> 256: the FPN P2 lateral)
+    if bn == 256 and bp == 33:
+        return 'conv1x1_lw_kernel<%s>' % dtype              # weights-in-LDS persistent 1x1 kernel (HBM-bound bottleneck / lateral layers)
     if bn == 256 and bp == 256:
         return 'conv3x3_bt_kernel<%s,256,256>' % dtype      # big-tile kernel (one wave per SIMD)
     tps = {3: ',tps3', 4: ',tps3'}.get(tag % 10, '')

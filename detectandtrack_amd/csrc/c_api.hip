@@ -48,6 +48,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_ntap = env_int("DAT_CONV_NTAP", 1);   // 0 off, 1 default rule; bit 1 (2/3): unrolled 1x1 variant for every 1x1 layer; bit 2 (5): no dense stride-2 patches
         c->dbg_pack_simple = env_int("DAT_PACK_SIMPLE", 0) != 0;
         c->dbg_ws64 = env_int("DAT_CONV_WS64", 1);
+        c->dbg_pwlw = env_int("DAT_CONV_PWLW", 1);
         c->dbg_linear = env_int("DAT_CONV_LINEAR", 1);
         c->dbg_bt = env_int("DAT_CONV_BT", 0);   // opt-in: measured neutral on the full network (the part is power-limited)
         c->num_cu = 0;

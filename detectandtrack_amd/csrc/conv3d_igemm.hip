@@ -955,6 +955,9 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     } else if (pw256_eligible(ctx, d) && !force_bp && !force_ks) {
         tag = 256 * 10000 + 320 + d->dtype;     // (256 channels x 32 positions per wave: the weights-stationary 1x1 kernel)
         rc = launch_pw256(ctx, st, p);
+    } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks) {
+        tag = 256 * 10000 + 330 + d->dtype;     // (the weights-in-LDS 1x1 kernel: 32 positions per wave tile)
+        rc = launch_pwlw(ctx, st, p, d);
     } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
         tag = 64 * 10000 + 9990 + d->dtype;    // ("999 positions": the persistent weights-stationary kernel)
         rc = launch_ws64(ctx, st, p);

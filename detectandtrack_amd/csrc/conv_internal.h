@@ -104,6 +104,8 @@ bool ws64_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp);
 bool pw256_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp);
+bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
+int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_conv_desc* d);
 bool bt_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int bt_tile_twl(const ConvParams& p, long long* nblocks);
 int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p);

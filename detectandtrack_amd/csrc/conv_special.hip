@@ -366,6 +366,179 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef PW_LOAD
 }
 
+// ---- weights-in-LDS 1x1 kernel: K <= 512 -> C <= 512 (x cout parts), stride 1 | 2 (round 3) --------------------------------------
+// The bottleneck 1x1x1 convs of R-50's res2 / res3 (ResNet3D.py:21-55: 256 -> 64, 512 -> 128, 128 -> 512 + Sum, the stride-2 first
+// convs and shortcuts, :89-101) and the P2 / P3 laterals (FPN3D.py:111-134) are HBM-bound layers over 10^5..10^6 positions that the
+// generic kernel runs at ~2.4 TB/s of algorithmic traffic (profiles/r03/before_conv_layers_3d_r50_fpn3d.txt): short-lived blocks,
+// one 16-KB patch in flight per block, dependent residual loads.  This is conv1x1_k64_c256_ws_kernel's scheme for any K / C whose
+// weight matrix (of one cout part) fits 128 KB of LDS: a persistent block (one per CU) copies the fragment-order weights into LDS
+// once; then every wave streams its own 32-position tiles without ever synchronising -- B fragments straight from global memory
+// into registers (all K channels of a position: KC x 4 16-byte pieces per lane), the NEXT tile's fragments requested before this
+// tile's MFMAs, A fragments by ds_read_b128 (one per MFMA: at the <= 25 % matrix utilisation of these layers that is <= 25 % of the
+// LDS rate), and a per-wave LDS transpose of 32 channels x 32 positions at a time so that every store instruction writes 16
+// complete 64-byte channel runs; the residual rows of transpose group g + 1 are requested before group g is processed.
+// Layers whose weights exceed 128 KB are split into `nsplit` cout parts: block b serves part b % nsplit (the parts read the same
+// input tiles at about the same time: second reads hit L2 / MALL).
+struct PwLwParams {
+    const char* x;
+    const char* w;              // MFMA-fragment order: [64-channel chunk][32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    unsigned npos;              // output positions: frames * Ho * Wo
+    int Ho, Wo, H, W, stride;
+    int in_cs, out_cs, cout;    // channel strides (elements), real output channels
+    int relu, res_mode;
+    int ntiles;                 // wave tiles of 32 positions
+    unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo)
+    int nsplit, mb_total;       // cout parts; Cout_pad / 32
+};
+
+template <int KC, int MBW>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_lw_kernel(const PwLwParams p) {
+    constexpr int EPITCH = 32 * 4 + 16;                 // fp32 transpose row of one position: 32 channels + pad
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    const int part = blockIdx.x % p.nsplit;
+    const int mb_part = p.mb_total / p.nsplit;          // 32-row blocks of this block's cout part
+    const int npass = mb_part / MBW;
+    const int wbytes = KC * mb_part * 4096;
+    char* const wl = smem;                              // [kc][mb_part][ks][lane][16 B]
+    char* const est = smem + wbytes + wave * (32 * EPITCH);
+    // ---- the part's weights -> LDS (once per block) ----
+    for (int i = tid; i < wbytes / 16; i += NTHREADS) {
+        const int frag = i >> 6, l16 = i & 63;          // fragment (kc, mb, ks) of the part, 16-byte piece
+        const int ks = frag & 3, mbl = (frag >> 2) % mb_part, kc = (frag >> 2) / mb_part;
+        const size_t src = ((((size_t)kc * p.mb_total + (size_t)part * mb_part + mbl) * 4 + ks) * 64 + l16) * 16;
+        *(uint4*)(wl + (size_t)i * 16) = *(const uint4*)(p.w + src);
+    }
+    __syncthreads();
+    const int c_part0 = part * mb_part * 32;            // first output channel of the part
+    // store phase: lane = 8 channels (q) of one of 16 positions per round
+    const int sq = lane & 3, spl = lane >> 2;
+    const int nwaves = (gridDim.x / p.nsplit) * 4;
+    int tile = (blockIdx.x / p.nsplit) * 4 + wave;
+    uint4 bcur[KC * 4], bnext[KC * 4];
+#define LW_LOAD(DST_, TILE_)                                                                                          \
+    {                                                                                                                 \
+        const unsigned pos_ = min((unsigned)(TILE_) * 32u + (unsigned)n, p.npos - 1u);                                \
+        unsigned ip_ = pos_;                                                                                          \
+        if (p.stride == 2) {                                                                                          \
+            const unsigned f_ = pos_ / p.how, rem_ = pos_ - f_ * p.how;                                               \
+            const unsigned oh_ = __umulhi(rem_, p.wo_magic), ow_ = rem_ - oh_ * (unsigned)p.Wo;                       \
+            ip_ = (f_ * (unsigned)p.H + 2u * oh_) * (unsigned)p.W + 2u * ow_;                                         \
+        }                                                                                                             \
+        const char* src_ = p.x + ((size_t)ip_ * (unsigned)p.in_cs + (unsigned)khalf * 8u) * 2u;                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < KC * 4; ++i_) DST_[i_] = *(const uint4*)(src_ + (i_ >> 2) * 128 + (i_ & 3) * 32); \
+    }
+    if (tile < p.ntiles) LW_LOAD(bcur, tile);
+    for (; tile < p.ntiles; tile += nwaves) {
+        const int next = tile + nwaves;
+        if (next < p.ntiles) LW_LOAD(bnext, next);
+        const unsigned pos0 = (unsigned)tile * 32u;
+        // residual row address of (round r, this lane's position) -- the same for every channel group of the tile
+        unsigned rrow[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned pos = pos0 + (unsigned)(r * 16 + spl);
+            live[r] = pos < p.npos;
+            const unsigned pc = min(pos, p.npos - 1u);
+            unsigned rpos = pc;
+            if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map (FPN top-down, FPN3D.py:186-222)
+                const unsigned fr = pc / p.how, rem = pc - fr * p.how;
+                const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
+                rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
+            }
+            rrow[r] = rpos;
+        }
+        for (int pass = 0; pass < npass; ++pass) {
+            f32x16_t acc[MBW];
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            const char* wp = wl + (size_t)(pass * MBW) * 4096 + lane * 16;
+            // the residual rows of the pass's first channel group are requested before its MFMAs, the later groups' one group ahead
+            const int cg0 = c_part0 + pass * MBW * 32;         // first channel of this pass
+            uint4 rr[2], rr_next[2];
+            if (p.res_mode) {
+                const unsigned cn = (unsigned)min(cg0 + sq * 8, p.out_cs - 8);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) rr[r] = *(const uint4*)(p.res + ((size_t)rrow[r] * (unsigned)p.out_cs + cn) * 2u);
+            }
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        const uint4 a = *(const uint4*)(wp + ((size_t)(kc * mb_part + mb) * 4 + ks) * 1024);
+                        Mma<DAT_BF16>::step(a, bcur[kc * 4 + ks], acc[mb]);
+                    }
+            // ---- epilogue: 32 channels x 32 positions at a time through this wave's LDS slice ----
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) {
+                const int c0 = cg0 + mb * 32 + sq * 8;         // this lane's 8 channels
+                if (p.res_mode && mb + 1 < MBW) {
+                    const unsigned cn = (unsigned)min(c0 + 32, p.out_cs - 8);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) rr_next[r] = *(const uint4*)(p.res + ((size_t)rrow[r] * (unsigned)p.out_cs + cn) * 2u);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(est + n * EPITCH + (g * 8 + khalf * 4) * 4) =
+                        make_float4(acc[mb][g * 4 + 0], acc[mb][g * 4 + 1], acc[mb][g * 4 + 2], acc[mb][g * 4 + 3]);
+                __builtin_amdgcn_wave_barrier();
+                // scale / bias of the stored channels (padded to p.cout = the stored Cout); channels past it stay the zeros the
+                // zero weight rows produce (the generic kernel does not write them: the blob was allocated zeroed)
+                float sc[8], bi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = c0 + e < p.cout;
+                    sc[e] = ok ? (p.scale ? p.scale[c0 + e] : 1.f) : 0.f;
+                    bi[e] = (ok && p.bias) ? p.bias[c0 + e] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int pl = r * 16 + spl;
+                    const float4 t0 = *(const float4*)(est + pl * EPITCH + sq * 32);
+                    const float4 t1 = *(const float4*)(est + pl * EPITCH + sq * 32 + 16);
+                    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                    if (p.res_mode) {
+                        const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                            v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (live[r] && c0 < p.cout) {
+                        const unsigned pos = pos0 + (unsigned)pl;
+                        *(uint4*)(p.y + ((size_t)pos * (unsigned)p.out_cs + (unsigned)c0) * 2u) =
+                            make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) rr[r] = rr_next[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KC * 4; ++i) bcur[i] = bnext[i];
+    }
+#undef LW_LOAD
+}
+
 // ---- big-tile 3x3 kernel: 256 output channels x 256 positions per block, one block per CU, one wave per SIMD ---------------------
 // The 128 x 256 kernel above feeds 8 MFMAs per k-slice from 6 operand fragments per wave, two blocks per CU: the CU's operand
 // delivery (L1 64 B/clk for the weight fragments, LDS for the patch) is what holds it at ~55 % of the matrix peak (DESIGN.md
@@ -723,6 +896,69 @@ int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     if (dat_ensure_lds(ctx, (const void*)conv1x1_k64_c256_ws_kernel, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
     hipLaunchKernelGGL(conv1x1_k64_c256_ws_kernel, dim3(grid), dim3(NTHREADS), lds, st, p);
     DAT_CHECK_LAUNCH(ctx, "conv1x1_k64_c256_ws");
+    return DAT_OK;
+}
+
+// weights-in-LDS 1x1 kernel (conv1x1_lw_kernel): layers whose weights fit LDS in <= 4 cout parts and that have enough positions
+// for a persistent grid to amortise the weight copy (>= 2 wave tiles per wave)
+static int lw_nsplit(const dat_conv_desc* d) {
+    const long long wbytes = (long long)d->Cin * cout_pad_of(d) * 2;
+    int ns = 1;
+    while (wbytes / ns > 128 * 1024) ns *= 2;
+    return ns;
+}
+
+bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    if (!(ctx->dbg_pwlw && d->dtype == DAT_BF16 && d->KT == 1 && d->KH == 1 && d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->pad_t == 0 &&
+          d->out_tn <= 0 && d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && weights_direct(ctx, d)))
+        return false;
+    const int kc = d->Cin / 64;
+    if (d->Cin % 64 || !(kc == 1 || kc == 2 || kc == 4 || kc == 8)) return false;
+    const int ns = lw_nsplit(d), mbt = cout_pad_of(d) / 32;
+    if (ns > 4 || mbt % ns) return false;
+    const int mbp = mbt / ns;
+    if (!(mbp == 2 || mbp == 4 || mbp % 8 == 0) || (kc == 8 && mbp > 4 && mbp % 4)) return false;
+    if (d->out_cstride % 8 || d->out_cstride < d->Cout) return false;
+    int Ho, Wo;
+    dat_conv3d_out_shape(d, &Ho, &Wo);
+    const long long npos = (long long)d->frames * Ho * Wo;
+    if ((long long)Ho * Wo < 32 || (long long)Ho * Wo * Wo >= (1ll << 32)) return false;
+    if (npos >= (1ll << 31) || (long long)d->frames * d->H * d->W >= (1ll << 31)) return false;
+    // enough work per wave: 256 CUs x 4 waves, at least 2 tiles each per cout part
+    return npos / 32 >= 2ll * 4 * ctx->num_cu / ns;
+}
+
+template <int KC, int MBW>
+static int launch_pwlw_t(dat_ctx* ctx, hipStream_t st, const PwLwParams& p, unsigned grid, size_t lds) {
+    if (dat_ensure_lds(ctx, (const void*)conv1x1_lw_kernel<KC, MBW>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv1x1_lw_kernel<KC, MBW>), dim3(grid), dim3(NTHREADS), lds, st, p);
+    return DAT_OK;
+}
+
+int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_conv_desc* d) {
+    ctx_num_cu(ctx);
+    PwLwParams p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.npos = (unsigned)((long long)cp.frames * cp.Ho * cp.Wo);
+    p.Ho = cp.Ho; p.Wo = cp.Wo; p.H = cp.H; p.W = cp.W; p.stride = cp.sh;
+    p.in_cs = cp.Cin; p.out_cs = cp.out_cs; p.cout = cp.Cout; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    p.ntiles = (int)cdiv_ll(p.npos, 32);
+    p.how = (unsigned)(cp.Ho * cp.Wo);
+    p.wo_magic = cp.Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.Wo - 1) / (unsigned)cp.Wo);
+    p.nsplit = lw_nsplit(d); p.mb_total = cp.Cout_pad / 32;
+    const int kc = cp.Cin / 64, mbp = p.mb_total / p.nsplit;
+    const int mbw = mbp % 8 == 0 && kc <= 4 ? 8 : mbp % 4 == 0 ? 4 : 2;
+    const long long per_part = std::min<long long>(cdiv_ll(p.ntiles, 4), ctx->num_cu / p.nsplit);
+    const unsigned grid = (unsigned)(per_part * p.nsplit);
+    const size_t lds = (size_t)kc * mbp * 4096 + 4 * 32 * (32 * 4 + 16);
+    DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv1x1_lw: %zu bytes of LDS", lds);
+    int rc = DAT_ERR_UNSUPPORTED;
+#define LW_CASE(KC_, MBW_) if (kc == KC_ && mbw == MBW_) rc = launch_pwlw_t<KC_, MBW_>(ctx, st, p, grid, lds);
+    LW_CASE(1, 2) LW_CASE(1, 4) LW_CASE(1, 8) LW_CASE(2, 2) LW_CASE(2, 4) LW_CASE(2, 8) LW_CASE(4, 2) LW_CASE(4, 4) LW_CASE(4, 8)
+    LW_CASE(8, 2) LW_CASE(8, 4)
+#undef LW_CASE
+    if (rc != DAT_OK) DAT_FAIL(ctx, rc, "conv1x1_lw: no instantiation for K chunks %d x %d row blocks", kc, mbw);
+    DAT_CHECK_LAUNCH(ctx, "conv1x1_lw");
     return DAT_OK;
 }
 

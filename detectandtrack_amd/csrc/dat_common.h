@@ -34,6 +34,7 @@ struct dat_ctx {
     int dbg_linear;                         // DAT_CONV_LINEAR (default 1): linear position tiling of small maps (RoI-head 3x3 convs on 14 x 14 maps); 5 = also the 320-position one-block-per-CU tiles
     int dbg_bt;                             // DAT_CONV_BT (default 0 = off; 1 = on for evenly filling grids): big-tile (256 x 256, one wave per SIMD) kernel for 3x3 layers with 256-channel-multiple outputs and an evenly filling grid; 2 = for every grid of >= 1.5 blocks per CU (tests)
     int dbg_ws64;                           // DAT_CONV_WS64 (default 1): weights-stationary persistent kernel for 3x3 64 -> 64 bf16 layers
+    int dbg_pwlw;                           // DAT_CONV_PWLW (default 1): weights-in-LDS persistent kernel for HBM-bound 1x1 layers (K <= 512, weights of a cout part <= 128 KB)
     int num_cu;                             // compute units of the device (persistent-kernel grids)
     int dbg_ntap;                           // DAT_CONV_NTAP (default 1): unrolled-tap variants of the WD kernels (3x3 stride 1, 1x1)
     int dbg_wd;                             // DAT_CONV_WD (default 2): tiles read their weights straight from global memory (1: only the 128-channel ones)

@@ -1212,3 +1212,65 @@ def test_device_preprocessing_is_bit_identical_to_the_host_path(ops, h, w, targe
         assert not mine[:, oh:].any() and not mine[:, :, ow:].any()
     if stride:
         assert got.shape[3] % stride == 0 and got.shape[4] % stride == 0 and got.shape[3] - oh < stride
+
+
+LW_CASES = [
+    # name, T, H, W (input), Cin, Cout, stride, relu, res_mode, affine: layers the weights-in-LDS 1x1 kernel (conv1x1_lw_kernel) takes
+    ('k64_c64', 2, 192, 200, 64, 64, 1, True, 0, True),                     # res2_0_branch2a
+    ('k256_c64', 2, 192, 200, 256, 64, 1, True, 0, True),                   # res2_x_branch2a (R-50)
+    ('k512_c128', 2, 192, 200, 512, 128, 1, True, 0, True),                 # res3_x_branch2a
+    ('k128_c512_sum', 2, 192, 200, 128, 512, 1, True, 1, True),             # res3_x_branch2c + Sum + ReLU: two passes of 256 channels
+    ('k256_c256_up2', 2, 192, 200, 256, 256, 1, False, 2, False),           # FPN P2 lateral of R-50 + top-down Sum
+    ('k512_c256_up2_parts2', 2, 192, 200, 512, 256, 1, False, 2, False),    # P3 lateral: weights 256 KB -> two cout parts
+    ('k256_c512_s2_parts2', 2, 384, 400, 256, 512, 2, False, 0, True),      # res3_0_branch1: stride 2, two cout parts
+    ('k256_c128_s2', 2, 384, 400, 256, 128, 2, True, 0, True),              # res3_0_branch2a: stride 2 (STRIDE_1X1)
+    ('k256_c200_ragged', 2, 191, 201, 256, 200, 1, True, 1, True),          # Cout not a multiple of 32, ragged last tile, odd W
+    ('k128_c15', 3, 190, 202, 128, 15, 1, False, 0, False),                 # an RPN-head-sized output (padded to 64 stored channels)
+]
+
+
+@pytest.mark.parametrize('case', LW_CASES, ids=[c[0] for c in LW_CASES])
+def test_conv1x1_weights_in_lds_kernel(ops, case):
+    """conv1x1_lw_kernel (round 3: HBM-bound 1x1x1 layers of R-50's res2 / res3 and the FPN laterals; ResNet3D.py:21-55, :89-101,
+    FPN3D.py:111-134) against torch and -- bit for bit -- against the generic kernel (forced plan): K = 64..512, one or two
+    channel passes, two cout parts, stride 2, both residual modes, Cout padding, ragged tiles."""
+    name, T, H, W, Cin, Cout, stride, relu, res_mode, affine = case
+    rs = np.random.RandomState(abs(hash(name)) % 1000)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(1, Cin, T, H, W).astype(np.float32))
+    w = q((rs.randn(Cout, Cin, 1, 1, 1) * np.sqrt(2.0 / Cin)).astype(np.float32))
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32) if affine else None
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = res_small = None
+    if res_mode == 1:
+        res = q(rs.randn(1, Cout, T, Ho, Wo).astype(np.float32))
+    elif res_mode == 2:
+        res_small = q(rs.randn(1, Cout, T, Ho // 2, Wo // 2).astype(np.float32))
+        res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    ref = _conv_ref(x, w, scale, bias, res, (stride, stride), (0, 0, 0), relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(stride, stride), pads=(0, 0, 0),
+                          relu=relu, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    rd = None
+    if res_mode == 1:
+        rd = ops.to_ndhwc(_dev(res), 1, layer.cstride)
+    elif res_mode == 2:
+        rd = ops.to_ndhwc(_dev(res_small), 1, layer.cstride)
+    prof = ops.ConvProfiler(capacity=8)
+    prof.start()
+    y = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    rec = prof.stop()
+    assert [t for t, _, _ in rec] == [2560331], 'the layer did not take the weights-in-LDS kernel: tags %r' % ([t for t, _, _ in rec],)
+    try:
+        assert ops.tune_plan(128, 1) == 0
+        y_gen = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    finally:
+        ops.tune_plan(0, 0)
+    assert torch.equal(y, y_gen), 'differs from the generic kernel in %d elements' % int((y != y_gen).sum())
+    got = ops.to_ncdhw(y, 1, 1, Cout, T).cpu().numpy()
+    err = np.abs(got - ref).max()
+    print('lw %s max-abs err %.3e (ref max %.2f)' % (name, err, np.abs(ref).max()))
+    assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    if layer.cstride > Cout:          # the padding channels of the blob stay zero
+        assert not y[..., Cout:].any()

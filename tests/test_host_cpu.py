@@ -733,6 +733,7 @@ def test_bench_kernel_names_and_side_run_table():
     assert bench.conv_kernel_name(649991, 'bf16') == 'conv3x3_c64_ws_kernel<bf16>'
     assert bench.conv_kernel_name(2560321, 'bf16') == 'conv1x1_k64_c256_ws_kernel<bf16>'
     assert bench.conv_kernel_name(2562561, 'bf16') == 'conv3x3_bt_kernel<bf16,256,256>'
+    assert bench.conv_kernel_name(2560331, 'bf16') == 'conv1x1_lw_kernel<bf16>'
     import inspect
     src = inspect.getsource(bench.other_configs)
     for w in ('2d_r50_fpn', '3d_r50_fpn3d', "'--mode', 'train'"):
