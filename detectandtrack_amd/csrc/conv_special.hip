@@ -395,29 +395,36 @@ struct PwLwParams {
     int nsplit, mb_total;       // cout parts; Cout_pad / 32
 };
 
-template <int KC, int MBW>
+template <int KC, int MBW, int NPASS>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_lw_kernel(const PwLwParams p) {
     constexpr int EPITCH = 32 * 4 + 16;                 // fp32 transpose row of one position: 32 channels + pad
+    constexpr int MBP = MBW * NPASS;                    // 32-row blocks of a block's cout part
+    constexpr int WBYTES = KC * MBP * 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, n = lane & 31;
     const int part = blockIdx.x % p.nsplit;
-    const int mb_part = p.mb_total / p.nsplit;          // 32-row blocks of this block's cout part
-    const int npass = mb_part / MBW;
-    const int wbytes = KC * mb_part * 4096;
-    char* const wl = smem;                              // [kc][mb_part][ks][lane][16 B]
-    char* const est = smem + wbytes + wave * (32 * EPITCH);
-    // ---- the part's weights -> LDS (once per block) ----
-    for (int i = tid; i < wbytes / 16; i += NTHREADS) {
+    char* const wl = smem;                              // [kc][MBP][ks][lane][16 B]
+    float* const sbl = (float*)(smem + WBYTES);         // scale[MBP * 32], bias[MBP * 32] of the part's channels
+    char* const est = smem + WBYTES + MBP * 32 * 8 + wave * (32 * EPITCH);
+    const int c_part0 = part * MBP * 32;                // first output channel of the part
+    // ---- the part's weights, scale and bias -> LDS (once per block).  No global load may sit inside the store phase of a tile:
+    // vmcnt is one in-order counter for loads AND stores, so waiting for such a load waits for every store issued before it ----
+    for (int i = tid; i < WBYTES / 16; i += NTHREADS) {
         const int frag = i >> 6, l16 = i & 63;          // fragment (kc, mb, ks) of the part, 16-byte piece
-        const int ks = frag & 3, mbl = (frag >> 2) % mb_part, kc = (frag >> 2) / mb_part;
-        const size_t src = ((((size_t)kc * p.mb_total + (size_t)part * mb_part + mbl) * 4 + ks) * 64 + l16) * 16;
+        const int ks = frag & 3, mbl = (frag >> 2) % MBP, kc = (frag >> 2) / MBP;
+        const size_t src = ((((size_t)kc * p.mb_total + (size_t)part * MBP + mbl) * 4 + ks) * 64 + l16) * 16;
         *(uint4*)(wl + (size_t)i * 16) = *(const uint4*)(p.w + src);
     }
+    for (int i = tid; i < MBP * 32; i += NTHREADS) {
+        const int c = c_part0 + i;
+        const bool ok = c < p.cout;                     // channels past the stored Cout stay the zeros their zero weight rows produce
+        sbl[i] = ok ? (p.scale ? p.scale[c] : 1.f) : 0.f;
+        sbl[MBP * 32 + i] = (ok && p.bias) ? p.bias[c] : 0.f;
+    }
     __syncthreads();
-    const int c_part0 = part * mb_part * 32;            // first output channel of the part
-    // store phase: lane = 8 channels (q) of one of 16 positions per round
+    // store phase: lane = 8 channels (sq) of one of 16 positions per round
     const int sq = lane & 3, spl = lane >> 2;
     const int nwaves = (gridDim.x / p.nsplit) * 4;
     int tile = (blockIdx.x / p.nsplit) * 4 + wave;
@@ -439,69 +446,63 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int next = tile + nwaves;
         if (next < p.ntiles) LW_LOAD(bnext, next);
         const unsigned pos0 = (unsigned)tile * 32u;
-        // residual row address of (round r, this lane's position) -- the same for every channel group of the tile
-        unsigned rrow[2];
         bool live[2];
+        // ALL residual rows of the tile are requested now, before its MFMAs: one wave per SIMD has nothing else to hide their latency
+        // behind, and a load issued between the stores would make its wait a wait for those stores
+        uint4 rr[NPASS][MBW][2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const unsigned pos = pos0 + (unsigned)(r * 16 + spl);
             live[r] = pos < p.npos;
-            const unsigned pc = min(pos, p.npos - 1u);
-            unsigned rpos = pc;
-            if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map (FPN top-down, FPN3D.py:186-222)
-                const unsigned fr = pc / p.how, rem = pc - fr * p.how;
-                const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
-                rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
+            if (p.res_mode) {
+                const unsigned pc = min(pos, p.npos - 1u);
+                unsigned rpos = pc;
+                if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map (FPN top-down, FPN3D.py:186-222)
+                    const unsigned fr = pc / p.how, rem = pc - fr * p.how;
+                    const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
+                    rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
+                }
+                const char* rb = p.res + ((size_t)rpos * (unsigned)p.out_cs) * 2u;
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
+                        rr[pass][mb][r] = *(const uint4*)(rb + c * 2u);
+                    }
             }
-            rrow[r] = rpos;
         }
-        for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
             f32x16_t acc[MBW];
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             const char* wp = wl + (size_t)(pass * MBW) * 4096 + lane * 16;
-            // the residual rows of the pass's first channel group are requested before its MFMAs, the later groups' one group ahead
-            const int cg0 = c_part0 + pass * MBW * 32;         // first channel of this pass
-            uint4 rr[2], rr_next[2];
-            if (p.res_mode) {
-                const unsigned cn = (unsigned)min(cg0 + sq * 8, p.out_cs - 8);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) rr[r] = *(const uint4*)(p.res + ((size_t)rrow[r] * (unsigned)p.out_cs + cn) * 2u);
-            }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb) {
-                        const uint4 a = *(const uint4*)(wp + ((size_t)(kc * mb_part + mb) * 4 + ks) * 1024);
+                        const uint4 a = *(const uint4*)(wp + ((size_t)(kc * MBP + mb) * 4 + ks) * 1024);
                         Mma<DAT_BF16>::step(a, bcur[kc * 4 + ks], acc[mb]);
                     }
-            // ---- epilogue: 32 channels x 32 positions at a time through this wave's LDS slice ----
+            // ---- epilogue: 32 channels x 32 positions at a time through this wave's LDS slice; LDS and stores only ----
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) {
-                const int c0 = cg0 + mb * 32 + sq * 8;         // this lane's 8 channels
-                if (p.res_mode && mb + 1 < MBW) {
-                    const unsigned cn = (unsigned)min(c0 + 32, p.out_cs - 8);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) rr_next[r] = *(const uint4*)(p.res + ((size_t)rrow[r] * (unsigned)p.out_cs + cn) * 2u);
-                }
+                const int cl = (pass * MBW + mb) * 32 + sq * 8;    // this lane's 8 channels inside the part
+                const int c0 = c_part0 + cl;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *(float4*)(est + n * EPITCH + (g * 8 + khalf * 4) * 4) =
                         make_float4(acc[mb][g * 4 + 0], acc[mb][g * 4 + 1], acc[mb][g * 4 + 2], acc[mb][g * 4 + 3]);
                 __builtin_amdgcn_wave_barrier();
-                // scale / bias of the stored channels (padded to p.cout = the stored Cout); channels past it stay the zeros the
-                // zero weight rows produce (the generic kernel does not write them: the blob was allocated zeroed)
-                float sc[8], bi[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool ok = c0 + e < p.cout;
-                    sc[e] = ok ? (p.scale ? p.scale[c0 + e] : 1.f) : 0.f;
-                    bi[e] = (ok && p.bias) ? p.bias[c0 + e] : 0.f;
-                }
+                const float4 s0 = *(const float4*)(sbl + cl), s1 = *(const float4*)(sbl + cl + 4);
+                const float4 b0 = *(const float4*)(sbl + MBP * 32 + cl), b1 = *(const float4*)(sbl + MBP * 32 + cl + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float bi[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int pl = r * 16 + spl;
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
                     if (p.res_mode) {
-                        const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
+                        const uint4 q = rr[pass][mb][r];
+                        const uint32_t ru[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int e2 = 0; e2 < 4; ++e2) {
                             v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
@@ -529,8 +531,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 2; ++r) rr[r] = rr_next[r];
             }
         }
 #pragma unroll
@@ -917,7 +917,8 @@ bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
     const int ns = lw_nsplit(d), mbt = cout_pad_of(d) / 32;
     if (ns > 4 || mbt % ns) return false;
     const int mbp = mbt / ns;
-    if (!(mbp == 2 || mbp == 4 || mbp % 8 == 0) || (kc == 8 && mbp > 4 && mbp % 4)) return false;
+    if (!(mbp == 2 || mbp == 4 || mbp == 8 || mbp == 16) || (kc == 8 && mbp > 4)) return false;
+    if ((long long)kc * mbp * 4096 + mbp * 256 + 4 * 32 * 144 > 160 * 1024) return false;
     if (d->out_cstride % 8 || d->out_cstride < d->Cout) return false;
     int Ho, Wo;
     dat_conv3d_out_shape(d, &Ho, &Wo);
@@ -928,10 +929,10 @@ bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
     return npos / 32 >= 2ll * 4 * ctx->num_cu / ns;
 }
 
-template <int KC, int MBW>
+template <int KC, int MBW, int NPASS>
 static int launch_pwlw_t(dat_ctx* ctx, hipStream_t st, const PwLwParams& p, unsigned grid, size_t lds) {
-    if (dat_ensure_lds(ctx, (const void*)conv1x1_lw_kernel<KC, MBW>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_lw_kernel<KC, MBW>), dim3(grid), dim3(NTHREADS), lds, st, p);
+    if (dat_ensure_lds(ctx, (const void*)conv1x1_lw_kernel<KC, MBW, NPASS>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv1x1_lw_kernel<KC, MBW, NPASS>), dim3(grid), dim3(NTHREADS), lds, st, p);
     return DAT_OK;
 }
 
@@ -947,17 +948,19 @@ int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_co
     p.wo_magic = cp.Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.Wo - 1) / (unsigned)cp.Wo);
     p.nsplit = lw_nsplit(d); p.mb_total = cp.Cout_pad / 32;
     const int kc = cp.Cin / 64, mbp = p.mb_total / p.nsplit;
-    const int mbw = mbp % 8 == 0 && kc <= 4 ? 8 : mbp % 4 == 0 ? 4 : 2;
+    const int mbw = kc <= 4 ? std::min(mbp, 8) : std::min(mbp, 4), npass = mbp / mbw;
     const long long per_part = std::min<long long>(cdiv_ll(p.ntiles, 4), ctx->num_cu / p.nsplit);
     const unsigned grid = (unsigned)(per_part * p.nsplit);
-    const size_t lds = (size_t)kc * mbp * 4096 + 4 * 32 * (32 * 4 + 16);
+    const size_t lds = (size_t)kc * mbp * 4096 + (size_t)mbp * 32 * 8 + 4 * 32 * (32 * 4 + 16);
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv1x1_lw: %zu bytes of LDS", lds);
     int rc = DAT_ERR_UNSUPPORTED;
-#define LW_CASE(KC_, MBW_) if (kc == KC_ && mbw == MBW_) rc = launch_pwlw_t<KC_, MBW_>(ctx, st, p, grid, lds);
-    LW_CASE(1, 2) LW_CASE(1, 4) LW_CASE(1, 8) LW_CASE(2, 2) LW_CASE(2, 4) LW_CASE(2, 8) LW_CASE(4, 2) LW_CASE(4, 4) LW_CASE(4, 8)
-    LW_CASE(8, 2) LW_CASE(8, 4)
+#define LW_CASE(KC_, MBW_, NP_) if (kc == KC_ && mbw == MBW_ && npass == NP_) rc = launch_pwlw_t<KC_, MBW_, NP_>(ctx, st, p, grid, lds);
+    LW_CASE(1, 2, 1) LW_CASE(1, 4, 1) LW_CASE(1, 8, 1) LW_CASE(1, 8, 2)
+    LW_CASE(2, 2, 1) LW_CASE(2, 4, 1) LW_CASE(2, 8, 1) LW_CASE(2, 8, 2)
+    LW_CASE(4, 2, 1) LW_CASE(4, 4, 1) LW_CASE(4, 8, 1)
+    LW_CASE(8, 2, 1) LW_CASE(8, 4, 1)
 #undef LW_CASE
-    if (rc != DAT_OK) DAT_FAIL(ctx, rc, "conv1x1_lw: no instantiation for K chunks %d x %d row blocks", kc, mbw);
+    if (rc != DAT_OK) DAT_FAIL(ctx, rc, "conv1x1_lw: no instantiation for K chunks %d x %d row blocks x %d passes", kc, mbw, npass);
     DAT_CHECK_LAUNCH(ctx, "conv1x1_lw");
     return DAT_OK;
 }
