@@ -43,7 +43,13 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False):
+def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
+    if tube:    # the declared FPN tube-head extension (dead reference design lib/modeling/FPN3D.py:232-330 + tube rois on
+        # the 2-MLP head, head_builder.py:29-33, + the 3D keypoint head): the body stays 3D up to the heads (BODY_HEAD_LINK '')
+        c = model_cfg(arch, T, dtype)
+        c['VIDEO']['BODY_HEAD_LINK'] = ''
+        c['KRCNN'].update(ROI_KEYPOINTS_HEAD='keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d', NO_3D_DECONV_TIME_TO_CH=True)
+        return c
     if two_d:   # BASELINE configs 1-2: pure 2D R-50-FPN keypoint R-CNN (lib/modeling/FPN.py:114-202, ResNet.py:231-266)
         c = model_cfg(arch, 1, dtype)
         c['MODEL'].update(CONV_BODY='FPN.add_fpn_ResNet%s_conv5_body' % arch, VIDEO_ON=False)
@@ -184,13 +190,13 @@ def synthetic_clip(T, H, W, seed):
     return (data - means).contiguous()
 
 
-def build(arch, T, dtype, keyframe_dce=False, two_d=False):
+def build(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
     from detectandtrack_amd.utils import net as net_utils
     from detectandtrack_amd import workspace
     reset_cfg()
-    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce, two_d))
+    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce, two_d, tube))
     assert_and_infer_cfg()
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     workspace.ResetWorkspace()
@@ -354,7 +360,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn'],
+    ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn', '3d_r18_fpn3d_tube'],
                     help='default 3d_r18_fpn3d (BASELINE config 3); 2d_r50_fpn = config 2 (a step = 8 frames, one forward per frame)')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help='train: one training iteration per step (config 4)')
     ap.add_argument('--arch', default=None, choices=['18', '50', '101'], help='shorthand for --workload 3d_r<arch>_fpn3d')
@@ -373,7 +379,7 @@ def main():
     ap.add_argument('--h2d', type=int, default=1,
                     help='1: also time the same pipeline fed from HOST uint8 720 x 1280 frames (pinned staging, uint8 upload on a copy stream, '
                          'dat_preprocess_frames) and report it as value_including_upload next to value (which is the resident-input rate)')
-    ap.add_argument('--pipeline', type=int, default=4, help='clips in flight per GPU (1 = strictly sequential; 2 / 3 / 4 / 5 measured 206.9 / 214.7 / 217.9 / 208.9 clips/s)')
+    ap.add_argument('--pipeline', type=int, default=None, help='clips in flight per GPU (1 = strictly sequential; 2 / 3 / 4 / 5 measured 206.9 / 214.7 / 217.9 / 208.9 clips/s)')
     ap.add_argument('--fifo', action='store_true', help='service the clips in flight in submission order (A/B switch; default: completion order)')
     ap.add_argument('--graph', type=int, default=1, help='1: every slot replays its clip as one captured hipGraph (core/clip_graph.py); 0: eager launches')
     ap.add_argument('--keyframe-dce', action='store_true',
@@ -382,10 +388,13 @@ def main():
     a = ap.parse_args()
     if a.workload is None:
         a.workload = '3d_r%s_fpn3d' % (a.arch or '18')
+    if a.pipeline is None:
+        a.pipeline = 3 if a.workload == '3d_r18_fpn3d' and a.mode == 'infer' and not a.batch else 4 if not a.workload.endswith('_tube') else 2
     two_d = a.workload == '2d_r50_fpn'
+    tube = a.workload.endswith('_tube')
     a.arch = '50' if two_d else a.workload.split('_')[1][1:]
     train = a.mode == 'train'
-    assert not (train and two_d), '--mode train benches the 3D FPN models (BASELINE config 4)'
+    assert not (train and (two_d or tube)), '--mode train benches the 3D FPN models with 2D heads (BASELINE config 4)'
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -406,7 +415,8 @@ def main():
     from detectandtrack_amd.ops import hip_ops as ops
     T, H, W = a.frames, a.height, a.width
     # images per forward B; a step = ONE forward of B clips (3D) or the T frames of a 2D step in T / B forwards
-    B = a.batch if a.batch else (T if two_d else 1)
+    # default: 4 clips per forward for the headline workload (3 forwards in flight: measured best), all 8 frames of a 2D step
+    B = a.batch if a.batch else (T if two_d else 4 if (a.workload == '3d_r18_fpn3d' and not train) else 1)
     assert B >= 1 and (not two_d or T % B == 0), '--batch must divide --frames for the 2D workload'
     fwd_per_step = T // B if two_d else 1
     clips_per_step = 1 if two_d else B          # what `value` counts per step: a 2D step is one 8-frame clip, a 3D step B clips
@@ -428,7 +438,7 @@ def main():
             torch.cuda.synchronize()
         n_det = 512
     else:
-        model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d)
+        model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d, tube)
         # every rank gets its own clips (weak scaling): seed by rank.  2D: the frames of a clip are fed one by one.
         from detectandtrack_amd.core.pipeline import ClipPipeline
         if two_d:   # a step = T frames in T / B forwards of B frames
@@ -662,6 +672,11 @@ def main():
         workload = ('2D R-%s-FPN keypoint R-CNN inference, a step = %d frames of 1x3x%dx%d run as %d forward(s) of %d frame(s) '
                     '(per frame: 1000 proposals, %d detections in the last frame -> kps_score -> decoded keypoints)'
                     % (a.arch, T, H, W, fwd_per_step, B, n_det))
+    elif tube:
+        workload = ('3D R-%s FPN3D keypoint R-CNN with TUBE heads (declared extension of the reference\'s dead FPN3D RPN design), %d clip(s) of '
+                    '1x3x%dx%dx%d per step per GPU (kT=3 body+FPN kept 3D to the heads, tube RPN per level, tube rois on the 2-MLP head, 3D keypoint '
+                    'head; per clip: 1000 tube proposals, %d tube detections -> kps_score [R, 17*T, 56, 56] -> decoded keypoints)'
+                    % (a.arch, B, T, H, W, n_det))
     else:
         workload = ('3D R-%s FPN3D keypoint R-CNN inference, %d clip(s) of 1x3x%dx%dx%d per step (= per forward) per GPU '
                     '(kT=3 body+FPN, slice-center 2D heads, per clip: 1000 proposals, %d detections -> kps_score -> decoded keypoints)'
@@ -673,7 +688,8 @@ def main():
         'config': {'workload': workload, 'mode': a.mode, 'name': a.workload,
                    'weights': 'random-init (synthetic_params, seed 3)', 'clips_per_step_per_gpu': 1 if train else clips_per_step,
                    'images_per_forward': 1 if train else B,
-                   'clips_in_flight': 1 if train else a.pipeline, 'keyframe_dce': bool(a.keyframe_dce),
+                   'forwards_in_flight': 1 if train else a.pipeline, 'clips_in_flight': 1 if train else a.pipeline * clips_per_step,
+                   'keyframe_dce': bool(a.keyframe_dce),
                    'hip_graph': bool(graph_on),
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
@@ -695,7 +711,7 @@ def main():
         from detectandtrack_amd.utils import precision
         out['accuracy_vs_fp32'] = precision.bf16_vs_fp32(model, slots[0][0], clips[0][0][:1].contiguous(), im_info[:1], n_kp=100)
     if not a.no_cpu_baseline and a.gpus == 1:     # CPU baselines are timed on rank 0 of the single-GPU run only
-        if not train:
+        if not train and not tube:
             out['cpu_baseline'] = cpu_baseline(a.arch, T, H, W, two_d, T)
             out['cpu_proposal_path'] = cpu_proposal_path(H, W)
         out['cpu_tracker'] = cpu_tracker_baseline()
@@ -717,7 +733,8 @@ def other_configs():
     runs = [('config2_2d_r50_fpn_inference', ['--workload', '2d_r50_fpn']),
             ('config4_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']),
             ('config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
-            ('config3_3d_r18_fpn3d_training', ['--mode', 'train'])]
+            ('config3_3d_r18_fpn3d_training', ['--mode', 'train']),
+            ('extension_3d_r18_fpn3d_tube_heads_inference', ['--workload', '3d_r18_fpn3d_tube'])]
     res = {}
     for name, extra in runs:
         cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline',
