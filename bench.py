@@ -41,6 +41,31 @@ def _dbg(msg):
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E, MI355X_MICROARCH.md
+
+
+def stem_roofline(ws, data_dev, dtype, reps=20):
+    """conv1 + AffineChannelNd + ReLU + pool1 (one launch of stem_pool_kernel) on the benched input: algorithmic bytes = the fp32 `data`
+    blob read once + `pool1` written once (the 264 MB-per-clip `conv1` blob never exists), timed with an event pair around `reps`
+    back-to-back launches on the current stream."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    stem = [l for l in ws._layers.values() if isinstance(l, ops.StemConv)]
+    assert stem, 'no fused stem layer in this workspace'
+    data = data_dev if data_dev.dim() == 5 else data_dev[:, :, None]
+    out = stem[0].pooled(data)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        stem[0].pooled(data)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = data.numel() * 4 + out.numel() * out.element_size()
+    return {'kernel': 'stem_pool_kernel<%s>' % dtype, 'bound': 'hbm', 'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(ms, 4),
+            'algorithmic_bytes_per_launch': int(nbytes),
+            'measured': '%d back-to-back launches on the benched `data` blob (%s) between one HIP-event pair' % (reps, 'x'.join(str(v) for v in data.shape))}
 
 
 def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
@@ -664,6 +689,22 @@ def main():
             'all_conv_event_pair_ms_per_step': round(sum(ms for _, _, ms in c_rec) / max(a.steps, 1), 3),
             'note': 'event pairs of different streams overlap in time: their sum exceeds the wall-clock ms_per_step; they bound a launch\'s '
                     'queueing + execution, not its execution'}
+    # ---- the HBM-bound kernel class, scored in GB/s against the 8 TB/s HBM3E peak (1x1x1 convs, conv1, pooling are
+    # HBM-bound): the persistent 1x1 kernels from the same per-launch event pairs, the fused stem from its own timed launches ----
+    roofline_hbm = []
+    for tags_, kname in (((2560331,), 'conv1x1_lw_kernel<%s>' % a.dtype), ((2560321,), 'conv1x1_k64_c256_ws_kernel<%s>' % a.dtype)):
+        sel = [(ms, nb) for (tag, _, ms), (_, _fl, nb) in zip(records, conv_log) if tag in tags_ and nb > 0]
+        if sel:
+            tms, tb = sum(m for m, _ in sel), sum(b for _, b in sel)
+            roofline_hbm.append({'kernel': kname, 'bound': 'hbm', 'achieved': round(tb / (tms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,
+                                 'unit': 'GB/s', 'frac': round(tb / (tms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'launches_per_step': round(len(sel) / float(max(prof_steps, 1)), 2),
+                                 'avg_launch_ms': round(tms / len(sel), 4), 'algorithmic_bytes_per_launch': round(tb / len(sel)),
+                                 'measured': 'the same per-launch HIP-event pairs as `roofline` (bytes: each logical tensor read / written once)'})
+    if not train:
+        try:
+            roofline_hbm.append(stem_roofline(slots[0][0], clips[0][0], a.dtype))
+        except Exception as e:   # noqa: BLE001
+            roofline_hbm.append({'kernel': 'stem_pool_kernel', 'error': repr(e)})
     value = a.gpus * a.steps * (1 if train else clips_per_step) / elapsed
     if train:
         workload = ('3D R-%s FPN3D keypoint R-CNN TRAINING iteration, 1x3x%dx%dx%d clip per step per GPU (forward + 13 losses + backward + '
@@ -695,6 +736,7 @@ def main():
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
         'ranks_seen': ranks_seen,
         'roofline': roofline,
+        'roofline_hbm': roofline_hbm,
     }
     if host_enqueue_ms is not None:
         # host time spent enqueueing a step's kernel launches (Python executor + ctypes, no synchronisation): the step is

@@ -937,15 +937,17 @@ int dat_nms_host(dat_ctx* ctx, int* keep_out, int* num_out, const float* boxes_h
 // The one real C ABI of the reference tree, lib/nms/gpu_nms.hpp:3-9, with its exact prototype and conventions
 // (lib/nms/nms_kernel.cu:94-150): HOST pointers, boxes [boxes_num, 5] PRE-SORTED by score and visited as given, a box is
 // suppressed when IoU > thresh (strict, :71 -- the Cython CPU path uses >=), keep_out = positions in the given order,
-// synchronous, selects the device, errors are only printed.  One lazily created context per device, calls serialised.
+// synchronous, selects the device, errors are only printed.  One lazily created context + lock per device.
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh,
           int device_id) {
-    static std::mutex mu;
+    // one lazily created context AND one lock per device: callers on different GPUs of one process (one-process-N-GPU training, the
+    // reference's NUM_GPUS loop) do not serialise behind each other; calls on the same device do (the context's scratch is shared)
+    static std::mutex mu[64];
     static dat_ctx* per_device[64] = {nullptr};
-    std::lock_guard<std::mutex> lock(mu);
     if (num_out) *num_out = 0;
     if (device_id < 0 || device_id >= 64) { fprintf(stderr, "_nms: device_id %d out of range\n", device_id); return; }
     if (boxes_dim != 5) { fprintf(stderr, "_nms: boxes_dim %d != 5 (the reference kernel indexes rows of 5 floats)\n", boxes_dim); return; }
+    std::lock_guard<std::mutex> lock(mu[device_id]);
     if (!per_device[device_id] && dat_ctx_create(&per_device[device_id], device_id) != DAT_OK) {
         fprintf(stderr, "_nms: no usable device %d\n", device_id);
         per_device[device_id] = nullptr;

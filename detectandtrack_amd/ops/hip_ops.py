@@ -192,7 +192,10 @@ class ConvLayer(object):
         ho, wo = self.out_hw(H, W)
         in_frames = frames if oframes is None else min(frames, oframes * self.kt)   # key-frame outputs read kt frames
         oframes = frames if oframes is None else oframes
-        b = in_frames * H * W * self.cin * es + self.kt * self.kh * self.kw * self.cout * self.cin * es
+        in_pos = H * W
+        if self.kh == 1 and self.kw == 1:        # a strided 1x1 conv touches only the sampled positions of its input
+            in_pos = ho * wo
+        b = in_frames * in_pos * self.cin * es + self.kt * self.kh * self.kw * self.cout * self.cin * es
         b += oframes * ho * wo * self.cstride * es
         if res_mode == 1:
             b += oframes * ho * wo * self.cstride * es

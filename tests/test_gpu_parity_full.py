@@ -136,3 +136,67 @@ def test_2d_r50_fpn_bf16_frames_run_through_the_engine_surface():
         assert len(cls_keyps[1]) == n and cls_keyps[1][0].shape == (4, 17)
         k = np.stack(cls_keyps[1])
         assert np.isfinite(k).all() and k[:, 0].min() >= -1 and k[:, 0].max() <= 1281 and k[:, 1].max() <= 721
+
+
+def test_2d_r50_fpn_eight_frames_in_one_forward_match_the_oracle_frame_by_frame():
+    """BASELINE config 2 (S-B) the way round 3 runs it: EIGHT 768 x 1344 frames in ONE forward (N = 8 on the blob axis, the image as a
+    grid dimension of the proposal / detection kernels) against the oracle looped one frame at a time (the reference's own
+    protocol, lib/core/test.py:212-214) -- fp32 parity mode; three of the eight frames (first, middle, last) are checked in full:
+    pyramid blobs, that frame's proposals, box head, kps_score < 1e-3."""
+    from oracle.net3d import Net
+    from oracle import proposals as op
+    from detectandtrack_amd.utils.precision import set_agreement
+    H, W, B = 768, 1344, 8
+    model, ws, weights = build_product(fpn2d_kps_cfg('50', dtype='fp32', pre=1000, post=1000))
+    frames = [synthetic_clip(1, H, W, seed=3 + i)[:, :, 0] for i in range(B)]
+    data = np.concatenate(frames, axis=0)                                     # 8 x 3 x H x W
+    im_info = np.tile(np.array([[H, W, 800.0 / 600.0]], dtype=np.float32), (B, 1))
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    rois_all = ws.FetchBlob('rois')
+    assert rois_all.shape[1] == 5 and set(np.unique(rois_all[:, 0])) == set(range(B))
+    cls_all, bbox_all = ws.FetchBlob('cls_prob'), ws.FetchBlob('bbox_pred')
+    assert cls_all.shape[0] == rois_all.shape[0] == bbox_all.shape[0]
+    names = ['pool1', 'res2_2_sum', 'res3_3_sum', 'res4_5_sum', 'res5_2_sum', 'fpn_res5_2_sum', 'fpn_res4_5_sum', 'fpn_res3_3_sum',
+             'fpn_res2_2_sum']
+    got_blobs = {n: ws.FetchBlob(n) for n in names}
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    ow = oracle_weights_2d(weights)
+    kp_rois_all, kp_ref = [], []
+    for i in (0, 3, 7):
+        net = Net(ow, oracle_opts('50', 1, 1, 'slice-center', 1000, 1000))
+        net.body(torch.from_numpy(frames[i][:, :, None]))
+        pyr = net.fpn()
+        for n in names:
+            ref = net.blobs[n][:, :, 0]
+            got = got_blobs[n][i:i + 1]
+            err, mx = _max_abs(got, ref), float(ref.abs().max())
+            assert err < 1e-3 * max(1.0, mx), (i, n, err, mx)
+        p2d = net.time_link(pyr)
+        ref_rois, _, _ = net.fpn_rpn(p2d, im_info[i:i + 1])
+        sel = np.where(rois_all[:, 0] == i)[0]
+        rois = rois_all[sel].copy()
+        assert rois.shape == ref_rois.shape, (i, rois.shape, ref_rois.shape)
+        agree = set_agreement(rois[:, 1:], ref_rois[:, 1:], 0.05)
+        print('frame %d: %d rois, %.2f%% in the oracle set' % (i, rois.shape[0], 100 * agree))
+        assert agree > 0.95
+        sub = rois[:100].copy()
+        sub[:, 0] = 0                                                         # the oracle sees this frame as image 0
+        _, per_level, restore = op.distribute(sub, 2, 5)
+        cls_prob, bbox_pred = net.box_head_2mlp(net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2))
+        np.testing.assert_allclose(cls_all[sel[:100]], cls_prob, atol=1e-4)
+        np.testing.assert_allclose(bbox_all[sel[:100]], bbox_pred, atol=1e-3)
+        k = sub[:6].copy()
+        _, per_level, restore = op.distribute(k, 2, 5)
+        kp_ref.append(net.kps_head_2d(net.roi_feat_fpn(p2d[1:], per_level, restore, 14, 2)))
+        kr = rois[:6].copy()                                                  # (col 0 = i: the frame's index in the batch)
+        kp_rois_all.append(kr)
+    ws.FeedBlob('keypoint_rois', np.concatenate(kp_rois_all, axis=0))
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    ref = torch.cat(kp_ref, dim=0)
+    assert kps.shape == tuple(ref.shape)
+    err = _max_abs(kps, ref)
+    print('kps_score max-abs %.3e over %d rois of 3 frames of the batch' % (err, kps.shape[0]))
+    assert err < 1e-3, err
