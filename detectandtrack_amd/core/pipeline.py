@@ -17,6 +17,7 @@ arguments (tests/test_gpu_model.py).
 
 `bench.py` measures this class; `core/test_engine.test_net` runs on it (cfg.HIP.PIPELINE_DEPTH / IMS_PER_FORWARD / CLIP_GRAPH).
 """
+import os
 import time
 
 import numpy as np
@@ -58,6 +59,8 @@ class ClipPipeline(object):
         self.fifo = bool(fifo)
         self.host_enqueue_s = 0.0
         self.upload_bytes = 0
+        self.stage_s = 0.0          # host time in the pageable -> pinned staging copies
+        self._stagers = None
         self.host_path_images = 0   # images that took the host glue (exact score ties beyond the device buffers' spare rows)
         self.finish_times = []      # perf_counter() at every completed forward (steady-state rate of a run: see rate())
         self.device_glue = engine.device_results_supported()
@@ -137,13 +140,16 @@ class ClipPipeline(object):
             s.pinned = torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory()
             s.dev_u8 = torch.empty((n, h, w, 3), dtype=torch.uint8, device=s.ws.device)
         host = s.pinned.numpy()
-        k = 0
-        for clip in clips:
-            assert len(clip) == T
-            for f in clip:
-                assert f.dtype == np.uint8 and f.shape == (h, w, 3), (f.dtype, f.shape)
-                np.copyto(host[k], f)
-                k += 1
+        frames = [f for clip in clips for f in clip]
+        assert len(frames) == n and all(f.dtype == np.uint8 and f.shape == (h, w, 3) for f in frames), 'clips of one frame size, uint8 HxWx3'
+        t1 = time.perf_counter()
+        # pageable -> pinned staging copy, frames in parallel (NumPy releases the GIL inside a large copy): a 720p clip is 22 MB, one
+        # core moves it in 2-4 ms -- as long as the whole GPU forward
+        if self._stagers is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._stagers = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        list(self._stagers.map(lambda kf: np.copyto(host[kf[0]], kf[1]), enumerate(frames)))
+        self.stage_s += time.perf_counter() - t1
         with torch.cuda.stream(self.copy_stream):
             s.dev_u8.copy_(s.pinned, non_blocking=True)
             s.copy_event.record(self.copy_stream)

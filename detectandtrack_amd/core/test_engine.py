@@ -127,7 +127,8 @@ def test_net(roidb, ind_range=None, output_dir=None):
         pipe = _test_net_pipelined(model, part, all_boxes, all_keyps, timers)
         rate = pipe.rate()
         test_net.last_stats = {'clips': len(part), 'seconds': timers['im_detect_bbox'].total_time, 'steady_clips_per_s': rate,
-                               'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
+                               'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'host_submit_ms_per_clip': 1e3 * pipe.host_enqueue_s / len(part),
+                               'host_staging_ms_per_clip': 1e3 * pipe.stage_s / len(part), 'host_path_images': pipe.host_path_images, 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
                                'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH)}
         logger.info('im_detect: range [%d, %d] of %d: %d clips in %.3fs incl. warm-up%s (pipelined: %d in flight, %d per forward, '
                     'hipGraph %s, %.1f MB uploaded per clip)', start + 1, end, len(roidb), len(part), timers['im_detect_bbox'].total_time,

@@ -254,7 +254,10 @@ class TrainExecutor(Executor):
         if train_b:     # the kernel ACCUMULATES the bias reduction: straight into the (zeroed) arena view when there is one
             dbias = self.arena[train_b] if (self.arena is not None and train_b in self.arena) else \
                 torch.zeros(cout, dtype=torch.float32, device=ws.device)
-        g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=a['relu'], dbias=dbias)
+        if a['relu'] or dbias is not None:
+            g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=a['relu'], dbias=dbias)
+        else:
+            g = dy          # no ReLU to mask by, no trainable bias to reduce into (the shortcut convs: AffineChannelNd has no gradient)
         if train_b:
             self._pgrad(train_b, dbias)
         if a['residual']:

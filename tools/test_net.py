@@ -72,6 +72,10 @@ def main():
         test_engine.test_net(roidb, tuple(args.range), out)
     else:
         test_engine.test_net_on_dataset(roidb, multi_gpu=args.multi_gpu_testing, output_dir=out)
+    stats = getattr(test_engine.test_net, 'last_stats', None)
+    if stats:       # the pipelined engine's own account of the run (steady state: the first forwards include graph capture / packing)
+        import json
+        print(json.dumps({'test_net': stats}))
 
 
 if __name__ == '__main__':
