@@ -24,11 +24,18 @@ from detectandtrack_amd import workspace
 logger = logging.getLogger(__name__)
 
 
+SYNTHETIC_WEIGHTS = False     # tools/test_net.py --synthetic-weights: utils.net.synthetic_params instead of the builder's init
+
+
 def initialize_model_from_cfg():
     """(:50-74) build the inference model, load TEST.WEIGHTS (or random-init when empty), create the nets."""
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     ws = workspace.GlobalWorkspace()
-    net_utils.initialize_params(model, ws)
+    if SYNTHETIC_WEIGHTS and not cfg.TEST.WEIGHTS:
+        for k, v in net_utils.synthetic_params(model, cfg.RNG_SEED).items():
+            ws.set_param(k, v)
+    else:
+        net_utils.initialize_params(model, ws)
     if cfg.TEST.WEIGHTS:
         net_utils.initialize_from_weights_file(model, ws, cfg.TEST.WEIGHTS)
     ws.CreateNet(model.net)

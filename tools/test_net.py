@@ -30,6 +30,10 @@ def parse_args():
     p.add_argument('--synthetic-video', type=int, default=0,
                    help='one synthetic video of N frames scored like the reference scores a video: a clip around every frame, stride 1, '
                         'border frames replicated (entries carry frame_ids, so HIP.FRAME_TRUNK_CACHE can reuse the per-frame trunk)')
+    p.add_argument('--synthetic-weights', action='store_true',
+                   help='with no TEST.WEIGHTS: well-conditioned random weights (utils.net.synthetic_params, what bench.py uses) instead of the '
+                        'builder\'s own init -- the reference init (std-0.01 score layers) gives every roi the same score, i.e. exact ties at '
+                        'the detection limit for every clip, which is not what a trained model does')
     p.add_argument('opts', default=None, nargs=argparse.REMAINDER)
     return p.parse_args()
 
@@ -67,6 +71,8 @@ def main():
         roidb = synthetic_video_roidb(args.synthetic_video, max(cfg.VIDEO.NUM_FRAMES, 1))
     else:
         roidb = synthetic_roidb(max(args.synthetic, 1), max(cfg.VIDEO.NUM_FRAMES, 1))
+    if args.synthetic_weights:
+        test_engine.SYNTHETIC_WEIGHTS = True
     out = get_output_dir(training=False)
     if args.range is not None:
         test_engine.test_net(roidb, tuple(args.range), out)
