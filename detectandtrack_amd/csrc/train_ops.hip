@@ -219,6 +219,146 @@ __global__ __launch_bounds__(NT, 2) void wgrad_gemm_kernel(const WgradParams p) 
         }
 }
 
+// ---- the direct weight-gradient GEMM (round 3, bf16): no re-pack passes ------------------------------------------------------------
+// G[co][ci][tap] = sum_p g[p][co] * x[in(p, tap)][ci] reduces over POSITIONS, the slow axis of both NDHWC tensors, while an MFMA
+// fragment wants 8 consecutive k per lane.  Rounds 1-2 re-packed both tensors channel-major first (cq_pack_kernel: 2-5 extra passes
+// per layer, 7-10 % of a training iteration).  gfx950 has a transposing LDS read, ds_read_b64_tr_b16: within a 16-lane group lane i
+// supplies the address of 4 contiguous bf16 (row i / 4, columns 4 (i % 4) ... of a 4 x 16 block, any row pitch) and receives
+// column i of the block -- 4 consecutive ROWS (probed on the box: tools/probes/tr_probe.hip).  So the tiles are staged in LDS exactly as
+// they lie in memory -- [64 positions][128 channels], one 256-byte run per position -- and read k-contiguous by the hardware:
+//   * a block owns a (128 co x 128 ci) tile of one tap and a K range; per chunk of 64 output positions it stages the g rows and the x
+//     rows of those positions' tap inputs (zero rows outside the frame: the conv's padding; stride folded into the row address);
+//   * global -> registers -> LDS, the next chunk's loads in flight behind the current chunk's MFMAs, double-buffered LDS, one barrier
+//     per chunk; row pitch 320 B (+64): a group's 4 rows x 8 dwords and the neighbouring group's columns fall on distinct banks;
+//   * per 16-k step a wave (64 x 64) issues 8 transposing reads for 4 v_mfma_f32_32x32x16_bf16.
+// Partial tiles go to Gt[tap][co][ci] exactly like wgrad_gemm_kernel (atomics when the K range is split), wgrad_finish_kernel follows.
+struct WgradDirectParams {
+    const char* g;        // [frames * Ho * Wo][g_cs] bf16
+    const char* x;        // [frames * H * W][x_cs] bf16
+    float* G;             // [ntaps][Cout][Cin] fp32
+    int Cout, Cin, g_cs, x_cs;
+    int T, H, W, Ho, Wo, stride;
+    int KT, KH, KW, pt, ph, pw;
+    int ntaps, ksplit, n_ci_tiles, n_co_tiles;
+    unsigned p_begin, p_end;    // output positions [p_begin, p_end) carry a non-zero gradient (frame window)
+    unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo): row = umulhi(position in frame, wo_magic) (Ho * Wo * Wo < 2^32 checked by the launcher)
+};
+
+constexpr int WD_PITCH = 320;                 // bytes per staged position row: 128 channels + 64 B (bank rotation, see above)
+constexpr int WD_TILE = 64 * WD_PITCH;        // one operand tile: 64 positions
+
+__device__ __forceinline__ uint4 wd_tr_frag(const char* base) {
+    // two transposing reads = the 8 consecutive k of this lane's fragment row (k 0..3 | 4..7: rows +4 of the staged tile)
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t lo, hi;
+    const unsigned a = (unsigned)(size_t)base;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(4 * WD_PITCH) : "memory");
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (g tile, x tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    unsigned bid = blockIdx.x;
+    const int tap = bid % p.ntaps; bid /= p.ntaps;
+    const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+    const int co_t = bid % p.n_co_tiles;
+    const int split = bid / p.n_co_tiles;
+    const int kw = tap % p.KW, kh = (tap / p.KW) % p.KH, kt = tap / (p.KW * p.KH);
+    const unsigned nchunks = (p.p_end - p.p_begin + 63u) / 64u;
+    const unsigned c_lo = (unsigned)((unsigned long long)nchunks * split / p.ksplit), c_hi = (unsigned)((unsigned long long)nchunks * (split + 1) / p.ksplit);
+
+    // staging: thread -> 16-byte piece `pc` (0..15) of rows r0 + 16 i (i < 4) of both tiles
+    const int pc = tid & 15, r0 = tid >> 4;
+    const bool g_col_ok = co_t * 128 + pc * 8 < p.g_cs, x_col_ok = ci_t * 128 + pc * 8 < p.x_cs;
+    uint4 gq[4], xq[4];
+#define WD_FETCH(CH_)                                                                                                   \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+            const unsigned pos_ = p.p_begin + (unsigned)(CH_) * 64u + (unsigned)(r0 + 16 * i_);                          \
+            gq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            xq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (pos_ < p.p_end) {                                                                                       \
+                if (g_col_ok) gq[i_] = *(const uint4*)(p.g + ((size_t)pos_ * (unsigned)p.g_cs + (unsigned)(co_t * 128 + pc * 8)) * 2u); \
+                const unsigned f_ = pos_ / p.how, rem_ = pos_ - f_ * p.how;                                             \
+                const unsigned oy_ = __umulhi(rem_, p.wo_magic), ox_ = rem_ - oy_ * (unsigned)p.Wo;                     \
+                const unsigned clip_ = f_ / (unsigned)p.T, t_ = f_ - clip_ * (unsigned)p.T;                             \
+                const int ti_ = (int)t_ + kt - p.pt, yi_ = (int)oy_ * p.stride + kh - p.ph, xi_ = (int)ox_ * p.stride + kw - p.pw; \
+                if (x_col_ok && ti_ >= 0 && ti_ < p.T && yi_ >= 0 && yi_ < p.H && xi_ >= 0 && xi_ < p.W) {             \
+                    const size_t row_ = ((size_t)(clip_ * (unsigned)p.T + (unsigned)ti_) * (unsigned)p.H + (unsigned)yi_) * (unsigned)p.W + (unsigned)xi_; \
+                    xq[i_] = *(const uint4*)(p.x + (row_ * (unsigned)p.x_cs + (unsigned)(ci_t * 128 + pc * 8)) * 2u);  \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+#define WD_STAGE(BUF_)                                                                                                  \
+    {                                                                                                                   \
+        char* gd_ = smem + (BUF_) * (2 * WD_TILE);                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+            *(uint4*)(gd_ + (r0 + 16 * i_) * WD_PITCH + pc * 16) = gq[i_];                                              \
+            *(uint4*)(gd_ + WD_TILE + (r0 + 16 * i_) * WD_PITCH + pc * 16) = xq[i_];                                    \
+        }                                                                                                               \
+    }
+    // fragment addressing: 16-lane group G = lane >> 4 reads the 4 x 16 block (rows k0 + (G >> 1) * 8 [+4], columns c0 + (G & 1) * 16);
+    // lane i of the group supplies row i >> 2, columns 4 (i & 3)
+    const int grp = lane >> 4, li = lane & 15;
+    const int frag_off = ((grp >> 1) * 8 + (li >> 2)) * WD_PITCH + ((grp & 1) * 16 + (li & 3) * 4) * 2;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_lo < c_hi) {
+        WD_FETCH(c_lo);
+        WD_STAGE(0);
+    }
+    __syncthreads();
+    for (unsigned c = c_lo; c < c_hi; ++c) {
+        const int buf = (int)((c - c_lo) & 1u);
+        if (c + 1 < c_hi) WD_FETCH(c + 1);          // in flight behind this chunk's MFMAs
+        const char* gb = smem + buf * (2 * WD_TILE) + frag_off + (wave_m * 64) * 2;
+        const char* xb = smem + buf * (2 * WD_TILE) + WD_TILE + frag_off + (wave_n * 64) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = wd_tr_frag(gb + ks * 16 * WD_PITCH + i * 64);
+                b[i] = wd_tr_frag(xb + ks * 16 * WD_PITCH + i * 64);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) MmaT<DAT_BF16>::step(a[i], b[j], acc[i][j]);
+        }
+        if (c + 1 < c_hi) WD_STAGE(buf ^ 1);
+        __syncthreads();
+    }
+#undef WD_FETCH
+#undef WD_STAGE
+    const int khalf = lane >> 5;
+    float* Gt = p.G + (size_t)tap * p.Cout * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci_t * 128 + wave_n * 64 + j * 32 + (lane & 31);
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_t * 128 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co >= p.Cout) continue;
+                if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[i][j][r]);
+                else Gt[(size_t)co * p.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // Gt[tap][co][ci] -> dW[co][ci][tap] * scale[co] (the fused AffineChannelNd scale; NULL = 1)
 __global__ void wgrad_finish_kernel(const float* __restrict__ Gt, const float* __restrict__ scale, float* __restrict__ dW, int Cout,
                                     int Cin, int ntaps) {
@@ -531,6 +671,44 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     const int s = d->stride_h;
     const size_t es = dat_esize(d->dtype);
     const int clips = d->frames / d->T;
+    // ---- bf16: the direct kernel (no re-pack passes; transposing LDS reads) ----
+    const long long npos_out = (long long)d->frames * Ho * Wo, npos_in = (long long)d->frames * d->H * d->W;
+    if (d->dtype == DAT_BF16 && ctx->dbg_wgrad_direct && d->Cin % 64 == 0 && g_cstride % 64 == 0 && npos_out < (1ll << 31) && npos_in < (1ll << 31) &&
+        (long long)Ho * Wo * Wo < (1ll << 32)) {
+        WgradDirectParams wp;
+        memset(&wp, 0, sizeof(wp));
+        float* Gt = (float*)workspace;
+        wp.g = (const char*)g; wp.x = (const char*)x; wp.G = Gt;
+        wp.Cout = Cout_real; wp.Cin = Cin_real; wp.g_cs = g_cstride; wp.x_cs = d->Cin;
+        wp.T = d->T; wp.H = d->H; wp.W = d->W; wp.Ho = Ho; wp.Wo = Wo; wp.stride = s;
+        wp.KT = d->KT; wp.KH = d->KH; wp.KW = d->KW; wp.pt = d->pad_t; wp.ph = d->pad_h; wp.pw = d->pad_w;
+        wp.ntaps = d->KT * d->KH * d->KW;
+        wp.n_co_tiles = (Cout_real + 127) / 128; wp.n_ci_tiles = (Cin_real + 127) / 128;
+        wp.how = (unsigned)(Ho * Wo);
+        wp.wo_magic = Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)Wo - 1) / (unsigned)Wo);
+        wp.p_begin = 0; wp.p_end = (unsigned)npos_out;
+        if (d->out_tn > 0 && clips == 1) {   // g is non-zero only in frames [out_t0, out_t0 + out_tn) of the clip
+            DAT_ENFORCE(ctx, d->out_t0 >= 0 && d->out_t0 + d->out_tn <= d->T, "conv3d_wgrad: gradient frames [%d, %d) outside T %d",
+                        d->out_t0, d->out_t0 + d->out_tn, d->T);
+            wp.p_begin = (unsigned)d->out_t0 * wp.how; wp.p_end = (unsigned)(d->out_t0 + d->out_tn) * wp.how;
+        }
+        // (__umulhi(p, ceil(2^32 / n)) == p / n needs p * n < 2^32 or so: checked exactly for the ranges used)
+        const long long tiles = (long long)wp.ntaps * wp.n_co_tiles * wp.n_ci_tiles;
+        const long long nchunks = ((long long)(wp.p_end - wp.p_begin) + 63) / 64;
+        long long ks = 1024 / tiles;                        // ~2 rounds of the 512 resident blocks; every split costs a partial tile
+        if (ks > nchunks / 8) ks = nchunks / 8;             // at least 8 chunks per block
+        if (ks < 1) ks = 1;
+        wp.ksplit = (int)ks;
+        const size_t g_elems = (size_t)Cout_real * Cin_real * wp.ntaps;
+        if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+            DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
+        if (dat_ensure_lds(ctx, (const void*)wgrad_direct_kernel, 4 * WD_TILE) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 4 * WD_TILE, st, wp);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                           Cout_real, Cin_real, wp.ntaps);
+        DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct");
+        return DAT_OK;
+    }
     char* gT = (char*)workspace;
     char* xT = gT + (((size_t)Cout_real * Qa * es + 255) & ~(size_t)255);
     const size_t plane_bytes = (size_t)Cin_real * Qa * es;

@@ -1,8 +1,13 @@
-cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_i; mkdir -p $o /tmp/out
-T="timeout 600 python tools/test_net.py --cfg configs/test_r18_fpn3d_synthetic.yaml --synthetic-weights"
-O="OUTPUT_DIR /tmp/out HIP.FRAME_TRUNK_CACHE 0 TEST.SCALES (800,) TEST.MAX_SIZE 1333"
-$T --synthetic 128 $O > $o/testnet.log 2>&1; grep -E "test_net" $o/testnet.log | tail -1
-$T --synthetic 128 $O HIP.IMS_PER_FORWARD 4 HIP.PIPELINE_DEPTH 3 > $o/testnet_b4.log 2>&1; grep -E "test_net" $o/testnet_b4.log | tail -1
-$T --synthetic 128 $O HIP.PIPELINE_DEPTH 1 > $o/testnet_p1.log 2>&1; grep -E "test_net" $o/testnet_p1.log | tail -1
-$T --synthetic 16 $O HIP.PIPELINE_DEPTH 0 > $o/testnet_eager.log 2>&1; grep -E "im_detect:" $o/testnet_eager.log | tail -1
-tail -3 $o/testnet.log
+cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_j; mkdir -p $o
+timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_full.py -m gpu -q -x > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
+B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 20 --warmup 4 --mode train"
+for w in 3d_r18_fpn3d 3d_r50_fpn3d; do
+  $B --workload $w > $o/train_$w.json 2> $o/train_$w.err; DAT_WGRAD_DIRECT=0 $B --workload $w > $o/train_${w}_off.json 2> $o/train_${w}_off.err
+  python - $o/train_$w.json $o/train_${w}_off.json <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['ms_per_step'], 'ms/iter')
+    except Exception as e: print(f, 'ERR', e)
+PY
+done
