@@ -16,7 +16,14 @@
 // Split-K over q across blocks; fp32 partial tiles are accumulated into G with atomics (G is tiny: Cout*Cin*taps).
 #include "dat_common.h"
 
+#include <utility>
+
 namespace {
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 constexpr int ROWB = 128;
 constexpr int NT = 256;
@@ -247,13 +254,32 @@ struct WgradDirectParams {
 constexpr int WD_PITCH = 320;                 // bytes per staged position row: 128 channels + 64 B (bank rotation, see above)
 constexpr int WD_TILE = 64 * WD_PITCH;        // one operand tile: 64 positions
 
-__device__ __forceinline__ uint4 wd_tr_frag(const char* base) {
-    // two transposing reads = the 8 consecutive k of this lane's fragment row (k 0..3 | 4..7: rows +4 of the staged tile)
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    u32x2_t lo, hi;
-    const unsigned a = (unsigned)(size_t)base;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(4 * WD_PITCH) : "memory");
-    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+// The four fragments of one 16-k step (2 of the g tile, 2 of the x tile; each = two transposing reads: k 0..3 | 4..7 of the lane's
+// fragment row, rows +4 of the staged tile) in ONE asm statement that ends with the wait: nothing outside may touch the result
+// registers before the data has landed (the hardware does not interlock VGPR reads on outstanding LDS operations, and the compiler
+// does not know that these are loads).
+typedef unsigned wd_u32x2_t __attribute__((ext_vector_type(2)));
+template <int KS>
+__device__ __forceinline__ void wd_read_step(unsigned ga, unsigned xa, uint4 (&a)[2], uint4 (&b)[2]) {
+    wd_u32x2_t a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
+    constexpr int O = KS * 16 * WD_PITCH, H = 4 * WD_PITCH;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h)
+        : "v"(ga), "v"(xa), "n"(O), "n"(O + H), "n"(O + 64), "n"(O + 64 + H)
+        : "memory");
+    a[0] = make_uint4(a0l.x, a0l.y, a0h.x, a0h.y);
+    a[1] = make_uint4(a1l.x, a1l.y, a1h.x, a1h.y);
+    b[0] = make_uint4(b0l.x, b0l.y, b0h.x, b0h.y);
+    b[1] = make_uint4(b1l.x, b1l.y, b1h.x, b1h.y);
 }
 
 __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectParams p) {
@@ -320,22 +346,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectPa
     for (unsigned c = c_lo; c < c_hi; ++c) {
         const int buf = (int)((c - c_lo) & 1u);
         if (c + 1 < c_hi) WD_FETCH(c + 1);          // in flight behind this chunk's MFMAs
-        const char* gb = smem + buf * (2 * WD_TILE) + frag_off + (wave_m * 64) * 2;
-        const char* xb = smem + buf * (2 * WD_TILE) + WD_TILE + frag_off + (wave_n * 64) * 2;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        const unsigned ga = (unsigned)(size_t)(smem + buf * (2 * WD_TILE) + frag_off + (wave_m * 64) * 2);
+        const unsigned xa = (unsigned)(size_t)(smem + buf * (2 * WD_TILE) + WD_TILE + frag_off + (wave_n * 64) * 2);
+        static_for(std::make_integer_sequence<int, 4>{}, [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
             uint4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = wd_tr_frag(gb + ks * 16 * WD_PITCH + i * 64);
-                b[i] = wd_tr_frag(xb + ks * 16 * WD_PITCH + i * 64);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wd_read_step<ks>(ga, xa, a, b);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) MmaT<DAT_BF16>::step(a[i], b[j], acc[i][j]);
-        }
+        });
         if (c + 1 < c_hi) WD_STAGE(buf ^ 1);
         __syncthreads();
     }
