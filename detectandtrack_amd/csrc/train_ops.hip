@@ -254,32 +254,17 @@ struct WgradDirectParams {
 constexpr int WD_PITCH = 320;                 // bytes per staged position row: 128 channels + 64 B (bank rotation, see above)
 constexpr int WD_TILE = 64 * WD_PITCH;        // one operand tile: 64 positions
 
-// The four fragments of one 16-k step (2 of the g tile, 2 of the x tile; each = two transposing reads: k 0..3 | 4..7 of the lane's
-// fragment row, rows +4 of the staged tile) in ONE asm statement that ends with the wait: nothing outside may touch the result
-// registers before the data has landed (the hardware does not interlock VGPR reads on outstanding LDS operations, and the compiler
-// does not know that these are loads).
-typedef unsigned wd_u32x2_t __attribute__((ext_vector_type(2)));
-template <int KS>
-__device__ __forceinline__ void wd_read_step(unsigned ga, unsigned xa, uint4 (&a)[2], uint4 (&b)[2]) {
-    wd_u32x2_t a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
-    constexpr int O = KS * 16 * WD_PITCH, H = 4 * WD_PITCH;
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
-        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
-        "ds_read_b64_tr_b16 %2, %8 offset:%12\n\t"
-        "ds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
-        "ds_read_b64_tr_b16 %4, %9 offset:%10\n\t"
-        "ds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
-        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
-        "ds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h)
-        : "v"(ga), "v"(xa), "n"(O), "n"(O + H), "n"(O + 64), "n"(O + 64 + H)
-        : "memory");
-    a[0] = make_uint4(a0l.x, a0l.y, a0h.x, a0h.y);
-    a[1] = make_uint4(a1l.x, a1l.y, a1h.x, a1h.y);
-    b[0] = make_uint4(b0l.x, b0l.y, b0h.x, b0h.y);
-    b[1] = make_uint4(b1l.x, b1l.y, b1h.x, b1h.y);
+// One MFMA fragment = two transposing reads (k 0..3 | 4..7 of the lane's fragment row: rows +4 of the staged tile).  The compiler
+// builtin (not inline asm): it knows these are LDS loads, counts lgkmcnt for them and schedules them ahead of the MFMAs -- an asm
+// version with its own s_waitcnt could not be pipelined (the hardware does not interlock VGPR reads on outstanding LDS operations,
+// so nothing may touch an asm read's result before a wait the compiler cannot see).
+typedef short wd_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 wd_tr_frag(const char* base) {
+    typedef __attribute__((address_space(3))) wd_v4s* lp_t;
+    const wd_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(base));
+    const wd_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(base + 4 * WD_PITCH));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
 }
 
 __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectParams p) {
@@ -346,17 +331,31 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectPa
     for (unsigned c = c_lo; c < c_hi; ++c) {
         const int buf = (int)((c - c_lo) & 1u);
         if (c + 1 < c_hi) WD_FETCH(c + 1);          // in flight behind this chunk's MFMAs
-        const unsigned ga = (unsigned)(size_t)(smem + buf * (2 * WD_TILE) + frag_off + (wave_m * 64) * 2);
-        const unsigned xa = (unsigned)(size_t)(smem + buf * (2 * WD_TILE) + WD_TILE + frag_off + (wave_n * 64) * 2);
-        static_for(std::make_integer_sequence<int, 4>{}, [&](auto ks_c) {
-            constexpr int ks = decltype(ks_c)::value;
-            uint4 a[2], b[2];
-            wd_read_step<ks>(ga, xa, a, b);
+        const char* gb = smem + buf * (2 * WD_TILE) + frag_off + (wave_m * 64) * 2;
+        const char* xb = smem + buf * (2 * WD_TILE) + WD_TILE + frag_off + (wave_n * 64) * 2;
+        // fragments of step ks + 1 are requested before the MFMAs of step ks (register double buffer)
+        uint4 a[2][2], b[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[0][i] = wd_tr_frag(gb + i * 64);
+            b[0][i] = wd_tr_frag(xb + i * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[(ks + 1) & 1][i] = wd_tr_frag(gb + (ks + 1) * 16 * WD_PITCH + i * 64);
+                    b[(ks + 1) & 1][i] = wd_tr_frag(xb + (ks + 1) * 16 * WD_PITCH + i * 64);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these reads behind the MFMAs, next to their use)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) MmaT<DAT_BF16>::step(a[i], b[j], acc[i][j]);
-        });
+                for (int j = 0; j < 2; ++j) MmaT<DAT_BF16>::step(a[ks & 1][i], b[ks & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (c + 1 < c_hi) WD_STAGE(buf ^ 1);
         __syncthreads();
     }
@@ -378,6 +377,140 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectPa
                 else Gt[(size_t)co * p.Cin + ci] = acc[i][j][r];
             }
         }
+}
+
+// ---- direct weight gradient of 3 x 3 (x KT) stride-1 convs: the nine spatial taps of one temporal tap share ONE staged input patch -------
+// wgrad_direct_kernel runs one block per tap, so a 3 x 3 x 3 layer streams both tensors 27 times through L2 -> LDS (res3-res5, the FPN
+// post-hoc convs and the keypoint head: ~25 GB per training iteration -- the bound of rounds 1-2's kernel too).  With positions as LDS
+// ROWS a spatial tap is a row offset: a block stages the g rows of an 8 x 8 patch of output positions (64 k) and the 10 x 10 patch of
+// input positions around it ONCE and accumulates all nine (kh, kw) taps from it -- the B fragment of tap (kh, kw) is the same
+// per-lane address + (kh * 10 + kw) rows, an immediate.  Block = (64 co x 64 ci) x one temporal tap, a wave = 32 x 32 x 9 taps (144
+// accumulator registers); K = frames x patches, split across blocks.  Row pitch 192 B (64 channels + 64 B): the four rows of a
+// transposing read and the neighbouring 16-column group fall on distinct banks.  Operand traffic per layer: 9 x less.
+struct Wgrad9Params {
+    const char* g;
+    const char* x;
+    float* G;             // [ntaps][Cout][Cin] fp32
+    int Cout, Cin, g_cs, x_cs;
+    int T, H, W;          // stride 1, pad 1: the output map is H x W too
+    int KT, pt;
+    int ksplit, n_ci_tiles, n_co_tiles;
+    int f_begin, f_end;   // output frames [f_begin, f_end) carry a non-zero gradient (frame window; whole clips otherwise)
+    int tiles_h, tiles_w; // 8 x 8 patches per frame
+};
+
+constexpr int W9_PITCH = 192;
+constexpr int W9_GT = 64 * W9_PITCH;          // g tile: 64 positions
+constexpr int W9_XT = 100 * W9_PITCH;         // x patch: 10 x 10 positions
+constexpr int W9_STAGE = W9_GT + W9_XT + 256; // (+ pad: the last transposing reads of a tile reach 3 rows past their first row)
+
+__device__ __forceinline__ uint4 w9_tr_frag(const char* base) {
+    typedef __attribute__((address_space(3))) wd_v4s* lp_t;
+    const wd_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(base));
+    const wd_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(base + 4 * W9_PITCH));
+    uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+// the x fragment of 8 consecutive k = the two 4-k groups (ox 0..3 | 4..7 of one patch row): rows +4 of the patch
+__device__ __forceinline__ uint4 w9_tr_frag_x(const char* base) { return w9_tr_frag(base); }
+
+__global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (g tile, x patch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    unsigned bid = blockIdx.x;
+    const int kt = bid % p.KT; bid /= p.KT;
+    const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+    const int co_t = bid % p.n_co_tiles;
+    const int split = bid / p.n_co_tiles;
+    const unsigned per_frame = (unsigned)(p.tiles_h * p.tiles_w);
+    const unsigned nchunks = (unsigned)(p.f_end - p.f_begin) * per_frame;
+    const unsigned c_lo = (unsigned)((unsigned long long)nchunks * split / p.ksplit), c_hi = (unsigned)((unsigned long long)nchunks * (split + 1) / p.ksplit);
+
+    // staging: 16-byte piece pc (8 per 64-channel row); g: rows r0 + 32 i (i < 2), x: patch rows r0 + 32 i (i < 4, < 100)
+    const int pc = tid & 7, r0 = tid >> 3;
+    const bool g_col_ok = co_t * 64 + pc * 8 < p.g_cs, x_col_ok = ci_t * 64 + pc * 8 < p.x_cs;
+    uint4 gq[2], xq[4];
+#define W9_FETCH(CH_)                                                                                                   \
+    {                                                                                                                   \
+        const unsigned fr_ = (unsigned)(CH_) / per_frame, tl_ = (unsigned)(CH_) - fr_ * per_frame;                       \
+        const int f_ = p.f_begin + (int)fr_;                                                                            \
+        const int ty_ = (int)(tl_ / (unsigned)p.tiles_w), tx_ = (int)tl_ - ty_ * p.tiles_w;                             \
+        const int clip_ = f_ / p.T, t_ = f_ - clip_ * p.T, ti_ = t_ + kt - p.pt;                                        \
+        const bool tin_ = ti_ >= 0 && ti_ < p.T;                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
+            const int r_ = r0 + 32 * i_, oy_ = ty_ * 8 + (r_ >> 3), ox_ = tx_ * 8 + (r_ & 7);                           \
+            gq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (g_col_ok && tin_ && oy_ < p.H && ox_ < p.W)                                                             \
+                gq[i_] = *(const uint4*)(p.g + ((((size_t)f_ * p.H + oy_) * p.W + ox_) * (unsigned)p.g_cs + (unsigned)(co_t * 64 + pc * 8)) * 2u); \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+            const int r_ = r0 + 32 * i_, py_ = r_ / 10, px_ = r_ - py_ * 10;                                            \
+            const int iy_ = ty_ * 8 + py_ - 1, ix_ = tx_ * 8 + px_ - 1;                                                 \
+            xq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (x_col_ok && tin_ && r_ < 100 && iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W)                         \
+                xq[i_] = *(const uint4*)(p.x + ((((size_t)(clip_ * p.T + ti_) * p.H + iy_) * p.W + ix_) * (unsigned)p.x_cs + (unsigned)(ci_t * 64 + pc * 8)) * 2u); \
+        }                                                                                                               \
+    }
+#define W9_STAGE_WRITE(BUF_)                                                                                            \
+    {                                                                                                                   \
+        char* gd_ = smem + (BUF_) * W9_STAGE;                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) *(uint4*)(gd_ + (r0 + 32 * i_) * W9_PITCH + pc * 16) = gq[i_];  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                \
+            if (r0 + 32 * i_ < 100) *(uint4*)(gd_ + W9_GT + (r0 + 32 * i_) * W9_PITCH + pc * 16) = xq[i_];             \
+    }
+    // fragment addressing.  g tile (rows = k = oy * 8 + ox): group G = lane >> 4 reads rows k0 + (G >> 1) * 8 [+4], columns (G & 1) * 16,
+    // lane i of the group row i >> 2, columns 4 (i & 3).  x patch: k -> patch row (oy + kh) * 10 + ox + kw; the 8 k of a fragment
+    // half are ONE output row (oy = 2 ks + (G >> 1)), so its two 4-k groups are patch rows ... + ox (0..3 | 4..7): +4 rows again.
+    const int grp = lane >> 4, li = lane & 15;
+    const int g_off = ((grp >> 1) * 8 + (li >> 2)) * W9_PITCH + ((grp & 1) * 16 + (li & 3) * 4) * 2 + (wave_m * 32) * 2;
+    const int x_off = ((grp >> 1) * 10 + (li >> 2)) * W9_PITCH + ((grp & 1) * 16 + (li & 3) * 4) * 2 + (wave_n * 32) * 2;
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (c_lo < c_hi) {
+        W9_FETCH(c_lo);
+        W9_STAGE_WRITE(0);
+    }
+    __syncthreads();
+    for (unsigned c = c_lo; c < c_hi; ++c) {
+        const int buf = (int)((c - c_lo) & 1u);
+        if (c + 1 < c_hi) W9_FETCH(c + 1);          // in flight behind this chunk's MFMAs
+        const char* gb = smem + buf * W9_STAGE + g_off;
+        const char* xb = smem + buf * W9_STAGE + W9_GT + x_off;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {            // 16 k = output rows 2 ks, 2 ks + 1 of the patch
+            const uint4 a = w9_tr_frag(gb + ks * 16 * W9_PITCH);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const uint4 b = w9_tr_frag_x(xb + ((2 * ks + kh) * 10 + kw) * W9_PITCH);
+                    MmaT<DAT_BF16>::step(a, b, acc[kh * 3 + kw]);
+                }
+        }
+        if (c + 1 < c_hi) W9_STAGE_WRITE(buf ^ 1);
+        __syncthreads();
+    }
+#undef W9_FETCH
+#undef W9_STAGE_WRITE
+    const int khalf = lane >> 5;
+    const int ci = ci_t * 64 + wave_n * 32 + (lane & 31);
+    if (ci >= p.Cin) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* Gt = p.G + (size_t)(kt * 9 + t) * p.Cout * p.Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_t * 64 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (co >= p.Cout) continue;
+            if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
+            else Gt[(size_t)co * p.Cin + ci] = acc[t][r];
+        }
+    }
 }
 
 // Gt[tap][co][ci] -> dW[co][ci][tap] * scale[co] (the fused AffineChannelNd scale; NULL = 1)
@@ -696,9 +829,40 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     const long long npos_out = (long long)d->frames * Ho * Wo, npos_in = (long long)d->frames * d->H * d->W;
     if (d->dtype == DAT_BF16 && ctx->dbg_wgrad_direct && d->Cin % 64 == 0 && g_cstride % 64 == 0 && npos_out < (1ll << 31) && npos_in < (1ll << 31) &&
         (long long)Ho * Wo * Wo < (1ll << 32)) {
+        float* Gt = (float*)workspace;
+        if (d->KH == 3 && d->KW == 3 && s == 1 && d->pad_h == 1 && d->pad_w == 1 && (ctx->dbg_wgrad_direct & 2) == 0) {
+            // nine spatial taps from one staged patch (wgrad_direct9_kernel)
+            Wgrad9Params q;
+            memset(&q, 0, sizeof(q));
+            q.g = (const char*)g; q.x = (const char*)x; q.G = Gt;
+            q.Cout = Cout_real; q.Cin = Cin_real; q.g_cs = g_cstride; q.x_cs = d->Cin;
+            q.T = d->T; q.H = d->H; q.W = d->W; q.KT = d->KT; q.pt = d->pad_t;
+            q.n_co_tiles = (Cout_real + 63) / 64; q.n_ci_tiles = (Cin_real + 63) / 64;
+            q.f_begin = 0; q.f_end = d->frames;
+            if (d->out_tn > 0 && clips == 1) {
+                DAT_ENFORCE(ctx, d->out_t0 >= 0 && d->out_t0 + d->out_tn <= d->T, "conv3d_wgrad: gradient frames [%d, %d) outside T %d",
+                            d->out_t0, d->out_t0 + d->out_tn, d->T);
+                q.f_begin = d->out_t0; q.f_end = d->out_t0 + d->out_tn;
+            }
+            q.tiles_h = (d->H + 7) / 8; q.tiles_w = (d->W + 7) / 8;
+            const long long tiles = (long long)d->KT * q.n_co_tiles * q.n_ci_tiles;
+            const long long nchunks = (long long)(q.f_end - q.f_begin) * q.tiles_h * q.tiles_w;
+            long long ks = 1024 / tiles;
+            if (ks > nchunks / 4) ks = nchunks / 4;             // at least 4 patches per block
+            if (ks < 1) ks = 1;
+            q.ksplit = (int)ks;
+            const size_t g_elems = (size_t)Cout_real * Cin_real * d->KT * 9;
+            if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+                DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
+            if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
+            hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                               Cout_real, Cin_real, d->KT * 9);
+            DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct9");
+            return DAT_OK;
+        }
         WgradDirectParams wp;
         memset(&wp, 0, sizeof(wp));
-        float* Gt = (float*)workspace;
         wp.g = (const char*)g; wp.x = (const char*)x; wp.G = Gt;
         wp.Cout = Cout_real; wp.Cin = Cin_real; wp.g_cs = g_cstride; wp.x_cs = d->Cin;
         wp.T = d->T; wp.H = d->H; wp.W = d->W; wp.Ho = Ho; wp.Wo = Wo; wp.stride = s;

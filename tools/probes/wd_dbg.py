@@ -27,3 +27,6 @@ run(64, 64, (1, 1, 1), 1, (0, 0, 0), 1, 1, 8, 8)
 run(64, 128, (1, 1, 1), 1, (0, 0, 0), 1, 2, 12, 14)
 run(64, 128, (3, 3, 3), 1, (1, 1, 1), 1, 3, 12, 14)
 run(128, 256, (1, 1, 1), 2, (0, 0, 0), 1, 2, 12, 16)
+run(128, 128, (3, 3, 3), 1, (1, 1, 1), 1, 3, 13, 19)
+run(64, 192, (1, 3, 3), 1, (0, 1, 1), 2, 2, 9, 11)
+run(130, 70, (3, 3, 3), 1, (1, 1, 1), 1, 4, 8, 10)
