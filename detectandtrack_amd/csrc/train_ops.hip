@@ -402,7 +402,7 @@ struct Wgrad9Params {
 constexpr int W9_PITCH = 192;
 constexpr int W9_GT = 64 * W9_PITCH;          // g tile: 64 positions
 constexpr int W9_XT = 100 * W9_PITCH;         // x patch: 10 x 10 positions
-constexpr int W9_STAGE = W9_GT + W9_XT + 256; // (+ pad: the last transposing reads of a tile reach 3 rows past their first row)
+constexpr int W9_STAGE = W9_GT + W9_XT + 512; // (+ pad: the 12-k row reads of the last patch rows reach two rows past the patch)
 
 __device__ __forceinline__ uint4 w9_tr_frag(const char* base) {
     typedef __attribute__((address_space(3))) wd_v4s* lp_t;
@@ -411,8 +411,11 @@ __device__ __forceinline__ uint4 w9_tr_frag(const char* base) {
     uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
     return make_uint4(l.x, l.y, h.x, h.y);
 }
-// the x fragment of 8 consecutive k = the two 4-k groups (ox 0..3 | 4..7 of one patch row): rows +4 of the patch
-__device__ __forceinline__ uint4 w9_tr_frag_x(const char* base) { return w9_tr_frag(base); }
+// one transposing read: 4 consecutive k (patch rows) of this lane's column
+__device__ __forceinline__ uint2 w9_tr4(const char* base) {
+    typedef __attribute__((address_space(3))) wd_v4s* lp_t;
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(base)));
+}
 
 __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (g tile, x patch)
@@ -485,12 +488,20 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
         for (int ks = 0; ks < 4; ++ks) {            // 16 k = output rows 2 ks, 2 ks + 1 of the patch
             const uint4 a = w9_tr_frag(gb + ks * 16 * W9_PITCH);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const uint4 b = w9_tr_frag_x(xb + ((2 * ks + kh) * 10 + kw) * W9_PITCH);
-                    MmaT<DAT_BF16>::step(a, b, acc[kh * 3 + kw]);
-                }
+            for (int kh = 0; kh < 3; ++kh) {
+                // the three kw taps read three 8-wide windows of the SAME 10-wide patch row: 12 k (three 4-k transposing reads; the last
+                // two are past the row, never used) are fetched once and the windows cut out of the registers -- LDS reads per MFMA
+                // 2.2 -> 1.2 (the kernel was LDS-bandwidth-bound)
+                const char* rb = xb + ((2 * ks + kh) * 10) * W9_PITCH;
+                const uint2 q0 = w9_tr4(rb), q1 = w9_tr4(rb + 4 * W9_PITCH), q2 = w9_tr4(rb + 8 * W9_PITCH);
+                const uint4 b0 = make_uint4(q0.x, q0.y, q1.x, q1.y);
+                const uint4 b2 = make_uint4(q0.y, q1.x, q1.y, q2.x);
+                const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(q0.y, q0.x, 2), __builtin_amdgcn_alignbyte(q1.x, q0.y, 2),
+                                            __builtin_amdgcn_alignbyte(q1.y, q1.x, 2), __builtin_amdgcn_alignbyte(q2.x, q1.y, 2));
+                MmaT<DAT_BF16>::step(a, b0, acc[kh * 3 + 0]);
+                MmaT<DAT_BF16>::step(a, b1, acc[kh * 3 + 1]);
+                MmaT<DAT_BF16>::step(a, b2, acc[kh * 3 + 2]);
+            }
         }
         if (c + 1 < c_hi) W9_STAGE_WRITE(buf ^ 1);
         __syncthreads();
@@ -579,6 +590,7 @@ __global__ void relu_bwd_kernel(const void* __restrict__ dy, const void* __restr
             if ((relu && !(o[e] > 0.f)) || c + e >= C) v[e] = 0.f;
             s[e] += v[e];
         }
+        if (!g) continue;      // reduction only (no ReLU, no padded channels: the caller keeps using dy itself)
         if (DT == DAT_BF16) {
             uint2 w;
             w.x = f2bf2(v[0], v[1]);
@@ -847,8 +859,10 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
             q.tiles_h = (d->H + 7) / 8; q.tiles_w = (d->W + 7) / 8;
             const long long tiles = (long long)d->KT * q.n_co_tiles * q.n_ci_tiles;
             const long long nchunks = (long long)(q.f_end - q.f_begin) * q.tiles_h * q.tiles_w;
-            long long ks = 1024 / tiles;
+            long long ks = 640 / tiles;                         // ~1.25 rounds of the 512 resident blocks (per-layer sweep, tools/probes/wgrad_bench.py)
             if (ks > nchunks / 4) ks = nchunks / 4;             // at least 4 patches per block
+            if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
+            if (ks > nchunks) ks = nchunks;
             if (ks < 1) ks = 1;
             q.ksplit = (int)ks;
             const size_t g_elems = (size_t)Cout_real * Cin_real * d->KT * 9;
@@ -971,7 +985,7 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
 
 int dat_relu_bias_bwd(dat_ctx* ctx, dat_stream s, int dtype, const void* dy, const void* dy2, const void* y, void* g,
                       float* dbias, long long npos, int C, int cstride, int relu) {
-    DAT_ENFORCE(ctx, dy && g && (y || !relu), "relu_bias_bwd: null argument");
+    DAT_ENFORCE(ctx, dy && (y || !relu) && (g || (!relu && !dy2 && dbias && C == cstride)), "relu_bias_bwd: null argument");
     const int nq = cstride / 4;
     const int block = nq > 256 ? nq : 256;              // a thread keeps ONE channel quad: block % nq == 0
     DAT_ENFORCE(ctx, cstride % 4 == 0 && block <= 1024 && block % nq == 0,

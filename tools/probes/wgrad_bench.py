@@ -1,0 +1,57 @@
+"""Per-layer timing of dat_conv3d_wgrad at the training bench's layer shapes (bf16): direct kernels vs the re-pack path, K-split sweep."""
+import os, sys
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import torch
+from detectandtrack_amd.ops import hip_ops as ops
+
+LAYERS = [  # name, cin, cout, k, stride, T, H, W (input), g frames window (t0, n) or None
+    ('res3 3x3x3 128', 128, 128, (3, 3, 3), 1, 8, 96, 168, None),
+    ('res4 3x3x3 256', 256, 256, (3, 3, 3), 1, 8, 48, 84, None),
+    ('res5 3x3x3 512', 512, 512, (3, 3, 3), 1, 8, 24, 42, None),
+    ('fpn P2 posthoc 1-frame g', 256, 256, (3, 3, 3), 1, 3, 192, 336, (1, 1)),
+    ('fpn P3 posthoc 1-frame g', 256, 256, (3, 3, 3), 1, 3, 96, 168, (1, 1)),
+    ('res4_0 2a 3x3x3 s2', 128, 256, (3, 3, 3), 2, 8, 96, 168, None),
+    ('lateral P3 1x1 128->256', 128, 256, (1, 1, 1), 1, 3, 96, 168, None),
+    ('r50 res3 2c 1x1 128->512', 128, 512, (1, 1, 1), 1, 8, 96, 168, None),
+    ('r50 res4 2a 1x1 1024->256', 1024, 256, (1, 1, 1), 1, 8, 48, 84, None),
+]
+
+def run(tag):
+    for name, cin, cout, k, st, T, H, W, win in LAYERS:
+        g = torch.Generator().manual_seed(1)
+        pads = (k[0] // 2, k[1] // 2, k[2] // 2)
+        Ho, Wo = (H + 2 * pads[1] - k[1]) // st + 1, (W + 2 * pads[2] - k[2]) // st + 1
+        x = torch.randn((T, H, W, cin), generator=g).bfloat16().cuda()
+        gy = torch.randn((T, Ho, Wo, cout), generator=g).bfloat16().cuda()
+        w = torch.randn((cout, cin) + k, generator=g).cuda() * 0.05
+        cg = ops.ConvGrad(w, None, (st, st), pads, ops.BF16, cin, cout)
+        kw = dict(g_frames=win) if win else {}
+        cg.weight(x, gy, T, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            cg.weight(x, gy, T, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        frames = win[1] if win else T
+        fl = 2.0 * cin * cout * k[0] * k[1] * k[2] * frames * Ho * Wo
+        print('%-8s %-28s %7.3f ms  %7.1f TFLOP/s' % (tag, name, ms, fl / ms / 1e9), flush=True)
+
+def fresh(env, tag):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            run(tag)
+            torch.cuda.synchronize()
+    finally:
+        for k, v in old.items():
+            if v is None: del os.environ[k]
+            else: os.environ[k] = v
+
+fresh({'DAT_WGRAD_DIRECT': '0'}, 'repack')
+fresh({'DAT_WGRAD_DIRECT': '1'}, 'direct')
+for ks in (4, 8, 16, 32, 64):
+    fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_KS': str(ks)}, 'ks%d' % ks)
