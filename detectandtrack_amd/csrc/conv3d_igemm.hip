@@ -549,11 +549,12 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                     const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int e2 = 0; e2 < CPL / 2; ++e2) {
-                        v[2 * e2] += bf2f((uint16_t)(ru[e2 % 4] & 0xffff));
-                        v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2 % 4] >> 16));
+                        v[2 * e2] = res_combine(v[2 * e2], bf2f((uint16_t)(ru[e2 % 4] & 0xffff)), p.res_mode);
+                        v[2 * e2 + 1] = res_combine(v[2 * e2 + 1], bf2f((uint16_t)(ru[e2 % 4] >> 16)), p.res_mode);
                     }
                 } else {
-                    v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y); v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
+                    v[0] = res_combine(v[0], __uint_as_float(r.x), p.res_mode); v[1] = res_combine(v[1], __uint_as_float(r.y), p.res_mode);
+                    v[2] = res_combine(v[2], __uint_as_float(r.z), p.res_mode); v[3] = res_combine(v[3], __uint_as_float(r.w), p.res_mode);
                 }
             } else if (p.res_mode) {
                 unsigned rpos = lpos;
@@ -564,12 +565,15 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                     for (int e4 = 0; e4 < CPL / 4; ++e4)
                         if (e4 * 4 < nch) {
                             const uint2 r = *(const uint2*)(rp + e4 * 8);
-                            v[e4 * 4 + 0] += bf2f((uint16_t)(r.x & 0xffff)); v[e4 * 4 + 1] += bf2f((uint16_t)(r.x >> 16));
-                            v[e4 * 4 + 2] += bf2f((uint16_t)(r.y & 0xffff)); v[e4 * 4 + 3] += bf2f((uint16_t)(r.y >> 16));
+                            v[e4 * 4 + 0] = res_combine(v[e4 * 4 + 0], bf2f((uint16_t)(r.x & 0xffff)), p.res_mode);
+                            v[e4 * 4 + 1] = res_combine(v[e4 * 4 + 1], bf2f((uint16_t)(r.x >> 16)), p.res_mode);
+                            v[e4 * 4 + 2] = res_combine(v[e4 * 4 + 2], bf2f((uint16_t)(r.y & 0xffff)), p.res_mode);
+                            v[e4 * 4 + 3] = res_combine(v[e4 * 4 + 3], bf2f((uint16_t)(r.y >> 16)), p.res_mode);
                         }
                 } else {
                     const float4 r = *(const float4*)rp;
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    v[0] = res_combine(v[0], r.x, p.res_mode); v[1] = res_combine(v[1], r.y, p.res_mode);
+                    v[2] = res_combine(v[2], r.z, p.res_mode); v[3] = res_combine(v[3], r.w, p.res_mode);
                 }
             }
             if (p.relu) {
@@ -637,11 +641,12 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
             }
             if (DT == DAT_BF16) {
                 const uint2 r = *(const uint2*)(res + (rpos * out_cs + c) * 2);
-                v[0] += bf2f((uint16_t)(r.x & 0xffff)); v[1] += bf2f((uint16_t)(r.x >> 16));
-                v[2] += bf2f((uint16_t)(r.y & 0xffff)); v[3] += bf2f((uint16_t)(r.y >> 16));
+                v[0] = res_combine(v[0], bf2f((uint16_t)(r.x & 0xffff)), res_mode); v[1] = res_combine(v[1], bf2f((uint16_t)(r.x >> 16)), res_mode);
+                v[2] = res_combine(v[2], bf2f((uint16_t)(r.y & 0xffff)), res_mode); v[3] = res_combine(v[3], bf2f((uint16_t)(r.y >> 16)), res_mode);
             } else {
                 const float4 r = *(const float4*)(res + (rpos * out_cs + c) * 4);
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                v[0] = res_combine(v[0], r.x, res_mode); v[1] = res_combine(v[1], r.y, res_mode);
+                v[2] = res_combine(v[2], r.z, res_mode); v[3] = res_combine(v[3], r.w, res_mode);
             }
         }
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -860,6 +865,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     DAT_ENFORCE(ctx, d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_cstride >= d->Cout,
                 "conv3d_fwd: Cout %d / out_cstride %d must be multiples of 4", d->Cout, d->out_cstride);
     DAT_ENFORCE(ctx, d->frames % d->T == 0, "conv3d_fwd: frames %d not a multiple of T %d", d->frames, d->T);
+    DAT_ENFORCE(ctx, d->res_mode >= 0 && d->res_mode <= 3, "conv3d_fwd: res_mode %d", d->res_mode);
     DAT_ENFORCE(ctx, d->res_mode == 0 || residual, "conv3d_fwd: res_mode %d needs a residual pointer", d->res_mode);
     // full-length outputs need "same" temporal padding; an explicit output-frame window may use any pad_t (taps that
     // fall outside [0, T) read zeros) -- e.g. KT == T, pad_t == 0, window {0}: a 1x1 conv over time-moved-to-channels
@@ -949,16 +955,17 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     if (bt_eligible(ctx, d)) bt_tile_twl(p, &bt_blocks);
     const long long ncu = ctx_num_cu(ctx), bt_rounds = cdiv_ll(bt_blocks, ncu);
     const bool bt_fits = ctx->dbg_bt >= 2 ? bt_blocks * 2 >= 3 * ncu : (bt_blocks >= 4 * ncu && bt_blocks * 100 >= bt_rounds * ncu * 95);
-    if (bt_fits && ksplit == 1 && !force_bp && !force_ks) {
+    const bool mask_mode = d->res_mode == 3;     // only the generic kernel's epilogue knows the masking combine
+    if (bt_fits && ksplit == 1 && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 2560 + d->dtype;
         rc = launch_bt(ctx, st, p);
-    } else if (pw256_eligible(ctx, d) && !force_bp && !force_ks) {
+    } else if (pw256_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 320 + d->dtype;     // (256 channels x 32 positions per wave: the weights-stationary 1x1 kernel)
         rc = launch_pw256(ctx, st, p);
-    } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks) {
+    } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 330 + d->dtype;     // (the weights-in-LDS 1x1 kernel: 32 positions per wave tile)
         rc = launch_pwlw(ctx, st, p, d);
-    } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks) {
+    } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {
         tag = 64 * 10000 + 9990 + d->dtype;    // ("999 positions": the persistent weights-stationary kernel)
         rc = launch_ws64(ctx, st, p);
     } else if (thin3) {

@@ -79,6 +79,11 @@ template <> struct Mma<DAT_F32> {
     }
 };
 
+// residual combine of the fused epilogue: modes 1 / 2 add (Sum shortcut, FPN top-down map); mode 3 MASKS -- out = res > 0 ? v : 0, the
+// ReLU backward of the conv's INPUT blob fused into the data-gradient conv (round 3: `res` is the forward input x = relu(...) of the
+// conv whose data gradient the launch computes; training.py bwd_Conv)
+__device__ __forceinline__ float res_combine(float v, float r, int mode) { return mode == 3 ? (r > 0.f ? v : 0.f) : v + r; }
+
 __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + (((slot ^ (row >> 1)) & 7) << 4); }
 
 

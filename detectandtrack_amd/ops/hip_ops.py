@@ -270,8 +270,10 @@ class ConvGrad(object):
         dscale = (dW * self.w).sum(dim=(1, 2, 3, 4)) / self.scale
         return dW, dscale
 
-    def data(self, g, T, H, W, accumulate_into=None, g_frames=None):
-        """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given)."""
+    def data(self, g, T, H, W, accumulate_into=None, g_frames=None, mask=None):
+        """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given).  mask: the conv's
+        forward input x = relu(...) in the shape of dL/dx -- the ReLU backward of x's producer is applied in this conv's epilogue
+        (dL/dx := x > 0 ? dL/dx : 0, res_mode 3), which saves that producer's elementwise mask pass."""
         if self._data_layer is None:
             # flipped / transposed / scale-folded weights are packed straight from the forward master (no ATen flip, mul, copy)
             pads = (self.kt - 1 - self.pads[0], self.kh - 1 - self.pads[1], self.kw - 1 - self.pads[2])
@@ -290,7 +292,11 @@ class ConvGrad(object):
         lay = self._data_layer
         in_t = g_frames if (g_frames is not None and frames == T) else None   # zero frames of g: their temporal taps are skipped
         if accumulate_into is not None:
+            assert mask is None
             return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into, in_t=in_t)
+        if mask is not None:
+            assert mask.is_contiguous() and mask.dtype == gz.dtype
+            return lay(gz, T=T, residual=mask, res_mode=3, in_t=in_t)
         return lay(gz, T=T, in_t=in_t)
 
 

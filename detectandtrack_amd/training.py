@@ -36,6 +36,12 @@ class TrainExecutor(Executor):
         # Trainer's gradient arena: param name -> a zeroed fp32 view of ONE flat buffer (the all-reduce and the SGD update run on
         # the flat buffer; weight-gradient kernels write into the views directly).  None: gradients are separate tensors.
         self.arena = arena
+        self._masked, self._last_masked = set(), False      # gradient tensors that already carry their producer's ReLU mask
+        self._readers = {}
+        for o in net.ops:
+            res = o.args.get('residual') if isinstance(o.args, dict) else None
+            for b in list(o.inputs) + ([res] if res else []):
+                self._readers[b] = self._readers.get(b, 0) + 1
         self.losses = {}         # loss blob name -> fp32 CUDA scalar tensor
         self.metrics = {}
         self._cg = {}
@@ -159,15 +165,22 @@ class TrainExecutor(Executor):
     # A gradient of a T-frame feature map may cover only a WINDOW of frames [lo, lo + n) (everything else is exactly zero):
     # with BODY_HEAD_LINK 'slice-center' the heads read one frame, so the FPN post-hoc convs (60 % of the forward FLOPs)
     # receive a 1-frame gradient and hand a 3-frame gradient down; each kT = 3 conv widens the window by its temporal reach.
-    def _add_grad(self, name, t, lo=0):
+    def _add_grad(self, name, t, lo=0, masked=False):
+        """masked: the ReLU backward of `name`'s producer is already applied to `t` (fused into the data-gradient conv that made it)."""
+        if masked:
+            self._masked.add(id(t))
         self.grads.setdefault(name, []).append((t, lo))
 
     def _take_grad(self, name, dtype):
         """-> (dy, lo) with dy in the activation dtype covering frames [lo, lo + dy.shape[0]), or (None, 0)."""
         lst = self.grads.pop(name, None)
+        self._last_masked = False
         if not lst:
             return None, 0
         tdt = ops.tdtype(dtype)
+        self._last_masked = len(lst) == 1 and id(lst[0][0]) in self._masked
+        for t, _l in lst:        # (ids are unique only while the tensors live in self.grads)
+            self._masked.discard(id(t))
         lo = min(l for _, l in lst)
         hi = max(l + t.shape[0] for t, l in lst)
         if len(lst) == 1:
@@ -223,6 +236,7 @@ class TrainExecutor(Executor):
 
     # ---- backward -----------------------------------------------------------------------------------------------------------
     def backward(self):
+        self._masked.clear()
         for i in range(len(self.net.ops) - 1, -1, -1):
             op = self.net.ops[i]
             if i in self._skip and i not in self._fused:
@@ -254,8 +268,10 @@ class TrainExecutor(Executor):
         if train_b:     # the kernel ACCUMULATES the bias reduction: straight into the (zeroed) arena view when there is one
             dbias = self.arena[train_b] if (self.arena is not None and train_b in self.arena) else \
                 torch.zeros(cout, dtype=torch.float32, device=ws.device)
-        if a['relu'] or dbias is not None:
-            g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=a['relu'], dbias=dbias)
+        # (the mask may already be in dy: the data-gradient conv of this blob's only reader applied it in its epilogue)
+        need_relu = bool(a['relu']) and not self._last_masked
+        if need_relu or dbias is not None:
+            g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=need_relu, dbias=dbias)
         else:
             g = dy          # no ReLU to mask by, no trainable bias to reduce into (the shortcut convs: AffineChannelNd has no gradient)
         if train_b:
@@ -296,9 +312,17 @@ class TrainExecutor(Executor):
                 if l0 == ilo and t0.shape[0] == ihi - ilo and t0.dtype == ops.tdtype(y.dt) and tuple(t0.shape[1:3]) == (H, W) and \
                         t0.is_contiguous() and not getattr(t0, '_roi_acc', False) and t0.shape[3] == ops.round_up(cg.cin, 64):
                     into = t0
-            dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None)
+            # ReLU backward of the input blob fused into this launch's epilogue: x = relu(...) is read by this conv only, its
+            # gradient has this one contribution, and its producer is a conv this executor differentiates
+            mask = None
+            prod = self.net.producer(op.inputs[0])
+            if (into is None and cfg.HIP.get('FUSE_RELU_BWD', True) and prod is not None and prod.type == 'Conv' and
+                    isinstance(prod.args, dict) and prod.args.get('relu') and self._readers.get(op.inputs[0], 0) == 1 and
+                    not pend and xin.keyframe is None and not xin.t2c and xin.t.shape[3] == ops.round_up(cg.cin, 64)):
+                mask = x_win if x_win.is_contiguous() else None
+            dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None, mask=mask)
             if into is None:
-                self._add_grad(op.inputs[0], dx, ilo)
+                self._add_grad(op.inputs[0], dx, ilo, masked=mask is not None)
 
     def _bwd_rpn_head(self, i):
         ws = self.ws

@@ -82,7 +82,8 @@ typedef struct {
     int stride_h, stride_w;  /* temporal stride is 1 (VIDEO.TIME_STRIDE_ON unsupported: FPN3D.py:199-203) */
     int pad_t, pad_h, pad_w; /* symmetric explicit pads, Caffe2 `pads=2*[..]` */
     int relu;                /* fused Relu */
-    int res_mode;            /* 0 none | 1 residual same shape | 2 residual at (h/2, w/2) (nearest 2x) */
+    int res_mode;            /* 0 none | 1 residual same shape | 2 residual at (h/2, w/2) (nearest 2x) | 3 MASK: y = residual > 0 ? v : 0
+                                (ReLU backward fused into a data-gradient conv: residual = the forward input of the conv, same shape as y) */
     int out_t0, out_tn;      /* out_tn > 0: write only output frames t in [out_t0, out_t0+out_tn) of every clip, stored
                                 compactly as [N*out_tn, Ho, Wo, C] (the frames a following SliceKeyFrame keeps,
                                 FPN3D.py:170-183 'slice-center'); out_tn == 0: all T frames.  residual (if any) is
