@@ -198,7 +198,8 @@ def pmc_traffic(a, kernel_name):
         rec = json.load(f)
     w = rec.get('workload', {})
     same = (w.get('arch') == a.arch and w.get('frames') == a.frames and w.get('height') == a.height and
-            w.get('width') == a.width and w.get('dtype') == a.dtype and bool(w.get('keyframe_dce')) == bool(a.keyframe_dce))
+            w.get('width') == a.width and w.get('dtype') == a.dtype and bool(w.get('keyframe_dce')) == bool(a.keyframe_dce) and
+            int(w.get('batch', 1)) == int(getattr(a, 'batch_resolved', 1)))
     k = rec.get('kernels', {}).get(kernel_name)
     if not same or k is None:
         return None
@@ -443,6 +444,7 @@ def main():
     # default: 4 clips per forward for the headline workload (3 forwards in flight: measured best), all 8 frames of a 2D step
     B = a.batch if a.batch else (T if two_d else 4 if (a.workload == '3d_r18_fpn3d' and not train) else 1)
     assert B >= 1 and (not two_d or T % B == 0), '--batch must divide --frames for the 2D workload'
+    a.batch_resolved = B
     fwd_per_step = T // B if two_d else 1
     clips_per_step = 1 if two_d else B          # what `value` counts per step: a 2D step is one 8-frame clip, a 3D step B clips
     units_per_step = fwd_per_step

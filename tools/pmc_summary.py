@@ -41,7 +41,7 @@ def short(name):
         rest = [int(x) for x in m.group(5).replace(',', ' ').split()]
         tps = ',tps%d' % rest[0] if rest and rest[0] != 1 else ''
         return 'conv3d_igemm_kernel<%s,%s,%s%s>' % ('bf16' if m.group(1) == '1' else 'fp32', m.group(2), m.group(3), tps)
-    m = re.search(r'(conv3x3_c64_ws_kernel|conv3x3_bt_kernel|conv1x1_k64_c256_ws_kernel|stem_pool_kernel|stem_conv_kernel)', name)
+    m = re.search(r'(conv3x3_c64_ws_kernel|conv3x3_bt_kernel|conv1x1_k64_c256_ws_kernel|conv1x1_lw_kernel|stem_pool_kernel|stem_conv_kernel)', name)
     if m:
         return m.group(1) + ('<bf16,256,256>' if m.group(1) == 'conv3x3_bt_kernel' else '<bf16>')
     m = re.search(r'([A-Za-z_0-9]+)(<[^(]*>)?\(', name)
@@ -110,11 +110,12 @@ def main():
         bench = json.loads(f.read().strip().splitlines()[-1])
     wl = bench['config']['workload']
     m = re.search(r'R-(\d+) .* 1x3x(\d+)x(\d+)x(\d+)', wl)
+    batch = int(bench['config'].get('images_per_forward', 1))
     rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python bench.py '
                      '--steps 3 --warmup 1 --pipeline 1; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
            'workload': {'arch': m.group(1), 'frames': int(m.group(2)), 'height': int(m.group(3)),
                         'width': int(m.group(4)), 'dtype': bench['dtype'],
-                        'keyframe_dce': bench['config'].get('keyframe_dce', False)},
+                        'keyframe_dce': bench['config'].get('keyframe_dce', False), 'batch': batch},
            'kernels': kernels}
     with open(os.path.join(os.path.dirname(dst.rstrip('/')), 'pmc_traffic.json'), 'w') as f:
         json.dump(rec, f, indent=1, sort_keys=True)
