@@ -256,7 +256,7 @@ def _build_defaults():
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
-                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True})
+                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4})
     return c
 
 

@@ -216,9 +216,9 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     T = (cols - 1) // 4
     D = int(cfg.TEST.DETECTIONS_PER_IM)
     # rows per image: the limit rule keeps EVERY score tied with the D-th best (test.py:795-800), so D rows are not always enough --
-    # frequent with bf16 logits; D/8 spare rows make the overflow (host path for that image) rare.  No limit: every roi may survive
-    # in every class.
-    out_cap = D + max(4, D // 8) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
+    # frequent with bf16 logits; a few spare rows (cfg.HIP.DET_SPARE_ROWS, default 4: ties at the cut are pairs, and every spare row is a
+    # row of keypoint-head work) make the overflow (host path for that image) rare.  No limit: every roi may survive in every class.
+    out_cap = D + max(0, int(cfg.HIP.get('DET_SPARE_ROWS', 4))) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
     dets, kp_rois, n_out = ops.box_results(
         rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,

@@ -556,48 +556,66 @@ __global__ void relu_bwd_kernel(const void* __restrict__ dy, const void* __restr
     const int c = (int)(gid % nq) * 4;
     const long long pstep = stride / nq;
     (void)total;
-    for (long long pos = gid / nq; pos < npos; pos += pstep) {
-        float v[4], o[4] = {1.f, 1.f, 1.f, 1.f};
-        const size_t at = (size_t)pos * cs + c;
-        if (DT == DAT_BF16) {
-            const uint2 a = ((const uint2*)dy)[at >> 2];
-            v[0] = bf2f((uint16_t)(a.x & 0xffff)); v[1] = bf2f((uint16_t)(a.x >> 16));
-            v[2] = bf2f((uint16_t)(a.y & 0xffff)); v[3] = bf2f((uint16_t)(a.y >> 16));
-            if (dy2) {
-                const uint2 b = ((const uint2*)dy2)[at >> 2];
-                v[0] += bf2f((uint16_t)(b.x & 0xffff)); v[1] += bf2f((uint16_t)(b.x >> 16));
-                v[2] += bf2f((uint16_t)(b.y & 0xffff)); v[3] += bf2f((uint16_t)(b.y >> 16));
-            }
-            if (relu) {
-                const uint2 q = ((const uint2*)y)[at >> 2];
-                o[0] = bf2f((uint16_t)(q.x & 0xffff)); o[1] = bf2f((uint16_t)(q.x >> 16));
-                o[2] = bf2f((uint16_t)(q.y & 0xffff)); o[3] = bf2f((uint16_t)(q.y >> 16));
-            }
-        } else {
-            const float4 a = ((const float4*)dy)[at >> 2];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            if (dy2) {
-                const float4 b = ((const float4*)dy2)[at >> 2];
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (relu) {
-                const float4 q = ((const float4*)y)[at >> 2];
-                o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+    // U positions per trip, all loads of a trip issued before their first use: with <= 512 blocks (bias-reducing launches) a thread
+    // has 20-40 trips, and one 8-byte load in flight per trip made the launch a chain of memory round trips (77 us for a 20 MB
+    // tensor = 0.26 TB/s, profiles/r03/train_r18 kernel trace)
+    constexpr int U = 4;
+    for (long long pos0 = gid / nq; pos0 < npos; pos0 += pstep * U) {
+        float vv[U][4], oo[U][4];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pos = pos0 + pstep * u;
+            live[u] = pos < npos;
+            const size_t at = (size_t)(live[u] ? pos : pos0) * cs + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oo[u][e] = 1.f;
+            if (DT == DAT_BF16) {
+                const uint2 a = ((const uint2*)dy)[at >> 2];
+                vv[u][0] = bf2f((uint16_t)(a.x & 0xffff)); vv[u][1] = bf2f((uint16_t)(a.x >> 16));
+                vv[u][2] = bf2f((uint16_t)(a.y & 0xffff)); vv[u][3] = bf2f((uint16_t)(a.y >> 16));
+                if (dy2) {
+                    const uint2 b = ((const uint2*)dy2)[at >> 2];
+                    vv[u][0] += bf2f((uint16_t)(b.x & 0xffff)); vv[u][1] += bf2f((uint16_t)(b.x >> 16));
+                    vv[u][2] += bf2f((uint16_t)(b.y & 0xffff)); vv[u][3] += bf2f((uint16_t)(b.y >> 16));
+                }
+                if (relu) {
+                    const uint2 q = ((const uint2*)y)[at >> 2];
+                    oo[u][0] = bf2f((uint16_t)(q.x & 0xffff)); oo[u][1] = bf2f((uint16_t)(q.x >> 16));
+                    oo[u][2] = bf2f((uint16_t)(q.y & 0xffff)); oo[u][3] = bf2f((uint16_t)(q.y >> 16));
+                }
+            } else {
+                const float4 a = ((const float4*)dy)[at >> 2];
+                vv[u][0] = a.x; vv[u][1] = a.y; vv[u][2] = a.z; vv[u][3] = a.w;
+                if (dy2) {
+                    const float4 b = ((const float4*)dy2)[at >> 2];
+                    vv[u][0] += b.x; vv[u][1] += b.y; vv[u][2] += b.z; vv[u][3] += b.w;
+                }
+                if (relu) {
+                    const float4 q = ((const float4*)y)[at >> 2];
+                    oo[u][0] = q.x; oo[u][1] = q.y; oo[u][2] = q.z; oo[u][3] = q.w;
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((relu && !(o[e] > 0.f)) || c + e >= C) v[e] = 0.f;
-            s[e] += v[e];
-        }
-        if (!g) continue;      // reduction only (no ReLU, no padded channels: the caller keeps using dy itself)
-        if (DT == DAT_BF16) {
-            uint2 w;
-            w.x = f2bf2(v[0], v[1]);
-            w.y = f2bf2(v[2], v[3]);
-            ((uint2*)g)[at >> 2] = w;
-        } else {
-            ((float4*)g)[at >> 2] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const size_t at = (size_t)(pos0 + pstep * u) * cs + c;
+            float* v = vv[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((relu && !(oo[u][e] > 0.f)) || c + e >= C) v[e] = 0.f;
+                s[e] += v[e];
+            }
+            if (!g) continue;      // reduction only (no ReLU, no padded channels: the caller keeps using dy itself)
+            if (DT == DAT_BF16) {
+                uint2 w;
+                w.x = f2bf2(v[0], v[1]);
+                w.y = f2bf2(v[2], v[3]);
+                ((uint2*)g)[at >> 2] = w;
+            } else {
+                ((float4*)g)[at >> 2] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     }
     if (!dbias) return;

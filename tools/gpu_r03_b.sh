@@ -1,13 +1,13 @@
-cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_j; mkdir -p $o
-timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_full.py -m gpu -q -x > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
-B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 20 --warmup 4 --mode train"
-for w in 3d_r18_fpn3d 3d_r50_fpn3d; do
-  $B --workload $w > $o/train_$w.json 2> $o/train_$w.err; DAT_WGRAD_DIRECT=0 $B --workload $w > $o/train_${w}_off.json 2> $o/train_${w}_off.err
-  python - $o/train_$w.json $o/train_${w}_off.json <<'PY'
+cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_k; mkdir -p $o
+B="timeout 300 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 40 --warmup 6 --h2d 0"
+run() { n=$1; shift; "$@" > $o/$n.json 2> $o/$n.err; python - $o/$n.json $n <<'PY'
 import json,sys
-for f in sys.argv[1:]:
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['ms_per_step'], 'ms/iter')
-    except Exception as e: print(f, 'ERR', e)
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
+    print(sys.argv[2], d['value'], d['unit'], d['ms_per_step'], 'seq', d.get('sequential_clips_per_s'), r['kernel'], r['achieved'], r['all_conv_kernels']['tflops'], 'hostpath', d.get('host_path_images'))
+except Exception as e: print(sys.argv[2], 'ERR', e)
 PY
-done
+}
+run base $B; run bt env DAT_CONV_BT=1 $B; run base2 $B; run bt2 env DAT_CONV_BT=1 $B
+run r50 $B --workload 3d_r50_fpn3d; run r50bt env DAT_CONV_BT=1 $B --workload 3d_r50_fpn3d
+run d2 $B --workload 2d_r50_fpn
