@@ -1,9 +1,14 @@
-cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_l; mkdir -p $o
-B="timeout 300 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 40 --warmup 6 --h2d 0"
-$B --keyframe-dce > $o/dce.json 2> $o/dce.err; python - <<'PY'
-import json
-try:
-    d=json.loads(open('gpurun_out/r03_l/dce.json').read().strip().splitlines()[-1]); print('dce', d['value'], d['ms_per_step'], d.get('sequential_clips_per_s'))
-except Exception as e: print('ERR', e); print(open('gpurun_out/r03_l/dce.err').read()[-1500:])
+cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_j; mkdir -p $o
+timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_full.py -m gpu -q -x > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
+B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 20 --warmup 4 --mode train"
+for w in 3d_r18_fpn3d 3d_r50_fpn3d; do
+  $B --workload $w > $o/train_$w.json 2> $o/train_$w.err
+  python - $o/train_$w.json <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['ms_per_step'], 'ms/iter')
+    except Exception as e: print(f, 'ERR', e)
 PY
-bash tools/gpu_r03.sh all r03_all2
+done
+bash tools/probes/prof_train.sh | grep -E "relu_bwd|bias_partial" | cut -c1-200
