@@ -777,3 +777,44 @@ def test_bench_gpus_n_without_n_ranks_never_prints_an_n_gpu_line():
     assert "'config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']" in src
     ap_src = inspect.getsource(bench.main)
     assert "'--steps', type=int, default=100" in ap_src
+
+
+def test_segmented_row_counts_and_test_scale_host_logic():
+    """Round 3 host logic that needs no GPU: (a) a row-counted blob of a forward with several images holds equal row segments with one
+    count per image and is fetched as the images' live rows concatenated (what the reference's batched blobs hold, column 0 = image);
+    (b) `utils.blob.test_scale` is the scale `prep_im_for_blob` applies (lib/utils/blob.py:78-85); (c) the pipeline's geometry key
+    separates forwards that must not share a captured graph."""
+    import torch
+    from detectandtrack_amd import workspace as W
+    from detectandtrack_amd.utils import blob as blob_utils
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    reset_cfg()
+    b = W.Blob(torch.zeros(12, 5), 'rois')
+    arr = np.arange(60, dtype=np.float32).reshape(12, 5)
+    b.count = torch.tensor([2, 0, 3], dtype=torch.int32)
+    got = W._valid_rows(b, arr)
+    np.testing.assert_array_equal(got, np.concatenate([arr[0:2], arr[8:11]]))
+    np.testing.assert_array_equal(W._valid_rows(b, arr.reshape(3, 4, 5)), got)           # [n_images, rows, cols] view of a per-level blob
+    b.count = torch.tensor([7], dtype=torch.int32)
+    np.testing.assert_array_equal(W._valid_rows(b, arr), arr[:7])
+    b.count = None
+    assert W._valid_rows(b, arr) is arr
+    rs = np.random.RandomState(0)
+    for h, w, target, mx in ((720, 1280, 800, 1333), (600, 800, 800, 1333), (97, 53, 64, 100), (480, 854, 800, 1333), (1080, 1920, 800, 1333)):
+        im = rs.randint(0, 255, (h, w, 3)).astype(np.uint8)
+        ims, scales = blob_utils.prep_im_for_blob(im, cfg.PIXEL_MEANS, (target,), mx)
+        s = blob_utils.test_scale((h, w), target, mx)
+        assert s == scales[0] and ims[0].shape[:2] == (int(np.rint(h * s)), int(np.rint(w * s)))
+    # (the key is a pure function of blob shape, im_info rows and unscaled image sizes)
+    import importlib
+    key = None
+    try:
+        pipeline = importlib.import_module('detectandtrack_amd.core.pipeline')
+        key = pipeline.ClipPipeline._geometry
+    except ImportError:
+        pytest.skip('pipeline imports the device library')
+    k1 = key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (4, 1)), [(720, 1280, 3)] * 4)
+    assert k1 == key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (4, 1)), [(720, 1280, 3)] * 4)
+    assert k1 != key((2, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (2, 1)), [(720, 1280, 3)] * 2)
+    assert k1 != key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.11]], (4, 1)), [(720, 1280, 3)] * 4)
+    assert k1 != key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (4, 1)), [(719, 1280, 3)] * 4)

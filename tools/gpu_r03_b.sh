@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_j; mkdir -p $o
-timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_full.py -m gpu -q -x > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
+timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_kernels.py -m gpu -q -x -k "not full_size and not bench_size" > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
 B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 20 --warmup 4 --mode train"
 for w in 3d_r18_fpn3d 3d_r50_fpn3d; do
   $B --workload $w > $o/train_$w.json 2> $o/train_$w.err
@@ -11,4 +11,4 @@ for f in sys.argv[1:]:
     except Exception as e: print(f, 'ERR', e)
 PY
 done
-bash tools/probes/prof_train.sh | grep -E "relu_bwd|bias_partial" | cut -c1-200
+bash tools/probes/prof_train.sh | grep -E "pack_weights" | cut -c1-200
