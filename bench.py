@@ -415,7 +415,7 @@ def main():
     if a.workload is None:
         a.workload = '3d_r%s_fpn3d' % (a.arch or '18')
     if a.pipeline is None:
-        a.pipeline = 3 if a.workload == '3d_r18_fpn3d' and a.mode == 'infer' and not a.batch else 4 if not a.workload.endswith('_tube') else 2
+        a.pipeline = 3 if a.workload in ('3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d') and a.mode == 'infer' and not a.batch else 4 if not a.workload.endswith('_tube') else 2
     two_d = a.workload == '2d_r50_fpn'
     tube = a.workload.endswith('_tube')
     a.arch = '50' if two_d else a.workload.split('_')[1][1:]
@@ -441,8 +441,8 @@ def main():
     from detectandtrack_amd.ops import hip_ops as ops
     T, H, W = a.frames, a.height, a.width
     # images per forward B; a step = ONE forward of B clips (3D) or the T frames of a 2D step in T / B forwards
-    # default: 4 clips per forward for the headline workload (3 forwards in flight: measured best), all 8 frames of a 2D step
-    B = a.batch if a.batch else (T if two_d else 4 if (a.workload == '3d_r18_fpn3d' and not train) else 1)
+    # default: 4 clips per forward for the 3D FPN workloads (3 forwards in flight: measured best for R-18 and R-50), all 8 frames of a 2D step
+    B = a.batch if a.batch else (T if two_d else 4 if (a.workload in ('3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d') and not train) else 1)
     assert B >= 1 and (not two_d or T % B == 0), '--batch must divide --frames for the 2D workload'
     a.batch_resolved = B
     fwd_per_step = T // B if two_d else 1
