@@ -397,6 +397,7 @@ struct Wgrad9Params {
     int ksplit, n_ci_tiles, n_co_tiles;
     int f_begin, f_end;   // output frames [f_begin, f_end) carry a non-zero gradient (frame window; whole clips otherwise)
     int tiles_h, tiles_w; // 8 x 8 patches per frame
+    int ablate;           // DEBUG (DAT_WGRAD_ABLATE): 1 no global loads, 2 no LDS fragment reads / MFMAs, 4 no final atomics / stores
 };
 
 constexpr int W9_PITCH = 192;
@@ -433,8 +434,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
     // staging: 16-byte piece pc (8 per 64-channel row); g: rows r0 + 32 i (i < 2), x: patch rows r0 + 32 i (i < 4, < 100)
     const int pc = tid & 7, r0 = tid >> 3;
     const bool g_col_ok = co_t * 64 + pc * 8 < p.g_cs, x_col_ok = ci_t * 64 + pc * 8 < p.x_cs;
-    uint4 gq[2], xq[4];
-#define W9_FETCH(CH_)                                                                                                   \
+    uint4 gqA[2], xqA[4], gqB[2], xqB[4];        // two register sets: the loads of chunk c + 2 are issued while chunk c computes
+#define W9_FETCH(CH_, GQ_, XQ_)                                                                                                   \
     {                                                                                                                   \
         const unsigned fr_ = (unsigned)(CH_) / per_frame, tl_ = (unsigned)(CH_) - fr_ * per_frame;                       \
         const int f_ = p.f_begin + (int)fr_;                                                                            \
@@ -443,24 +444,24 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
         const bool tin_ = ti_ >= 0 && ti_ < p.T;                                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                              \
             const int r_ = r0 + 32 * i_, oy_ = ty_ * 8 + (r_ >> 3), ox_ = tx_ * 8 + (r_ & 7);                           \
-            gq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            GQ_[i_] = make_uint4(0, 0, 0, 0);                                                                            \
             if (g_col_ok && tin_ && oy_ < p.H && ox_ < p.W)                                                             \
-                gq[i_] = *(const uint4*)(p.g + ((((size_t)f_ * p.H + oy_) * p.W + ox_) * (unsigned)p.g_cs + (unsigned)(co_t * 64 + pc * 8)) * 2u); \
+                GQ_[i_] = *(const uint4*)(p.g + ((((size_t)f_ * p.H + oy_) * p.W + ox_) * (unsigned)p.g_cs + (unsigned)(co_t * 64 + pc * 8)) * 2u); \
         }                                                                                                               \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
             const int r_ = r0 + 32 * i_, py_ = r_ / 10, px_ = r_ - py_ * 10;                                            \
             const int iy_ = ty_ * 8 + py_ - 1, ix_ = tx_ * 8 + px_ - 1;                                                 \
-            xq[i_] = make_uint4(0, 0, 0, 0);                                                                            \
+            XQ_[i_] = make_uint4(0, 0, 0, 0);                                                                            \
             if (x_col_ok && tin_ && r_ < 100 && iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W)                         \
-                xq[i_] = *(const uint4*)(p.x + ((((size_t)(clip_ * p.T + ti_) * p.H + iy_) * p.W + ix_) * (unsigned)p.x_cs + (unsigned)(ci_t * 64 + pc * 8)) * 2u); \
+                XQ_[i_] = *(const uint4*)(p.x + ((((size_t)(clip_ * p.T + ti_) * p.H + iy_) * p.W + ix_) * (unsigned)p.x_cs + (unsigned)(ci_t * 64 + pc * 8)) * 2u); \
         }                                                                                                               \
     }
-#define W9_STAGE_WRITE(BUF_)                                                                                            \
+#define W9_STAGE_WRITE(BUF_, GQ_, XQ_)                                                                                            \
     {                                                                                                                   \
         char* gd_ = smem + (BUF_) * W9_STAGE;                                                                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) *(uint4*)(gd_ + (r0 + 32 * i_) * W9_PITCH + pc * 16) = gq[i_];  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) *(uint4*)(gd_ + (r0 + 32 * i_) * W9_PITCH + pc * 16) = GQ_[i_];  \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                \
-            if (r0 + 32 * i_ < 100) *(uint4*)(gd_ + W9_GT + (r0 + 32 * i_) * W9_PITCH + pc * 16) = xq[i_];             \
+            if (r0 + 32 * i_ < 100) *(uint4*)(gd_ + W9_GT + (r0 + 32 * i_) * W9_PITCH + pc * 16) = XQ_[i_];             \
     }
     // fragment addressing.  g tile (rows = k = oy * 8 + ox): group G = lane >> 4 reads rows k0 + (G >> 1) * 8 [+4], columns (G & 1) * 16,
     // lane i of the group row i >> 2, columns 4 (i & 3).  x patch: k -> patch row (oy + kh) * 10 + ox + kw; the 8 k of a fragment
@@ -474,24 +475,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    if (c_lo < c_hi) {
-        W9_FETCH(c_lo);
-        W9_STAGE_WRITE(0);
-    }
-    __syncthreads();
-    for (unsigned c = c_lo; c < c_hi; ++c) {
-        const int buf = (int)((c - c_lo) & 1u);
-        if (c + 1 < c_hi) W9_FETCH(c + 1);          // in flight behind this chunk's MFMAs
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* gb = smem + buf * W9_STAGE + g_off;
         const char* xb = smem + buf * W9_STAGE + W9_GT + x_off;
+        if (p.ablate & 2) return;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {            // 16 k = output rows 2 ks, 2 ks + 1 of the patch
             const uint4 a = w9_tr_frag(gb + ks * 16 * W9_PITCH);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 // the three kw taps read three 8-wide windows of the SAME 10-wide patch row: 12 k (three 4-k transposing reads; the last
-                // two are past the row, never used) are fetched once and the windows cut out of the registers -- LDS reads per MFMA
-                // 2.2 -> 1.2 (the kernel was LDS-bandwidth-bound)
+                // two are past the row, never used) are fetched once and the windows cut out of the registers (LDS reads per MFMA 2.2 -> 1.2)
                 const char* rb = xb + ((2 * ks + kh) * 10) * W9_PITCH;
                 const uint2 q0 = w9_tr4(rb), q1 = w9_tr4(rb + 4 * W9_PITCH), q2 = w9_tr4(rb + 8 * W9_PITCH);
                 const uint4 b0 = make_uint4(q0.x, q0.y, q1.x, q1.y);
@@ -503,14 +497,33 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
                 MmaT<DAT_BF16>::step(a, b2, acc[kh * 3 + 2]);
             }
         }
-        if (c + 1 < c_hi) W9_STAGE_WRITE(buf ^ 1);
+    };
+    // Prefetch distance TWO chunks (ablation, tools/probes/wgrad_bench.py ablate: loads, MFMAs and the final atomics each cost about a
+    // quarter of a launch and did not overlap -- a chunk's MFMA phase (~0.5 us) is shorter than a memory round trip): chunk c computes
+    // from LDS, chunk c + 1 is in registers on its way to the other LDS buffer, chunk c + 2 is being requested.
+    const bool ld = !(p.ablate & 1);
+    if (c_lo < c_hi) {
+        W9_FETCH(c_lo, gqA, xqA);
+        W9_STAGE_WRITE(0, gqA, xqA);
+        if (c_lo + 1 < c_hi && ld) W9_FETCH(c_lo + 1, gqA, xqA);
+    }
+    __syncthreads();
+    for (unsigned c = c_lo; c < c_hi; c += 2) {
+        if (c + 2 < c_hi && ld) W9_FETCH(c + 2, gqB, xqB);
+        compute(0);
+        if (c + 1 < c_hi) W9_STAGE_WRITE(1, gqA, xqA);
+        __syncthreads();
+        if (c + 1 >= c_hi) break;
+        if (c + 3 < c_hi && ld) W9_FETCH(c + 3, gqA, xqA);
+        compute(1);
+        if (c + 2 < c_hi) W9_STAGE_WRITE(0, gqB, xqB);
         __syncthreads();
     }
 #undef W9_FETCH
 #undef W9_STAGE_WRITE
     const int khalf = lane >> 5;
     const int ci = ci_t * 64 + wave_n * 32 + (lane & 31);
-    if (ci >= p.Cin) return;
+    if (ci >= p.Cin || (p.ablate & 4)) return;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float* Gt = p.G + (size_t)(kt * 9 + t) * p.Cout * p.Cin;
@@ -902,6 +915,7 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
                 q.f_begin = d->out_t0; q.f_end = d->out_t0 + d->out_tn;
             }
             q.tiles_h = (d->H + 7) / 8; q.tiles_w = (d->W + 7) / 8;
+            q.ablate = ctx->dbg_ablate_wgrad;
             const long long tiles = (long long)d->KT * q.n_co_tiles * q.n_ci_tiles;
             const long long nchunks = (long long)(q.f_end - q.f_begin) * q.tiles_h * q.tiles_w;
             long long ks = 640 / tiles;                         // ~1.25 rounds of the 512 resident blocks (per-layer sweep, tools/probes/wgrad_bench.py)

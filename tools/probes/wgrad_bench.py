@@ -51,7 +51,13 @@ def fresh(env, tag):
             if v is None: del os.environ[k]
             else: os.environ[k] = v
 
-fresh({'DAT_WGRAD_DIRECT': '0'}, 'repack')
-fresh({'DAT_WGRAD_DIRECT': '1'}, 'direct')
-for ks in (4, 8, 16, 32, 64):
-    fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_KS': str(ks)}, 'ks%d' % ks)
+import sys as _s
+if len(_s.argv) > 1 and _s.argv[1] == 'ablate':
+    LAYERS[:] = LAYERS[:5]
+    for ab in (0, 1, 2, 4, 3, 7):
+        fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_ABLATE': str(ab)}, 'abl%d' % ab)
+else:
+    fresh({'DAT_WGRAD_DIRECT': '0'}, 'repack')
+    fresh({'DAT_WGRAD_DIRECT': '1'}, 'direct')
+    for ks in (4, 8, 16, 32, 64):
+        fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_KS': str(ks)}, 'ks%d' % ks)
