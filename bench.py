@@ -363,6 +363,7 @@ def build_train(arch, T, H, W, dtype, world, rank):
     c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 2000, 'RPN_POST_NMS_TOP_N': 2000, 'IMS_PER_BATCH': 1, 'MAX_SIZE': max(H, W),
                   'BATCH_SIZE_PER_IM': 512}
     c['NUM_GPUS'] = world
+    c['HIP']['FUSE_RELU_BWD'] = os.environ.get('DAT_FUSE_RELU_BWD', '1') != '0'      # (A/B switch for tools/)
     reset_cfg()
     cfg_from_cfg(c)
     assert_and_infer_cfg()

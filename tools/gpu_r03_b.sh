@@ -1,13 +1,12 @@
-cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_j; mkdir -p $o
-timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_full.py -m gpu -q -x > $o/pytest.log 2>&1; echo "pytest rc $?" | tee -a $o/pytest.log; grep -E "passed|failed|Error|assert|rel err" $o/pytest.log | tail -12
-B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 20 --warmup 4 --mode train"
-for w in 3d_r18_fpn3d 3d_r50_fpn3d; do
-  $B --workload $w > $o/train_$w.json 2> $o/train_$w.err
-  python - $o/train_$w.json <<'PY'
+cd $GRAFT_REPO_ROOT; o=gpurun_out/r03_n; mkdir -p $o
+B="timeout 600 python bench.py --no-cpu-baseline --no-accuracy --no-other-configs --steps 30 --warmup 5 --mode train"
+t() { n=$1; shift; "$@" > $o/$n.json 2> $o/$n.err; python - $o/$n.json $n <<'PY'
 import json,sys
-for f in sys.argv[1:]:
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d['ms_per_step'], 'ms/iter')
-    except Exception as e: print(f, 'ERR', e)
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], d['ms_per_step'], 'ms/iter')
+except Exception as e: print(sys.argv[2], 'ERR', e)
 PY
-done
+}
+t r18_on $B; t r18_off env DAT_EARLY_RPN_BWD=0 $B; t r18_on2 $B; t r18_off2 env DAT_EARLY_RPN_BWD=0 $B
+t r18_nofuse env DAT_FUSE_RELU_BWD=0 $B
+t r50_on $B --workload 3d_r50_fpn3d; t r50_off env DAT_EARLY_RPN_BWD=0 $B --workload 3d_r50_fpn3d
