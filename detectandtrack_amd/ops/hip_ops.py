@@ -22,8 +22,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _stream_handle(device=None):
+    """Raw hipStream_t of torch's current stream on `device`.  `torch.cuda.current_stream()` builds a Stream object through four
+    Python layers (8 us; two calls per launch were 3.6 ms of host time per training iteration of ~220 launches): the raw query
+    is one C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if device is None else device)
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def round_up(v, m):
@@ -38,7 +50,7 @@ def ctx(device=None):
     kernels of ONE stream may use at a time, so concurrent streams (clip pipelining) get their own context."""
     if device is None:
         device = torch.cuda.current_device()
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream_handle(device))
     if key not in _CTX:
         _CTX[key] = L.Ctx(device)
     return _CTX[key]
