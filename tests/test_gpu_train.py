@@ -646,3 +646,29 @@ def test_allreduce_bucket_through_the_c_abi_world1():
     finally:
         red.close()
     assert torch.equal(flat, want)
+
+
+@pytest.mark.parametrize('k,win', [((3, 3, 3), (2, 1)), ((3, 3, 3), (0, 2)), ((1, 1, 1), (1, 2)), ((1, 3, 3), (3, 1))])
+def test_direct_weight_gradient_over_a_frame_window(ops, k, win):
+    """Round 3: the bf16 direct weight-gradient kernels (transposing LDS reads, no re-pack) with a gradient that is non-zero only in
+    frames [t0, t0 + n) of the clip (the key-frame gradient of the FPN post-hoc convs, training.py bwd_Conv): the window launch must
+    equal the full launch on the zero-embedded gradient and torch autograd."""
+    cin, cout, T, H, W = 128, 192, 4, 17, 22
+    pads = (k[0] // 2, k[1] // 2, k[2] // 2)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((1, cin, T, H, W), generator=g).bfloat16().float()
+    w = torch.randn((cout, cin) + k, generator=g) * 0.05
+    gy = torch.zeros((1, cout, T, H, W))
+    t0, n = win
+    gy[:, :, t0:t0 + n] = torch.randn((1, cout, n, H, W), generator=g).bfloat16().float()
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, None, stride=1, padding=pads).backward(gy)
+    xd, gd = _ndhwc(x, cin, torch.bfloat16), _ndhwc(gy, cout, torch.bfloat16)
+    cg = ops.ConvGrad(w.cuda(), None, (1, 1), pads, ops.BF16, cin, cout)
+    full, _ = cg.weight(xd, gd, T)
+    part, _ = cg.weight(xd, gd, T, g_frames=(t0, n))
+    ref = wr.grad
+    scale = float(ref.abs().max())
+    assert float((full.cpu() - ref).abs().max()) < 2e-3 * scale
+    assert float((part.cpu() - ref).abs().max()) < 2e-3 * scale
+    assert float((part - full).abs().max()) < 1e-4 * scale      # (same products; the K split differs, fp32 sums in another order)
