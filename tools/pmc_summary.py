@@ -81,7 +81,8 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
     mfma_summary(src, dst)
-    shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
+    if os.path.exists(os.path.join(src, 'stats', 'r1_kernel_stats.csv')):
+        shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
     def by_short(agg):      # template variants of one tile shape (table-driven / unrolled-tap loops) are one bench bucket
         out = collections.OrderedDict()
         for name, (n, v) in agg.items():
@@ -117,8 +118,12 @@ def main():
                         'width': int(m.group(4)), 'dtype': bench['dtype'],
                         'keyframe_dce': bench['config'].get('keyframe_dce', False), 'batch': batch},
            'kernels': kernels}
-    with open(os.path.join(os.path.dirname(dst.rstrip('/')), 'pmc_traffic.json'), 'w') as f:
-        json.dump(rec, f, indent=1, sort_keys=True)
+    # (a third argument names another file -- or '-' for none -- when the passes are of a workload other than the bench default,
+    #  whose record bench.py reads as profiles/pmc_traffic.json)
+    out_json = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(dst.rstrip('/')), 'pmc_traffic.json')
+    if out_json != '-':
+        with open(out_json, 'w') as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
     for r in rows[:8]:
         print('%-40s n=%4d read %8.1f MB write %8.1f MB' % (r[0], r[1], r[4] / 1e6, r[5] / 1e6))
 
