@@ -87,10 +87,19 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
         const unsigned xcd = bid % nx, k = bid / nx;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int split = bid % p.ksplit;
-    bid /= p.ksplit;
-    const int nb = bid % p.nblk_n;
-    unsigned tile = bid / p.nblk_n;
+    int split, nb;
+    unsigned tile;
+    if (p.order) {   // weight-stationary order: all tiles of one (cout block, split) before the next one
+        tile = bid % p.ntiles;
+        bid /= p.ntiles;
+        split = bid % p.ksplit;
+        nb = bid / p.ksplit;
+    } else {
+        split = bid % p.ksplit;
+        bid /= p.ksplit;
+        nb = bid % p.nblk_n;
+        tile = bid / p.nblk_n;
+    }
     // frame index fastest: the blocks that share an input frame through the temporal taps (outputs t-1, t, t+1 of one
     // spatial tile) are neighbours in the XCD's queue, so the re-reads hit that XCD's L2 instead of HBM / MALL
     const int fc = tile % p.otn;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
       constexpr int NT = NTAP == 10 ? 9 : NTAP;   // NTAP = 10: the 9 taps of a 3x3 stride-2 conv on ONE dense (2*TH+1) x (2*TW+1) patch
       if (total > 0) {
         static_assert(TPS == 1, "unrolled taps: one tap per step");
-        constexpr int MAXCH = NTAP == 10 ? 19 : BP >= 256 ? 11 : 6;   // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
+        constexpr int MAXCH = patch_pieces_per_wave(NTAP, BP);   // 1-KiB patch pieces per wave (the launcher checks nchunks <= 4 * MAXCH)
         const int kt_hi_x = kt_lo + n_kt;
         int kshift = 0;
         if (n_kt == p.KT && (DAT_KT_ROTATE)) kshift = (p.KT - (t + kt_lo - p.pt) % p.KT) % p.KT;
@@ -661,6 +670,22 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
     }
 }
 
+// Tiles of the LINEAR position tiling (launch_conv) of a 3x3 stride-1 same-size layer at `bpv` positions per tile, or 0 when the layer
+// cannot use it: kT = 1 layers tile the whole frames x H x W sequence, layers with temporal taps one strip per frame.
+static long long linear_tiles(const dat_ctx* ctx, const dat_conv_desc* d, const ConvParams& p, int bpv) {
+    if (!ctx->dbg_linear || !ctx->dbg_ntap || d->KH != 3 || d->KW != 3 || d->stride_h != 1 || d->stride_w != 1 || d->res_mode == 2 ||
+        p.H != p.Ho || p.W != p.Wo)
+        return 0;
+    if (d->KT == 1 && (d->pad_t != 0 || d->out_tn > 0)) return 0;
+    if (d->KT > 1 && (ctx->dbg_linear & 8)) return 0;   // (DAT_CONV_LINEAR=9: A/B switch, no per-frame strips)
+    const long long per = d->KT > 1 ? (long long)p.Ho * p.Wo : (long long)p.frames * p.Ho * p.Wo;
+    const long long nr = bpv + 2 * (p.Wo + 1) + 1;
+    if (((nr * 8 + 63) >> 6) > 4 * patch_pieces_per_wave(9, bpv) || nr * PPITCH >= 65536 ||
+        per * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 >= (1ll << 31))
+        return 0;
+    return (d->KT > 1 ? (long long)p.frames : 1) * ((per + bpv - 1) / bpv);
+}
+
 struct TileChoice {
     int th_log2, tw_log2;
 };
@@ -702,15 +727,19 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         // tap (kh, kw) of position i reads patch row i + kh*W + kw.  Where that neighbour is not the lane's own map any more (row, column
         // or map border) the precomputed fragment address points at an all-zero patch row instead: masking costs nothing in the loop.
         // The kernel sees the whole thing as a 1 x N strip with 1 x BP tiles (its epilogue and patch loader need nothing else).
-        const long long total = (long long)p.frames * p.Ho * p.Wo;
-        DAT_ENFORCE(ctx, NTAP == 9 && p.KT == 1 && p.pt == 0 && p.sh == 1 && p.sw == 1 && p.H == p.Ho && p.W == p.Wo && p.res_mode != 2 &&
+        // Layers with temporal taps (round 3: res4 / res5 / P4 / P5 of the 3-D bodies, 24 x 42 and 48 x 84 maps -- 2-D tiles of 256
+        // positions cover 66 % / 87 % of what they compute there) get one strip PER FRAME instead: a tile must not span frames, whose
+        // temporal taps differ; the frame / clip bookkeeping of the kernel stays as it is.
+        const bool per_frame = p.KT > 1;
+        const long long total = per_frame ? (long long)p.Ho * p.Wo : (long long)p.frames * p.Ho * p.Wo;
+        DAT_ENFORCE(ctx, NTAP == 9 && (per_frame || p.pt == 0) && p.sh == 1 && p.sw == 1 && p.H == p.Ho && p.W == p.Wo && p.res_mode != 2 &&
                              total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31),
                     "conv3d: linear tiling on an unsupported layer");
         p.lin_h = p.H; p.lin_w = p.W;
         const int wr = p.W, nr = BP + 2 * (wr + 1) + 1;
         tc = TileChoice{0, bp_log2};
         p.H = p.Ho = 1; p.W = p.Wo = (int)total;
-        p.frames = 1; p.T = 1; p.ot0 = 0; p.otn = 1; p.in_lo = 0; p.in_hi = 1;
+        if (!per_frame) { p.frames = 1; p.T = 1; p.ot0 = 0; p.otn = 1; p.in_lo = 0; p.in_hi = 1; }
         p.ph = 0; p.pw = wr + 1;
         p.lin_zero_row = nr - 1;
         p.th_log2 = 0; p.tw_log2 = bp_log2;      // (bp_log2 = 9 for the 320-position tiles: pos >> tw_log2 == 0, pos & (TW - 1) == pos)
@@ -790,6 +819,13 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     DAT_ENFORCE(ctx, (long long)p.Ho * p.Wo * std::max(p.out_cs, p.Cout) * 4 < (1ll << 31),
                 "conv3d: one output frame of %dx%dx%d exceeds the 2-GB range of the epilogue's 32-bit offsets", p.Ho, p.Wo, p.out_cs);
     p.nblocks = (unsigned)nblocks;
+    p.ntiles = (unsigned)(nblocks / ((long long)p.ksplit * p.nblk_n));
+    // Which blocks are neighbours in an XCD's queue (DAT_CONV_ORDER, default 0).  The ~64 resident blocks of an XCD read the weight slices
+    // of every (cout block, split) they cover and the patches of their tiles through one 4-MB L2.  Order 1 (tile fastest) keeps ONE weight
+    // slice resident and re-reads the input once per (cout block, split).  Measured: fabric reads -41 % over
+    // the forward (res5's 512 -> 512 x 27 taps 2.09 -> 0.46 GB per launch, P2 7.8 -> 4.6 GB) and every such layer 2-4 % SLOWER -- the
+    // sibling cout block no longer finds the patch in L2, and patch misses are waited for while weight misses are not.  Kept as a switch.
+    p.order = ctx->dbg_order > 0;
     DAT_ENFORCE(ctx, p.tab_n % TPS == 0 && (TPS == 1 || p.tab_new == 1u), "conv3d: %d taps per step need one stride plane of a multiple of %d taps", TPS, TPS);
     size_t lds = (WD ? 0 : (size_t)2 * TPS * BN * ROWB) + (((size_t)p.PH * p.PW * PPITCH + 1023) & ~(size_t)1023);   // whole 1-KiB DMA pieces
     if (lds < 4 * 32 * (64 * 4 + 16)) lds = 4 * 32 * (64 * 4 + 16);                                   // epilogue staging slices
@@ -799,7 +835,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP>;
     if (NTAP > 0) {   // what the unrolled variant assumes (the dispatcher only picks it for these shapes)
         DAT_ENFORCE(ctx, p.tab_n == (NTAP == 10 ? 9 : NTAP) && p.tab_new == 1u &&
-                             (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * (NTAP == 10 ? 19 : BP >= 256 ? 11 : 6) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
+                             (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * patch_pieces_per_wave(NTAP, BP) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
                     "conv3d: unrolled-tap variant on an unsupported shape (%d taps, patch %dx%d)", p.tab_n, p.PH, p.PW);
         for (int i = 0; i < p.tab_n; ++i) DAT_ENFORCE(ctx, p.tab_tap[i] == i, "conv3d: unrolled-tap variant needs taps in natural order");
     }
@@ -917,7 +953,11 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
             if (force_bp && cand_bp != force_bp && !(force_bp == 256 && (small_n || ntaps == 1))) continue;
             const int lg = cand_bp == 256 ? 8 : 7;
             const TileChoice tc = choose_tile(p.Ho, p.Wo, lg, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
-            const long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * p.frames;
+            long long tiles = cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2) * p.frames;
+            if (weights_direct(ctx, d)) {   // (the dispatcher's rule below: linear tiles when they save >= 10 %)
+                const long long tl = linear_tiles(ctx, d, p, cand_bp);
+                if (tl > 0 && tl * 10 <= tiles * 9) tiles = tl;
+            }
             const int ks_max = (ntaps > 1 || deep_1x1) ? (deep_1x1 ? 8 : 4) : 1;
             for (int ks = 1; ks <= ks_max && ks <= npatch_min; ++ks) {
                 if (force_ks && ks != std::min(force_ks, npatch_min)) continue;
@@ -977,7 +1017,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
         // grid are bandwidth-bound and do better with the leaner table-driven loop (one block more per CU), measured.
         const TileChoice tc = choose_tile(p.Ho, p.Wo, big ? 8 : 7, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
         const long long prow = ((1ll << tc.th_log2) + (p.KH - 1) / p.sh) * ((1ll << tc.tw_log2) + (p.KW - 1) / p.sw);
-        const bool fits = ((prow * 8 + 63) >> 6) <= 4 * (big ? 11 : 6);
+        const bool fits = ((prow * 8 + 63) >> 6) <= 4 * patch_pieces_per_wave(9, big ? 256 : 128);
         const bool pw_small = (long long)p.frames * p.Ho * p.Wo <= 65536;
         // strided 3x3: ONE dense patch of (2*TH+1) x (2*TW+1) cells serves all 9 taps (the table-driven loop stages four stride-parity
         // patches per channel chunk and synchronises around each); 128-position tiles only (the patch is 70 KiB: two blocks per CU)
@@ -988,19 +1028,19 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
                           (d->KH == 1 && d->KW == 1 && (pw_small || (ctx->dbg_ntap & 2))) ? 1 : 0;
         // small maps (RoI heads): linear position tiling when it saves >= 10 % of the tiles (see launch_conv)
         bool lin = false, lin320 = false;
-        if (ntapv == 9 && ctx->dbg_linear && d->KT == 1 && d->pad_t == 0 && d->res_mode != 2 && d->out_tn <= 0 && p.H == p.Ho && p.W == p.Wo) {
-            const long long bpv = big ? 256 : 128, total = (long long)p.frames * p.Ho * p.Wo;
-            const long long t2d = (long long)p.frames * cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2), tlin = cdiv_ll(total, bpv);
-            const long long nr = bpv + 2 * (p.Wo + 1) + 1;
-            lin = tlin * 10 <= t2d * 9 && ((nr * 8 + 63) >> 6) <= 4 * (big ? 11 : 6) && total * std::max(p.Cin, std::max(p.out_cs, p.Cout)) * 4 < (1ll << 31);
+        const long long tlin = ntapv == 9 ? linear_tiles(ctx, d, p, big ? 256 : 128) : 0;
+        if (tlin > 0) {
+            const long long total = (long long)p.frames * p.Ho * p.Wo;
+            const long long t2d = (long long)p.frames * cdiv_ll(p.Ho, 1ll << tc.th_log2) * cdiv_ll(p.Wo, 1ll << tc.tw_log2);
+            lin = tlin * 10 <= t2d * 9;
             // One block per CU runs a tap step in ~1.1 us, two co-resident ones in ~2.15 us each, so a grid just above the CU count
             // costs a whole second block lifetime (keypoint head, 100 x 14 x 14 maps: 83 maps = 256 blocks 0.081 ms, 84 maps = 260
             // blocks 0.119 ms).  320-position tiles bring such a grid back under one block per CU.
             const long long ncu320 = ctx_num_cu(ctx), blk256 = tlin * nbn * ksplit, blk320 = cdiv_ll(total, 320) * nbn * ksplit;
             // (opt-in, DAT_CONV_LINEAR=5: one clip at a time +2.9 % (170.6 -> 175.5 clips/s), but with four clips in flight -2 % (221.8 -> 217.5):
             //  a 293-register block per CU on 248 CUs leaves no room for the other clips' kernels to run beside it)
-            lin320 = lin && big && !small_n && (ctx->dbg_linear & 4) && blk256 > ncu320 && blk320 <= ncu320 &&
-                     ((((320 + 2 * (p.Wo + 1) + 1) * 8 + 63) >> 6) <= 44);
+            lin320 = lin && d->KT == 1 && big && !small_n && (ctx->dbg_linear & 4) && blk256 > ncu320 && blk320 <= ncu320 &&
+                     ((((320 + 2 * (p.Wo + 1) + 1) * 8 + 63) >> 6) <= 4 * patch_pieces_per_wave(9, 320));
         }
 #define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit, lin) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit, lin)) \
                             : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \

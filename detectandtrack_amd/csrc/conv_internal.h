@@ -20,6 +20,10 @@ constexpr int NTHREADS = 256;
 #define DAT_KT_ROTATE 1
 #endif
 
+// 1-KiB pieces of the patch one wave of the unrolled-tap kernels copies (a register of source offsets each): 2-D tiles need
+// (16+2)x(16+2) rows = 41 pieces at 256 positions; the linear strips of wide maps (res4: 256 + 2 * 85 + 1 rows) up to 54
+constexpr int patch_pieces_per_wave(int ntap, int bp) { return ntap == 10 ? 19 : bp >= 256 ? 14 : 10; }
+
 struct ConvParams {
     const char* x;
     const char* w;
@@ -59,6 +63,9 @@ struct ConvParams {
     int ablate;               // DEBUG (DAT_CONV_ABLATE): 1 skip patch reloads, 2 skip weight streaming
     int nblk_n;               // Cout_pad / BN
     unsigned nblocks;
+    unsigned ntiles;          // position tiles (frames x tiles_h x tiles_w)
+    int order;                // block order inside an XCD's queue: 0 = (split, cout block) fastest -- the blocks of one tile share its input patch;
+                              // 1 = tile fastest -- the resident blocks share ONE (cout block, split) weight slice (layers whose weights exceed the L2)
 };
 
 template <int DT> struct Mma;

@@ -89,6 +89,9 @@ CONV_CASES = [
     ('heads_5x9_odd', 11, 1, 5, 9, 64, 192, (1, 3, 3), (1, 1), True, 1, False),
     # 308 blocks of 256 positions > 256 CUs, 248 blocks of 320 positions: the one-block-per-CU 320-position linear tiles
     ('heads_100x14x14_c512', 100, 1, 14, 14, 64, 512, (1, 3, 3), (1, 1), True, 1, True),
+    # temporal taps on maps that 2-D tiles cover badly (res5 / res4 of the 3-D bodies): one linear strip per frame, two clips
+    ('res5_like_24x42', 2, 4, 24, 42, 128, 256, (3, 3, 3), (1, 1), True, 1, True),
+    ('res4_like_48x84', 1, 3, 48, 84, 64, 128, (3, 3, 3), (1, 1), True, 0, True),
 ]
 
 
@@ -293,6 +296,38 @@ def test_conv3x3_linear_320_position_tiles(ops):
     assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
 
 
+@pytest.mark.parametrize('plan', [(256, 1), (256, 2), (128, 1), (128, 3)], ids=lambda p: 'bp%d_ks%d' % p)
+@pytest.mark.parametrize('shape', [(2, 4, 24, 42, 128, 256), (1, 3, 48, 84, 64, 128), (2, 2, 12, 21, 64, 64)], ids=lambda s: '%dx%dx%dx%d_%d_%d' % s)
+def test_conv3x3x3_linear_strips_per_frame(ops, shape, plan):
+    """3x3x3 layers on maps that power-of-two tiles cover badly run one LINEAR strip of positions per frame (round 3: res4 / res5 / P4 /
+    P5 of the 3-D bodies; a tile must not span frames because the valid temporal taps differ): against torch and bit for bit against the
+    2-D tiling (DAT_CONV_LINEAR=0; same patch / tap / k-slice accumulation order), at both tile sizes and with split-K, residual + ReLU,
+    two clips (the clip / frame decode and the temporal zero padding at clip borders)."""
+    N, T, H, W, Cin, Cout = shape
+    rs = np.random.RandomState(H * W + Cin)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(N, Cin, T, H, W).astype(np.float32))
+    w = q((rs.randn(Cout, Cin, 3, 3, 3) * np.sqrt(2.0 / (Cin * 27))).astype(np.float32))
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32)
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    res = q(rs.randn(N, Cout, T, H, W).astype(np.float32))
+    ref = _conv_ref(x, w, scale, bias, res, (1, 1), (1, 1, 1), True)
+    layer = ops.ConvLayer(_dev(w), _dev(scale), _dev(bias), stride=(1, 1), pads=(1, 1, 1), relu=True, dtype=1)
+    xd, rd = ops.to_ndhwc(_dev(x), 1), ops.to_ndhwc(_dev(res), 1, layer.cstride)
+
+    def run():
+        try:
+            assert ops.tune_plan(*plan) == 0
+            return layer(xd, T=T, residual=rd, res_mode=1)
+        finally:
+            ops.tune_plan(0, 0)
+    y_lin = _in_fresh_context({'DAT_CONV_LINEAR': '1'}, run)
+    y_2d = _in_fresh_context({'DAT_CONV_LINEAR': '0'}, run)
+    assert torch.equal(y_lin, y_2d)
+    got = ops.to_ncdhw(y_lin, 1, N, Cout, T).cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+
+
 BT_CASES = [
     # name, T, H, W, Cin, Cout, kt, relu, res_mode, affine   (3x3 bf16 layers with >= 384 tiles of 256 x 256: the big-tile kernel)
     ('3x3x3_ragged_16x16', 3, 120, 250, 128, 256, 3, True, 1, True),
@@ -340,6 +375,27 @@ def test_conv3x3_big_tile(ops, case):
     assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4), err
     # (the generic kernel and torch agree as well: the comparison above is not vacuous)
     assert np.abs(ops.to_ncdhw(y_gen, 1, 1, Cout, T).cpu().numpy() - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+
+
+@pytest.mark.parametrize('case', [('split_k_4_cout_blocks', 4, 24, 42, 512, 512, 3), ('two_cout_blocks', 3, 60, 84, 128, 256, 3), ('2d', 2, 48, 84, 256, 384, 1)],
+                         ids=lambda c: c[0])
+def test_conv_block_order_switch_is_bit_identical(ops, case):
+    """DAT_CONV_ORDER=1 (tile-fastest / weight-stationary block order inside an XCD's queue, an experiment switch: DESIGN.md section 3)
+    only permutes which block computes which (tile, cout block, split): same bits as the default order, split-K included."""
+    name, T, H, W, Cin, Cout, kt = case
+    rs = np.random.RandomState(len(name) + W)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(1, Cin, T, H, W).astype(np.float32))
+    w = q((rs.randn(Cout, Cin, kt, 3, 3) * np.sqrt(2.0 / (Cin * 9 * kt))).astype(np.float32))
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    layer = ops.ConvLayer(_dev(w), None, _dev(bias), stride=(1, 1), pads=(kt // 2, 1, 1), relu=True, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    run = lambda: layer(xd, T=T)
+    y1 = _in_fresh_context({'DAT_CONV_ORDER': '1'}, run)
+    y0 = _in_fresh_context({'DAT_CONV_ORDER': '0'}, run)
+    assert torch.equal(y0, y1)
+    ref = _conv_ref(x, w, None, bias, None, (1, 1), (kt // 2, 1, 1), True)
+    assert np.abs(ops.to_ncdhw(y1, 1, 1, Cout, T).cpu().numpy() - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
 
 
 PW_CASES = [
