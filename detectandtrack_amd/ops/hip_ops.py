@@ -56,6 +56,15 @@ def ctx(device=None):
     return _CTX[key]
 
 
+def drop_ctx(device=None):
+    """Forgets (and thereby destroys) the context of the current (device, stream) pair; the next launch on it creates a new one, which
+    reads the library's environment switches again.  The stream must be idle.  (torch hands out pooled stream handles: a test that
+    wants a context made under a particular environment must not inherit one cached for an earlier stream with the same handle.)"""
+    if device is None:
+        device = torch.cuda.current_device()
+    _CTX.pop((device, _stream_handle(device)), None)
+
+
 def tune_plan(positions_per_block, ksplit):
     """dat_conv3d_tune_plan on the context of the current (device, stream): forces the launch plan of the conv launches that
     follow on THAT context (0, 0 = back to the makespan model).  Returns the C-ABI return code."""

@@ -263,9 +263,17 @@ def _in_fresh_context(env, fn):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
+        from detectandtrack_amd.ops import hip_ops
         with torch.cuda.stream(torch.cuda.Stream()):
-            out = fn()
-            torch.cuda.synchronize()
+            # torch's stream handles come from a pool and recur: drop whatever context is cached for this handle, and drop ours
+            # afterwards so that a later user of the handle does not inherit a context made under THIS environment
+            hip_ops.drop_ctx()
+            try:
+                out = fn()
+                torch.cuda.synchronize()
+            finally:
+                torch.cuda.synchronize()
+                hip_ops.drop_ctx()
         return out
     finally:
         for k, v in old.items():

@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--arch', default='R18')
     ap.add_argument('--iters', type=int, default=8)
+    ap.add_argument('--clips', type=int, default=1, help='clips per forward (bench.py --batch): frames / rois of every layer x this')
+    ap.add_argument('--only', default='', help='substring filter on the layer names')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     T, H, W = 8, 768, 1344
@@ -43,13 +45,17 @@ def main():
     total_model = total_best = 0.0
     for l in layers:
         name, cin, cout, k, st, hi, wi, cnt = l[:8]
-        frames = l[8] if len(l) > 8 else T
+        if a.only and a.only not in name:
+            continue
+        frames = (l[8] if len(l) > 8 else T) * a.clips
         Tl = T if len(l) <= 8 else 1
         w = torch.randn(cout, cin, *k, device=dev) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
         layer = ops.ConvLayer(w, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), stride=(st, st),
                               pads=(k[0] // 2, k[1] // 2, k[2] // 2), relu=True, dtype=ops.BF16)
         x = torch.randn(frames, hi, wi, layer.cin, device=dev).to(torch.bfloat16)
         y = layer(x, T=Tl)
+        if x.numel() * 2 > (4 << 30):   # (the P2 post-hoc conv at 4 clips: 1 GB in + 1 GB out is fine; guard against anything larger)
+            continue
         ops.tune_plan(0, 0)
         t_model = timed(layer, x, y, Tl, a.iters)
         res = {}
