@@ -336,6 +336,24 @@ def test_conv3x3x3_linear_strips_per_frame(ops, shape, plan):
     assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max() / 4)
 
 
+def test_conv3x3x3_linear_strips_with_key_frame_outputs(ops):
+    """out_t (only the centre frame of every clip is computed: cfg.HIP.KEYFRAME_DCE) on a map that takes the per-frame linear strips:
+    the selected frames equal those of the full conv bit for bit, with the 2-D tiling as well."""
+    N, T, H, W, Cin, Cout = 2, 4, 24, 42, 128, 256
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.randn(N, Cin, T, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3, 3) * np.sqrt(2.0 / (Cin * 27))).astype(np.float32))
+    layer = ops.ConvLayer(_dev(w.numpy()), None, _dev(np.zeros(Cout, np.float32)), stride=(1, 1), pads=(1, 1, 1), relu=True, dtype=1)
+    xd = ops.to_ndhwc(_dev(x.numpy()), 1)
+    full = layer(xd, T=T)                                     # [N*T, H, W, C]
+    t0 = T // 2
+    key = layer(xd, T=T, out_t=(t0, 1))                       # [N, H, W, C]
+    assert key.shape[0] == N
+    assert torch.equal(key, full.view(N, T, H, W, -1)[:, t0])
+    key2d = _in_fresh_context({'DAT_CONV_LINEAR': '0'}, lambda: layer(xd, T=T, out_t=(t0, 1)))
+    assert torch.equal(key, key2d)
+
+
 BT_CASES = [
     # name, T, H, W, Cin, Cout, kt, relu, res_mode, affine   (3x3 bf16 layers with >= 384 tiles of 256 x 256: the big-tile kernel)
     ('3x3x3_ragged_16x16', 3, 120, 250, 128, 256, 3, True, 1, True),
