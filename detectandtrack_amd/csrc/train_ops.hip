@@ -398,6 +398,7 @@ struct Wgrad9Params {
     int f_begin, f_end;   // output frames [f_begin, f_end) carry a non-zero gradient (frame window; whole clips otherwise)
     int tiles_h, tiles_w; // 8 x 8 patches per frame
     int ablate;           // DEBUG (DAT_WGRAD_ABLATE): 1 no global loads, 2 no LDS fragment reads / MFMAs, 4 no final atomics / stores
+    const char* zeros;    // >= 16 zero bytes in global memory (LDS-DMA source of halo / out-of-range pieces)
 };
 
 constexpr int W9_PITCH = 192;
@@ -521,6 +522,149 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
     }
 #undef W9_FETCH
 #undef W9_STAGE_WRITE
+    const int khalf = lane >> 5;
+    const int ci = ci_t * 64 + wave_n * 32 + (lane & 31);
+    if (ci >= p.Cin || (p.ablate & 4)) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* Gt = p.G + (size_t)(kt * 9 + t) * p.Cout * p.Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_t * 64 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (co >= p.Cout) continue;
+            if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
+            else Gt[(size_t)co * p.Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+// ---- the same tile with the operands brought in by LDS-DMA (round 3, late) -------------------------------------------------------
+// wgrad_direct9_kernel stages its operands through registers: two chunks in flight cost 48 registers next to 144 accumulators, and the
+// counters (profiles/r03/train_r18/pmc_mfma.csv) show the MFMA pipe busy 21 % of the time: a 64-position chunk is ~0.5 us of MFMAs
+// behind a 20.8-KB operand fetch with ~2 us of loaded latency.  Here `global_load_lds_dwordx4` writes the 128-byte rows straight into
+// one of THREE LDS stages (no staging registers, no ds_write pass): chunk c computes while chunks c + 1 and c + 2 are in flight.
+//   * stage = 192 rows x 128 B (64 g rows, 100 patch rows, 28 spare rows that make 24 one-KiB DMA pieces: every wave issues exactly
+//     six per chunk, so `s_waitcnt vmcnt(6)` at the top of an iteration means "my pieces of THIS chunk have landed");
+//   * rows are contiguous (the DMA writes lane * 16 B), so the bank spread the 192-byte pitch gave the transposing reads comes from a
+//     swizzle instead: 16-byte piece p of row r sits in slot p ^ 4 * bit1(r).  A transposing read touches four consecutive rows x 64 B per
+//     half wave: rows r .. r + 3 then start at banks 0 / 32 / 16 / 48 -- all 64 banks once.  The swizzle is applied by choosing which
+//     global piece a lane fetches; on the read side it is a per-lane constant XOR of 64 (g tile), toggled by kh == 1 for the patch rows
+//     ((2 ks + kh) * 10 flips bit 1 of the row exactly when kh == 1).
+constexpr int W9D_STAGE = 192 * 128;
+constexpr int W9D_STAGES = 3;
+
+__global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    unsigned bid = blockIdx.x;
+    const int kt = bid % p.KT; bid /= p.KT;
+    const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+    const int co_t = bid % p.n_co_tiles;
+    const int split = bid / p.n_co_tiles;
+    const unsigned per_frame = (unsigned)(p.tiles_h * p.tiles_w);
+    const unsigned nchunks = (unsigned)(p.f_end - p.f_begin) * per_frame;
+    const unsigned c_lo = (unsigned)((unsigned long long)nchunks * split / p.ksplit), c_hi = (unsigned)((unsigned long long)nchunks * (split + 1) / p.ksplit);
+
+    // ---- this lane's six DMA pieces: stage row (wave + 4 u) * 8 + lane / 8, slot lane % 8 holds data piece slot ^ 4 * bit1(row) ----
+    // kind 0: g row (dy, dx) = (row / 8, row % 8); kind 1: patch row (dy, dx) = (xr / 10 - 1, xr % 10 - 1); kind 2: spare (zeros)
+    int pk_dy[6], pk_dx[6], pk_col[6];     // pk_col: byte offset of the piece inside the 64-channel run, -1 = always zeros
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int row = (wave + 4 * u) * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        int dy = 0, dx = 0, col = -1;
+        if (row < 64) {
+            dy = row >> 3; dx = row & 7;
+            if (co_t * 64 + piece * 8 < p.g_cs) col = (co_t * 64 + piece * 8) * 2;
+        } else if (row < 164) {
+            const int xr = row - 64, py = xr / 10;
+            dy = py - 1; dx = xr - py * 10 - 1;
+            if (ci_t * 64 + piece * 8 < p.x_cs) col = (ci_t * 64 + piece * 8) * 2;
+        }
+        pk_dy[u] = dy; pk_dx[u] = dx; pk_col[u] = col;
+    }
+    const char* const zeros = p.zeros;
+    auto issue = [&](unsigned ch, int stage) __attribute__((always_inline)) {
+        // (chunks past the block's range are requested as zeros: the instruction count per chunk stays six, the counted wait stays valid)
+        const bool live = ch < c_hi && !(p.ablate & 1);
+        const unsigned chc = live ? ch : c_lo;
+        const unsigned fr = chc / per_frame, tl = chc - fr * per_frame;
+        const int f = p.f_begin + (int)fr;
+        const int ty = (int)(tl / (unsigned)p.tiles_w), tx = (int)tl - ty * p.tiles_w;
+        const int clip = f / p.T, t = f - clip * p.T, ti = t + kt - p.pt;
+        const bool tin = live && ti >= 0 && ti < p.T;
+        const size_t g_frame = (size_t)f * p.H, x_frame = (size_t)(clip * p.T + (tin ? ti : 0)) * p.H;
+        char* dst0 = smem + stage * W9D_STAGE + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const bool is_g = wave + 4 * u < 8;                         // pieces 0..7 are the g rows (uniform per wave and u)
+            const int y = ty * 8 + pk_dy[u], x = tx * 8 + pk_dx[u];
+            const bool ok = tin && pk_col[u] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const char* src = zeros;
+            if (ok) src = is_g ? p.g + (((g_frame + y) * p.W + x) * (size_t)p.g_cs) * 2 + pk_col[u]
+                               : p.x + (((x_frame + y) * p.W + x) * (size_t)p.x_cs) * 2 + pk_col[u];
+            // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler orders every later ds_read behind an LDS-DMA it can see with
+            //  s_waitcnt vmcnt(0) -- one LDS array, everything may alias -- which would wait for the chunks still in flight; the counted
+            //  wait + barrier at the top of the loop is the ordering this pipeline needs)
+            // (M0 is written without telling the compiler: nothing else in this kernel uses it -- no other LDS-DMA, no s_movrel)
+            const unsigned lds_at = (unsigned)(size_t)(lptr_t)(dst0 + u * 4096);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_at) : "memory");
+        }
+    };
+    // fragment addressing (see wgrad_direct9_kernel), rows 128 B apart, the piece swizzle as a per-lane XOR
+    const int grp = lane >> 4, li = lane & 15;
+    const int g_row = (grp >> 1) * 8 + (li >> 2), x_row = (grp >> 1) * 10 + (li >> 2);
+    const int g_off = g_row * 128 + ((((grp & 1) * 16 + (li & 3) * 4) * 2 + wave_m * 64) ^ (((g_row >> 1) & 1) << 6));
+    const int x_off0 = 64 * 128 + x_row * 128 + ((((grp & 1) * 16 + (li & 3) * 4) * 2 + wave_n * 64) ^ (((x_row >> 1) & 1) << 6));   // kh even
+    const int x_off1 = x_off0 ^ 64;                                                                                                  // kh == 1
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    typedef __attribute__((address_space(3))) wd_v4s* lp_t;
+    auto tr4 = [&](const char* a) __attribute__((always_inline)) { return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)a)); };
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        if (p.ablate & 2) return;
+        const char* sb = smem + stage * W9D_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint2 al = tr4(sb + g_off + ks * 16 * 128), ah = tr4(sb + g_off + ks * 16 * 128 + 4 * 128);
+            const uint4 a = make_uint4(al.x, al.y, ah.x, ah.y);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const char* rb = sb + (kh == 1 ? x_off1 : x_off0) + ((2 * ks + kh) * 10) * 128;
+                const uint2 q0 = tr4(rb), q1 = tr4(rb + 4 * 128), q2 = tr4(rb + 8 * 128);
+                const uint4 b0 = make_uint4(q0.x, q0.y, q1.x, q1.y);
+                const uint4 b2 = make_uint4(q0.y, q1.x, q1.y, q2.x);
+                const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(q0.y, q0.x, 2), __builtin_amdgcn_alignbyte(q1.x, q0.y, 2),
+                                            __builtin_amdgcn_alignbyte(q1.y, q1.x, 2), __builtin_amdgcn_alignbyte(q2.x, q1.y, 2));
+                MmaT<DAT_BF16>::step(a, b0, acc[kh * 3 + 0]);
+                MmaT<DAT_BF16>::step(a, b1, acc[kh * 3 + 1]);
+                MmaT<DAT_BF16>::step(a, b2, acc[kh * 3 + 2]);
+            }
+        }
+    };
+    if (c_lo < c_hi) {
+        issue(c_lo, 0);
+        issue(c_lo + 1, 1);
+        int stage = 0;
+        for (unsigned c = c_lo; c < c_hi; ++c) {
+            // all but the six pieces of chunk c + 1 have landed (mine of chunk c), my LDS reads of chunk c - 1 are done; then the barrier:
+            // chunk c is complete for every wave and stage (c - 1) % 3 is free.  A bare s_barrier: __syncthreads() carries a fence that
+            // the compiler lowers to vmcnt(0) -- it would wait for chunk c + 1 as well and serialise the pipeline again.
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int nstage = stage == 0 ? 2 : stage - 1;      // (c + 2) % 3 == (c - 1) % 3
+            issue(c + 2, nstage);
+            compute(stage);
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing zero chunks: nothing may still be writing LDS at exit
+    }
     const int khalf = lane >> 5;
     const int ci = ci_t * 64 + wave_n * 32 + (lane & 31);
     if (ci >= p.Cin || (p.ablate & 4)) return;
@@ -927,8 +1071,14 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
             const size_t g_elems = (size_t)Cout_real * Cin_real * d->KT * 9;
             if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
                 DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
-            if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
-            hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);
+            q.zeros = (const char*)ctx->zeros;
+            if (ctx->dbg_wgrad_dma) {   // operands by LDS-DMA into three stages (DAT_WGRAD_DMA, default 1)
+                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel, W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL(wgrad_dma9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), W9D_STAGES * W9D_STAGE, st, q);
+            } else {
+                if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);
+            }
             hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
                                Cout_real, Cin_real, d->KT * 9);
             DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct9");

@@ -44,15 +44,22 @@ def fresh(env, tag):
     os.environ.update(env)
     try:
         with torch.cuda.stream(torch.cuda.Stream()):
+            ops.drop_ctx()          # (pooled stream handles recur: make sure the context is created under THIS environment)
             run(tag)
             torch.cuda.synchronize()
+            ops.drop_ctx()
     finally:
         for k, v in old.items():
             if v is None: del os.environ[k]
             else: os.environ[k] = v
 
 import sys as _s
-if len(_s.argv) > 1 and _s.argv[1] == 'ablate':
+if len(_s.argv) > 1 and _s.argv[1] == 'dma':      # register-staged vs LDS-DMA nine-tap kernel (DAT_WGRAD_DMA), twice each
+    LAYERS[:] = LAYERS[:5]
+    for rep in range(2):
+        fresh({'DAT_WGRAD_DMA': '0'}, 'regs')
+        fresh({'DAT_WGRAD_DMA': '1'}, 'dma')
+elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
     for ab in (0, 1, 2, 4, 3, 7):
         fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_ABLATE': str(ab)}, 'abl%d' % ab)
