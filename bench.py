@@ -364,6 +364,7 @@ def build_train(arch, T, H, W, dtype, world, rank):
                   'BATCH_SIZE_PER_IM': 512}
     c['NUM_GPUS'] = world
     c['HIP']['FUSE_RELU_BWD'] = os.environ.get('DAT_FUSE_RELU_BWD', '1') != '0'      # (A/B switch for tools/)
+    c['HIP']['DEFER_WGRAD_FINISH'] = os.environ.get('DAT_DEFER_WGRAD_FINISH', '1') != '0'
     reset_cfg()
     cfg_from_cfg(c)
     assert_and_infer_cfg()

@@ -252,11 +252,14 @@ def _build_defaults():
     # 0 = the reference's eager loop through im_detect_all (host pre-processing, fp32 upload).  CLIP_GRAPH: every slot replays its
     # forward as one captured hipGraph.  IMS_PER_FORWARD: independent images (2D models) / clips (3D models) per forward -- the N
     # axis of the blobs; every image keeps the results it gets alone (the reference runs one image per forward, core/test.py:212-214)
+    # DEFER_WGRAD_FINISH (training): conv weight gradients accumulate in the kernels' own [tap][Cout][Cin] order in one flat buffer and ONE
+    # launch per iteration turns them into gradients (training.py), instead of a memset + a finish launch around every layer's kernel.
     # FUSE_RELU_BWD (training): the ReLU backward of a blob with ONE reader is applied in the epilogue of that reader's data-gradient
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
-                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4})
+                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
+                      'DEFER_WGRAD_FINISH': True})
     return c
 
 

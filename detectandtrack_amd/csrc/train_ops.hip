@@ -247,6 +247,7 @@ struct WgradDirectParams {
     int T, H, W, Ho, Wo, stride;
     int KT, KH, KW, pt, ph, pw;
     int ntaps, ksplit, n_ci_tiles, n_co_tiles;
+    int atomic;                 // add into G with atomics (K split, or a caller-owned accumulator: dat_conv3d_wgrad_acc) instead of storing
     unsigned p_begin, p_end;    // output positions [p_begin, p_end) carry a non-zero gradient (frame window)
     unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo): row = umulhi(position in frame, wo_magic) (Ho * Wo * Wo < 2^32 checked by the launcher)
 };
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct_kernel(const WgradDirectPa
             for (int r = 0; r < 16; ++r) {
                 const int co = co_t * 128 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (co >= p.Cout) continue;
-                if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[i][j][r]);
+                if (p.atomic) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[i][j][r]);
                 else Gt[(size_t)co * p.Cin + ci] = acc[i][j][r];
             }
         }
@@ -399,6 +400,7 @@ struct Wgrad9Params {
     int tiles_h, tiles_w; // 8 x 8 patches per frame
     int ablate;           // DEBUG (DAT_WGRAD_ABLATE): 1 no global loads, 2 no LDS fragment reads / MFMAs, 4 no final atomics / stores
     const char* zeros;    // >= 16 zero bytes in global memory (LDS-DMA source of halo / out-of-range pieces)
+    int atomic;           // add into G with atomics (K split, or a caller-owned accumulator) instead of storing
 };
 
 constexpr int W9_PITCH = 192;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
         for (int r = 0; r < 16; ++r) {
             const int co = co_t * 64 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             if (co >= p.Cout) continue;
-            if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
+            if (p.atomic) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
             else Gt[(size_t)co * p.Cin + ci] = acc[t][r];
         }
     }
@@ -555,7 +557,6 @@ constexpr int W9D_STAGES = 3;
 
 __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p)
         for (int r = 0; r < 16; ++r) {
             const int co = co_t * 64 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             if (co >= p.Cout) continue;
-            if (p.ksplit > 1) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
+            if (p.atomic) atomicAdd(Gt + (size_t)co * p.Cin + ci, acc[t][r]);
             else Gt[(size_t)co * p.Cin + ci] = acc[t][r];
         }
     }
@@ -1024,9 +1025,19 @@ size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, in
            (size_t)Cout_real * Cin_real * d->KT * d->KH * d->KW * sizeof(float);
 }
 
-int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
-                     int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW) {
-    DAT_ENFORCE(ctx, d && x && g && workspace && dW, "conv3d_wgrad: null argument");
+static bool wgrad_direct_eligible(const dat_ctx* ctx, const dat_conv_desc* d, int g_cstride) {
+    int Ho, Wo;
+    dat_conv3d_out_shape(d, &Ho, &Wo);
+    const long long npos_out = (long long)d->frames * Ho * Wo, npos_in = (long long)d->frames * d->H * d->W;
+    return d->dtype == DAT_BF16 && ctx->dbg_wgrad_direct && d->Cin % 64 == 0 && g_cstride % 64 == 0 && npos_out < (1ll << 31) && npos_in < (1ll << 31) &&
+           (long long)Ho * Wo * Wo < (1ll << 32);
+}
+
+// acc_mode (dat_conv3d_wgrad_acc): `workspace` IS the caller's fp32 accumulator in the kernels' [tap][Cout][Cin] order -- no zeroing, always
+// atomics, no finish launch (the caller zeroes it once per iteration and runs ONE dat_wgrad_finish_batch for all layers)
+static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                      int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW, int acc_mode) {
+    DAT_ENFORCE(ctx, d && x && g && workspace && (dW || acc_mode), "conv3d_wgrad: null argument");
     DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_wgrad: bad dtype %d", d->dtype);
     DAT_ENFORCE(ctx, d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2), "conv3d_wgrad: stride %dx%d", d->stride_h, d->stride_w);
     DAT_ENFORCE(ctx, d->frames % d->T == 0 && d->pad_t * 2 + 1 == d->KT, "conv3d_wgrad: needs same-T convs");
@@ -1041,8 +1052,9 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     const int clips = d->frames / d->T;
     // ---- bf16: the direct kernel (no re-pack passes; transposing LDS reads) ----
     const long long npos_out = (long long)d->frames * Ho * Wo, npos_in = (long long)d->frames * d->H * d->W;
-    if (d->dtype == DAT_BF16 && ctx->dbg_wgrad_direct && d->Cin % 64 == 0 && g_cstride % 64 == 0 && npos_out < (1ll << 31) && npos_in < (1ll << 31) &&
-        (long long)Ho * Wo * Wo < (1ll << 32)) {
+    (void)npos_out; (void)npos_in;
+    DAT_ENFORCE(ctx, !acc_mode || wgrad_direct_eligible(ctx, d, g_cstride), "conv3d_wgrad_acc: the layer does not take the direct kernels (ask dat_conv3d_wgrad_acc_supported)");
+    if (wgrad_direct_eligible(ctx, d, g_cstride)) {
         float* Gt = (float*)workspace;
         if (d->KH == 3 && d->KW == 3 && s == 1 && d->pad_h == 1 && d->pad_w == 1 && (ctx->dbg_wgrad_direct & 2) == 0) {
             // nine spatial taps from one staged patch (wgrad_direct9_kernel)
@@ -1068,8 +1080,9 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
             if (ks > nchunks) ks = nchunks;
             if (ks < 1) ks = 1;
             q.ksplit = (int)ks;
+            q.atomic = ks > 1 || acc_mode;
             const size_t g_elems = (size_t)Cout_real * Cin_real * d->KT * 9;
-            if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+            if (ks > 1 && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
                 DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
             q.zeros = (const char*)ctx->zeros;
             if (ctx->dbg_wgrad_dma) {   // operands by LDS-DMA into three stages (DAT_WGRAD_DMA, default 1)
@@ -1079,8 +1092,9 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
                 if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
                 hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);
             }
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
-                               Cout_real, Cin_real, d->KT * 9);
+            if (!acc_mode)
+                hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                                   Cout_real, Cin_real, d->KT * 9);
             DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct9");
             return DAT_OK;
         }
@@ -1107,13 +1121,15 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
         if (ks > nchunks / 8) ks = nchunks / 8;             // at least 8 chunks per block
         if (ks < 1) ks = 1;
         wp.ksplit = (int)ks;
+        wp.atomic = ks > 1 || acc_mode;
         const size_t g_elems = (size_t)Cout_real * Cin_real * wp.ntaps;
-        if (ks > 1 && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+        if (ks > 1 && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
             DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
         if (dat_ensure_lds(ctx, (const void*)wgrad_direct_kernel, 4 * WD_TILE) != DAT_OK) return DAT_ERR_LAUNCH;
         hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 4 * WD_TILE, st, wp);
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
-                           Cout_real, Cin_real, wp.ntaps);
+        if (!acc_mode)
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                               Cout_real, Cin_real, wp.ntaps);
         DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct");
         return DAT_OK;
     }
@@ -1189,6 +1205,52 @@ int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const 
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
                        Cout_real, Cin_real, wp.ntaps);
     DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad gemm");
+    return DAT_OK;
+}
+
+int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                     int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW) {
+    return wgrad_impl(ctx, s, d, x, g, g_cstride, Cin_real, Cout_real, scale, workspace, dW, 0);
+}
+
+int dat_conv3d_wgrad_acc_supported(dat_ctx* ctx, const dat_conv_desc* d, int g_cstride) {
+    return ctx && d && wgrad_direct_eligible(ctx, d, g_cstride) ? 1 : 0;
+}
+
+int dat_conv3d_wgrad_acc(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                         int Cin_real, int Cout_real, float* Gt) {
+    return wgrad_impl(ctx, s, d, x, g, g_cstride, Cin_real, Cout_real, nullptr, Gt, nullptr, 1);
+}
+
+// dW[co][ci][tap] (+)= scale[co] * Gt[tap][co][ci] for a table of layers in ONE launch (blocks of 256 threads x 8 elements; an item owns
+// the blocks [block0, block0 + ceil(elems / 2048))): the same arithmetic per element as wgrad_finish_kernel
+__global__ __launch_bounds__(256) void wgrad_finish_batch_kernel(const dat_wfinish_item* __restrict__ items, int n) {
+    const long long b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const dat_wfinish_item it = items[lo];
+    const long long total = (long long)it.Cout * it.Cin * it.ntaps;
+    const long long i0 = (b - it.block0) * 2048 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long i = i0 + u * 256;
+        if (i >= total) break;
+        const int tap = (int)(i % it.ntaps);
+        const long long r = i / it.ntaps;
+        const int ci = (int)(r % it.Cin), co = (int)(r / it.Cin);
+        const float v = it.Gt[((size_t)tap * it.Cout + co) * it.Cin + ci];
+        const float o = it.scale ? v * it.scale[co] : v;
+        it.dW[i] = it.accumulate ? it.dW[i] + o : o;
+    }
+}
+
+int dat_wgrad_finish_batch(dat_ctx* ctx, dat_stream s, const dat_wfinish_item* items_dev, int n, long long total_blocks) {
+    DAT_ENFORCE(ctx, items_dev && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "wgrad_finish_batch: bad argument");
+    hipLaunchKernelGGL(wgrad_finish_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)s, items_dev, n);
+    DAT_CHECK_LAUNCH(ctx, "wgrad_finish_batch");
     return DAT_OK;
 }
 

@@ -33,6 +33,11 @@ class PackItem(C.Structure):
                [(n, C.c_int) for n in ('rows', 'cols', 'ntap', 'cout_pad', 'cin', 'frag', 'dgrad', 'dtype', 'tile0', 'tiles_x')]
 
 
+class WFinishItem(C.Structure):
+    _fields_ = [('Gt', C.c_void_p), ('scale', C.c_void_p), ('dW', C.c_void_p)] + \
+               [(n, C.c_int) for n in ('Cout', 'Cin', 'ntaps', 'accumulate')] + [('block0', C.c_longlong)]
+
+
 class RoiLevel(C.Structure):
     _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
 
@@ -110,6 +115,9 @@ _PROTOS = {
     'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc), _i, _i]),
     'dat_conv3d_wgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p, _p, _p]),
+    'dat_conv3d_wgrad_acc_supported': (_i, [_p, C.POINTER(ConvDesc), _i]),
+    'dat_conv3d_wgrad_acc': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p]),
+    'dat_wgrad_finish_batch': (_i, [_p, _p, _p, _i, C.c_longlong]),
     'dat_relu_bias_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i]),
     'dat_zero_insert2x': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i]),
     'dat_upsample2x_bwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i]),

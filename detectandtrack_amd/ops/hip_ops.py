@@ -291,6 +291,21 @@ class ConvGrad(object):
         dscale = (dW * self.w).sum(dim=(1, 2, 3, 4)) / self.scale
         return dW, dscale
 
+    def weight_acc(self, x, g, T, gt, g_frames=None):
+        """Deferred-finish form of `weight` (dat_conv3d_wgrad_acc): ADDS this conv's weight gradient, unscaled and in the kernels'
+        [tap][Cout][Cin] order, into the caller's fp32 accumulator `gt` (numel of the weight; zeroed by the caller once per iteration);
+        WeightFinishBatch turns all accumulators into gradients with one launch.  Returns False -- nothing launched -- when the layer
+        does not take the direct kernels (the caller then uses `weight`)."""
+        frames, H, W, _ = x.shape
+        d = self._fwd_desc(frames, T, H, W)
+        if g_frames is not None and frames == T:
+            d.out_t0, d.out_tn = int(g_frames[0]), int(g_frames[1])
+        if not L.lib().dat_conv3d_wgrad_acc_supported(ctx().h, C.byref(d), self.g_cstride):
+            return False
+        assert gt.dtype == torch.float32 and gt.is_contiguous() and gt.numel() == self.w.numel()
+        ctx().call('dat_conv3d_wgrad_acc', _stream(), C.byref(d), _ptr(x), _ptr(g), self.g_cstride, self.cin, self.cout, _ptr(gt))
+        return True
+
     def data(self, g, T, H, W, accumulate_into=None, g_frames=None, mask=None):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given).  mask: the conv's
         forward input x = relu(...) in the shape of dL/dx -- the ReLU backward of x's producer is applied in this conv's epilogue
@@ -387,6 +402,32 @@ class PackBatch(object):
         for l in self.layers:
             if l.bias_src is not None:
                 l.bias[:l.cout_real] = l.bias_src.float()
+
+
+class WeightFinishBatch(object):
+    """One launch for the finish of many deferred weight gradients (dat_wgrad_finish_batch): entries = (gt accumulator, scale or None,
+    dW fp32 [Cout, Cin, KT, KH, KW] view, accumulate).  The device table is valid as long as those buffers are (training: flat buffers)."""
+
+    def __init__(self, entries):
+        assert entries
+        items = (L.WFinishItem * len(entries))()
+        total = 0
+        for i, (gt, scale, dW, acc) in enumerate(entries):
+            cout, cin = int(dW.shape[0]), int(dW.shape[1])
+            ntaps = dW.numel() // (cout * cin)
+            assert gt.numel() == dW.numel() and dW.is_contiguous() and gt.is_contiguous()
+            items[i].Gt, items[i].dW = gt.data_ptr(), dW.data_ptr()
+            items[i].scale = scale.data_ptr() if scale is not None else None
+            items[i].Cout, items[i].Cin, items[i].ntaps, items[i].accumulate = cout, cin, ntaps, int(bool(acc))
+            items[i].block0 = total
+            total += (dW.numel() + 2047) // 2048
+        self.n, self.total = len(entries), total
+        self.keep = [e[:3] for e in entries]
+        raw = np.frombuffer(items, dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(entries[0][0].device)
+
+    def run(self):
+        ctx().call('dat_wgrad_finish_batch', _stream(), _ptr(self.table), self.n, C.c_longlong(self.total))
 
 
 def _convgrad_repack(self):

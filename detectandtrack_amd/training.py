@@ -29,13 +29,19 @@ logger = logging.getLogger(__name__)
 class TrainExecutor(Executor):
     """Forward (inherits the inference handlers) + loss ops + backward + update for one net on one workspace."""
 
-    def __init__(self, ws, net, arena=None):
+    def __init__(self, ws, net, arena=None, gt_arena=None):
         super(TrainExecutor, self).__init__(ws, net)
         self.grads = {}          # blob name -> list of gradient tensors (blob layout; activation dtype or fp32)
         self.param_grads = {}    # param name -> fp32 CUDA tensor (reference blob layout)
         # Trainer's gradient arena: param name -> a zeroed fp32 view of ONE flat buffer (the all-reduce and the SGD update run on
         # the flat buffer; weight-gradient kernels write into the views directly).  None: gradients are separate tensors.
         self.arena = arena
+        # Deferred weight-gradient finish (cfg.HIP.DEFER_WGRAD_FINISH): weight name -> a ZEROED fp32 accumulator of the weight's size
+        # (views of one flat buffer the Trainer zeroes per iteration).  The conv weight-gradient kernels add into it in their own
+        # [tap][Cout][Cin] order and ONE batched launch at the end of backward() writes the gradients into the arena -- instead of a
+        # memset + a transposing finish launch around every layer's kernel (46 + 46 launches of an R-18 iteration).
+        self.gt_arena = gt_arena if arena is not None else None
+        self._deferred = {}      # weight name -> the fused AffineChannelNd scale (tensor or None) its finish multiplies by
         self._masked, self._last_masked = set(), False      # gradient tensors that already carry their producer's ReLU mask
         self._trainable_set = None
         self._readers = {}
@@ -248,7 +254,24 @@ class TrainExecutor(Executor):
             h = getattr(self, 'bwd_' + op.type, None)
             if h is not None:
                 h(i, op)
+        self._finish_deferred()
         self.grads.clear()
+
+    def _finish_deferred(self):
+        if not self._deferred:
+            return
+        names = sorted(self._deferred)
+        ent = [(self.gt_arena[n], self._deferred[n], self.arena[n], n in self.param_grads) for n in names]
+        key = tuple((n, bool(acc), gt.data_ptr(), sc.data_ptr() if sc is not None else 0, dw.data_ptr())
+                    for n, (gt, sc, dw, acc) in zip(names, ent))
+        cache = self.ws.__dict__.setdefault('_wfinish_cache', {})
+        if key not in cache:
+            cache.clear()                       # (one live table: the previous one pointed at buffers that are gone)
+            cache[key] = ops.WeightFinishBatch(ent)
+        cache[key].run()
+        for n in names:
+            self.param_grads[n] = self.arena[n]
+        self._deferred.clear()
 
     def bwd_Conv(self, i, op):
         ws, a = self.ws, op.args
@@ -301,8 +324,13 @@ class TrainExecutor(Executor):
             return ops.ConvGrad(w5, scale, a['strides'], a['pads'], y.dt, xin.t.shape[3], g.shape[3])
         cg = self._conv_grad(i, build)
         if self._trainable(a['w']):
-            dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=(lo - ilo, n) if xin.N == 1 else None, out=self._pgrad_out(a['w']))
-            self._pgrad(a['w'], dW)
+            gfr = (lo - ilo, n) if xin.N == 1 else None
+            gt = self.gt_arena.get(a['w']) if (self.gt_arena is not None and a['w'] in self.arena) else None
+            if gt is not None and cg.weight_acc(x_win, g_emb, Tw, gt, g_frames=gfr):
+                self._deferred[a['w']] = cg.scale
+            else:
+                dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=gfr, out=self._pgrad_out(a['w']))
+                self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             f, H, W, _ = xin.t.shape
             # a gradient of the same frame window that already waits for this input (the block's shortcut): the data-gradient conv
@@ -585,6 +613,8 @@ class Trainer(object):
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.momentum, self.arena = {}, {}
+        self.flat_gt = torch.zeros(self.n_weights, dtype=torch.float32, device=dev) if cfg.HIP.get('DEFER_WGRAD_FINISH', True) else None
+        self.gt_arena = {} if self.flat_gt is not None else None
         off = 0
         for n, sz in zip(order, sizes):
             shape = tuple(ws.params[n].shape)
@@ -593,6 +623,8 @@ class Trainer(object):
             ws._dev_params[n] = view                      # the workspace's device master IS the slice of the flat buffer
             self.momentum[n] = self.flat_v[off:off + sz].view(shape)
             self.arena[n] = self.flat_g[off:off + sz].view(shape)
+            if self.gt_arena is not None and n not in self.biases and len(shape) >= 4:
+                self.gt_arena[n] = self.flat_gt[off:off + sz]      # (weights come first in the flat order: off < n_weights)
             off += sz
         ws._layers.clear()                                # layers built before held the old master tensors
         self._train_ptrs = {ws._dev_params[n].data_ptr() for n in order}
@@ -614,7 +646,9 @@ class Trainer(object):
             self._pack_sig = None        # layers were rebuilt since the last step: the cached pack table holds stale pointers
             self._param_epoch = getattr(ws, 'param_epoch', 0)
         self.flat_g.zero_()
-        ex = TrainExecutor(ws, self.model.net, arena=self.arena)
+        if self.flat_gt is not None:
+            self.flat_gt.zero_()
+        ex = TrainExecutor(ws, self.model.net, arena=self.arena, gt_arena=self.gt_arena)
         ex.run()
         ex.backward()
         if self.dist is not None and self.dist.get_world_size() > 1:

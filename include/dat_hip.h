@@ -344,6 +344,23 @@ int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, con
 size_t dat_conv3d_wgrad_workspace_bytes(const dat_conv_desc* d, int Cin_real, int Cout_real);
 int dat_conv3d_wgrad(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
                      int Cin_real, int Cout_real, const float* scale, void* workspace, float* dW);
+/* Deferred finish (training: one zeroing and one transposing launch per ITERATION instead of one memset + one finish per layer).
+ * dat_conv3d_wgrad_acc ADDS the layer's weight gradient, in the kernels' own fp32 [tap][Cout][Cin] order and without the scale, into the
+ * caller's accumulator Gt -- zeroed by the caller at the start of the iteration; several calls may add into one Gt (a weight shared by
+ * several convs: the RPN conv of every FPN level).  Only layers that take the direct bf16 kernels (dat_conv3d_wgrad_acc_supported == 1;
+ * anything else is a DAT_ERR_ARG).  dat_wgrad_finish_batch then writes dW[co][ci][tap] (+)= scale[co] * Gt[tap][co][ci] for a table of
+ * layers in one launch: an item owns the blocks [block0, block0 + ceil(Cout * Cin * ntaps / 2048)) of the grid; total_blocks = their sum. */
+typedef struct dat_wfinish_item {
+    const float* Gt;
+    const float* scale;      /* fp32 [Cout] or NULL */
+    float* dW;
+    int Cout, Cin, ntaps, accumulate;
+    long long block0;
+} dat_wfinish_item;
+int dat_conv3d_wgrad_acc_supported(dat_ctx* ctx, const dat_conv_desc* d, int g_cstride);
+int dat_conv3d_wgrad_acc(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
+                         int Cin_real, int Cout_real, float* Gt);
+int dat_wgrad_finish_batch(dat_ctx* ctx, dat_stream s, const dat_wfinish_item* items_dev, int n, long long total_blocks);
 /* g = (dy [+ dy2]) * (y > 0 if relu) over [npos][cstride] (channels >= C zeroed); dbias[c] += sum_p g (may be NULL).
  * Relu backward on the fused conv's output + the bias / AffineChannelNd-bias reduction
  * (affine_channel_nd_op.cu:74-92). */
