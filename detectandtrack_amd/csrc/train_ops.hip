@@ -1074,7 +1074,11 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
             q.ablate = ctx->dbg_ablate_wgrad;
             const long long tiles = (long long)d->KT * q.n_co_tiles * q.n_ci_tiles;
             const long long nchunks = (long long)(q.f_end - q.f_begin) * q.tiles_h * q.tiles_w;
-            long long ks = 640 / tiles;                         // ~1.25 rounds of the 512 resident blocks (per-layer sweep, tools/probes/wgrad_bench.py)
+            // K split (per-layer sweep of the LDS-DMA kernel, tools/probes/wgrad_bench.py, blocks = tiles x ks): ~384 blocks -- 1.5 per CU --
+            // beat the 640 (1.25 rounds of the 512 slots) the register-staged kernel liked: res3 (12 tiles) ks 53 -> 32 0.181 -> 0.157 ms,
+            // res4 / P3 (48) 13 -> 8 0.192 -> 0.167 / 0.136 -> 0.109, P2 13 -> 8 0.328 -> 0.304; fewer, longer blocks mean fewer atomics and
+            // fewer pipeline fills.  Layers with many tiles (res5: 192) want two blocks per CU again: ks 3 -> 4 0.224 -> 0.205.
+            long long ks = ctx->dbg_wgrad_dma ? (tiles <= 96 ? (384 + tiles - 1) / tiles : (768 + tiles - 1) / tiles) : 640 / tiles;
             if (ks > nchunks / 4) ks = nchunks / 4;             // at least 4 patches per block
             if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
             if (ks > nchunks) ks = nchunks;
