@@ -17,6 +17,13 @@ from detectandtrack_amd import workspace as wsmod
 from detectandtrack_amd.core import test as engine
 
 
+def ops_ws_generation():
+    """How often the C-ABI context's scratch buffer has grown (dat_ws_info).  Captured launches keep the buffer they were captured
+    with -- growth retires a buffer instead of freeing it (csrc/c_api.hip dat_ensure_ws) -- so this is bookkeeping for tests."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    return ops.ws_info()[2]
+
+
 class ClipGraph(object):
     """model.net + device post-processing (+ keypoint net + decode) for ONE input geometry on one workspace / HIP stream.  The
     geometry -- blob shape, im_info rows (blob height / width / scale per image) and the unscaled image shapes -- is baked into the
@@ -46,6 +53,12 @@ class ClipGraph(object):
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
             self.dev = self._enqueue()
         torch.cuda.synchronize()
+        # the blob namespace as THIS graph's replays fill it: a workspace that holds several graphs (one per input geometry) has
+        # `ws.blobs` pointing at the tensors of whichever graph was captured last, so whoever reads blobs by name after a replay
+        # (the exact-tie host path of core/pipeline.py, FetchBlob in tests) restores this snapshot first
+        self.blobs = dict(ws.blobs)
+        with torch.cuda.stream(self.stream):
+            self.ws_generation = ops_ws_generation()
 
     def _enqueue(self):
         prev, wsmod._GLOBAL = wsmod._GLOBAL, self.ws    # the engine functions talk to the global workspace
@@ -72,6 +85,11 @@ class ClipGraph(object):
                 self.static_data.copy_(data_dev, non_blocking=True)
             self.graph.replay()
         return self.dev
+
+    def restore_blobs(self):
+        """Point the workspace's blob names at the tensors this graph's replays write (a copy: eager ops run afterwards may rebind
+        names without touching the snapshot)."""
+        self.ws.blobs = dict(self.blobs)
 
     def results(self):
         """Per-image (cls_boxes, cls_keyps) list of the last launched forward (None entries: exact-tie overflow, see

@@ -254,12 +254,18 @@ def _build_defaults():
     # axis of the blobs; every image keeps the results it gets alone (the reference runs one image per forward, core/test.py:212-214)
     # DEFER_WGRAD_FINISH (training): conv weight gradients accumulate in the kernels' own [tap][Cout][Cin] order in one flat buffer and ONE
     # launch per iteration turns them into gradients (training.py), instead of a memset + a finish launch around every layer's kernel.
+    # MAX_GRAPHS_PER_SLOT: captured hipGraphs (one per input geometry, each with a private pool holding a forward's activations) kept
+    # per pipeline slot, least recently used evicted.  PAD_TAIL_FORWARD: a last group of fewer than IMS_PER_FORWARD clips is padded
+    # with repeats of its last clip (results dropped) instead of capturing a second graph for the smaller batch.
+    # OVERLAP_ALLREDUCE (training, world size > 1): gradients are finished and all-reduced per bucket in reverse layer order on a
+    # communication stream while the backward of the earlier layers continues (training.py); False = one exchange after the backward
     # FUSE_RELU_BWD (training): the ReLU backward of a blob with ONE reader is applied in the epilogue of that reader's data-gradient
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
                       'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
-                      'DEFER_WGRAD_FINISH': True})
+                      'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
+                      'OVERLAP_ALLREDUCE': True})
     return c
 
 

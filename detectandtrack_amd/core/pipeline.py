@@ -17,6 +17,7 @@ arguments (tests/test_gpu_model.py).
 
 `bench.py` measures this class; `core/test_engine.test_net` runs on it (cfg.HIP.PIPELINE_DEPTH / IMS_PER_FORWARD / CLIP_GRAPH).
 """
+import collections
 import os
 import time
 
@@ -34,7 +35,7 @@ class _Slot(object):
     def __init__(self, ws):
         self.ws, self.stream = ws, torch.cuda.Stream()
         self.event, self.copy_event = torch.cuda.Event(), torch.cuda.Event()
-        self.graphs = {}            # geometry key -> ClipGraph
+        self.graphs = collections.OrderedDict()   # geometry key -> ClipGraph, least recently used first (bounded: max_graphs)
         self.pinned = self.dev_u8 = None
         self.data = {}              # geometry key -> the eager path's `data` buffer
 
@@ -45,14 +46,17 @@ class ClipPipeline(object):
     drain in submission order).  depth=1 is the strictly sequential reference order.  graph=True: every slot replays its forward
     as one captured hipGraph per input geometry (core/clip_graph.py), False: eager launches."""
 
-    def __init__(self, model, ws, depth=4, graph=True, fifo=False, keep_results=True):
+    def __init__(self, model, ws, depth=4, graph=True, fifo=False, keep_results=True, max_graphs=None):
         assert depth >= 1
+        # graphs (and their private memory pools: every activation of a forward) cached per slot, least recently used evicted
+        self.max_graphs = max(1, int(cfg.HIP.get('MAX_GRAPHS_PER_SLOT', 6) if max_graphs is None else max_graphs))
+        self.graphs_captured = self.graphs_evicted = 0
         self.model, self.depth = model, depth
         self.slots = [_Slot(ws if i == 0 else ws.fork()) for i in range(depth)]
         self.copy_stream = torch.cuda.Stream()
         self.free = list(range(depth))
         self.use_graph = bool(graph)
-        self.pending = []           # (slot index, tag, im_info, im_shapes, dev, frames) in submission order
+        self.pending = []           # (slot index, tag, im_info, im_shapes, dev, frames, ClipGraph | None) in submission order
         self.results = []           # (tag, [per-image (cls_boxes, cls_segms, cls_keyps)]) in completion order
         self.keep_results = keep_results
         self.n_det = 0
@@ -97,9 +101,16 @@ class ClipPipeline(object):
             g = s.graphs.get(key)
             if g is None:
                 from detectandtrack_amd.core.clip_graph import ClipGraph
+                while len(s.graphs) >= self.max_graphs:     # the slot is idle here (acquired): nothing replays the evicted graph
+                    _, old = s.graphs.popitem(last=False)
+                    del old                                 # frees the graph and its memory pool
+                    self.graphs_evicted += 1
                 g = s.graphs[key] = ClipGraph(self.model, s.ws, data_dev, im_info, im_shapes, stream=s.stream,
                                               static_data=data_dev if in_place else None)
-            return g.launch(data_dev, im_info=im_info, im_shape=im_shapes)
+                self.graphs_captured += 1
+            else:
+                s.graphs.move_to_end(key)
+            return g.launch(data_dev, im_info=im_info, im_shape=im_shapes), g
         with torch.cuda.stream(s.stream):
             prev, wsmod._GLOBAL = wsmod._GLOBAL, s.ws          # the engine functions talk to the global workspace
             try:
@@ -107,7 +118,7 @@ class ClipPipeline(object):
                 s.ws.FeedBlob('im_info', np.asarray(im_info, np.float32))
                 s.ws.RunNet(self.model.net.name)
                 scales = [float(v) for v in np.asarray(im_info, np.float32).reshape(-1, 3)[:, 2]]
-                return engine.enqueue_results_on_device(self.model, list(im_shapes), scales)
+                return engine.enqueue_results_on_device(self.model, list(im_shapes), scales), None
             finally:
                 wsmod._GLOBAL = prev
 
@@ -121,10 +132,10 @@ class ClipPipeline(object):
         im_info = np.asarray(im_info, np.float32).reshape(-1, 3)
         assert im_info.shape[0] == B, (im_info.shape, B)
         shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
-        dev = self._enqueue(slot, data_dev, im_info, shapes, in_place=False)
+        dev, g = self._enqueue(slot, data_dev, im_info, shapes, in_place=False)
         self.slots[slot].event.record(self.slots[slot].stream)
         self.host_enqueue_s += time.perf_counter() - t0       # host time to enqueue one forward (no synchronisation inside)
-        self.pending.append((slot, tag, im_info, shapes, dev, None))
+        self.pending.append((slot, tag, im_info, shapes, dev, None, g))
 
     def submit_frames(self, clips, tag=None):
         """One forward from HOST frames: `clips` = B entries, each a list of T uint8 BGR frames (HxWx3 arrays of one size).  The
@@ -165,14 +176,14 @@ class ClipPipeline(object):
                 s.data[gkey] = data
             finally:
                 wsmod._GLOBAL = prev
-        dev = self._enqueue(slot, s.data[gkey], im_info, shapes, in_place=True)
+        dev, g = self._enqueue(slot, s.data[gkey], im_info, shapes, in_place=True)
         s.event.record(s.stream)
         self.host_enqueue_s += time.perf_counter() - t0
-        self.pending.append((slot, tag, im_info, shapes, dev, clips))
+        self.pending.append((slot, tag, im_info, shapes, dev, clips, g))
 
     # ---- completion ------------------------------------------------------------------------------------------------------------
     def _finish(self, item):
-        slot, tag, im_info, shapes, dev, clips = item
+        slot, tag, im_info, shapes, dev, clips, g = item
         s = self.slots[slot]
         prev, wsmod._GLOBAL = wsmod._GLOBAL, s.ws
         try:
@@ -181,6 +192,8 @@ class ClipPipeline(object):
                 out = []
                 for i, r in enumerate(res):
                     if r is None:      # exact score ties at the detection limit: this image through the reference's host path
+                        if g is not None:   # blob names -> the tensors of the graph that was REPLAYED (not of the last captured one)
+                            g.restore_blobs()
                         out.append(self._host_path(s, i, im_info, shapes, clips))
                         continue
                     cls_boxes, cls_keyps = r

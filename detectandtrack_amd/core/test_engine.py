@@ -79,10 +79,9 @@ def _pipelined(part):
         return False
     if cfg.TEST.COMPETITION_MODE or cfg.HIP.FRAME_TRUNK_CACHE > 0 or cfg.HIP.KEYFRAME_DCE:
         return False
-    for entry in part[:1] + part[-1:]:
-        for f in load_clip(entry):
-            if f.dtype != np.uint8:
-                return False
+    first = load_clip(part[0])          # (frame dtypes are checked clip by clip inside the loop: a non-uint8 clip takes the eager path)
+    if any(f.dtype != np.uint8 for f in first):
+        return False
     return True
 
 
@@ -97,16 +96,46 @@ def _test_net_pipelined(model, part, all_boxes, all_keyps, timers):
     def place(done):
         for tags, res in done:
             for i, (cls_boxes_i, _, cls_keyps_i) in zip(tags, res):
+                if i is None:           # a padding clip of a tail group
+                    continue
                 extend_results(i, all_boxes, cls_boxes_i)
                 if cls_keyps_i is not None:
                     extend_results(i, all_keyps, cls_keyps_i)
+
+    def submit(group):
+        clips, tags = [c for _, c in group], [j for j, _ in group]
+        if pipe.use_graph and cfg.HIP.get('PAD_TAIL_FORWARD', True) and len(clips) < per and per in batches_seen.get(shape_of(clips[0]), ()):
+            # a short group of a geometry whose full-size graph exists: repeat the last clip (results dropped) instead of capturing a
+            # second graph -- with its own pool of activations -- for the smaller batch
+            pad = per - len(clips)
+            clips, tags = clips + [clips[-1]] * pad, tags + [None] * pad
+        batches_seen.setdefault(shape_of(clips[0]), set()).add(len(clips))
+        pipe.submit_frames(clips, tag=tags)
+
+    def shape_of(clip):
+        return (len(clip),) + tuple(clip[0].shape)
+
+    def eager(i, clip, entry):
+        """a clip the pipelined engine does not take (frames that are not uint8): the reference loop, with nothing else in flight"""
+        place(pipe.drain())
+        cls_boxes_i, _, cls_keyps_i = im_detect_all(model, clip, None, timers, frame_ids=entry.get('frame_ids'))
+        extend_results(i, all_boxes, cls_boxes_i)
+        if cls_keyps_i is not None:
+            extend_results(i, all_keyps, cls_keyps_i)
+    batches_seen = {}
     timers['im_detect_bbox'].tic()
     group, gshape = [], None
     for i, entry in enumerate(part):
         clip = load_clip(entry)
-        shape = (len(clip),) + tuple(clip[0].shape)
+        if any(f.dtype != np.uint8 for f in clip):
+            if group:
+                submit(group)
+                group = []
+            eager(i, clip, entry)
+            continue
+        shape = shape_of(clip)
         if group and (shape != gshape or len(group) == per):
-            pipe.submit_frames([c for _, c in group], tag=[j for j, _ in group])
+            submit(group)
             group = []
         group.append((i, clip))
         gshape = shape
@@ -114,7 +143,7 @@ def _test_net_pipelined(model, part, all_boxes, all_keyps, timers):
             done, pipe.results = pipe.results, []
             place(done)
     if group:
-        pipe.submit_frames([c for _, c in group], tag=[j for j, _ in group])
+        submit(group)
     place(pipe.drain())
     timers['im_detect_bbox'].toc()
     return pipe

@@ -5,15 +5,19 @@
 
 int dat_ensure_ws(dat_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return DAT_OK;
-    if (ctx->ws) {
-        hipDeviceSynchronize();
-        hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
-    }
+    // Growth is graph-safe: launches captured into a hipGraph have the OLD buffer's address baked in (proposal scratch, split-K
+    // partials, bias partials) and may be replayed at any later time, so an outgrown buffer is retired, not freed -- it stays
+    // valid until dat_ctx_destroy.  Buffers grow by >= 25 % a time, so the retired ones sum to less than 4x the live one.
     const size_t want = bytes + (bytes >> 2);
-    if (hipMalloc(&ctx->ws, want) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
+    void* grown = nullptr;
+    if (hipMalloc(&grown, want) != hipSuccess) {
+        (void)hipGetLastError();
+        DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
+    }
+    if (ctx->ws) ctx->ws_retired.push_back(ctx->ws);
+    ctx->ws = grown;
     ctx->ws_bytes = want;
+    ctx->ws_generation++;
     return DAT_OK;
 }
 
@@ -35,6 +39,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
     c->prof_tag = nullptr;
     c->ws = nullptr;
     c->ws_bytes = 0;
+    c->ws_generation = 0;
     c->zeros = nullptr;
     {
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -87,6 +92,7 @@ void dat_ctx_destroy(dat_ctx* ctx) {
         delete[] ctx->prof_tag;
     }
     if (ctx->ws) hipFree(ctx->ws);
+    for (void* p : ctx->ws_retired) hipFree(p);
     if (ctx->zeros) hipFree(ctx->zeros);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->util_stream) hipStreamDestroy((hipStream_t)ctx->util_stream);
@@ -94,6 +100,19 @@ void dat_ctx_destroy(dat_ctx* ctx) {
 }
 
 const char* dat_last_error(dat_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null dat_ctx"; }
+
+int dat_ws_info(dat_ctx* ctx, void** ptr, size_t* bytes, int* generation) {
+    if (!ctx) return DAT_ERR_ARG;
+    if (ptr) *ptr = ctx->ws;
+    if (bytes) *bytes = ctx->ws_bytes;
+    if (generation) *generation = ctx->ws_generation;
+    return DAT_OK;
+}
+
+int dat_ws_reserve(dat_ctx* ctx, size_t bytes) {
+    if (!ctx) return DAT_ERR_ARG;
+    return dat_ensure_ws(ctx, bytes);
+}
 
 int dat_prof_enable(dat_ctx* ctx, int capacity) {
     if (!ctx) return DAT_ERR_ARG;

@@ -7,6 +7,7 @@
 
 #include <string>
 #include <unordered_set>
+#include <vector>
 
 #include "../../include/dat_hip.h"
 
@@ -22,6 +23,8 @@ struct dat_ctx {
     // scratch owned by the ctx, grown on demand (proposal path)
     void* ws;
     size_t ws_bytes;
+    std::vector<void*> ws_retired;   // outgrown scratch buffers: captured hipGraphs may still replay launches that point at them
+    int ws_generation;               // bumped at every growth (dat_ws_info)
     void* zeros;           // 512 B in HBM: [0,256) zeros (conv patch loader: source of out-of-frame halo lanes),
                            // [256,272) profiling clock counters of the conv kernel
     void* util_stream;     // private non-blocking hipStream_t for the context's own small transfers

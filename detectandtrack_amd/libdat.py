@@ -64,6 +64,8 @@ _PROTOS = {
     'dat_ctx_create': (_i, [C.POINTER(_p), _i]),
     'dat_ctx_destroy': (None, [_p]),
     'dat_last_error': (C.c_char_p, [_p]),
+    'dat_ws_info': (_i, [_p, C.POINTER(_p), C.POINTER(C.c_size_t), C.POINTER(_i)]),
+    'dat_ws_reserve': (_i, [_p, C.c_size_t]),
     'dat_prof_enable': (_i, [_p, _i]),
     'dat_prof_read': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_f)]),
     'dat_prof_clock': (_i, [_p, C.POINTER(_d)]),

@@ -65,6 +65,19 @@ def drop_ctx(device=None):
     _CTX.pop((device, _stream_handle(device)), None)
 
 
+def ws_info():
+    """(device pointer, bytes, growth count) of the scratch buffer owned by the context of the current (device, stream)
+    (dat_ws_info).  Growth retires the outgrown buffer instead of freeing it, so captured hipGraphs stay replayable."""
+    p, n, g = C.c_void_p(), C.c_size_t(), C.c_int()
+    ctx().check(L._lib.dat_ws_info(ctx().h, C.byref(p), C.byref(n), C.byref(g)))
+    return (p.value or 0), int(n.value), int(g.value)
+
+
+def ws_reserve(nbytes):
+    """Grow the current context's scratch to at least `nbytes` now (dat_ws_reserve)."""
+    ctx().check(L._lib.dat_ws_reserve(ctx().h, C.c_size_t(int(nbytes))))
+
+
 def tune_plan(positions_per_block, ksplit):
     """dat_conv3d_tune_plan on the context of the current (device, stream): forces the launch plan of the conv launches that
     follow on THAT context (0, 0 = back to the makespan model).  Returns the C-ABI return code."""

@@ -39,6 +39,12 @@ int dat_version(void);
 int dat_ctx_create(dat_ctx** out, int device);
 void dat_ctx_destroy(dat_ctx* ctx);
 const char* dat_last_error(dat_ctx* ctx);
+/* The context's scratch buffer (proposal path, split-K partials, bias partials): current device pointer, size and
+ * the number of times it has grown.  Growth never frees the outgrown buffer before dat_ctx_destroy, so launches
+ * captured into a hipGraph (which have the old address baked in) stay replayable.  Any out pointer may be NULL. */
+int dat_ws_info(dat_ctx* ctx, void** ptr, size_t* bytes, int* generation);
+/* Make sure the scratch holds at least `bytes` (tests / callers that want the growth outside a timed region). */
+int dat_ws_reserve(dat_ctx* ctx, size_t bytes);
 
 /* Per-launch HIP-event timing of the conv kernel (used by bench.py's roofline leg).
  * enable: start recording (capacity launches); read: sync the events and return

@@ -498,3 +498,74 @@ def test_pipelined_engine_writes_the_same_detections_as_the_eager_loop(tmp_path)
         a, b = got['all_boxes'][1][i], eager['all_boxes'][1][i]
         assert a.shape[0] >= 15 and abs(a.shape[0] - b.shape[0]) <= 3 and a.shape[1] == 5
         assert _boxes_agree(a, b, 0.5) > 0.85, (i, a[:3], b[:3])
+
+
+def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypatch):
+    """ADVICE r3 (high + medium).  One pipeline slot holds a captured hipGraph per input geometry; the captured launches have the
+    C-ABI context's scratch pointer baked in (proposal scratch, split-K partials).  (1) small geometry, then a LARGER one whose
+    warm-up grows that scratch, then the small one again: the first graph must still replay correctly -- growth retires the outgrown
+    buffer instead of freeing it (csrc/c_api.hip dat_ensure_ws).  (2) The exact-tie host fallback (`ClipPipeline._host_path`) reads
+    `rois` / `cls_prob` / `bbox_pred` / the FPN blobs BY NAME: after the large geometry was captured last, a small forward that
+    takes the fallback must read the tensors of the graph that was replayed, not the last captured one's.  (3) The per-slot graph
+    cache is bounded (LRU)."""
+    import torch
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.pipeline import ClipPipeline
+    from detectandtrack_amd.ops import hip_ops as ops
+    T = 2
+    c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)
+    c['TEST'].update(SCALES=(96,), MAX_SIZE=1000, SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+    model, ws, _ = build_product(c)
+    rs = np.random.RandomState(7)
+    small = [[rs.randint(0, 255, (96, 128, 3)).astype(np.uint8) for _ in range(T)] for _ in range(2)]
+    # scale 96 / min side: a 96 x 320 frame keeps its size -> a 2.5x larger map AND more anchors than the small geometry
+    large = [[rs.randint(0, 255, (96, 320, 3)).astype(np.uint8) for _ in range(T)] for _ in range(4)]
+    ref_small = [engine.im_detect_all(model, clip, None) for clip in small]
+    ref_large = engine.im_detect_all(model, large[0], None)
+
+    pipe = ClipPipeline(model, ws, depth=1, graph=True, max_graphs=2)
+    stream = pipe.slots[0].stream
+
+    def info():
+        with torch.cuda.stream(stream):
+            return ops.ws_info()
+
+    def run(clips):
+        pipe.submit_frames(clips, tag='x')
+        (_, out), = pipe.drain()
+        return out
+
+    def same(out, ref):
+        np.testing.assert_array_equal(out[0][1], ref[0][1])
+        assert len(out[2][1]) == len(ref[2][1])
+        for a, b in zip(out[2][1], ref[2][1]):
+            np.testing.assert_array_equal(a, b)
+    same(run([small[0]])[0], ref_small[0])
+    p0, n0, g0 = info()
+    assert p0 and n0 > 0
+    out = run(large)                                    # four clips of the larger geometry: the scratch must grow
+    assert _boxes_agree(out[0][0][1], ref_large[0][1], 0.5) > 0.85      # (four clips per forward: other conv plans, not bit-equal)
+    p1, n1, g1 = info()
+    assert g1 > g0 and n1 > n0 and p1 != p0, 'the second geometry was meant to outgrow the scratch: %r -> %r' % ((p0, n0, g0), (p1, n1, g1))
+    # (1) the first graph again, twice, with different clips: replayed launches still point at the retired buffer
+    same(run([small[1]])[0], ref_small[1])
+    same(run([small[0]])[0], ref_small[0])
+    assert pipe.graphs_captured == 2 and pipe.graphs_evicted == 0
+    # (2) force the host fallback for a SMALL forward while `ws.blobs` still names the large graph's tensors
+    orig = engine.read_batch_results_from_device
+    monkeypatch.setattr(engine, 'read_batch_results_from_device', lambda *dev: [None] * len(orig(*dev)))
+    out = run([small[1]])
+    assert pipe.host_path_images == 1
+    a, b = out[0][0][1], ref_small[1][0][1]
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, atol=1e-4)
+    assert len(out[0][2][1]) == len(ref_small[1][2][1])
+    for x, y in zip(out[0][2][1], ref_small[1][2][1]):
+        np.testing.assert_allclose(x[:2], y[:2], atol=1e-3)
+    monkeypatch.setattr(engine, 'read_batch_results_from_device', orig)
+    # (3) a third geometry evicts the least recently used graph (the large one); the small one is still live
+    third = [[rs.randint(0, 255, (96, 160, 3)).astype(np.uint8) for _ in range(T)]]
+    run(third)
+    assert pipe.graphs_captured == 3 and pipe.graphs_evicted == 1 and len(pipe.slots[0].graphs) == 2
+    same(run([small[0]])[0], ref_small[0])
+    assert pipe.graphs_captured == 3
