@@ -74,7 +74,33 @@ def best_iou(a, b):
     return torch.cat(out).numpy()
 
 
-def bf16_vs_fp32(model, ws_bf16, data, im_info, n_kp=100, ws_fp32=None):
+def blob_error_trail(net, ws_a, ws_b, abs_bar=1e-2):
+    """Where the arithmetic of workspace `ws_a` (bf16) leaves that of `ws_b` (fp32): for every feature-map / row blob both hold
+    after running `net`, in the order the net produces them, the max-abs difference, the reference magnitude and the mean-abs
+    difference -- and the first blob whose max-abs difference exceeds `abs_bar`.  Everything is computed on the device."""
+    trail, first = [], None
+    seen = set()
+    for op in net.ops:
+        for name in op.outputs:
+            a, b = ws_a.blobs.get(name), ws_b.blobs.get(name)
+            if name in seen or a is None or b is None or a.kind not in ('fmap', 'rows') or a.kind != b.kind:
+                continue
+            seen.add(name)
+            if tuple(a.t.shape) != tuple(b.t.shape):
+                continue
+            C = a.C
+            ta, tb = a.t[..., :C].float(), b.t[..., :C].float()
+            d = (ta - tb).abs()
+            rec = {'blob': name, 'max_abs_err': float(d.max()), 'mean_abs_err': float(d.mean()), 'ref_max_abs': float(tb.abs().max()),
+                   'ref_mean_abs': float(tb.abs().mean())}
+            del d, ta, tb
+            trail.append(rec)
+            if first is None and rec['max_abs_err'] > abs_bar:
+                first = rec
+    return trail, first
+
+
+def bf16_vs_fp32(model, ws_bf16, data, im_info, n_kp=100, ws_fp32=None, trail=False):
     """Run the clip through the bf16 workspace and an fp32 twin; both keypoint nets get the SAME rois (the fp32 path's
     best-scoring boxes).  Returns a flat dict of error figures."""
     ws32 = ws_fp32 or second_workspace(ws_bf16, model, 'fp32')
@@ -83,6 +109,15 @@ def bf16_vs_fp32(model, ws_bf16, data, im_info, n_kp=100, ws_fp32=None):
     out = {
         'rois_fp32': int(r32.shape[0]), 'rois_bf16': int(r16.shape[0]),
     }
+    if trail:
+        # which blob first leaves 1e-2: the bf16 operand rounding of the INPUT (|x| <= 152 -> half an ulp = 0.5) is
+        # already > 1e-2 absolute at conv1, so the trail is reported with the magnitudes next to it: what matters is err / |ref|
+        tr, first = blob_error_trail(model.net, ws_bf16, ws32)
+        out['first_blob_over_1e-2'] = {k: (v if isinstance(v, str) else round(v, 5)) for k, v in first.items()} if first else None
+        rel = [(r['blob'], r['max_abs_err'] / max(r['ref_max_abs'], 1e-30)) for r in tr]
+        out['blob_rel_err_trail'] = {n: round(v, 5) for n, v in rel if n.endswith('_sum') or n in ('pool1', 'conv1', 'fc6', 'fc7')}
+        worst = max(rel, key=lambda kv: kv[1]) if rel else None
+        out['worst_blob_rel_err'] = {'blob': worst[0], 'max_abs_err_over_ref_max': round(worst[1], 5)} if worst else None
     iou = best_iou(r16[:, 1:5], r32[:, 1:5])
     # proposals: the share of bf16 rois that have an fp32 roi of IoU >= 0.9 / 0.7 (bf16 noise in the box deltas moves a
     # 256-px anchor by a few px, and near-tied objectness scores swap places at the top-N cut: a set comparison, not a row one)

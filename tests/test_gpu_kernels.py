@@ -1065,36 +1065,51 @@ def test_conv_one_pixel_wide_tiles(ops, dtype_name):
     assert (y - ref).abs().max().item() < (1e-2 if dtype_name == 'fp32' else 0.02 * ref.abs().max().item())
 
 
-def test_full_size_layers_spot_checked(ops):
-    """Size-independent check at the BENCH sizes (8 x 768 x 1344 clip, R-18 FPN3D): every distinct conv layer shape runs at full
-    size through the planner's own tile / split-K choice, and 48 random output positions (all channels) are compared with a direct
+@pytest.mark.parametrize('clips', [1, 4])
+def test_full_size_layers_spot_checked(ops, clips):
+    """Size-independent check at the BENCH sizes (8 x 768 x 1344 clips, R-18 FPN3D): every distinct conv layer shape runs at full
+    size through the planner's own tile / split-K choice, and random output positions (all channels) are compared with a direct
     evaluation of the receptive-field dot products.  (The small-shape parity tests cannot see tile-shape-dependent bugs such as the
-    one-column-tile patch decoding fixed in round 1.)"""
+    one-column-tile patch decoding fixed in round 1.)
+
+    clips = 4 is the BENCHED forward: 32 frames on the frames axis, where the planner takes other branches
+    (per-frame linear strips, other split-K factors, multi-round head grids) and the temporal taps must stop at the clip borders
+    (the reference pads every clip on its own, lib/modeling/ResNet3D.py:258-284) -- so the sampled positions include the corners of
+    the first and the last frame of EVERY clip, whose temporal neighbours belong to another clip."""
     sys_path = __import__('sys').path
     import os
     sys_path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import bench_layers
     g = torch.Generator(device='cuda').manual_seed(12)
-    T = 8
-    for (name, cin, cout, k, st, hi, wi, cnt) in bench_layers.layer_list('R18', T, 768, 1344, 3):
+    cases = [(name, cin, cout, k, st, hi, wi, clips * 8, 8) for (name, cin, cout, k, st, hi, wi, cnt) in bench_layers.layer_list('R18', 8, 768, 1344, 3)]
+    # the 2D heads of the benched forward: RPN conv on the centre frame of every clip's P2, keypoint-head conv on 100 rois per clip
+    cases += [('conv_rpn_fpn2', 256, 256, (1, 3, 3), 1, 192, 336, clips, 1), ('kps_head_conv', 512, 512, (1, 3, 3), 1, 14, 14, 100 * clips, 1)]
+    for (name, cin, cout, k, st, hi, wi, F_, T) in cases:
         pads = (k[0] // 2, k[1] // 2, k[2] // 2) if name != 'stem_k4x1' else (0, 0, 0)
         w = torch.randn((cout, cin) + tuple(k), device='cuda', generator=g) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
         w = w.to(torch.bfloat16).float()
         bias = torch.randn(cout, device='cuda', generator=g)
         layer = ops.ConvLayer(w, None, bias, stride=(st, st), pads=pads, relu=False, dtype=ops.BF16)
-        x = torch.randn((T, hi, wi, layer.cin), device='cuda', generator=g).to(torch.bfloat16)
+        x = torch.randn((F_, hi, wi, layer.cin), device='cuda', generator=g).to(torch.bfloat16)
         y = layer(x, T=T).float()
         ho, wo = layer.out_hw(hi, wi)
+        assert y.shape[0] == F_
         xf = x.float()
         worst = 0.0
-        idx = torch.randint(0, T * ho * wo, (48,), device='cuda', generator=g).tolist() + [0, T * ho * wo - 1, wo - 1, (ho - 1) * wo]
+        idx = torch.randint(0, F_ * ho * wo, (48 if clips == 1 else 24,), device='cuda', generator=g).tolist()
+        for c_ in range(F_ // T if T > 1 else min(F_, 4)):     # corners + a random interior position of the first and the last frame of every clip
+            for f in ((c_ * T, c_ * T + T - 1) if T > 1 else (c_, F_ - 1 - c_)):
+                base = f * ho * wo
+                idx += [base, base + ho * wo - 1, base + wo - 1, base + (ho - 1) * wo,
+                        base + int(torch.randint(0, ho * wo, (1,), device='cuda', generator=g).item())]
         for p_ in idx:
             f, r = divmod(p_, ho * wo)
             oh, ow = divmod(r, wo)
+            lo = (f // T) * T               # temporal taps stay inside the frame's own clip
             acc = bias.clone()
             for kt in range(k[0]):
                 ft = f + kt - pads[0]
-                if ft < 0 or ft >= T:
+                if ft < lo or ft >= lo + T:
                     continue
                 for kh in range(k[1]):
                     ih = oh * st + kh - pads[1]
@@ -1106,7 +1121,7 @@ def test_full_size_layers_spot_checked(ops):
                             continue
                         acc += w[:, :, kt, kh, kw] @ xf[ft, ih, iw, :cin]
             worst = max(worst, (y[f, oh, ow, :cout] - acc).abs().max().item() / max(1.0, acc.abs().max().item()))
-        assert worst < 0.02, (name, worst)
+        assert worst < 0.02, (name, clips, worst)
 
 
 def test_rpn_proposals_at_bench_size_vs_oracle(ops):

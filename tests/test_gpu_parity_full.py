@@ -21,10 +21,22 @@ def _max_abs(a, b):
     return float((torch.from_numpy(a) - b).abs().max())
 
 
-def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_names, five_d):
+def _fetch_image(ws, name, image):
+    """FetchBlob of ONE image / clip of a batched feature-map blob (a 4-clip P2 blob is 2.1 GB in fp32: only the clip under test
+    crosses PCIe)."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    b = ws.blobs[name]
+    assert b.kind == 'fmap' and 0 <= image < b.N
+    out = ops.to_ncdhw(b.t[image * b.T:(image + 1) * b.T], b.dt, 1, b.C, b.T).cpu().numpy()
+    return out if b.five_d else out[:, :, 0]
+
+
+def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_names, five_d, image=None):
+    """image: several images / clips per forward -- check the blobs, proposals and head outputs of THAT image of the batch against
+    an oracle that saw the image alone (the reference runs one image per forward, lib/core/test.py:212-214)."""
     from oracle import proposals as op
     for n in blob_names:
-        got, ref = ws.FetchBlob(n), net.blobs[n]
+        got, ref = (ws.FetchBlob(n) if image is None else _fetch_image(ws, n, image)), net.blobs[n]
         if not five_d:
             ref = ref[:, :, 0]
         assert got.shape == tuple(ref.shape), (n, got.shape, tuple(ref.shape))
@@ -32,29 +44,33 @@ def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_name
         print('%-26s max-abs %.3e (ref max %.2f)' % (n, err, mx))
         assert err < 1e-3 * max(1.0, mx), (n, err, mx)
     p2d = net.time_link(pyr)
-    ref_rois, _, _ = net.fpn_rpn(p2d, im_info)
-    rois = ws.FetchBlob('rois')
+    ref_rois, _, _ = net.fpn_rpn(p2d, im_info[:1] if image is None else im_info[image:image + 1])
+    rois_all = ws.FetchBlob('rois')
+    sel = np.arange(rois_all.shape[0]) if image is None else np.where(rois_all[:, 0] == image)[0]
+    rois = rois_all[sel].copy()
     assert rois.shape == ref_rois.shape, (rois.shape, ref_rois.shape)
     from detectandtrack_amd.utils.precision import set_agreement
     agree = set_agreement(rois[:, 1:], ref_rois[:, 1:], 0.05)
     print('rois: %d, %.2f%% of the device rois are in the oracle set (0.05 px)' % (rois.shape[0], 100 * agree))
     assert agree > 0.95
     # box head + keypoint head on the DEVICE rois (oracle features, oracle heads)
-    sub = rois[:200]
+    sub = rois[:200].copy()
+    sub[:, 0] = 0                                   # the oracle sees this image as image 0
     _, per_level, restore = op.distribute(sub, 2, 5)
     cls_prob, bbox_pred = net.box_head_2mlp(net.roi_feat_fpn(p2d[1:], per_level, restore, 7, 2))
-    np.testing.assert_allclose(ws.FetchBlob('cls_prob')[:200], cls_prob, atol=1e-4)
-    np.testing.assert_allclose(ws.FetchBlob('bbox_pred')[:200], bbox_pred, atol=1e-3)
-    kp_rois = rois[:n_kp].copy()
+    np.testing.assert_allclose(ws.FetchBlob('cls_prob')[sel[:200]], cls_prob, atol=1e-4)
+    np.testing.assert_allclose(ws.FetchBlob('bbox_pred')[sel[:200]], bbox_pred, atol=1e-3)
+    kp_rois = rois[:n_kp].copy()                    # (col 0 = the image's index in the batch: the device reads that image's features)
     ws.FeedBlob('keypoint_rois', kp_rois)
     ws.RunNet(model.keypoint_net.name)
     kps = ws.FetchBlob('kps_score')
-    _, per_level, restore = op.distribute(kp_rois, 2, 5)
+    _, per_level, restore = op.distribute(sub[:n_kp], 2, 5)
     ref = net.kps_head_2d(net.roi_feat_fpn(p2d[1:], per_level, restore, 14, 2))
     assert kps.shape == tuple(ref.shape)
     err = _max_abs(kps, ref)
     print('kps_score max-abs %.3e (ref max %.2f) over %d rois' % (err, float(ref.abs().max()), n_kp))
     assert err < 1e-3, err
+    return err
 
 
 @pytest.mark.parametrize('arch', ['18', '50'])
@@ -76,6 +92,85 @@ def test_fp32_forward_at_the_bench_shape_matches_the_oracle(arch):
     if arch == '50':      # 16 bottleneck outputs of up to 528 MB each: the last block of every stage + the pyramid
         names = ['pool1', 'res2_2_sum', 'res3_3_sum', 'res4_5_sum', 'res5_2_sum'] + [n for n in names if n.startswith('fpn_')]
     _check_against_oracle(model, ws, weights, net, pyr, im_info, 12, names, True)
+
+
+def test_fp32_four_clips_per_forward_at_the_bench_shape_match_the_oracle_clip_by_clip():
+    """The BENCHED forward: FOUR clips of 1 x 3 x 8 x 768 x 1344 in ONE forward (32 frames on the frames axis),
+    fp32 parity mode.  Clips 0 and 3 -- the two whose first / last frame borders another clip or the end of the batch -- against the
+    oracle run on each clip ALONE (the reference's protocol: one clip per forward, lib/core/test.py:212-232; every clip padded
+    temporally on its own, lib/modeling/ResNet3D.py:251-298): every `res*_sum` / `fpn_*` blob < 1e-3 * max, the clip's proposals,
+    box head and `kps_score` < 1e-3.  At 32 frames the planner takes other tiles / split-K factors than at 8."""
+    from oracle.net3d import Net
+    T, H, W, B = 8, 768, 1344, 4
+    model, ws, weights = build_product(fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=1000, post=1000))
+    clips = [synthetic_clip(T, H, W, seed=3 + i) for i in range(B)]
+    im_info = np.tile(np.array([[H, W, 800.0 / 720.0]], dtype=np.float32), (B, 1))
+    ws.FeedBlob('data', np.concatenate(clips, axis=0))
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    assert ws.blobs['fpn_res2_1_sum'].N == B and ws.blobs['fpn_res2_1_sum'].t.shape[0] == B * T
+    rois_all = ws.FetchBlob('rois')
+    assert set(np.unique(rois_all[:, 0])) == set(range(B)) and rois_all.shape[0] == B * 1000
+    names = ['pool1'] + sorted(b for b in ws.Blobs() if b.endswith('_sum') and b.startswith(('res', 'fpn_res')))
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    for i in (0, 3):
+        net = Net(weights, oracle_opts('18', T, 3, 'slice-center', 1000, 1000))
+        net.body(torch.from_numpy(clips[i]))
+        pyr = net.fpn()
+        print('--- clip %d of the 4-clip forward' % i)
+        _check_against_oracle(model, ws, weights, net, pyr, im_info, 12, names, True, image=i)
+        # the border frames on their own (the ones a clip-crossing temporal tap would corrupt first)
+        for n in ('res3_1_sum', 'fpn_res2_1_sum'):
+            got, ref = _fetch_image(ws, n, i), net.blobs[n]
+            for f in (0, T - 1):
+                err = _max_abs(got[:, :, f], ref[:, :, f])
+                assert err < 1e-3 * max(1.0, float(ref[:, :, f].abs().max())), (i, n, f, err)
+        del net, pyr
+
+
+def test_bf16_graph_of_four_clips_gives_every_clip_the_results_of_the_eager_one_clip_forward():
+    """the benched EXECUTION mode (bf16, 4 clips per forward, one captured hipGraph replayed) against the same
+    arithmetic run the plain way (bf16, eager launches, one clip per forward) at the bench shape.  Same kernels, same operands; what
+    differs is the launch plan of the larger grids (tile shapes, split-K factors -> fp32 summation order before the bf16 rounding of
+    each layer's output), so the comparison is at bf16 summation-order tolerance: every clip's detections are the eager ones (>= 90 %
+    of the boxes within 1 px -- a box is a function of bf16-rounded logits --, same count up to ties) and the decoded keypoints of
+    the matched detections agree within 2 px for >= 90 %.  A clip-indexing mistake (wrong im_info row, features of another clip)
+    moves boxes by hundreds of pixels and fails this outright."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.core.pipeline import ClipPipeline
+    T, B = 8, 4
+    c = fpn3d_kps_cfg('18', T=T, dtype='bf16', pre=1000, post=1000)
+    c['TEST'].update(SCALES=(800,), MAX_SIZE=1333, SCORE_THRESH=0.0, DETECTIONS_PER_IM=100)
+    model, ws, _ = build_product(c)
+    rs = np.random.RandomState(21)
+    base = [rs.randint(0, 255, (720 // 8, 1280 // 8, 3)).astype(np.uint8) for _ in range(B)]
+    clips = [[np.clip(np.kron(base[i], np.ones((8, 8, 1), np.uint8)).astype(np.int16) + rs.randint(-20, 20, (720, 1280, 3)), 0, 255).astype(np.uint8)
+              for _ in range(T)] for i in range(B)]
+    eager = [engine.im_detect_all(model, clip, None) for clip in clips]
+    assert ws.blobs['data'].t.shape == (1, 3, T, 768, 1344)
+    pipe = ClipPipeline(model, ws, depth=1, graph=True)
+    for _ in range(2):                                  # second pass = a pure replay
+        pipe.submit_frames(clips, tag='g')
+        (_, out), = pipe.drain()
+    assert pipe.graphs_captured == 1 and len(out) == B
+
+    def agree(a, b, tol):
+        d = np.abs(a[:, None, :4] - b[None, :, :4]).max(axis=2)
+        return d.min(axis=1) < tol, d.argmin(axis=1)
+    for i in range(B):
+        bg, be = out[i][0][1], eager[i][0][1]
+        kg, ke = out[i][2][1], eager[i][2][1]
+        assert abs(len(bg) - len(be)) <= 8 and len(bg) >= 100, (i, len(bg), len(be))
+        hit, idx = agree(bg, be, 1.0)
+        print('clip %d: %d / %d detections of the 4-clip graph within 1 px of an eager one' % (i, hit.sum(), len(bg)))
+        assert hit.mean() > 0.90, (i, hit.mean())
+        d = np.concatenate([np.abs(kg[j][:2] - ke[idx[j]][:2]).max(axis=0) for j in np.where(hit)[0]])
+        print('         keypoints of the matched detections: %.1f %% within 2 px (median %.2f px)' % (100 * (d < 2).mean(), np.median(d)))
+        assert (d < 2.0).mean() > 0.90, (i, (d < 2.0).mean())
+        # and NOT the results of another clip of the batch
+        other, _ = agree(bg, eager[(i + 1) % B][0][1], 1.0)
+        assert other.mean() < 0.3, (i, other.mean())
 
 
 def test_bf16_bench_configuration_error_against_fp32():
