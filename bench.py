@@ -461,9 +461,13 @@ def main():
         trainer = Trainer(model, ws, dist)
         slots = [(ws, torch.cuda.current_stream())]
 
-        def run_steps(n):
+        xstats = []
+
+        def run_steps(n, timing=False):
             for _ in range(n):
-                trainer.step(1e-4)
+                trainer.step(1e-4, timing=timing)
+                if timing and trainer.last_exchange_stats:
+                    xstats.append(dict(trainer.last_exchange_stats))
             torch.cuda.synchronize()
         n_det = 512
     else:
@@ -563,7 +567,7 @@ def main():
         _dbg('h2d region done')
     if train:
         start_profilers()
-        run_steps(prof_iters)
+        run_steps(prof_iters, timing=world > 1)      # (the exchange is timed in these extra iterations, outside the timed region)
     records, conv_log, mhz = [], [], []
     for (w, st), pr in zip(slots, profs):
         with torch.cuda.stream(st):
@@ -758,6 +762,19 @@ def main():
         'roofline': roofline,
         'roofline_hbm': roofline_hbm,
     }
+    if train:
+        # the one exchange step of the path: per-bucket sum all-reduce of the flat gradient buffer, started as the backward pass completes
+        # each bucket (training.GradExchange).  allreduce_ms = time the collectives ran on the communication stream, exposed = time the
+        # compute stream stood waiting for them before the SGD update (HIP events, averaged over the iterations after the timed region)
+        if world > 1 and xstats:
+            out['allreduce'] = {'allreduce_ms': round(float(np.mean([x['allreduce_ms'] for x in xstats])), 3),
+                                'exposed_allreduce_ms': round(float(np.mean([x['exposed_allreduce_ms'] for x in xstats])), 3),
+                                'buckets': xstats[0]['buckets'], 'gradient_mb': round(xstats[0]['bytes'] / 1e6, 1),
+                                'overlap': bool(trainer.exchange.overlap), 'backend': trainer.exchange.backend,
+                                'bucket_mb': round(trainer.BUCKET_BYTES / 1e6, 1)}
+        else:
+            out['allreduce'] = {'allreduce_ms': 0.0, 'exposed_allreduce_ms': 0.0, 'buckets': len(trainer.buckets),
+                                'gradient_mb': round(4 * trainer.flat_g.numel() / 1e6, 1), 'note': 'one rank: no exchange'}
     if host_enqueue_ms is not None:
         # host time spent enqueueing a step's kernel launches (Python executor + ctypes, no synchronisation): the step is
         # host-bound when this approaches ms_per_step

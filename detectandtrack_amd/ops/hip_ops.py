@@ -381,6 +381,11 @@ class BucketAllReduce(object):
             cnt = min(bucket_elems, n - off)
             ctx().call('dat_allreduce_bucket', _stream(), self.h, C.c_void_p(flat.data_ptr() + 4 * off), C.c_size_t(cnt))
 
+    def reduce_slice(self, flat, off, cnt):
+        """Sum elements [off, off + cnt) of `flat` over the ranks, in place, on the CURRENT stream (one ncclAllReduce)."""
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and 0 <= off and off + cnt <= flat.numel()
+        ctx().call('dat_allreduce_bucket', _stream(), self.h, C.c_void_p(flat.data_ptr() + 4 * off), C.c_size_t(cnt))
+
     def close(self):
         if self.h:
             L.lib().dat_comm_destroy(self.h)

@@ -42,6 +42,8 @@ class TrainExecutor(Executor):
         # memset + a transposing finish launch around every layer's kernel (46 + 46 launches of an R-18 iteration).
         self.gt_arena = gt_arena if arena is not None else None
         self._deferred = {}      # weight name -> the fused AffineChannelNd scale (tensor or None) its finish multiplies by
+        self._sealed = set()     # parameters whose gradient bucket is already on its way to the other ranks (Trainer, overlap)
+        self.accumulate_all = False   # the arena already holds gradients of an earlier clip (Trainer.step(zero_grad=False)): add, never overwrite
         self._masked, self._last_masked = set(), False      # gradient tensors that already carry their producer's ReLU mask
         self._trainable_set = None
         self._readers = {}
@@ -207,6 +209,9 @@ class TrainExecutor(Executor):
 
     def _pgrad(self, name, t):
         """Add a parameter-gradient contribution `t` (a fresh tensor the caller does not reuse)."""
+        if name in self._sealed:
+            raise RuntimeError('gradient contribution to %r after its bucket was handed to the all-reduce (static completion index '
+                               'of the parameter is wrong)' % name)
         if self.arena is not None and name in self.arena:
             view = self.arena[name]
             if t.data_ptr() != view.data_ptr():      # not produced in place (see _pgrad_out)
@@ -222,7 +227,7 @@ class TrainExecutor(Executor):
     def _pgrad_out(self, name):
         """Where a kernel may WRITE (overwrite) the gradient of `name` directly: its arena view on the first contribution of the
         step, else None (the kernel then returns a temporary that _pgrad adds)."""
-        if self.arena is None or name not in self.arena or name in self.param_grads:
+        if self.arena is None or name not in self.arena or name in self.param_grads or self.accumulate_all:
             return None
         return self.arena[name]
 
@@ -243,35 +248,44 @@ class TrainExecutor(Executor):
         return pname is not None and pname in self._trainable_set
 
     # ---- backward -----------------------------------------------------------------------------------------------------------
-    def backward(self):
+    def backward(self, on_op_done=None):
+        """on_op_done(i): called after the backward of op i (ops run from the last to the first) -- the Trainer's hook for finishing
+        and exchanging gradient buckets while the backward of the earlier layers continues."""
         self._masked.clear()
         for i in range(len(self.net.ops) - 1, -1, -1):
             op = self.net.ops[i]
-            if i in self._skip and i not in self._fused:
-                continue
-            if op.outputs and all(o in self.no_grad for o in op.outputs):
-                continue
-            h = getattr(self, 'bwd_' + op.type, None)
-            if h is not None:
-                h(i, op)
+            skip = (i in self._skip and i not in self._fused) or (op.outputs and all(o in self.no_grad for o in op.outputs))
+            if not skip:
+                h = getattr(self, 'bwd_' + op.type, None)
+                if h is not None:
+                    h(i, op)
+            if on_op_done is not None:
+                on_op_done(i)
         self._finish_deferred()
         self.grads.clear()
 
-    def _finish_deferred(self):
-        if not self._deferred:
+    def _finish_deferred(self, only=None):
+        """Turn the deferred weight-gradient accumulators into gradients (one batched launch).  only: restrict to these parameter
+        names (one gradient bucket); the others stay deferred."""
+        names = sorted(n for n in self._deferred if only is None or n in only)
+        if not names:
             return
-        names = sorted(self._deferred)
-        ent = [(self.gt_arena[n], self._deferred[n], self.arena[n], n in self.param_grads) for n in names]
+        ent = [(self.gt_arena[n], self._deferred[n], self.arena[n], n in self.param_grads or self.accumulate_all) for n in names]
         key = tuple((n, bool(acc), gt.data_ptr(), sc.data_ptr() if sc is not None else 0, dw.data_ptr())
                     for n, (gt, sc, dw, acc) in zip(names, ent))
         cache = self.ws.__dict__.setdefault('_wfinish_cache', {})
         if key not in cache:
-            cache.clear()                       # (one live table: the previous one pointed at buffers that are gone)
+            if len(cache) >= 64:                # (tables of an earlier configuration: they point at buffers that may be gone)
+                cache.clear()
             cache[key] = ops.WeightFinishBatch(ent)
         cache[key].run()
         for n in names:
             self.param_grads[n] = self.arena[n]
-        self._deferred.clear()
+            del self._deferred[n]
+
+    def seal(self, names):
+        """The gradients of `names` are final (their bucket is being exchanged): a later contribution is a bug, not a silent loss."""
+        self._sealed.update(names)
 
     def bwd_Conv(self, i, op):
         ws, a = self.ws, op.args
@@ -326,6 +340,8 @@ class TrainExecutor(Executor):
         if self._trainable(a['w']):
             gfr = (lo - ilo, n) if xin.N == 1 else None
             gt = self.gt_arena.get(a['w']) if (self.gt_arena is not None and a['w'] in self.arena) else None
+            if a['w'] in self._sealed:
+                self._pgrad(a['w'], None)       # raises: the bucket of this weight is already being exchanged
             if gt is not None and cg.weight_acc(x_win, g_emb, Tw, gt, g_frames=gfr):
                 self._deferred[a['w']] = cg.scale
             else:
@@ -587,6 +603,131 @@ class TrainExecutor(Executor):
         return {k: float(v.item()) for k, v in self.losses.items()}
 
 
+def param_ready_index(net, fused=None):
+    """For every parameter blob a net's ops reference (`w`, `b`): the SMALLEST index of an op that uses it.  The backward pass runs
+    the ops from the last to the first, so the parameter's gradient is final once the op of that index has been differentiated
+    (shared weights -- the RPN conv of the five FPN levels -- complete with their first use).  fused: Executor._fused, {index the
+    fused RPN head launch runs at: (logits op, deltas op, ...)} -- both heads' parameters complete at that index."""
+    idx = {}
+    pos = {id(op): i for i, op in enumerate(net.ops)}
+    for i, op in enumerate(net.ops):
+        a = op.args if isinstance(op.args, dict) else {}
+        for key in ('w', 'b'):
+            n = a.get(key)
+            if isinstance(n, str) and n:
+                idx[n] = min(idx.get(n, i), i)
+    for first, grp in (fused or {}).items():
+        for op in grp[:2]:
+            for key in ('w', 'b'):
+                n = op.args.get(key)
+                if isinstance(n, str) and n:
+                    idx[n] = min(idx.get(n, first), first, pos.get(id(op), first))
+    # parameters used only at or below the StopGradient marker (conv1 / res2: ResNet3D.py:273-274) never receive a gradient: their
+    # zeros are final before the backward pass starts
+    stop = [i for i, op in enumerate(net.ops) if op.type == 'StopGradient']
+    if stop:
+        last_use = {}
+        for i, op in enumerate(net.ops):
+            a = op.args if isinstance(op.args, dict) else {}
+            for key in ('w', 'b'):
+                n = a.get(key)
+                if isinstance(n, str) and n:
+                    last_use[n] = max(last_use.get(n, i), i)
+        for n, i in last_use.items():
+            if i <= stop[-1]:
+                idx[n] = len(net.ops)
+    return idx
+
+
+class GradExchange(object):
+    """The one exchange step of the path: sum all-reduce of the flat gradient buffer, bucket by bucket, each
+    bucket started AS SOON AS its gradients are final while the backward pass of the earlier layers keeps the GPU busy -- what the
+    reference gets from per-blob NCCLAllreduce ops scheduled by Caffe2's DAG executor (lib/modeling/model_builder.py:931-942).
+
+    buckets: [(lo, hi)] element ranges of `flat` in the order the backward pass completes them.  `ready(k)` hands bucket k to the
+    collective: on a CUDA buffer the reduce is enqueued on a COMMUNICATION stream behind an event of the compute stream (RCCL through
+    torch.distributed, or the C ABI's dat_allreduce_bucket with cfg.HIP.RCCL_DIRECT); `finish()` starts what was not started, and
+    makes the compute stream wait for the communication stream.  Backends: nccl (= RCCL over xGMI), gloo on a CPU buffer (tests), gloo
+    on a CUDA buffer (two ranks sharing one GPU in the tests: staged through pinned host memory, synchronous).  overlap=False: nothing
+    starts before finish() -- the serial exchange of rounds 1-3, kept as the A/B switch (cfg.HIP.OVERLAP_ALLREDUCE)."""
+
+    def __init__(self, flat, buckets, dist, overlap=True, direct=None):
+        self.flat, self.buckets, self.dist, self.overlap, self.direct = flat, list(buckets), dist, bool(overlap), direct
+        self.cuda = bool(flat.is_cuda)
+        self.backend = dist.get_backend() if dist is not None else None
+        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.stats = {}
+        self._host = None
+        self.begin()
+
+    def begin(self):
+        self.started = [False] * len(self.buckets)
+        self.order = []             # bucket indices in launch order (tests)
+        self._works, self._events = [], []
+
+    def ready(self, k):
+        if self.overlap:
+            self._start(k)
+
+    def _start(self, k):
+        if self.started[k]:
+            return
+        self.started[k] = True
+        self.order.append(k)
+        lo, hi = self.buckets[k]
+        if hi <= lo:
+            return
+        t = self.flat[lo:hi]
+        if not self.cuda:
+            self._works.append(self.dist.all_reduce(t, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        if self.backend == 'gloo':          # host-staged (tests: ranks that share one GPU cannot form an RCCL communicator)
+            ev.synchronize()
+            if self._host is None or self._host.numel() < t.numel():
+                self._host = torch.empty(max(t.numel(), max(h - l for l, h in self.buckets)), dtype=t.dtype).pin_memory()
+            h = self._host[:t.numel()]
+            h.copy_(t)
+            self.dist.all_reduce(h)
+            t.copy_(h)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            e0.record(self.comm_stream)
+            if self.direct is not None:
+                self.direct.reduce_slice(self.flat, lo, hi - lo)
+            else:
+                w = self.dist.all_reduce(t, async_op=True)
+                w.wait()                    # the COMMUNICATION stream waits for the collective (in order with the next bucket)
+            e1.record(self.comm_stream)
+        self._events.append((e0, e1))
+
+    def finish(self, timing=False):
+        """Start every bucket not started yet, then make the caller's stream wait for all of them.  timing=True (bench): synchronises
+        and fills `stats` = {allreduce_ms: time the collectives ran, exposed_allreduce_ms: time the compute stream stood waiting}."""
+        for k in range(len(self.buckets)):
+            self._start(k)
+        for w in self._works:
+            w.wait()
+        if self.cuda and self.backend != 'gloo':
+            cur = torch.cuda.current_stream()
+            a = b = None
+            if timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+            cur.wait_event(done)
+            if timing:
+                b.record(cur)
+                b.synchronize()
+                self.stats = {'allreduce_ms': sum(e0.elapsed_time(e1) for e0, e1 in self._events),
+                              'exposed_allreduce_ms': a.elapsed_time(b), 'buckets': len(self._events),
+                              'bytes': 4 * sum(h - l for l, h in self.buckets)}
+
+
 class Trainer(object):
     """One training process (one GPU): forward + backward + gradient all-reduce + momentum SGD on device fp32 masters
     (tools/train_net.py:120-170, model_builder.py:908-985).
@@ -604,7 +745,16 @@ class Trainer(object):
         self.trainable = list(model.TrainableParams())
         self.biases = set(model.biases)
         self.iter = 0
-        order = [n for n in self.trainable if n not in self.biases] + [n for n in self.trainable if n in self.biases]
+        # Flat order = the order in which the backward pass COMPLETES the gradients (heads first, res3 last; weights, then biases):
+        # a gradient bucket is then one contiguous slice that becomes final as a whole, early, and can be exchanged while the
+        # backward of the earlier layers still runs (GradExchange).
+        planner = TrainExecutor(ws, model.net)
+        planner._plan_rpn_siblings()
+        self.ready_index = param_ready_index(model.net, planner._fused)
+        n_ops = len(model.net.ops)
+        rank_of = {n: i for i, n in enumerate(self.trainable)}
+        by_done = sorted(self.trainable, key=lambda n: (-self.ready_index.get(n, -1), rank_of[n]))   # unreferenced parameters last
+        order = [n for n in by_done if n not in self.biases] + [n for n in by_done if n in self.biases]
         sizes = [int(np.prod(ws.params[n].shape)) for n in order]
         self.n_weights = sum(sz for n, sz in zip(order, sizes) if n not in self.biases)
         total = sum(sizes)
@@ -628,6 +778,24 @@ class Trainer(object):
             off += sz
         ws._layers.clear()                                # layers built before held the old master tensors
         self._train_ptrs = {ws._dev_params[n].data_ptr() for n in order}
+        # gradient buckets: consecutive parameters of the flat order up to BUCKET_BYTES; all biases (a few KB) are the last bucket.
+        # ready_at = the op index after whose backward every gradient of the bucket is final
+        self.buckets, cur, cur_lo, off = [], [], 0, 0
+        per = max(1, self.BUCKET_BYTES // 4)
+        for n, sz in zip(order, sizes):
+            if cur and (n in self.biases) != (cur[0] in self.biases or False):
+                self.buckets.append((cur_lo, off, cur))
+                cur, cur_lo = [], off
+            cur.append(n)
+            off += sz
+            if n not in self.biases and off - cur_lo >= per:
+                self.buckets.append((cur_lo, off, cur))
+                cur, cur_lo = [], off
+        if cur:
+            self.buckets.append((cur_lo, off, cur))
+        self.bucket_ready_at = [min(self.ready_index.get(n, -1) for n in names) for _, _, names in self.buckets]
+        self.exchange = None
+        self.last_exchange_stats = {}
 
     def _check_aliases(self):
         """The workspace's device masters of the trainable parameters must still BE the slices of `flat_w` (Workspace.set_param copies
@@ -639,21 +807,46 @@ class Trainer(object):
                 raise RuntimeError('device master of %r no longer aliases the Trainer\'s flat weight buffer (parameter replaced after '
                                    'the Trainer was built): rebuild the Trainer' % n)
 
-    def step(self, lr):
+    def step(self, lr, zero_grad=True, update=True, timing=False):
+        """One training iteration: forward + losses + backward (+ gradient exchange over the ranks) + momentum SGD.
+        zero_grad=False adds this clip's gradients to the ones already in the buffer, update=False stops before the exchange and
+        the update: `step(lr, update=False); step(lr, zero_grad=False)` is one iteration over two clips on one rank -- by linearity
+        what two ranks with one clip each compute (losses carry the reference's 1 / NUM_GPUS, model_builder.py:484,625,884)."""
         ws = self.ws
         self._check_aliases()
         if getattr(ws, 'param_epoch', 0) != getattr(self, '_param_epoch', None):
             self._pack_sig = None        # layers were rebuilt since the last step: the cached pack table holds stale pointers
             self._param_epoch = getattr(ws, 'param_epoch', 0)
-        self.flat_g.zero_()
+        if zero_grad:
+            self.flat_g.zero_()
         if self.flat_gt is not None:
             self.flat_gt.zero_()
         ex = TrainExecutor(ws, self.model.net, arena=self.arena, gt_arena=self.gt_arena)
+        ex.accumulate_all = not zero_grad
         ex.run()
-        ex.backward()
-        if self.dist is not None and self.dist.get_world_size() > 1:
+        multi = self.dist is not None and self.dist.get_world_size() > 1 and update
+        if multi:
             # every rank reduces the same flat buffer: a parameter without a gradient on this rank contributes its zeros
-            self._all_reduce()
+            xch = self._exchange()
+            xch.begin()
+            nxt = [0]
+
+            def on_op_done(i):
+                while nxt[0] < len(self.buckets) and i <= self.bucket_ready_at[nxt[0]]:
+                    k = nxt[0]
+                    if xch.overlap:
+                        names = self.buckets[k][2]
+                        ex._finish_deferred(only=set(names))       # this bucket's deferred weight gradients -> the flat buffer
+                        ex.seal(names)
+                        xch.ready(k)
+                    nxt[0] += 1
+            ex.backward(on_op_done)
+            xch.finish(timing=timing)
+            self.last_exchange_stats = dict(xch.stats)
+        else:
+            ex.backward()
+        if not update:
+            return ex
         nw, n = self.n_weights, self.flat_w.numel()
         if nw > 0:
             ops.sgd_momentum(self.flat_w[:nw], self.flat_v[:nw], self.flat_g[:nw], lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, False)
@@ -662,6 +855,16 @@ class Trainer(object):
         self._refresh_layers()
         self.iter += 1
         return ex
+
+    def _exchange(self):
+        if self.exchange is None:
+            direct = None
+            if cfg.HIP.get('RCCL_DIRECT', False) and self.flat_g.is_cuda:
+                # the same exchange through the C ABI (dat_allreduce_bucket); torch.distributed only carries the 128-byte communicator id
+                direct = ops.BucketAllReduce(self.dist.get_rank(), self.dist.get_world_size())
+            self.exchange = GradExchange(self.flat_g, [(lo, hi) for lo, hi, _ in self.buckets], self.dist,
+                                         overlap=bool(cfg.HIP.get('OVERLAP_ALLREDUCE', True)), direct=direct)
+        return self.exchange
 
     def _refresh_layers(self):
         """Packed weights follow the updated masters: layers (and cached gradient layers) packed straight from a trainable master are
@@ -703,14 +906,11 @@ class Trainer(object):
                 self.momentum[n].copy_(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(self.flat_v.device).view_as(self.momentum[n]))
 
     def _all_reduce(self):
-        """Bucketed sum all-reduce over slices of the flat gradient buffer (losses are already divided by NUM_GPUS,
-        model_builder.py:932-942)."""
+        """Serial bucketed sum all-reduce over slices of the flat gradient buffer (losses are already divided by NUM_GPUS,
+        model_builder.py:932-942): the exchange without overlap, BUCKET_BYTES per collective."""
         per = max(1, self.BUCKET_BYTES // 4)
-        if cfg.HIP.get('RCCL_DIRECT', False) and self.flat_g.is_cuda:
-            # the same exchange through the C ABI (dat_allreduce_bucket); torch.distributed only carries the 128-byte communicator id
-            if getattr(self, '_bucket_reducer', None) is None:
-                self._bucket_reducer = ops.BucketAllReduce(self.dist.get_rank(), self.dist.get_world_size())
-            self._bucket_reducer.all_reduce(self.flat_g, per)
-            return
-        for off in range(0, self.flat_g.numel(), per):
-            self.dist.all_reduce(self.flat_g[off:off + per])
+        n = self.flat_g.numel()
+        x = GradExchange(self.flat_g, [(off, min(off + per, n)) for off in range(0, n, per)], self.dist, overlap=False,
+                         direct=(ops.BucketAllReduce(self.dist.get_rank(), self.dist.get_world_size())
+                                 if cfg.HIP.get('RCCL_DIRECT', False) and self.flat_g.is_cuda else None))
+        x.finish()

@@ -131,14 +131,18 @@ def test_fp32_four_clips_per_forward_at_the_bench_shape_match_the_oracle_clip_by
 def test_bf16_graph_of_four_clips_gives_every_clip_the_results_of_the_eager_one_clip_forward():
     """the benched EXECUTION mode (bf16, 4 clips per forward, one captured hipGraph replayed) against the same
     arithmetic run the plain way (bf16, eager launches, one clip per forward) at the bench shape.  Same kernels, same operands; what
-    differs is the launch plan of the larger grids (tile shapes, split-K factors -> fp32 summation order before the bf16 rounding of
-    each layer's output), so the comparison is at bf16 summation-order tolerance: every clip's detections are the eager ones (>= 90 %
-    of the boxes within 1 px -- a box is a function of bf16-rounded logits --, same count up to ties) and the decoded keypoints of
-    the matched detections agree within 2 px for >= 90 %.  A clip-indexing mistake (wrong im_info row, features of another clip)
-    moves boxes by hundreds of pixels and fails this outright."""
+    differs is the launch plan of the larger grids (tile shapes, split-K factors -> another fp32 summation order before each layer's
+    bf16 rounding), i.e. one-ulp flips (2^-8 relative) that propagate.  Gated on the CONTINUOUS quantities, per clip:
+      * pyramid blobs of clip i in the 4-clip graph vs the eager forward of clip i alone: max-abs difference < 3 % of the blob's max
+        (measured ~1 %) -- and > 30 % against the blob of the NEXT clip (a clip-indexing mistake cannot pass);
+      * proposals: >= 90 % of the graph's rois have an eager roi of IoU >= 0.9;
+      * `kps_score` on the SAME boxes (the eager detections): max-abs difference < 5 % of the range, >= 90 % identical arg-max cells.
+    The detection SETS themselves are reported, not gated: with random weights the 100 best of 1000 near-equal scores are decided by
+    those one-ulp flips (measured 35-60 % of the boxes within 1 px)."""
     from detectandtrack_amd.core import test as engine
     from detectandtrack_amd.core.config import cfg
     from detectandtrack_amd.core.pipeline import ClipPipeline
+    from detectandtrack_amd.utils import precision
     T, B = 8, 4
     c = fpn3d_kps_cfg('18', T=T, dtype='bf16', pre=1000, post=1000)
     c['TEST'].update(SCALES=(800,), MAX_SIZE=1333, SCORE_THRESH=0.0, DETECTIONS_PER_IM=100)
@@ -147,30 +151,53 @@ def test_bf16_graph_of_four_clips_gives_every_clip_the_results_of_the_eager_one_
     base = [rs.randint(0, 255, (720 // 8, 1280 // 8, 3)).astype(np.uint8) for _ in range(B)]
     clips = [[np.clip(np.kron(base[i], np.ones((8, 8, 1), np.uint8)).astype(np.int16) + rs.randint(-20, 20, (720, 1280, 3)), 0, 255).astype(np.uint8)
               for _ in range(T)] for i in range(B)]
-    eager = [engine.im_detect_all(model, clip, None) for clip in clips]
-    assert ws.blobs['data'].t.shape == (1, 3, T, 768, 1344)
+    names = ['res3_1_sum', 'res5_1_sum', 'fpn_res5_1_sum', 'fpn_res3_1_sum', 'fpn_res2_1_sum']
+    scale = min(800.0 / 720, 1333.0 / 1280)
+    eager = []
+    for clip in clips:
+        res = engine.im_detect_all(model, clip, None)
+        assert ws.blobs['data'].t.shape == (1, 3, T, 768, 1344)
+        blobs = {n: ws.blobs[n].t.clone() for n in names}
+        rois = ws.FetchBlob('rois').copy()
+        kp_rois = np.concatenate([np.zeros((100, 1), np.float32), res[0][1][:100, :4] * scale], axis=1).astype(np.float32)
+        heat, _ = precision.keypoints(model, ws, kp_rois, scale)
+        eager.append((res, blobs, rois, kp_rois, heat.clone()))
     pipe = ClipPipeline(model, ws, depth=1, graph=True)
     for _ in range(2):                                  # second pass = a pure replay
         pipe.submit_frames(clips, tag='g')
         (_, out), = pipe.drain()
     assert pipe.graphs_captured == 1 and len(out) == B
-
-    def agree(a, b, tol):
-        d = np.abs(a[:, None, :4] - b[None, :, :4]).max(axis=2)
-        return d.min(axis=1) < tol, d.argmin(axis=1)
+    g = list(pipe.slots[0].graphs.values())[0]
+    g.restore_blobs()                                   # blob names -> the tensors the replay wrote
+    rois_all = ws.FetchBlob('rois')
     for i in range(B):
-        bg, be = out[i][0][1], eager[i][0][1]
-        kg, ke = out[i][2][1], eager[i][2][1]
-        assert abs(len(bg) - len(be)) <= 8 and len(bg) >= 100, (i, len(bg), len(be))
-        hit, idx = agree(bg, be, 1.0)
-        print('clip %d: %d / %d detections of the 4-clip graph within 1 px of an eager one' % (i, hit.sum(), len(bg)))
-        assert hit.mean() > 0.90, (i, hit.mean())
-        d = np.concatenate([np.abs(kg[j][:2] - ke[idx[j]][:2]).max(axis=0) for j in np.where(hit)[0]])
-        print('         keypoints of the matched detections: %.1f %% within 2 px (median %.2f px)' % (100 * (d < 2).mean(), np.median(d)))
-        assert (d < 2.0).mean() > 0.90, (i, (d < 2.0).mean())
-        # and NOT the results of another clip of the batch
-        other, _ = agree(bg, eager[(i + 1) % B][0][1], 1.0)
-        assert other.mean() < 0.3, (i, other.mean())
+        res_e, blobs_e, rois_e, kp_rois, heat_e = eager[i]
+        for n in names:
+            b = ws.blobs[n]
+            assert b.N == B
+            got = b.t[i * b.T:(i + 1) * b.T].float()
+            ref, nxt = blobs_e[n].float(), eager[(i + 1) % B][1][n].float()
+            mx = float(ref.abs().max())
+            err, err_other = float((got - ref).abs().max()) / mx, float((got - nxt).abs().max()) / mx
+            print('clip %d %-16s max-abs diff %.4f of max (vs the next clip: %.3f)' % (i, n, err, err_other))
+            assert err < 0.03 and err_other > 0.3, (i, n, err, err_other)
+        rg = rois_all[rois_all[:, 0] == i]
+        iou = precision.best_iou(rg[:, 1:5], rois_e[:, 1:5])
+        print('clip %d: %d rois, %.1f %% with an eager roi of IoU >= 0.9' % (i, len(rg), 100 * (iou >= 0.9).mean()))
+        assert len(rg) == len(rois_e) == 1000 and (iou >= 0.9).mean() > 0.90, (i, (iou >= 0.9).mean())
+        kr = kp_rois.copy()
+        kr[:, 0] = i                                    # the same boxes on clip i of the 4-clip forward
+        heat_g, _ = precision.keypoints(model, ws, kr, scale)
+        g.restore_blobs()
+        d = float((heat_g - heat_e).abs().max())
+        rng_ = float(heat_e.abs().max())
+        same = float((heat_g.flatten(2).argmax(2) == heat_e.flatten(2).argmax(2)).float().mean())
+        print('clip %d: kps_score on the same 100 boxes: max-abs diff %.4f (range %.2f), %.1f %% identical arg-max cells' % (i, d, rng_, 100 * same))
+        assert d < 0.05 * rng_ and same > 0.90, (i, d, rng_, same)
+        bg, be = out[i][0][1], res_e[0][1]
+        near = (np.abs(bg[:, None, :4] - be[None, :, :4]).max(axis=2).min(axis=1) < 1.0).mean()
+        print('clip %d: %d detections, %.0f %% within 1 px of an eager detection (reported, not gated)' % (i, len(bg), 100 * near))
+        assert abs(len(bg) - len(be)) <= 16 and len(bg) >= 100, (i, len(bg), len(be))
 
 
 def test_bf16_bench_configuration_error_against_fp32():

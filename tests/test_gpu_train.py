@@ -1,5 +1,7 @@
 """GPU parity of the training-side kernels against torch autograd on the CPU (fp32): weight and data
 gradients of the fused conv, ReLU/bias backward, FPN top-down backward, momentum SGD."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -733,3 +735,119 @@ def test_direct_weight_gradient_over_a_frame_window(ops, k, win):
     assert float((full.cpu() - ref).abs().max()) < 2e-3 * scale
     assert float((part.cpu() - ref).abs().max()) < 2e-3 * scale
     assert float((part - full).abs().max()) < 1e-4 * scale      # (same products; the K split differs, fp32 sums in another order)
+
+
+# ---- two ranks (VERDICT r3 item 4 / missing #3) ---------------------------------------------------------------------------------------
+def _ddp_model(num_gpus, dtype='fp32', T=2, H=128, W=160):
+    from tests.model_util import fpn3d_kps_cfg
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.utils import net as net_utils
+    from detectandtrack_amd import workspace
+    c = fpn3d_kps_cfg('18', T=T, dtype=dtype)
+    c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 400, 'RPN_POST_NMS_TOP_N': 200, 'IMS_PER_BATCH': 1, 'MAX_SIZE': W,
+                  'BATCH_SIZE_PER_IM': 64, 'RPN_STRADDLE_THRESH': -1}
+    c['NUM_GPUS'] = num_gpus            # the losses carry 1 / NUM_GPUS (reference model_builder.py:484,625,884)
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    model = model_builder.create(cfg.MODEL.TYPE, train=True)
+    workspace.ResetWorkspace()
+    ws = workspace.GlobalWorkspace()
+    for k, v in net_utils.synthetic_params(model, 3).items():
+        ws.set_param(k, v)
+    return model, ws
+
+
+def _ddp_clip(k, T=2, H=128, W=160):
+    """clip k of the job: data, RPN labels and a sampler that fixes its Fast R-CNN sample on first use (both runs then optimise the same objective)"""
+    from tests.model_util import synthetic_clip
+    from detectandtrack_amd.roi_data import rpn as rpn_data, fast_rcnn as frcn_data, synthetic
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=3, seed=5 + k)
+    rng = np.random.RandomState(k)
+    blobs = rpn_data.add_rpn_blobs({}, 1.0, entry, rng)
+    fixed = {}
+
+    def sampler(rois, info):
+        if not fixed:
+            fixed.update(frcn_data.sample_training_blobs(entry, rois, info, rng))
+        return fixed
+    return synthetic_clip(T, H, W, seed=3 + k), blobs, sampler
+
+
+def _ddp_feed(ws, clip):
+    data, blobs, sampler = clip
+    ws.FeedBlob('data', data)
+    for k, v in blobs.items():
+        ws.FeedBlob(k, v)
+    ws.train_sampler = sampler
+
+
+def _ddp_worker(rank, world, port, out, overlap):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                       # both ranks share the one GPU of the test box: gloo, host-staged buckets
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.training import Trainer
+    model, ws = _ddp_model(world)
+    cfg.HIP.OVERLAP_ALLREDUCE = bool(overlap)
+    _ddp_feed(ws, _ddp_clip(rank))
+    tr = Trainer(model, ws, dist)
+    losses = []
+    for _ in range(2):
+        ex = tr.step(0.01)
+        losses.append(sum(ex.loss_values().values()))
+    np.savez(out % rank, order=np.array(tr.exchange.order), buckets=np.array([(lo, hi) for lo, hi, _ in tr.buckets]), losses=np.array(losses),
+             **{'w_' + n: ws.dev_param(n).cpu().numpy() for n in tr.trainable})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, overlap):
+    """Data-parallel semantics of the training exchange (reference lib/modeling/model_builder.py:908-951 build_data_parallel_model:
+    every GPU runs its own minibatch with losses scaled by 1 / NUM_GPUS (:484, :625, :884), gradients are summed over the GPUs,
+    every GPU applies the same update).  Two PROCESSES (ranks 0 / 1, sharing this box's one GPU; gloo with host-staged buckets, RCCL
+    needs one device per rank) train clip r each with NUM_GPUS = 2 for two iterations -- with the buckets exchanged as the backward
+    pass completes them (cfg.HIP.OVERLAP_ALLREDUCE) or after it -- and must end with the weights of ONE rank that runs both clips
+    per iteration with the same 1 / NUM_GPUS scaling (gradients accumulated, one update).  fp32 mode; the weight-gradient kernels
+    reduce with float atomics, hence a 1e-5 relative tolerance instead of bit equality."""
+    import torch.multiprocessing as mp
+    from detectandtrack_amd.training import Trainer
+    ctx = mp.get_context('spawn')
+    port = 29500 + ((os.getpid() + 31 + int(overlap)) % 1000)
+    out = str(tmp_path / 'rank%d.npz')
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    # one rank, both clips per iteration
+    model, ws = _ddp_model(2)
+    clips = [_ddp_clip(0), _ddp_clip(1)]
+    tr = Trainer(model, ws)
+    ref_losses = []
+    for _ in range(2):
+        _ddp_feed(ws, clips[0])
+        ex0 = tr.step(0.01, update=False)
+        _ddp_feed(ws, clips[1])
+        ex1 = tr.step(0.01, zero_grad=False)
+        ref_losses.append((sum(ex0.loss_values().values()), sum(ex1.loss_values().values())))
+    assert len(r0['buckets']) >= 2
+    assert list(r0['order']) == list(range(len(r0['buckets']))) == list(r1['order'])
+    for it in range(2):     # each rank's loss is its own clip's (already divided by NUM_GPUS)
+        np.testing.assert_allclose(r0['losses'][it], ref_losses[it][0], rtol=2e-4)
+        np.testing.assert_allclose(r1['losses'][it], ref_losses[it][1], rtol=2e-4)
+    moved = 0
+    for n in tr.trainable:
+        a, b, ref = r0['w_' + n], r1['w_' + n], ws.dev_param(n).cpu().numpy()
+        np.testing.assert_array_equal(a, b, err_msg=n)                      # the ranks hold identical weights
+        tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(a - ref).max()) <= tol, (n, float(np.abs(a - ref).max()), tol)
+        moved += int(not n.startswith(('conv1', 'res2')) and np.abs(ref - ws.params[n]).max() > 0)
+    assert moved > 40           # the parameters above the StopGradient marker were really trained

@@ -457,6 +457,103 @@ def test_gradient_allreduce_buckets_gloo_world2():
         np.testing.assert_allclose(y, a + b, rtol=1e-6)
 
 
+def _exchange_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from detectandtrack_amd.training import GradExchange
+    g = torch.Generator().manual_seed(500 + rank)
+    n = 5000
+    buckets = [(0, 1800), (1800, 1800), (1800, 4100), (4100, 5000)]      # (one empty bucket)
+    final = torch.randn(n, generator=g)               # what this rank's backward will have produced at the end
+    results = {}
+    for mode in ('serial', 'overlap'):
+        flat = torch.full((n,), float('nan'))         # a gradient is garbage until its producer has run
+        x = GradExchange(flat, buckets, dist, overlap=(mode == 'overlap'))
+        x.begin()
+        for k, (lo, hi) in enumerate(buckets):        # the backward pass: bucket k becomes final, is handed over, the pass continues
+            flat[lo:hi] = final[lo:hi]
+            x.ready(k)
+        x.finish()
+        results[mode] = (flat.clone().numpy(), list(x.order))
+    q.put((rank, final.numpy(), results))
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_exchange_equals_the_serial_one_gloo_world2():
+    """gradient buckets all-reduced AS THEY BECOME FINAL (GradExchange.ready(k) from the backward pass, collectives
+    in flight while later buckets are still being written) give exactly the serial result -- the sum over the ranks of every
+    element -- and start in completion order; overlap=False starts nothing before finish()."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 17) % 1000)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, f0, r0), (_, f1, r1) = res
+    for r in (r0, r1):
+        for mode in ('serial', 'overlap'):
+            got, order = r[mode]
+            np.testing.assert_array_equal(got, f0 + f1)        # (two addends: the sum is order-independent, bit for bit)
+            assert order == [0, 1, 2, 3]
+    np.testing.assert_array_equal(r0['overlap'][0], r0['serial'][0])
+
+
+def test_gradient_completion_order_of_the_training_graph():
+    """The static rule the overlapped exchange rests on (training.param_ready_index): a parameter's gradient is final once the op
+    with the SMALLEST index that uses it has been differentiated (the backward pass runs the op list from the end).  On the
+    R-18 FPN3D training graph: the heads complete before the FPN, the FPN before res5 ... res3; the RPN conv shared by the five FPN
+    levels completes with its FIRST use; both fused RPN head convs complete at the fused launch's index; frozen parameters
+    (conv1 / res2, below StopGradient) are not trainable at all."""
+    from detectandtrack_amd.core.config import cfg, cfg_from_file, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.training import param_ready_index
+    from detectandtrack_amd.workspace import Executor
+    reset_cfg()
+    cfg_from_file(os.path.join(REPO, 'configs', 'train_r18_fpn3d_synthetic.yaml'))
+    assert_and_infer_cfg()
+    m = model_builder.create(cfg.MODEL.TYPE, train=True)
+    ex = Executor.__new__(Executor)
+    ex.net = m.net
+    ex._plan_rpn_siblings()
+    assert ex._fused, 'the RPN logits / deltas convs of every level are fused'
+    idx = param_ready_index(m.net, ex._fused)
+    train = list(m.TrainableParams())
+    assert all(n in idx for n in train), [n for n in train if n not in idx]
+    # conv1 / res2 sit below StopGradient: listed as trainable (they take part in the update with a zero gradient), final at once
+    frozen = [n for n in train if n.startswith(('conv1', 'res2'))]
+    assert frozen and all(idx[n] == len(m.net.ops) for n in frozen)
+    uses = {}
+    for i, op in enumerate(m.net.ops):
+        for key in ('w', 'b'):
+            n = op.args.get(key) if isinstance(op.args, dict) else None
+            if isinstance(n, str) and n:
+                uses.setdefault(n, []).append(i)
+    for n in train:
+        assert n in frozen or idx[n] <= min(uses[n]), n   # never later than the first use
+    shared = [n for n in train if len(uses[n]) > 1]
+    assert shared and all(idx[n] == min(uses[n]) or n.startswith('rpn_') for n in shared)
+    for first, (lo, do, _gi) in ex._fused.items():
+        for op in (lo, do):
+            assert idx[op.args['w']] <= first and idx[op.args['b']] <= first
+    # heads -> FPN -> res5 -> res4 -> res3 in completion (= backward) order
+    def done(prefix):
+        return max(idx[n] for n in train if n.startswith(prefix))
+    def last_done(prefix):
+        return min(idx[n] for n in train if n.startswith(prefix))
+    assert last_done('kps_score') > done('fpn_') or last_done('conv_fcn') > done('fpn_')
+    assert last_done('fc') > done('fpn_inner')
+    assert last_done('res5') > done('res4') > 0 and last_done('res4') > done('res3')
+    reset_cfg()
+
+
 def test_roi_data_matches_the_real_reference_golden():
     """detectandtrack_amd/roi_data (host label generation for training) against vectors produced by the REAL reference
     lib/roi_data + json_dataset + utils/keypoints under py3 shims (tests/golden/make_golden.py:golden_roi_data): same seeded
