@@ -52,9 +52,18 @@ namespace {
 // (strided 3x3 convs with their stride-parity planes, other kernel shapes).
 // (the unrolled 128-position variants are held to 168 registers -- three blocks per CU -- the 256-position ones to 256)
 template <int BP, int NTAP> struct MinWaves { static constexpr int value = BP == 320 ? 1 : (NTAP > 0 && NTAP != 10 && BP == 128) ? 3 : 2; };
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
+//
+// ODT = element type of the OUTPUT and of the residual (default: the operand type DT).  ODT = fp32 with DT = bf16 is the "bf16x3"
+// arithmetic mode (dat_conv_desc.dtype DAT_BF16X3): activations live in HBM as fp32, the conv reads a hi / lo bf16 SPLIT of its
+// input (x = hi + lo to 2^-17, dat_split_bf16x2: per 64-channel chunk q the pixel's line 2q holds hi, line 2q + 1 lo) and hi / lo
+// split weights packed as K' = 3 chunks per logical chunk -- [W_hi | W_lo | W_hi] against the input chunks [hi | hi | lo] -- so that
+// the MFMA loop, untouched, accumulates x_hi*W_hi + x_hi*W_lo + x_lo*W_hi in fp32: the fp32 product to ~2^-16 relative at three
+// bf16 MFMAs per k-slice instead of sixteen quarter-rate v_mfma_f32_32x32x2_f32.  Only the chunk -> source-line map (p.x3) and the
+// epilogue's element type know about it.
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0, int ODT = DT>
 __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_igemm_kernel(const ConvParams p) {
     constexpr int ES = ElemOf<DT>::size;
+    constexpr int OES = ElemOf<ODT>::size;
     constexpr int CK = Mma<DT>::CK;
     constexpr int WAVES_P = 4 / WAVES_N;
     constexpr int WN = BN / WAVES_N;      // channels per wave
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             if (!((p.ablate & 1) && pi > 0)) {
                 __syncthreads();                               // all waves finished reading the previous patch
                 const int fin = f_in + kt - p.pt;
-                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)(p.x3 ? (cc / 3) * 2 + (cc % 3 == 2) : cc) * CK * ES;
 #pragma unroll
                 for (int u = 0; u < MAXCH; ++u) {
                     if (poff[u] != -2) {
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                 // the patch in flight at once (no staging registers, no ds_write pass).  Lane (row, phys slot) fetches the
                 // pixel's logical 16-B slot phys ^ ((row >> 1) & 7); halo pixels outside the frame fetch zeros.
                 const int fin = f_in + kt - p.pt;
-                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)cc * CK * ES;
+                const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)(p.x3 ? (cc / 3) * 2 + (cc % 3 == 2) : cc) * CK * ES;
                 const int py0 = ih0 + p.tab_dy[ti], px0 = iw0 + p.tab_dx[ti];
 #pragma unroll 2
                 for (int c = wave; c < nchunks; c += 4) {
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     // back position-major, 16 B of output per lane, so one store instruction covers 4-8 complete position rows.
     static_assert(WN == 64, "epilogue staging assumes 64 channels per wave");
     constexpr int EPITCH = WN * 4 + 16;
-    constexpr int CPL = 16 / ES;                 // channels per lane in the store phase (8 bf16 / 4 fp32)
+    constexpr int CPL = 16 / OES;                 // channels per lane in the store phase (8 bf16 / 4 fp32)
     constexpr int LPP = WN / CPL;                // lanes per position (8 / 16)
     constexpr int PPI = 64 / LPP;                // positions per store instruction (8 / 4)
     __syncthreads();                             // every wave is done with the weight / patch buffers
@@ -493,9 +502,9 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     // checks that one frame of output / partials is < 2 GB): the stores take the "SGPR base + VGPR offset" form and the
     // epilogue's per-store 64-bit multiply-add chains (a third of its VALU work) disappear
     const size_t tile_pos = ((size_t)f * p.Ho + oh0) * p.Wo + ow0;
-    char* const ybase = p.y + tile_pos * p.out_cs * ES;
-    const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * ES
-                                              : p.res + tile_pos * p.out_cs * ES;
+    char* const ybase = p.y + tile_pos * p.out_cs * OES;
+    const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * OES
+                                              : p.res + tile_pos * p.out_cs * OES;
     float* const pbase = part_mode ? p.part + ((size_t)split * npos_all + tile_pos) * p.Cout : nullptr;
     // Residual rows (Sum shortcuts, the top-down map of the FPN laterals) are fetched one position group AHEAD of their use: a load
     // issued where its value is added costs a full memory round trip per store group -- with a top-down map the 64 -> 256 lateral
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             const bool live = oh < p.Ho && ow < p.Wo && !(p.ablate & 4);
             unsigned rpos = (unsigned)(ohl * p.Wo + owl);
             if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
-            dst[q] = *(const uint4*)(rbase + (live ? (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES : 0u));
+            dst[q] = *(const uint4*)(rbase + (live ? (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)OES : 0u));
         }
     };
     if (res_pre) res_fetch(0, rq[0]);
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             for (int e = 0; e < CPL; ++e) v[e] = v[e] * sc[e] + bi[e];
             if (res_pre) {
                 const uint4 r = rq[j & 1][q];
-                if (DT == DAT_BF16) {
+                if (ODT == DAT_BF16) {
                     const uint32_t ru[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int e2 = 0; e2 < CPL / 2; ++e2) {
@@ -568,8 +577,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             } else if (p.res_mode) {
                 unsigned rpos = lpos;
                 if (p.res_mode == 2) rpos = (unsigned)((oh >> 1) * (p.Wo >> 1) + (ow >> 1));
-                const char* rp = rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES;
-                if (DT == DAT_BF16) {
+                const char* rp = rbase + (rpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)OES;
+                if (ODT == DAT_BF16) {
 #pragma unroll
                     for (int e4 = 0; e4 < CPL / 4; ++e4)
                         if (e4 * 4 < nch) {
@@ -589,8 +598,8 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            char* yp = ybase + (lpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)ES;
-            if (DT == DAT_BF16) {
+            char* yp = ybase + (lpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)OES;
+            if (ODT == DAT_BF16) {
                 uint32_t o[CPL / 2];
 #pragma unroll
                 for (int e2 = 0; e2 < CPL / 2; ++e2) o[e2] = f2bf2(v[2 * e2], v[2 * e2 + 1]);
@@ -715,7 +724,7 @@ TileChoice choose_tile(int Ho, int Wo, int bp_log2, int sh, int sw, int KH, int 
     return best;
 }
 
-template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0>
+template <int DT, int BN, int BP, int WAVES_N, int TPS = 1, int WD = 0, int NTAP = 0, int ODT = DT>
 int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ksplit, bool linear = false) {
     TileChoice tc = choose_tile(p.Ho, p.Wo, bp_log2, p.sh, p.sw, p.KH, p.KW, ctx->dbg_tw_log2);
     p.lin_h = p.lin_w = 0;
@@ -797,7 +806,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         p.tab_n = n;
     }
     p.pw_magic = p.PW == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)p.PW - 1) / (unsigned)p.PW);
-    p.n_cchunks = p.Cin / Mma<DT>::CK;
+    p.n_cchunks = p.x3 ? p.Cin / Mma<DT>::CK / 2 * 3 : p.Cin / Mma<DT>::CK;   // bf16x3: [hi | hi | lo] against [W_hi | W_lo | W_hi]
     p.ablate = ctx->dbg_ablate;
     p.nblk_n = p.Cout_pad / BN;
     long long nblocks = (long long)p.frames * p.tiles_h * p.tiles_w * p.nblk_n;
@@ -832,7 +841,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
     lds += ctx->dbg_lds_pad;   // DEBUG: DAT_CONV_LDS_PAD=<bytes> lowers occupancy (blocks per CU) for experiments
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d: LDS patch of %zu bytes exceeds 160 KiB (tile %dx%d, stride %dx%d)", lds,
                 th, tw, p.sh, p.sw);
-    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP>;
+    auto kern = conv3d_igemm_kernel<DT, BN, BP, WAVES_N, TPS, WD, NTAP, ODT>;
     if (NTAP > 0) {   // what the unrolled variant assumes (the dispatcher only picks it for these shapes)
         DAT_ENFORCE(ctx, p.tab_n == (NTAP == 10 ? 9 : NTAP) && p.tab_new == 1u &&
                              (((size_t)p.PH * p.PW * 8 + 63) >> 6) <= (size_t)4 * patch_pieces_per_wave(NTAP, BP) && (NTAP == 10 || (size_t)p.PH * p.PW * PPITCH < 65536),
@@ -864,7 +873,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         const size_t npos = (size_t)p.frames * p.Ho * p.Wo;
         const size_t tot = npos * (p.Cout >> 2);
         const int blocks = (int)std::min<size_t>((tot + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(splitk_finish_kernel<DT>, dim3(blocks), dim3(256), 0, st, (const float*)p.part, p.ksplit, npos, p.Cout,
+        hipLaunchKernelGGL(splitk_finish_kernel<ODT>, dim3(blocks), dim3(256), 0, st, (const float*)p.part, p.ksplit, npos, p.Cout,
                            p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y);
     }
     DAT_CHECK_LAUNCH(ctx, "conv3d_igemm");
@@ -883,6 +892,8 @@ int dat_conv3d_out_shape(const dat_conv_desc* d, int* Ho, int* Wo) {
 }
 
 size_t dat_conv3d_packed_weight_bytes(const dat_conv_desc* d) {
+    // (bf16x3: three bf16 chunks [W_hi | W_lo | W_hi] per logical 64-channel chunk)
+    if (d->dtype == DAT_BF16X3) return (size_t)d->KT * d->KH * d->KW * cout_pad_of(d) * d->Cin * 3 * 2;
     return (size_t)d->KT * d->KH * d->KW * cout_pad_of(d) * d->Cin * dat_esize(d->dtype);
 }
 
@@ -896,7 +907,9 @@ double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
                    const float* scale, const float* bias, const void* residual, void* y) {
     DAT_ENFORCE(ctx, d && x && w_packed && y, "conv3d_fwd: null argument");
-    DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16, "conv3d_fwd: bad dtype %d", d->dtype);
+    DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16 || d->dtype == DAT_BF16X3, "conv3d_fwd: bad dtype %d", d->dtype);
+    const bool x3 = d->dtype == DAT_BF16X3;
+    DAT_ENFORCE(ctx, !x3 || weights_direct(ctx, d), "conv3d_fwd: the bf16x3 mode runs on the weights-direct kernel variants (DAT_CONV_WD)");
     DAT_ENFORCE(ctx, d->Cin % 64 == 0, "conv3d_fwd: Cin (channel stride) %d must be a multiple of 64", d->Cin);
     DAT_ENFORCE(ctx, d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_cstride >= d->Cout,
                 "conv3d_fwd: Cout %d / out_cstride %d must be multiples of 4", d->Cout, d->out_cstride);
@@ -921,7 +934,8 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     p.otn = d->out_tn > 0 ? d->out_tn : d->T;
     DAT_ENFORCE(ctx, p.ot0 >= 0 && p.ot0 + p.otn <= d->T, "conv3d_fwd: output frames [%d, %d) outside T %d", p.ot0,
                 p.ot0 + p.otn, d->T);
-    p.frames = d->frames / d->T * p.otn; p.T = d->T; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+    p.frames = d->frames / d->T * p.otn; p.T = d->T; p.H = d->H; p.W = d->W; p.Cin = x3 ? 2 * d->Cin : d->Cin;   // (x3: pixel pitch of the hi / lo split tensor)
+    p.x3 = x3;
     dat_conv3d_out_shape(d, &p.Ho, &p.Wo);
     DAT_ENFORCE(ctx, p.Ho > 0 && p.Wo > 0, "conv3d_fwd: empty output %dx%d", p.Ho, p.Wo);
     DAT_ENFORCE(ctx, d->res_mode != 2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0), "conv3d_fwd: res_mode 2 needs even output dims");
@@ -936,8 +950,8 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     // a BP=128 step costs ~1.35 us, a BP=256 step ~2.15 us (2x the work).  The grid runs in "rounds" of 512 blocks;
     // with few rounds the last partial round costs a full one.  Split-K adds an fp32 partial round trip.
     const int force_bp = ctx->force_bp, force_ks = ctx->force_ks;
-    const int ck = d->dtype == DAT_BF16 ? 64 : 32;
-    const int ncc = d->Cin / ck;
+    const int ck = d->dtype == DAT_F32 ? 32 : 64;
+    const int ncc = x3 ? d->Cin / 64 * 3 : d->Cin / ck;
     const int npatch = d->KT * ncc, npatch_min = (d->KT > 1 ? d->KT - 1 : 1) * ncc;
     const int ntaps = d->KH * d->KW;
     const long long nbn = p.Cout_pad / (small_n ? 64 : 128);
@@ -1042,13 +1056,14 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
             lin320 = lin && d->KT == 1 && big && !small_n && (ctx->dbg_linear & 4) && blk256 > ncu320 && blk320 <= ncu320 &&
                      ((((320 + 2 * (p.Wo + 1) + 1) * 8 + 63) >> 6) <= 4 * patch_pieces_per_wave(9, 320));
         }
-#define DAT_WD_LAUNCH(DT_, BN_, WN_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9>(ctx, st, p, 8, ksplit, lin) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9>(ctx, st, p, 7, ksplit, lin)) \
-                            : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1>(ctx, st, p, 7, ksplit)) \
-                            : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1>(ctx, st, p, 7, ksplit)))
-        if (lin320) rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 128, 320, 2, 1, 1, 9>(ctx, st, p, 9, ksplit, true)
+#define DAT_WD_LAUNCH(DT_, BN_, WN_, ODT_) (ntapv == 10 ? launch_conv<DT_, BN_, 128, WN_, 1, 1, 10, ODT_>(ctx, st, p, 7, ksplit) : ntapv == 9 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 9, ODT_>(ctx, st, p, 8, ksplit, lin) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 9, ODT_>(ctx, st, p, 7, ksplit, lin)) \
+                            : ntapv == 1 ? (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 1, ODT_>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 1, ODT_>(ctx, st, p, 7, ksplit)) \
+                            : (big ? launch_conv<DT_, BN_, 256, WN_, 1, 1, 0, ODT_>(ctx, st, p, 8, ksplit) : launch_conv<DT_, BN_, 128, WN_, 1, 1, 0, ODT_>(ctx, st, p, 7, ksplit)))
+        if (x3) rc = small_n ? DAT_WD_LAUNCH(DAT_BF16, 64, 1, DAT_F32) : DAT_WD_LAUNCH(DAT_BF16, 128, 2, DAT_F32);
+        else if (lin320) rc = d->dtype == DAT_BF16 ? launch_conv<DAT_BF16, 128, 320, 2, 1, 1, 9>(ctx, st, p, 9, ksplit, true)
                                               : launch_conv<DAT_F32, 128, 320, 2, 1, 1, 9>(ctx, st, p, 9, ksplit, true);
-        else if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1) : DAT_WD_LAUNCH(DAT_F32, 64, 1);
-        else rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 128, 2) : DAT_WD_LAUNCH(DAT_F32, 128, 2);
+        else if (small_n) rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 64, 1, DAT_BF16) : DAT_WD_LAUNCH(DAT_F32, 64, 1, DAT_F32);
+        else rc = d->dtype == DAT_BF16 ? DAT_WD_LAUNCH(DAT_BF16, 128, 2, DAT_BF16) : DAT_WD_LAUNCH(DAT_F32, 128, 2, DAT_F32);
 #undef DAT_WD_LAUNCH
     } else if (d->dtype == DAT_BF16) {
         if (big)

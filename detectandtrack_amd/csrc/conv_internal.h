@@ -64,6 +64,8 @@ struct ConvParams {
     int nblk_n;               // Cout_pad / BN
     unsigned nblocks;
     unsigned ntiles;          // position tiles (frames x tiles_h x tiles_w)
+    int x3;                   // bf16x3 mode: x is the hi / lo split tensor (pixel pitch Cin = 2 x logical channels), channel chunk cc of the K loop reads
+                              // source line (cc / 3) * 2 + (cc % 3 == 2); output / residual are fp32 (template parameter ODT)
     int order;                // block order inside an XCD's queue: 0 = (split, cout block) fastest -- the blocks of one tile share its input patch;
                               // 1 = tile fastest -- the resident blocks share ONE (cout block, split) weight slice (layers whose weights exceed the L2)
 };

@@ -1,5 +1,7 @@
 // HBM-bound elementwise / layout kernels of the hot path (gfx950).
 // Each is one pass: read-once + write-once of the logical tensor; 16-byte accesses where the layout allows.
+#include <algorithm>
+
 #include "dat_common.h"
 
 namespace {
@@ -238,6 +240,29 @@ __global__ void kps_finalize_kernel(const void* __restrict__ sub, int R, int Tr,
             hipLaunchKernelGGL((KERNEL<DAT_F32>), grid, block, 0, st, __VA_ARGS__);                       \
     } while (0)
 
+// fp32 NDHWC [npos, C] -> hi / lo bf16 split [npos, 2C]: per 64-channel chunk q the pixel's 128-byte line 2q holds bf16(x), line
+// 2q + 1 holds bf16(x - float(bf16(x))) -- x = hi + lo to 2^-17 relative (the difference is exact in fp32).  The operand format of
+// the bf16x3 conv mode (conv3d_igemm.hip).  One thread = 8 channels: two 16-byte loads, two 16-byte stores, all fully coalesced.
+__global__ void split_bf16x2_kernel(const float* __restrict__ x, uint4* __restrict__ y, long long n8, int c8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const long long pos = i / c8;
+        const int g = (int)(i - pos * c8);         // 8-channel group inside the pixel
+        const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+            const float r0 = v[2 * e] - __uint_as_float(hi[e] << 16), r1 = v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u);
+            lo[e] = f2bf2(r0, r1);
+        }
+        // output in 16-byte units: pixel pos has 2 * c8 of them; chunk q = g / 8 -> hi at unit 16 q + (g & 7), lo 8 units behind
+        uint4* dst = y + pos * (2 * c8) + (g >> 3) * 16 + (g & 7);
+        dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        dst[8] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 extern "C" {
 
 int dat_zero_even_fwd(dat_ctx* ctx, dat_stream s, float* x, long long n) {
@@ -341,6 +366,16 @@ int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int
     const size_t total = (size_t)R * Tr * K * (2 * S * up) * (2 * S * up);
     DISPATCH_DT(dtype, kps_finalize_kernel, dim3(grid_for(total)), dim3(TPB), (hipStream_t)s, sub, R, Tr, S, cs, K, up, out);
     DAT_CHECK_LAUNCH(ctx, "kps_finalize");
+    return DAT_OK;
+}
+
+int dat_split_bf16x2(dat_ctx* ctx, dat_stream s, const float* x, void* y, long long npos, int C) {
+    DAT_ENFORCE(ctx, x && y && npos >= 0 && C > 0 && C % 64 == 0, "split_bf16x2: C %d must be a positive multiple of 64", C);
+    const long long n8 = npos * (C / 8);
+    if (n8 == 0) return DAT_OK;
+    const int blocks = (int)std::min<long long>((n8 + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(split_bf16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, (uint4*)y, n8, C / 8);
+    DAT_CHECK_LAUNCH(ctx, "split_bf16x2");
     return DAT_OK;
 }
 

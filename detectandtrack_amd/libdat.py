@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DAT_LIB', os.path.join(_HERE, 'libdat_hip.so'))
 
-DAT_F32, DAT_BF16 = 0, 1
+DAT_F32, DAT_BF16, DAT_BF16X3 = 0, 1, 2
 DAT_OK = 0
 
 
@@ -89,6 +89,7 @@ _PROTOS = {
     'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),
     'dat_stem_pack': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'dat_stem_weights': (_i, [_p, _p, _p, _i, _p]),
+    'dat_split_bf16x2': (_i, [_p, _p, _p, _p, _ll, _i]),
     'dat_maxpool_hw': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     'dat_time_avg': (_i, [_p, _p, _i, _p, _p, _i, _i, _ll]),
     'dat_roi_align': (_i, [_p, _p, _i, C.POINTER(RoiLevel), _i, _i, _f, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p]),

@@ -31,7 +31,12 @@ extern "C" {
 typedef struct dat_ctx dat_ctx;
 typedef void* dat_stream; /* hipStream_t */
 
-enum { DAT_F32 = 0, DAT_BF16 = 1 };
+enum { DAT_F32 = 0, DAT_BF16 = 1,
+       /* conv descriptors only: fp32 activations in HBM, conv arithmetic on hi / lo bf16 splits of both operands
+        * (x_hi*W_hi + x_hi*W_lo + x_lo*W_hi, fp32 accumulate; ~2^-16 relative).  dat_conv3d_fwd then takes x = the split
+        * tensor made by dat_split_bf16x2 (pixel pitch 2 * Cin bf16), w_packed = dat_conv3d_pack_weights of a DAT_BF16 descriptor
+        * with Cin' = 3 * Cin over the master [W_hi | W_lo | W_hi] per 64-channel chunk; y / residual are fp32. */
+       DAT_BF16X3 = 2 };
 enum { DAT_OK = 0, DAT_ERR_ARG = -1, DAT_ERR_LAUNCH = -2, DAT_ERR_ALLOC = -3, DAT_ERR_UNSUPPORTED = -4 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -141,6 +146,11 @@ int dat_stem_pack(dat_ctx* ctx, dat_stream s, const float* data, void* packed, i
                   int W);
 /* conv1_w fp32 [64,3,1,7,7] -> fp32 [64,64,1,4,1] in the packed-channel order above (then dat_conv3d_pack_weights) */
 int dat_stem_weights(dat_ctx* ctx, dat_stream s, const float* conv1_w, int Cout, float* w_k4);
+
+/* ---- operand split of the bf16x3 conv mode (dtype DAT_BF16X3 of dat_conv_desc) ------------------ */
+/* x fp32 [npos, C] (C % 64 == 0) -> y bf16 [npos, 2C]: per 64-channel chunk q, line 2q = bf16(x), line 2q + 1 =
+ * bf16(x - float(bf16(x))).  HBM-bound: 4 bytes read + 4 written per element. */
+int dat_split_bf16x2(dat_ctx* ctx, dat_stream s, const float* x, void* y, long long npos, int C);
 
 /* ---- MaxPool [1,k,k]/s[1,st,st] (ResNet3D.py:263-265; FPN3D.py:158-163 with k=1) ------------- */
 int dat_maxpool_hw(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int frames, int H, int W, int C,
