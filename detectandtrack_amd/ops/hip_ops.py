@@ -143,7 +143,7 @@ class ConvLayer(object):
     """
 
     def __init__(self, w, scale=None, bias=None, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=BF16,
-                 cin_stride=None, dgrad_of=None):
+                 cin_stride=None, dgrad_of=None, x3=False):
         """dgrad_of = (w_fwd, scale_fwd): this layer is the DATA-GRADIENT conv of a forward conv with master weights w_fwd
         [CoutF, CinF, KT, KH, KW]; `w` is then ignored and the packed weights come straight from w_fwd (channels swapped, kernel
         flipped, AffineChannelNd scale folded in: dat_conv3d_pack_weights_dgrad)."""
@@ -160,6 +160,10 @@ class ConvLayer(object):
             self.cout_real, self.cin_real, self.kt, self.kh, self.kw = [int(v) for v in w.shape]
         self.is_dgrad = dgrad_of is not None
         self.dtype = dtype
+        # x3 (cfg.HIP.DTYPE 'bf16x3'): fp32 activations, the conv itself on hi / lo bf16 splits of both operands -- three bf16 MFMAs per
+        # k-slice, fp32 accumulate, ~2^-16 relative: the parity bar (kps_score < 1e-3) at several times the fp32-MFMA rate
+        self.x3 = bool(x3)
+        assert not self.x3 or (dtype == F32 and dgrad_of is None), 'bf16x3 is an inference mode over fp32 activations'
         self.cin = cin_stride or round_up(self.cin_real, 64)
         self.cout = round_up(self.cout_real, 4)
         self.cstride = round_up(self.cout_real, 64)  # outputs feed later convs: keep C % 64 == 0
@@ -185,10 +189,28 @@ class ConvLayer(object):
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.repack(weights_only=True)
 
+    def _x3_master(self):
+        """[Cout, 3 * cin, KT, KH, KW] fp32: per 64-channel chunk of the (padded) input channels the block [W_hi | W_lo | W_hi],
+        W_hi = bf16(W), W_lo = bf16(W - W_hi) -- met in the kernel by the input chunks [x_hi | x_hi | x_lo]."""
+        w = self.w_src
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        wp = torch.zeros((co, self.cin) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+        wp[:, :ci] = w
+        hi = wp.to(torch.bfloat16).float()
+        lo = (wp - hi).to(torch.bfloat16).float()
+        q = self.cin // 64
+        shp = (co, q, 64) + tuple(w.shape[2:])
+        m = torch.stack([hi.view(shp), lo.view(shp), hi.view(shp)], dim=2)        # [co, q, 3, 64, ...]
+        return m.reshape((co, 3 * self.cin) + tuple(w.shape[2:])).contiguous()
+
     def repack(self, weights_only=False):
         """(Re-)derive the packed weights (and a padded bias copy) from the fp32 masters -- after an SGD update in place."""
         d = self.desc(1, 1, 8, 8)
-        if self.is_dgrad:
+        if self.x3:
+            d.dtype, d.Cin = BF16, 3 * self.cin
+            ctx().call('dat_conv3d_pack_weights', _stream(), C.byref(d), _ptr(self._x3_master()), self.cout_real, 3 * self.cin,
+                       _ptr(self.packed))
+        elif self.is_dgrad:
             ctx().call('dat_conv3d_pack_weights_dgrad', _stream(), C.byref(d), _ptr(self.w_src), self.cin_real, self.cout_real,
                        _ptr(self.dgrad_scale), _ptr(self.packed))
         else:
@@ -199,7 +221,7 @@ class ConvLayer(object):
 
     def desc(self, frames, T, H, W, res_mode=0, relu=None, cstride=None, out_t=None, in_t=None):
         d = L.ConvDesc()
-        d.dtype = self.dtype
+        d.dtype = L.DAT_BF16X3 if self.x3 else self.dtype
         d.frames, d.T, d.H, d.W, d.Cin = frames, T, H, W, self.cin
         d.Cout = self.cout
         d.out_cstride = cstride or self.cstride
@@ -250,9 +272,19 @@ class ConvLayer(object):
         if out is None:
             alloc = torch.zeros if self.cstride != self.cout else torch.empty
             out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
-        ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
+        xin = split_bf16x2(x) if self.x3 else x
+        ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(xin), _ptr(self.packed), _ptr(self.scale),
                    _ptr(self.bias), _ptr(residual), _ptr(out))
         return out
+
+
+def split_bf16x2(x):
+    """fp32 [..., C] (C % 64 == 0, contiguous) -> the hi / lo bf16 split [..., 2C] the bf16x3 conv mode reads (dat_split_bf16x2)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 64 == 0
+    cs = int(x.shape[-1])
+    out = torch.empty(tuple(x.shape[:-1]) + (2 * cs,), dtype=torch.bfloat16, device=x.device)
+    ctx().call('dat_split_bf16x2', _stream(), _ptr(x), _ptr(out), C.c_longlong(x.numel() // cs), cs)
+    return out
 
 
 class ConvGrad(object):

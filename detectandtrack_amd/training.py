@@ -742,6 +742,8 @@ class Trainer(object):
 
     def __init__(self, model, ws, dist=None):
         self.model, self.ws, self.dist = model, ws, dist
+        from detectandtrack_amd.workspace import _x3
+        assert not _x3(ws), "cfg.HIP.DTYPE 'bf16x3' is an inference mode (train in 'bf16' or 'fp32')"
         self.trainable = list(model.TrainableParams())
         self.biases = set(model.biases)
         self.iter = 0

@@ -183,9 +183,20 @@ def _valid_rows(b, arr):
     return arr[:_count(b)]
 
 
-def _dt(ws=None):
+def _mode(ws=None):
     mode = (getattr(ws, 'dtype', None) if ws is not None else None) or cfg.HIP.DTYPE
-    return ops.BF16 if mode == 'bf16' else ops.F32
+    assert mode in ('bf16', 'fp32', 'bf16x3'), 'cfg.HIP.DTYPE %r: bf16 | fp32 | bf16x3' % (mode,)
+    return mode
+
+
+def _dt(ws=None):
+    """element type of the activations: bf16 in the performance mode; fp32 in the parity mode AND in 'bf16x3', whose convs split
+    their fp32 operands into bf16 hi / lo parts on the fly (ops.ConvLayer x3)"""
+    return ops.BF16 if _mode(ws) == 'bf16' else ops.F32
+
+
+def _x3(ws=None):
+    return _mode(ws) == 'bf16x3'
 
 
 def _w5(w):
@@ -390,7 +401,7 @@ class Executor(object):
             scale = ws.dev_param(a['scale']) if a['scale'] else None
             bias = ws.dev_param(a['shift']) if a['shift'] else (ws.dev_param(a['b']) if a['b'] else None)
             return ops.ConvLayer(w, scale, bias, stride=a['strides'], pads=a['pads'], relu=a['relu'], dtype=dt,
-                                 cin_stride=xin.t.shape[3])
+                                 cin_stride=xin.t.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         res = ws.blobs[a['residual']].t if a['residual'] else None
         k = self._keyframe.get(op.outputs[0])
@@ -421,7 +432,7 @@ class Executor(object):
             w = ws.dev_param(a['w']).reshape(a['dim_out'], T, C, 1, 1).permute(0, 2, 1, 3, 4).contiguous()
             bias = ws.dev_param(a['b']) if a['b'] else None
             return ops.ConvLayer(w, None, bias, stride=(1, 1), pads=(0, 0, 0), relu=a['relu'], dtype=dt,
-                                 cin_stride=xin.t.shape[3])
+                                 cin_stride=xin.t.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
         y = layer(xin.t, T=T, out_t=(0, 1))
@@ -500,7 +511,7 @@ class Executor(object):
                 w = w.reshape(w.shape[0], xin.T, xin.C, 1, 1).permute(0, 2, 1, 3, 4).contiguous()
             b = torch.cat([ws.dev_param(lo.args['b']), ws.dev_param(do.args['b'])], dim=0)
             return ops.ConvLayer(w, None, b, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt,
-                                 cin_stride=xin.t.shape[3])
+                                 cin_stride=xin.t.shape[3], x3=_x3(self.ws))
         layer = self._layer(('rpnhead', i), build)
         if xin.t2c:
             self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
@@ -687,7 +698,7 @@ class Executor(object):
                 c, tt, hh, ww = perm
                 w = w.reshape(w.shape[0], c, tt, hh, ww).permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
             return ops.ConvLayer(w.reshape(w.shape[0], -1, 1, 1, 1).contiguous(), None, ws.dev_param(a['b']), stride=(1, 1),
-                                 pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.shape[3])
+                                 pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         self._log_conv(op.outputs[0], layer, 1, 1, xin.shape[2])
         y = layer(xin, T=1)
@@ -714,7 +725,7 @@ class Executor(object):
             w3 = ops.deconv_k4s2_as_conv3x3(ws.dev_param(a['w']))
             bias = ws.dev_param(a['b']).repeat(4)
             return ops.ConvLayer(w3, None, bias, stride=(1, 1), pads=(0, 1, 1), relu=False, dtype=dt,
-                                 cin_stride=x.t.shape[3])
+                                 cin_stride=x.t.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         if ws.conv_log is not None:   # algorithmic flops of the deconv itself: 16 taps / 4 outputs per input position
             ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] * 16 * x.t.shape[0] * x.t.shape[1] * x.t.shape[2],

@@ -106,10 +106,13 @@ def _conv_ref(x, w, scale, bias, res, stride, pads, relu):
     return (F.relu(y) if relu else y).numpy()
 
 
-@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('dtype', [0, 1, 2], ids=['fp32', 'bf16', 'bf16x3'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv3d(ops, case, dtype):
+    """dtype 2 = the bf16x3 mode (round 4): fp32 tensors, the conv on hi / lo bf16 splits of both operands (three bf16 MFMAs per
+    k-slice, fp32 accumulate) -- held to 5e-4 against the fp32 reference (fp32 MFMA mode: 2e-4; plain bf16: 3e-2)."""
     name, N, T, H, W, Cin, Cout, k, s, relu, res_mode, affine = case
+    x3, dtype = dtype == 2, (0 if dtype == 2 else dtype)
     rs = np.random.RandomState(abs(hash(name)) % 1000)
     x = rs.randn(N, Cin, T, H, W).astype(np.float32)
     w = (rs.randn(Cout, Cin, *k) * np.sqrt(2.0 / (Cin * k[0] * k[1] * k[2]))).astype(np.float32)
@@ -133,7 +136,7 @@ def test_conv3d(ops, case, dtype):
             res_small = q(res_small) if res_small is not None else None
     ref = _conv_ref(x, w, scale, bias, res, s, pads, relu)
     layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=s, pads=pads,
-                          relu=relu, dtype=dtype)
+                          relu=relu, dtype=dtype, x3=x3)
     xd = ops.to_ndhwc(_dev(x), dtype)
     rd = None
     if res_mode == 1:
@@ -143,8 +146,8 @@ def test_conv3d(ops, case, dtype):
     y = layer(xd, T=T, residual=rd, res_mode=res_mode)
     got = ops.to_ncdhw(y, dtype, N, Cout, T).cpu().numpy()
     err = np.abs(got - ref).max()
-    tol = 2e-4 if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
-    print('conv %s dtype=%d max-abs err %.3e (ref max %.2f)' % (name, dtype, err, np.abs(ref).max()))
+    tol = (5e-4 if x3 else 2e-4) if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    print('conv %s dtype=%s max-abs err %.3e (ref max %.2f)' % (name, 'bf16x3' if x3 else dtype, err, np.abs(ref).max()))
     assert err < tol
 
 
@@ -463,7 +466,7 @@ def test_conv3d_large_pointwise_layers(ops, case, dtype):
             res_small = q(res_small) if res_small is not None else None
     ref = _conv_ref(x, w, scale, bias, res, (1, 1), (0, 0, 0), relu)
     layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(1, 1), pads=(0, 0, 0),
-                          relu=relu, dtype=dtype)
+                          relu=relu, dtype=dtype, x3=x3)
     xd = ops.to_ndhwc(_dev(x), dtype)
     rd = None
     if res_mode == 1:

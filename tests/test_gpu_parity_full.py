@@ -73,12 +73,14 @@ def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_name
     return err
 
 
-@pytest.mark.parametrize('arch', ['18', '50'])
-def test_fp32_forward_at_the_bench_shape_matches_the_oracle(arch):
-    """S-C, fp32: body, FPN, proposals, box head and kps_score (< 1e-3 max-abs) at 1 x 3 x 8 x 768 x 1344."""
+@pytest.mark.parametrize('arch,dtype', [('18', 'fp32'), ('50', 'fp32'), ('18', 'bf16x3'), ('50', 'bf16x3')])
+def test_fp32_forward_at_the_bench_shape_matches_the_oracle(arch, dtype):
+    """S-C: body, FPN, proposals, box head and kps_score (< 1e-3 max-abs) at 1 x 3 x 8 x 768 x 1344 against the oracle -- in the
+    fp32 parity mode (v_mfma_f32_32x32x2_f32) and in 'bf16x3' (round 4: fp32 activations, convs on hi / lo bf16 splits of both
+    operands), the mode that meets the same bar at several times the fp32 rate."""
     from oracle.net3d import Net
     T, H, W = 8, 768, 1344
-    model, ws, weights = build_product(fpn3d_kps_cfg(arch, T=T, dtype='fp32', pre=1000, post=1000))
+    model, ws, weights = build_product(fpn3d_kps_cfg(arch, T=T, dtype=dtype, pre=1000, post=1000))
     data = synthetic_clip(T, H, W)
     im_info = np.array([[H, W, 800.0 / 720.0]], dtype=np.float32)
     ws.FeedBlob('data', data)
@@ -94,7 +96,8 @@ def test_fp32_forward_at_the_bench_shape_matches_the_oracle(arch):
     _check_against_oracle(model, ws, weights, net, pyr, im_info, 12, names, True)
 
 
-def test_fp32_four_clips_per_forward_at_the_bench_shape_match_the_oracle_clip_by_clip():
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
+def test_fp32_four_clips_per_forward_at_the_bench_shape_match_the_oracle_clip_by_clip(dtype):
     """The BENCHED forward: FOUR clips of 1 x 3 x 8 x 768 x 1344 in ONE forward (32 frames on the frames axis),
     fp32 parity mode.  Clips 0 and 3 -- the two whose first / last frame borders another clip or the end of the batch -- against the
     oracle run on each clip ALONE (the reference's protocol: one clip per forward, lib/core/test.py:212-232; every clip padded
@@ -102,7 +105,7 @@ def test_fp32_four_clips_per_forward_at_the_bench_shape_match_the_oracle_clip_by
     box head and `kps_score` < 1e-3.  At 32 frames the planner takes other tiles / split-K factors than at 8."""
     from oracle.net3d import Net
     T, H, W, B = 8, 768, 1344, 4
-    model, ws, weights = build_product(fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=1000, post=1000))
+    model, ws, weights = build_product(fpn3d_kps_cfg('18', T=T, dtype=dtype, pre=1000, post=1000))
     clips = [synthetic_clip(T, H, W, seed=3 + i) for i in range(B)]
     im_info = np.tile(np.array([[H, W, 800.0 / 720.0]], dtype=np.float32), (B, 1))
     ws.FeedBlob('data', np.concatenate(clips, axis=0))
