@@ -259,8 +259,9 @@ class ConvLayer(object):
             b += oframes * (ho // 2) * (wo // 2) * self.cstride * es
         return float(b)
 
-    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None):
-        """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored."""
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None):
+        """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored.
+        x_split (bf16x3 layers): the hi / lo split of `x` when the caller already has it (a blob read by several convs is split once)."""
         frames, H, W, cin = x.shape
         assert cin == self.cin, 'channel stride %d != layer Cin %d' % (cin, self.cin)
         assert x.dtype == tdtype(self.dtype) and x.is_contiguous()
@@ -272,7 +273,7 @@ class ConvLayer(object):
         if out is None:
             alloc = torch.zeros if self.cstride != self.cout else torch.empty
             out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
-        xin = split_bf16x2(x) if self.x3 else x
+        xin = (x_split if x_split is not None else split_bf16x2(x)) if self.x3 else x
         ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(xin), _ptr(self.packed), _ptr(self.scale),
                    _ptr(self.bias), _ptr(residual), _ptr(out))
         return out

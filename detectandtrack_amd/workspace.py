@@ -22,7 +22,7 @@ logger = logging.getLogger(__name__)
 class Blob(object):
     """A device blob.  kind: 'fmap' [N*T,H,W,Cs] | 'rows' [1,1,R,Cs] (FC activations) | 'mat' fp32 tensor |
     'rois' fp32 [cap, cols] + device count."""
-    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe', 't2c')
+    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe', 't2c', 'split')
 
     def __init__(self, t, kind, N=1, T=1, C=0, dt=0, five_d=False, count=None):
         self.t, self.kind, self.N, self.T, self.C, self.dt = t, kind, N, T, C, dt
@@ -30,6 +30,7 @@ class Blob(object):
         self.count = count
         self.sigmoid_of = None
         self.host = None
+        self.split = None       # bf16x3 mode: the hi / lo bf16 split of `t`, made by the first conv that reads the blob and shared by the others
         self.t2c = False        # time moved into channels (detector.py:480-491): still stored as T frames of C channels
         self.keyframe = None    # set when only this frame of a T-frame blob was computed (cfg.HIP.KEYFRAME_DCE)
 
@@ -407,7 +408,7 @@ class Executor(object):
         k = self._keyframe.get(op.outputs[0])
         if k is not None and xin.T > 1 and xin.keyframe is None and res is None:
             self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
-            y = layer(xin.t, T=xin.T, out_t=(k, 1))
+            y = layer(xin.t, T=xin.T, out_t=(k, 1), x_split=self._split_of(xin, layer))
             b = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
             b.keyframe = k
             ws.blobs[op.outputs[0]] = b
@@ -415,11 +416,20 @@ class Executor(object):
         assert xin.keyframe is None or a['kernels'][0] == 1, 'temporal conv on a key-frame-only blob'
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
                        res_mode=(a['res_mode'] or 1) if res is not None else 0)
-        y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'])
+        y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'], x_split=self._split_of(xin, layer))
         b = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
         b.keyframe = xin.keyframe
         b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
         ws.blobs[op.outputs[0]] = b
+
+    @staticmethod
+    def _split_of(blob, layer):
+        """bf16x3 layers: the blob's hi / lo split, made once per blob (res2_1_sum feeds three convs)"""
+        if not layer.x3:
+            return None
+        if blob.split is None:
+            blob.split = ops.split_bf16x2(blob.t)
+        return blob.split
 
     def _conv_over_time_channels(self, i, op, xin):
         """1x1 conv on a blob whose T frames were moved into channels (index t*C + c): run as a KT = T conv with no
