@@ -484,18 +484,25 @@ def main():
         pipe = ClipPipeline(model, ws, a.pipeline, graph=a.graph, fifo=a.fifo, keep_results=False)
         slots = [(sl.ws, sl.stream) for sl in pipe.slots]
 
+        # the input blobs are resident in HBM (the contract of `value`); in the benched bf16 mode the graphs read them where they
+        # lie -- one captured graph per (slot, input buffer) -- instead of copying 99 MB per clip into a private graph input first
+        resident_in = a.dtype == 'bf16' and bool(a.graph)
+
         def run_steps(n):
             for i in range(n):
                 for unit in clips[i % 2]:
-                    pipe.submit(unit, im_info, im_shape)
+                    pipe.submit(unit, im_info, im_shape, resident=resident_in)
             pipe.drain()
 
     torch.cuda.synchronize()
     _dbg('built')
-    if not train:   # prime every slot once (each HIP stream has its own pool in the caching allocator): not a step, not timed
-        for _ in range(len(slots)):
-            pipe.submit(clips[0][0], im_info, im_shape)
-        pipe.drain()
+    if not train:   # prime every slot once per input buffer (each HIP stream has its own pool in the caching allocator; graphs are
+        # captured here): not a step, not timed
+        for i in range(2 if resident_in else 1):
+            for unit in clips[i]:
+                for _ in range(len(slots)):
+                    pipe.submit(unit, im_info, im_shape, resident=resident_in)
+                pipe.drain()
     _dbg('primed')
     run_steps(a.warmup)
     _dbg('warmed up')
@@ -607,7 +614,7 @@ def main():
             t1 = time.perf_counter()
             for i in range(n_seq):
                 for unit in clips[i % 2]:
-                    gseq.submit(unit, im_info, im_shape)
+                    gseq.submit(unit, im_info, im_shape, resident=resident_in)
             gseq.drain()
             seq_rate = n_seq * clips_per_step / (time.perf_counter() - t1)
             _dbg('graph sequential pass done')

@@ -92,11 +92,15 @@ class ClipPipeline(object):
         return (tuple(int(v) for v in data_shape), tuple(np.asarray(im_info, np.float32).reshape(-1).tolist()),
                 tuple(tuple(int(v) for v in sh[:2]) for sh in im_shapes))
 
-    def _enqueue(self, slot, data_dev, im_info, im_shapes, in_place):
+    def _enqueue(self, slot, data_dev, im_info, im_shapes, in_place, resident=False):
         """model.net + device glue + keypoint net + decode of one forward on the slot's stream: a graph replay or eager launches.
-        in_place: `data_dev` IS the slot's input buffer of this geometry (already filled on the slot's stream)."""
+        in_place: `data_dev` IS the slot's input buffer of this geometry (already filled on the slot's stream).
+        resident: `data_dev` is a caller-owned buffer that stays where it is (and filled) for the life of the pipeline: the graph is
+        captured reading IT -- one graph per (geometry, buffer) -- instead of a private input buffer that every launch copies into."""
         s = self.slots[slot]
         key = self._geometry(data_dev.shape, im_info, im_shapes)
+        if resident:
+            key, in_place = key + (int(data_dev.data_ptr()),), True
         if self.use_graph:
             g = s.graphs.get(key)
             if g is None:
@@ -123,16 +127,17 @@ class ClipPipeline(object):
                 wsmod._GLOBAL = prev
 
     # ---- feeding ---------------------------------------------------------------------------------------------------------------
-    def submit(self, data_dev, im_info, im_shape, tag=None):
+    def submit(self, data_dev, im_info, im_shape, tag=None, resident=False):
         """One forward on a `data` blob that is ALREADY RESIDENT in HBM (fp32 NC[T]HW, B = data_dev.shape[0] images / clips).
-        im_info [B, 3]; im_shape: the unscaled (h, w, 3) of the images (one tuple for all, or one per image)."""
+        im_info [B, 3]; im_shape: the unscaled (h, w, 3) of the images (one tuple for all, or one per image).  resident=True: the
+        caller keeps `data_dev` alive and in place (see _enqueue): no device-to-device copy of the input per forward."""
         slot = self._acquire()
         t0 = time.perf_counter()
         B = int(data_dev.shape[0])
         im_info = np.asarray(im_info, np.float32).reshape(-1, 3)
         assert im_info.shape[0] == B, (im_info.shape, B)
         shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
-        dev, g = self._enqueue(slot, data_dev, im_info, shapes, in_place=False)
+        dev, g = self._enqueue(slot, data_dev, im_info, shapes, in_place=False, resident=resident and self.use_graph)
         self.slots[slot].event.record(self.slots[slot].stream)
         self.host_enqueue_s += time.perf_counter() - t0       # host time to enqueue one forward (no synchronisation inside)
         self.pending.append((slot, tag, im_info, shapes, dev, None, g))

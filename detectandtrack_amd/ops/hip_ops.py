@@ -259,7 +259,7 @@ class ConvLayer(object):
             b += oframes * (ho // 2) * (wo // 2) * self.cstride * es
         return float(b)
 
-    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None):
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None, zero_pad=True):
         """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored.
         x_split (bf16x3 layers): the hi / lo split of `x` when the caller already has it (a blob read by several convs is split once)."""
         frames, H, W, cin = x.shape
@@ -271,7 +271,10 @@ class ConvLayer(object):
         ho, wo = self.out_hw(H, W)
         oframes = frames if out_t is None else frames // T * out_t[1]
         if out is None:
-            alloc = torch.zeros if self.cstride != self.cout else torch.empty
+            # channels [cout, cstride) of the output are never written by the kernel: zero them when a later conv / FC reads the whole
+            # channel stride against zero-padded weights (0 x garbage may be NaN); zero_pad=False: every reader stops at the real channels
+            # (RPN head -> proposal kernels, cls_score / bbox_pred -> softmax / box decode, the deconv -> kps_finalize) -- no fill launch
+            alloc = torch.zeros if (self.cstride != self.cout and zero_pad) else torch.empty
             out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
         xin = (x_split if x_split is not None else split_bf16x2(x)) if self.x3 else x
         ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(xin), _ptr(self.packed), _ptr(self.scale),
@@ -705,6 +708,19 @@ class RpnLevelSpec(object):
         self.per_frame = per_frame
 
 
+def zeros_packed(dev, specs):
+    """Several zero-initialised 4-byte-element tensors out of ONE zeroed allocation (one fill launch instead of one per tensor):
+    specs = [(shape, torch.float32 | torch.int32), ...]; every view starts on a 16-byte boundary."""
+    sizes = [(int(np.prod(shp)) + 3) // 4 * 4 for shp, _ in specs]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, off = [], 0
+    for (shp, dt), n in zip(specs, sizes):
+        v = flat[off:off + int(np.prod(shp))]
+        out.append((v if dt == torch.float32 else v.view(dt)).view(tuple(shp)))
+        off += n
+    return out
+
+
 def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_size, batch_idx=0., n_images=1, frame_stride=0):
     """One image: returns (rois [nl, post_nms, 4T+1], probs [nl, post_nms], counts int32 [nl]) CUDA tensors.  n_images > 1
     (dat_rpn_proposals_batch): image i reads frame `level.frame + i * frame_stride` of every head tensor and is clipped with
@@ -726,9 +742,8 @@ def rpn_proposals(levels, dtype, im_info, pre_nms, post_nms, nms_thresh, min_siz
     assert im_info.shape[0] == n_images, (im_info.shape, n_images)
     info = (C.c_float * (3 * n_images))(*[float(v) for v in im_info.reshape(-1)])
     lead = (n_images, nl) if n_images > 1 else (nl,)
-    rois = torch.zeros(lead + (post_nms, 4 * T + 1), dtype=torch.float32, device=dev)
-    probs = torch.zeros(lead + (post_nms,), dtype=torch.float32, device=dev)
-    counts = torch.zeros(lead, dtype=torch.int32, device=dev)
+    rois, probs, counts = zeros_packed(dev, [(lead + (post_nms, 4 * T + 1), torch.float32), (lead + (post_nms,), torch.float32),
+                                            (lead, torch.int32)])
     ctx().call('dat_rpn_proposals_batch', _stream(), dtype, heads, lv, anchors, nl, int(n_images), int(frame_stride), info, pre_nms,
                post_nms, C.c_float(nms_thresh), C.c_float(min_size), C.c_float(batch_idx), _ptr(rois), _ptr(probs), _ptr(counts))
     return rois, probs, counts
@@ -741,8 +756,7 @@ def collect_rois(rois, probs, counts, post_nms):
         ni, nl, cap, cols = rois.shape
     else:
         ni, (nl, cap, cols) = 1, rois.shape
-    out = torch.zeros((ni * post_nms, cols), dtype=torch.float32, device=rois.device)
-    n_out = torch.zeros((ni,), dtype=torch.int32, device=rois.device)
+    out, n_out = zeros_packed(rois.device, [((ni * post_nms, cols), torch.float32), ((ni,), torch.int32)])
     ctx().call('dat_collect_rois_batch', _stream(), _ptr(rois), _ptr(probs), _ptr(counts), nl, ni, cap, cols, post_nms,
                _ptr(out), _ptr(n_out))
     return out, n_out

@@ -28,6 +28,7 @@ logger = logging.getLogger(__name__)
 
 class TrainExecutor(Executor):
     """Forward (inherits the inference handlers) + loss ops + backward + update for one net on one workspace."""
+    training = True
 
     def __init__(self, ws, net, arena=None, gt_arena=None):
         super(TrainExecutor, self).__init__(ws, net)

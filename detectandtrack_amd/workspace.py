@@ -22,7 +22,7 @@ logger = logging.getLogger(__name__)
 class Blob(object):
     """A device blob.  kind: 'fmap' [N*T,H,W,Cs] | 'rows' [1,1,R,Cs] (FC activations) | 'mat' fp32 tensor |
     'rois' fp32 [cap, cols] + device count."""
-    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe', 't2c', 'split')
+    __slots__ = ('t', 'kind', 'N', 'T', 'C', 'dt', 'five_d', 'count', 'sigmoid_of', 'host', 'keyframe', 't2c', 'split', 'tsel')
 
     def __init__(self, t, kind, N=1, T=1, C=0, dt=0, five_d=False, count=None):
         self.t, self.kind, self.N, self.T, self.C, self.dt = t, kind, N, T, C, dt
@@ -31,6 +31,8 @@ class Blob(object):
         self.sigmoid_of = None
         self.host = None
         self.split = None       # bf16x3 mode: the hi / lo bf16 split of `t`, made by the first conv that reads the blob and shared by the others
+        self.tsel = None        # (k, T): a LAZY SliceKeyFrame -- `t` still holds all T frames of every clip, the blob is frame k of each (no copy:
+                                # the reading conv / RoIAlign address that frame themselves)
         self.t2c = False        # time moved into channels (detector.py:480-491): still stored as T frames of C channels
         self.keyframe = None    # set when only this frame of a T-frame blob was computed (cfg.HIP.KEYFRAME_DCE)
 
@@ -66,7 +68,11 @@ class Workspace(object):
             return self.params[name]
         b = self.blobs[name]
         if b.kind == 'fmap':
-            out = ops.to_ncdhw(b.t, b.dt, b.N, b.C, b.T).cpu().numpy()
+            t = b.t
+            if b.tsel is not None:      # lazy key-frame slice: pick frame k of every clip now
+                k, tf = b.tsel
+                t = t.view((b.N, tf) + tuple(t.shape[1:]))[:, k].contiguous()
+            out = ops.to_ncdhw(t, b.dt, b.N, b.C, b.T).cpu().numpy()
             if b.t2c:   # (N, C, T, H, W) -> (N, T*C, H, W), channel = t*C + c
                 return np.ascontiguousarray(out.transpose(0, 2, 1, 3, 4)).reshape(b.N, b.T * b.C, out.shape[3], out.shape[4])
             return out if b.five_d else out[:, :, 0]
@@ -212,6 +218,10 @@ def _w5d(w):
 
 class Executor(object):
     """Interprets one recorded net.  Prepared layers (packed weights) are cached in the workspace."""
+
+    # consumers that read a conv / FC output only up to its real channel count (never the zero padding up to the channel stride)
+    _PAD_BLIND = frozenset(['Softmax', 'Sigmoid', 'BilinearInterpolation', 'GenerateProposals', 'TimeMean', 'RpnDeltasPerFrame'])
+    training = False            # (TrainExecutor: True -- gradients are taken over whole channel strides)
 
     def __init__(self, ws, net):
         self.ws, self.net = ws, net
@@ -405,6 +415,15 @@ class Executor(object):
                                  cin_stride=xin.t.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         res = ws.blobs[a['residual']].t if a['residual'] else None
+        if xin.tsel is not None:    # lazy SliceKeyFrame: a kT = 1 conv computes output frame k of every clip from input frame k
+            kf, tfull = xin.tsel
+            assert a['kernels'][0] == 1 and res is None
+            self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
+            y = layer(xin.t, T=tfull, out_t=(kf, 1))
+            b = Blob(y, 'fmap', xin.N, 1, a['dim_out'], dt, False)
+            b.count = xin.count
+            ws.blobs[op.outputs[0]] = b
+            return
         k = self._keyframe.get(op.outputs[0])
         if k is not None and xin.T > 1 and xin.keyframe is None and res is None:
             self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2], oframes=xin.N)
@@ -421,6 +440,19 @@ class Executor(object):
         b.keyframe = xin.keyframe
         b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
         ws.blobs[op.outputs[0]] = b
+
+    def _pad_unread(self, name):
+        """True when no op of any registered net reads `name` beyond its real channels (inference only): the producing conv then
+        skips the zero fill of the padding channels (8 fill launches per forward on the R-18 FPN model)."""
+        if self.training:
+            return False
+        key = ('pad_unread', self.net.name, name)
+        hit = self.ws._layers.get(key)
+        if hit is None:
+            readers = [op for net in list(self.ws.nets.values()) + [self.net] for op in net.ops
+                       if name in op.inputs or (isinstance(op.args, dict) and op.args.get('residual') == name)]
+            hit = self.ws._layers[key] = all(op.type in self._PAD_BLIND for op in readers)
+        return hit
 
     @staticmethod
     def _split_of(blob, layer):
@@ -526,11 +558,11 @@ class Executor(object):
         if xin.t2c:
             self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
                            oframes=xin.N)
-            y = layer(xin.t, T=xin.T, out_t=(0, 1))
+            y = layer(xin.t, T=xin.T, out_t=(0, 1), zero_pad=self.training)
             head = Blob(y, 'fmap', xin.N, 1, A + do.args['dim_out'], dt, False)
         else:
             self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2])
-            y = layer(xin.t, T=xin.T)
+            y = layer(xin.t, T=xin.T, zero_pad=self.training)   # (read by the proposal / loss kernels through channel offsets only)
             head = Blob(y, 'fmap', xin.N, xin.T, A + do.args['dim_out'], dt, xin.five_d)
         ws.blobs[lo.outputs[0] + '+' + do.outputs[0]] = head
         ws.blobs['_rpnhead_for_%d' % gi] = head
@@ -550,8 +582,39 @@ class Executor(object):
             self.ws.blobs[op.outputs[0]] = Blob(x.t, 'fmap', x.N, 1, x.C, x.dt, False)
             return
         f, h, w, c = x.t.shape
+        if x.N > 1 and x.T > 1 and self._slice_readers_address_frames(op.outputs[0]):
+            # several clips per forward: the key frames are not contiguous, and the copy (132 MB r + w for P2 at 4 clips) is not needed --
+            # every reader (the shared RPN conv, RoIAlign of the box / keypoint heads) can address frame k of a T-frame map itself
+            b = Blob(x.t, 'fmap', x.N, 1, x.C, x.dt, False)
+            b.tsel = (k, x.T)
+            self.ws.blobs[op.outputs[0]] = b
+            return
         y = x.t.view(x.N, x.T, h, w, c)[:, k].contiguous() if x.N > 1 else x.t[k:k + 1]
         self.ws.blobs[op.outputs[0]] = Blob(y, 'fmap', x.N, 1, x.C, x.dt, False)
+
+    def _slice_readers_address_frames(self, name):
+        """Can the output of a SliceKeyFrame stay a view of the T-frame blob?  Yes when every op that reads it (in any registered net) is a
+        conv without temporal extent / residual or a RoIFeatureTransform, in an inference executor on plain tensors (bf16 / fp32)."""
+        if self.training or _x3(self.ws):
+            return False
+        key = ('slice_lazy', self.net.name, name)
+        hit = self.ws._layers.get(key)
+        if hit is None:
+            ok = True
+            for net in list(self.ws.nets.values()) + [self.net]:
+                for j, o in enumerate(net.ops):
+                    a = o.args if isinstance(o.args, dict) else {}
+                    if a.get('residual') == name:
+                        ok = False
+                    if name not in o.inputs:
+                        continue
+                    if o.type == 'Conv' and a.get('kernels', [0])[0] == 1 and o.inputs[0] == name:
+                        continue
+                    if o.type == 'RoIFeatureTransform' and name in o.inputs[:a['n_feat']]:
+                        continue
+                    ok = False
+            hit = self.ws._layers[key] = ok
+        return hit
 
     def op_TimePoolAvg(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
@@ -683,7 +746,13 @@ class Executor(object):
         Tr = (cols - 1) // 4
         f0 = feats[0]
         assert Tr == 1 or Tr == f0.T, 'tube rois of %d frames on features with T=%d' % (Tr, f0.T)
-        y = ops.roi_align([f.t for f in feats], a['scales'], f0.dt, rt.float().contiguous(), T=f0.T, Tr=Tr, t0=0,
+        t_feat, t0 = f0.T, 0
+        if f0.tsel is not None:     # lazy SliceKeyFrame: the maps still hold all T frames; RoIAlign reads frame k of the roi's clip
+            assert all(f.tsel == f0.tsel for f in feats) and Tr == 1
+            t0, t_feat = f0.tsel
+        else:
+            assert all(f.tsel is None for f in feats)
+        y = ops.roi_align([f.t for f in feats], a['scales'], f0.dt, rt.float().contiguous(), T=t_feat, Tr=Tr, t0=t0,
                           pooled=a['resolution'], sampling=a['sampling_ratio'], k_min=cfg.FPN.ROI_MIN_LEVEL,
                           canon_scale=float(cfg.FPN.ROI_CANONICAL_SCALE), canon_level=cfg.FPN.ROI_CANONICAL_LEVEL)
         b = Blob(y, 'fmap', R, Tr, f0.C, f0.dt, Tr > 1)
@@ -711,7 +780,7 @@ class Executor(object):
                                  pads=(0, 0, 0), relu=a['relu'], dtype=dt, cin_stride=xin.shape[3], x3=_x3(self.ws))
         layer = self._layer(i, build)
         self._log_conv(op.outputs[0], layer, 1, 1, xin.shape[2])
-        y = layer(xin, T=1)
+        y = layer(xin, T=1, zero_pad=not self._pad_unread(op.outputs[0]))
         b = Blob(y, 'rows', 1, 1, a['dim_out'], dt)
         b.count = x.count
         ws.blobs[op.outputs[0]] = b
@@ -740,7 +809,7 @@ class Executor(object):
         if ws.conv_log is not None:   # algorithmic flops of the deconv itself: 16 taps / 4 outputs per input position
             ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] * 16 * x.t.shape[0] * x.t.shape[1] * x.t.shape[2],
                                 layer.hbm_bytes(x.t.shape[0], x.t.shape[1], x.t.shape[2])))
-        y = layer(x.t, T=1)
+        y = layer(x.t, T=1, zero_pad=not self._pad_unread(op.outputs[0]))
         b = Blob(y, 'fmap', x.N, x.T, 4 * a['dim_out'], dt, x.five_d)
         ws.blobs[op.outputs[0]] = b
 
