@@ -486,7 +486,7 @@ def main():
 
         # the input blobs are resident in HBM (the contract of `value`); in the benched bf16 mode the graphs read them where they
         # lie -- one captured graph per (slot, input buffer) -- instead of copying 99 MB per clip into a private graph input first
-        resident_in = a.dtype == 'bf16' and bool(a.graph)
+        resident_in = a.dtype == 'bf16' and bool(a.graph) and os.environ.get('DAT_BENCH_RESIDENT', '1') != '0'   # (env: A/B switch)
 
         def run_steps(n):
             for i in range(n):
@@ -853,6 +853,12 @@ def other_configs():
             ('config3_3d_r18_fpn3d_training', ['--mode', 'train']),
             ('extension_3d_r18_fpn3d_tube_heads_inference', ['--workload', '3d_r18_fpn3d_tube'])]
     res = {}
+    try:    # config 5 END TO END: detector over a video-shaped clip list (host frames) -> detections.pkl -> host Hungarian tracker
+        p = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bench_config5.py')], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=240)
+        res['config5_end_to_end'] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        res['config5_end_to_end'] = {'error': '%s: %s' % (type(e).__name__, e)}
     for name, extra in runs:
         cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline',
                '--no-accuracy', '--no-other-configs'] + extra

@@ -58,17 +58,35 @@ def extend_results(index, all_res, im_res):
         all_res[cls_idx][index] = im_res[cls_idx]
 
 
+_FRAME_CACHE = None      # path -> decoded BGR uint8 frame, least recently used first (sliding-window clips share T - 1 of T frames)
+
+
+def read_frame(path, cache_frames=64):
+    """One image file -> HxWx3 uint8 BGR (the layout cv2.imread hands the reference, lib/utils/video.py / datasets roidb
+    `image` paths, lib/core/test_engine.py:124-204).  Decoded with Pillow (OpenCV is not in the image); an LRU of decoded frames
+    makes a stride-1 sliding window over a video decode every file once."""
+    global _FRAME_CACHE
+    import collections
+    if _FRAME_CACHE is None:
+        _FRAME_CACHE = collections.OrderedDict()
+    hit = _FRAME_CACHE.get(path)
+    if hit is not None:
+        _FRAME_CACHE.move_to_end(path)
+        return hit
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    _FRAME_CACHE[path] = bgr
+    while len(_FRAME_CACHE) > cache_frames:
+        _FRAME_CACHE.popitem(last=False)
+    return bgr
+
+
 def load_clip(entry):
-    """roidb entry -> list of T BGR frames (arrays are used as-is; paths need an image reader)."""
+    """roidb entry -> list of T BGR frames: arrays are used as they are, paths are decoded (read_frame)."""
     frames = entry['image'] if isinstance(entry['image'], (list, tuple)) else [entry['image']]
-    out = []
-    for f in frames:
-        if isinstance(f, np.ndarray):
-            out.append(f)
-        else:
-            raise NotImplementedError('image decoding is host I/O outside the hot-path scope (no OpenCV here): '
-                                      'provide frames as arrays (e.g. a pre-decoded roidb pickle)')
-    return out
+    return [f if isinstance(f, np.ndarray) else read_frame(str(f)) for f in frames]
 
 
 def _pipelined(part):

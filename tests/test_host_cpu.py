@@ -915,3 +915,27 @@ def test_segmented_row_counts_and_test_scale_host_logic():
     assert k1 != key((2, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (2, 1)), [(720, 1280, 3)] * 2)
     assert k1 != key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.11]], (4, 1)), [(720, 1280, 3)] * 4)
     assert k1 != key((4, 3, 8, 768, 1344), np.tile([[768, 1344, 1.04]], (4, 1)), [(719, 1280, 3)] * 4)
+
+
+def test_clips_given_as_image_files_are_decoded_to_bgr_frames(tmp_path):
+    """roidb entries whose `image` holds file paths (what the reference's dataset layer produces, lib/utils/video.py:149-201) are
+    decoded by core/test_engine.load_clip to HxWx3 uint8 BGR -- cv2.imread's layout -- and a sliding window decodes each file once."""
+    from PIL import Image
+    from detectandtrack_amd.core import test_engine
+    rs = np.random.RandomState(2)
+    frames = [rs.randint(0, 255, (36, 52, 3)).astype(np.uint8) for _ in range(5)]        # BGR
+    paths = []
+    for i, f in enumerate(frames):
+        p = str(tmp_path / ('%06d.png' % i))
+        Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])).save(p)                        # files hold RGB
+        paths.append(p)
+    test_engine._FRAME_CACHE = None
+    clip_a = test_engine.load_clip({'image': paths[0:4]})
+    clip_b = test_engine.load_clip({'image': paths[1:5]})
+    for got, ref in zip(clip_a + clip_b[-1:], frames):
+        assert got.dtype == np.uint8 and got.flags['C_CONTIGUOUS']
+        np.testing.assert_array_equal(got, ref)
+    assert clip_b[0] is clip_a[1] and len(test_engine._FRAME_CACHE) == 5              # shared frames were not decoded again
+    mixed = test_engine.load_clip({'image': [frames[0], paths[1]]})                     # arrays pass through untouched
+    assert mixed[0] is frames[0] and mixed[1] is clip_a[1]
+    test_engine._FRAME_CACHE = None
