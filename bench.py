@@ -537,6 +537,22 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _dbg('timed region done')
+    records, conv_log, mhz = [], [], []
+
+    def stop_profilers():
+        for (w, st), pr in zip(slots, profs):
+            with torch.cuda.stream(st):
+                rec = pr.stop()
+            if train:   # the data-gradient launches reuse the forward kernel without a host-side log entry: take the launch's
+                # own record (flops from the descriptor's channel strides, i.e. padded channels counted; bytes unknown)
+                w.conv_log = [('conv', fl, 0.0) for _, fl, _ in rec]
+            assert len(rec) == len(w.conv_log), (len(rec), len(w.conv_log))
+            records.extend(rec)
+            conv_log.extend(w.conv_log)
+            mhz.append(getattr(pr, 'shader_mhz', 0.0))
+            w.conv_log = None
+    if not train:       # (before anything else captures graphs on these streams: launches under capture carry no event pairs)
+        stop_profilers()
     # ---- the same pipeline fed from HOST frames: uint8 720 x 1280 BGR frames -> pinned staging -> uint8 H2D on
     # a copy stream -> dat_preprocess_frames (resize + mean + pad on the device) -> the same graphs.  Same step count, same
     # barrier / synchronize bracket; reported NEXT TO `value`, never as `value` ----
@@ -577,18 +593,8 @@ def main():
     if train:
         start_profilers()
         run_steps(prof_iters, timing=world > 1)      # (the exchange is timed in these extra iterations, outside the timed region)
-    records, conv_log, mhz = [], [], []
-    for (w, st), pr in zip(slots, profs):
-        with torch.cuda.stream(st):
-            rec = pr.stop()
-        if train:   # the data-gradient launches reuse the forward kernel without a host-side log entry: take the launch's
-            # own record (flops from the descriptor's channel strides, i.e. padded channels counted; bytes unknown)
-            w.conv_log = [('conv', fl, 0.0) for _, fl, _ in rec]
-        assert len(rec) == len(w.conv_log), (len(rec), len(w.conv_log))
-        records += rec
-        conv_log += w.conv_log
-        mhz.append(getattr(pr, 'shader_mhz', 0.0))
-        w.conv_log = None
+    if train:
+        stop_profilers()
     shader_mhz = float(np.mean([m for m in mhz if m > 0])) if any(m > 0 for m in mhz) else 0.0
     host_enqueue_ms = None
     if not train:

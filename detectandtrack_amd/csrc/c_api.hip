@@ -156,9 +156,12 @@ int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float
     if (!ctx) return DAT_ERR_ARG;
     const int n = ctx->prof_n < max_records ? ctx->prof_n : max_records;
     for (int i = 0; i < n; ++i) {
-        hipEventSynchronize(ctx->prof_ev[2 * i + 1]);
         float t = 0.f;
-        hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]);
+        if (hipEventSynchronize(ctx->prof_ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&t, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) {
+            (void)hipGetLastError();   // (never leave a sticky error behind for the caller's runtime to trip over)
+            t = 0.f;
+        }
         if (tags) tags[i] = ctx->prof_tag[i];
         if (flops) flops[i] = ctx->prof_flops[i];
         if (ms) ms[i] = t;

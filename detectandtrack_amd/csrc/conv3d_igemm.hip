@@ -994,7 +994,11 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     const bool big = bp == 256;
     int tag = (small_n ? 64 : 128) * 10000 + bp * 10 + d->dtype;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap) {
+    // (no event pairs inside a stream capture: an event recorded there becomes a graph node, and timing it later fails with
+    //  hipErrorInvalidHandle -- a sticky error the host framework then reports at an unrelated call)
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    if (ctx->prof_enabled && ctx->prof_n < ctx->prof_cap && hipStreamIsCapturing(st, &cap_st) == hipSuccess &&
+        cap_st == hipStreamCaptureStatusNone) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
         e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
         hipEventRecord(e0, st);
