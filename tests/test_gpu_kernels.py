@@ -439,7 +439,7 @@ PW_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('dtype', [0, 1, 2], ids=['fp32', 'bf16', 'bf16x3'])
 @pytest.mark.parametrize('case', PW_CASES, ids=[c[0] for c in PW_CASES])
 def test_conv3d_large_pointwise_layers(ops, case, dtype):
     """1x1x1 stride-1 convs with tens of thousands of positions (FPN laterals, bottleneck expanders): ragged last tile, Cout not
@@ -447,6 +447,7 @@ def test_conv3d_large_pointwise_layers(ops, case, dtype):
     must give the identical result (same K order)."""
     from detectandtrack_amd import libdat as L
     name, T, H, W, Cin, Cout, relu, res_mode, affine = case
+    x3, dtype = dtype == 2, (0 if dtype == 2 else dtype)       # (bf16x3: fp32 tensors, split-operand conv)
     rs = np.random.RandomState(abs(hash(name)) % 1000)
     x = rs.randn(1, Cin, T, H, W).astype(np.float32)
     w = (rs.randn(Cout, Cin, 1, 1, 1) * np.sqrt(2.0 / Cin)).astype(np.float32)
@@ -480,7 +481,7 @@ def test_conv3d_large_pointwise_layers(ops, case, dtype):
     finally:
         ops.tune_plan(0, 0)
     err = np.abs(got - ref).max()
-    tol = 2e-4 if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    tol = (5e-4 if x3 else 2e-4) if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
     print('pointwise %s dtype=%d max-abs err %.3e (ref max %.2f), vs forced plan %.3e' % (name, dtype, err, np.abs(ref).max(),
                                                                                             np.abs(got - gen).max()))
     assert err < tol
