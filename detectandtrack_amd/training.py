@@ -740,6 +740,7 @@ class Trainer(object):
     update; layers of frozen parameters are left alone."""
 
     BUCKET_BYTES = 64 << 20      # xGMI rings are per-link bound: few, large buckets
+    TAIL_BYTES = 8 << 20         # ... except the one that cannot overlap anything (see __init__)
 
     def __init__(self, model, ws, dist=None):
         self.model, self.ws, self.dist = model, ws, dist
@@ -796,6 +797,18 @@ class Trainer(object):
                 cur, cur_lo = [], off
         if cur:
             self.buckets.append((cur_lo, off, cur))
+        # the LAST weight bucket completes with the backward pass itself, so its exchange is the exposed one: keep it small by cutting
+        # it where the trailing part (the parameters that complete last: res3) drops under TAIL_BYTES
+        wb = [k for k, (_, _, names) in enumerate(self.buckets) if names[0] not in self.biases]
+        if wb:
+            lo, hi, names = self.buckets[wb[-1]]
+            szs = [int(np.prod(ws.params[n].shape)) for n in names]
+            tail, cut = 0, len(names)
+            while cut > 1 and (tail + szs[cut - 1]) * 4 <= self.TAIL_BYTES:
+                cut -= 1
+                tail += szs[cut]
+            if (hi - lo) * 4 > self.TAIL_BYTES and 0 < tail < hi - lo and cut < len(names):
+                self.buckets[wb[-1]:wb[-1] + 1] = [(lo, hi - tail, names[:cut]), (hi - tail, hi, names[cut:])]
         self.bucket_ready_at = [min(self.ready_index.get(n, -1) for n in names) for _, _, names in self.buckets]
         self.exchange = None
         self.last_exchange_stats = {}
