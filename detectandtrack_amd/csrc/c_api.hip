@@ -61,6 +61,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_linear = env_int("DAT_CONV_LINEAR", 1);
         c->dbg_order = env_int("DAT_CONV_ORDER", 0);
         c->dbg_bt = env_int("DAT_CONV_BT", 0);   // opt-in: measured neutral on the full network (the part is power-limited)
+        c->dbg_roi_fold = env_int("DAT_ROI_BWD_FOLD", 1);
         c->num_cu = 0;
     }
     if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemset(c->zeros, 0, 512) != hipSuccess) {

@@ -43,6 +43,7 @@ struct dat_ctx {
     int dbg_ablate_wgrad;                   // DAT_WGRAD_ABLATE (default 0): DEBUG timing ablations of the nine-tap weight-gradient kernel (wrong results)
     int dbg_wgrad_dma;                      // DAT_WGRAD_DMA (default 1): nine-tap weight gradient with LDS-DMA operand staging (three stages) instead of register staging
     int dbg_wgrad_ks;                       // DAT_WGRAD_KS (default 0 = heuristic): forced K split of the nine-tap direct weight-gradient kernel
+    int dbg_roi_fold;                       // DAT_ROI_BWD_FOLD (default 1): RoIAlign backward folds a bin's samples into one weight per distinct pixel before the atomics
     int num_cu;                             // compute units of the device (persistent-kernel grids)
     int dbg_ntap;                           // DAT_CONV_NTAP (default 1): unrolled-tap variants of the WD kernels (3x3 stride 1, 1x1)
     int dbg_wd;                             // DAT_CONV_WD (default 2): tiles read their weights straight from global memory (1: only the 128-channel ones)

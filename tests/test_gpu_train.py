@@ -814,7 +814,7 @@ def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, o
     needs one device per rank) train clip r each with NUM_GPUS = 2 for two iterations -- with the buckets exchanged as the backward
     pass completes them (cfg.HIP.OVERLAP_ALLREDUCE) or after it -- and must end with the weights of ONE rank that runs both clips
     per iteration with the same 1 / NUM_GPUS scaling (gradients accumulated, one update).  fp32 mode; the weight-gradient kernels
-    reduce with float atomics, hence a tolerance of 1 % of each parameter's two-iteration update instead of bit equality (a wrong
+    reduce with float atomics, hence a tolerance of 5 % of each parameter's two-iteration update instead of bit equality (a wrong
     loss scale or a bucket exchanged before it was final moves a parameter by ~100 % of its update)."""
     import torch.multiprocessing as mp
     from detectandtrack_amd.training import Trainer
@@ -849,7 +849,11 @@ def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, o
         a, b, ref = r0['w_' + n], r1['w_' + n], ws.dev_param(n).cpu().numpy()
         np.testing.assert_array_equal(a, b, err_msg=n)                      # the ranks hold identical weights
         step = float(np.abs(ref - ws.params[n]).max())                      # how far two iterations moved this parameter
-        tol = 0.01 * step + 2e-6 * max(1.0, float(np.abs(ref).max()))          # 1 % of the update (float-atomic summation noise measures 1e-3 of it)
+        # 5 % of the update.  Measured: < 1 % everywhere except the LAST convs of the keypoint head (conv_fcn7 / conv_fcn8: 1.0-1.5 %), whose
+        # weight gradient is a sum over the 56 x 56 map of (softmax - one-hot) x activation -- the per-map gradient sums to ZERO, so the
+        # K-split partial sums the kernels combine with float atomics are ~1e4 x larger than their total and the order they arrive in
+        # (different between two ranks + all-reduce and one rank accumulating) shows at the 1e-2 level of that small total
+        tol = 0.05 * step + 2e-6 * max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(a - ref).max()) <= tol, (n, float(np.abs(a - ref).max()), tol, step)
         moved += int(not n.startswith(('conv1', 'res2')) and step > 0)
     assert moved > 40           # the parameters above the StopGradient marker were really trained
