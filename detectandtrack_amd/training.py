@@ -45,7 +45,7 @@ class TrainExecutor(Executor):
         self._deferred = {}      # weight name -> the fused AffineChannelNd scale (tensor or None) its finish multiplies by
         self._sealed = set()     # parameters whose gradient bucket is already on its way to the other ranks (Trainer, overlap)
         self.accumulate_all = False   # the arena already holds gradients of an earlier clip (Trainer.step(zero_grad=False)): add, never overwrite
-        self._masked, self._last_masked = set(), False      # gradient tensors that already carry their producer's ReLU mask
+        self._last_masked = False       # set by _take_grad: the gradient just taken already carries its producer's ReLU mask
         self._trainable_set = None
         self._readers = {}
         for o in net.ops:
@@ -176,35 +176,34 @@ class TrainExecutor(Executor):
     # with BODY_HEAD_LINK 'slice-center' the heads read one frame, so the FPN post-hoc convs (60 % of the forward FLOPs)
     # receive a 1-frame gradient and hand a 3-frame gradient down; each kT = 3 conv widens the window by its temporal reach.
     def _add_grad(self, name, t, lo=0, masked=False):
-        """masked: the ReLU backward of `name`'s producer is already applied to `t` (fused into the data-gradient conv that made it)."""
-        if masked:
-            self._masked.add(id(t))
-        self.grads.setdefault(name, []).append((t, lo))
+        """masked: the ReLU backward of `name`'s producer is already applied to `t` (fused into the data-gradient conv that made it).
+        The flag travels WITH the entry (tensor, first frame, masked) -- not in a side table keyed by id(tensor)."""
+        self.grads.setdefault(name, []).append((t, lo, bool(masked)))
 
     def _take_grad(self, name, dtype):
-        """-> (dy, lo) with dy in the activation dtype covering frames [lo, lo + dy.shape[0]), or (None, 0)."""
+        """-> (dy, lo) with dy in the activation dtype covering frames [lo, lo + dy.shape[0]), or (None, 0).  `self._last_masked`
+        says whether the returned gradient already carries the ReLU mask of `name`'s producer (a single, masked contribution)."""
         lst = self.grads.pop(name, None)
         self._last_masked = False
         if not lst:
             return None, 0
         tdt = ops.tdtype(dtype)
-        self._last_masked = len(lst) == 1 and id(lst[0][0]) in self._masked
-        for t, _l in lst:        # (ids are unique only while the tensors live in self.grads)
-            self._masked.discard(id(t))
-        lo = min(l for _, l in lst)
-        hi = max(l + t.shape[0] for t, l in lst)
+        self._last_masked = len(lst) == 1 and lst[0][2]
+        assert not any(m for _, _, m in lst) or len(lst) == 1, 'a masked gradient must be the only contribution to %r' % name
+        lo = min(l for _, l, _ in lst)
+        hi = max(l + t.shape[0] for t, l, _ in lst)
         if len(lst) == 1:
-            t, l = lst[0]
+            t, l, _ = lst[0]
             return (t if t.dtype == tdt else t.to(tdt)), l
         acc = None
-        for t, l in lst:
+        for t, l, _ in lst:
             if t.shape[0] == hi - lo and acc is None and t.dtype == tdt and not getattr(t, '_roi_acc', False):
                 acc = t.clone()
-                lst = [(a, b) for a, b in lst if a is not t]
+                lst = [e for e in lst if e[0] is not t]
                 break
         if acc is None:
             acc = torch.zeros((hi - lo,) + tuple(lst[0][0].shape[1:]), dtype=tdt, device=lst[0][0].device)
-        for t, l in lst:
+        for t, l, _ in lst:
             acc[l - lo:l - lo + t.shape[0]] += t if t.dtype == tdt else t.to(tdt)
         return acc, lo
 
@@ -252,7 +251,6 @@ class TrainExecutor(Executor):
     def backward(self, on_op_done=None):
         """on_op_done(i): called after the backward of op i (ops run from the last to the first) -- the Trainer's hook for finishing
         and exchanging gradient buckets while the backward of the earlier layers continues."""
-        self._masked.clear()
         for i in range(len(self.net.ops) - 1, -1, -1):
             op = self.net.ops[i]
             skip = (i in self._skip and i not in self._fused) or (op.outputs and all(o in self.no_grad for o in op.outputs))
@@ -314,6 +312,11 @@ class TrainExecutor(Executor):
             g = ops.relu_bias_bwd(dy, y.t[lo:lo + n], y.dt, cout, relu=need_relu, dbias=dbias)
         else:
             g = dy          # no ReLU to mask by, no trainable bias to reduce into (the shortcut convs: AffineChannelNd has no gradient)
+            # g ALIASES dy here (it may also be queued as the residual's gradient below): everything downstream reads whole channel
+            # strides, so the padding channels [cout, stride) must be zero -- they are when dy came out of a conv epilogue or
+            # relu_bias_bwd of a layer with cout == stride; make it so otherwise instead of trusting the producer
+            if cout != dy.shape[3]:
+                dy[..., cout:].zero_()
         if train_b:
             self._pgrad(train_b, dbias)
         if a['residual']:
@@ -355,7 +358,8 @@ class TrainExecutor(Executor):
             into = None
             pend = self.grads.get(op.inputs[0])
             if pend and len(pend) == 1:
-                t0, l0 = pend[0]
+                t0, l0, m0 = pend[0]
+                assert not m0, 'a ReLU-masked gradient is the ONLY contribution of its blob (one reader): nothing may be added into it'
                 if l0 == ilo and t0.shape[0] == ihi - ilo and t0.dtype == ops.tdtype(y.dt) and tuple(t0.shape[1:3]) == (H, W) and \
                         t0.is_contiguous() and not getattr(t0, '_roi_acc', False) and t0.shape[3] == ops.round_up(cg.cin, 64):
                     into = t0
@@ -561,7 +565,7 @@ class TrainExecutor(Executor):
         accs = []
         for n, f in zip(names, feats):
             acc = None
-            for t, _l in self.grads.get(n, []):
+            for t, _l, _m in self.grads.get(n, []):
                 if t.dtype == torch.float32 and getattr(t, '_roi_acc', False):
                     acc = t
             if acc is None:

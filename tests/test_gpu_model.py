@@ -410,16 +410,39 @@ def test_several_images_per_forward_give_each_image_its_own_results(kind, B, T, 
     """Round 3 (SURVEY §8d config 2 'new build may batch N=8'): B frames (2D R-50-FPN) / B clips (3D R-18 FPN3D)
     through ONE forward -- the N axis of the blobs, the image as a grid dimension of the proposal / detection kernels -- must give
     every image what it gets alone through im_detect_all (reference order of results, lib/core/test.py:897-957): the same
-    proposals (`rois` rows of image i, col 0 = i), detections and keypoints.  fp32 parity mode; the conv plans of the two batch
-    sizes may sum in a different order, hence a 1e-2 px tolerance on boxes instead of bit equality."""
+    proposals (`rois` rows of image i, col 0 = i), detections and keypoints.  fp32 parity mode.  ADVICE r3: the comparison is TIGHT --
+    with split-K forced off (`dat_conv3d_tune_plan(0, 1)`) every output position sums its K axis in the same order whatever the
+    batch size and tile shape, so an image's proposals, detections and keypoints in the batch must EQUAL the ones it gets alone
+    (a wrong im_info row or batch index on a minority of rois cannot hide in a tolerance); the planner's own split-K choice is
+    then checked at the looser, summation-order tolerance."""
     from detectandtrack_amd.core import test as engine
     from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.ops import hip_ops
     from tests.model_util import fpn2d_kps_cfg
     c = fpn2d_kps_cfg('50', dtype='fp32', pre=400, post=150) if kind == '2d' else fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=400, post=150)
     c['TEST'].update(SCALES=(H,), MAX_SIZE=max(H, W), SCORE_THRESH=0.0, DETECTIONS_PER_IM=20)
     model, ws, _ = build_product(c)
     rs = np.random.RandomState(11)
     ims = [[rs.randint(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(T)] for _ in range(B)]
+    # ---- pass 1: no split-K -> bit-equal per image
+    assert hip_ops.tune_plan(0, 1) == 0
+    try:
+        singles = []
+        for i in range(B):
+            cls_boxes, _, cls_keyps = engine.im_detect_all(model, ims[i], None)
+            singles.append((cls_boxes, cls_keyps, ws.FetchBlob('rois').copy()))
+        batch = engine.im_detect_all_batch(model, ims)
+        rois = ws.FetchBlob('rois')
+    finally:
+        hip_ops.tune_plan(0, 0)
+    for i in range(B):
+        rb = rois[rois[:, 0] == i]
+        np.testing.assert_array_equal(rb[:, 1:], singles[i][2][:, 1:], err_msg='proposals of image %d' % i)
+        np.testing.assert_array_equal(batch[i][0][1], singles[i][0][1], err_msg='detections of image %d' % i)
+        assert len(batch[i][2][1]) == len(singles[i][1][1])
+        for a, b in zip(batch[i][2][1], singles[i][1][1]):
+            np.testing.assert_array_equal(a, b, err_msg='keypoints of image %d' % i)
+    # ---- pass 2: the planner's own plans (split-K where it pays): same results up to the fp32 summation order
     singles = []
     for i in range(B):
         cls_boxes, _, cls_keyps = engine.im_detect_all(model, ims[i], None)

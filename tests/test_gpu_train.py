@@ -857,3 +857,34 @@ def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, o
         assert float(np.abs(a - ref).max()) <= tol, (n, float(np.abs(a - ref).max()), tol, step)
         moved += int(not n.startswith(('conv1', 'res2')) and step > 0)
     assert moved > 40           # the parameters above the StopGradient marker were really trained
+
+
+@pytest.mark.parametrize('dtype_name', ['bf16', 'fp32'])
+@pytest.mark.parametrize('shape', [(64, 128, (3, 3, 3), (1, 1)), (128, 64, (1, 3, 3), (2, 2)), (192, 256, (1, 1, 1), (1, 1))])
+def test_relu_mask_in_the_data_gradient_epilogue_is_bit_identical_to_the_separate_pass(ops, dtype_name, shape):
+    """ADVICE r3 (training.py FUSE_RELU_BWD): the data-gradient conv that applies the ReLU backward of its INPUT blob in its own
+    epilogue (`dat_conv3d_fwd` res_mode 3: dx = x > 0 ? dx : 0) must give bit for bit what the two-launch path gives -- the plain data
+    gradient followed by `dat_relu_bias_bwd` masking by x -- including zeros in the padding channels [cin, stride) that every
+    consumer of the gradient reads."""
+    cin, cout, k, stride = shape
+    dt = ops.BF16 if dtype_name == 'bf16' else ops.F32
+    tdt = ops.tdtype(dt)
+    T, H, W = 4, 14, 18
+    g_ = torch.Generator(device='cuda').manual_seed(cin * 7 + cout)
+    w = torch.randn((cout, cin) + k, device='cuda', generator=g_) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
+    scale = torch.rand(cout, device='cuda', generator=g_) + 0.5
+    pads = (k[0] // 2, k[1] // 2, k[2] // 2)
+    cs_in, cs_out = ops.round_up(cin, 64), ops.round_up(cout, 64)
+    Ho, Wo = (H + 2 * pads[1] - k[1]) // stride[0] + 1, (W + 2 * pads[2] - k[2]) // stride[1] + 1
+    x = torch.relu(torch.randn((T, H, W, cs_in), device='cuda', generator=g_)).to(tdt)       # the forward input: a ReLU output
+    x[..., cin:] = 0
+    g = torch.randn((T, Ho, Wo, cs_out), device='cuda', generator=g_).to(tdt)
+    g[..., cout:] = 0
+    cg = ops.ConvGrad(w, scale, stride, pads, dt, cs_in, cs_out)
+    plain = cg.data(g, T, H, W)
+    two = ops.relu_bias_bwd(plain, x, dt, cin, relu=True)
+    fused = cg.data(g, T, H, W, mask=x.contiguous())
+    assert fused.shape == two.shape == x.shape
+    assert torch.equal(fused, two)
+    assert float(fused[..., cin:].abs().max()) == 0.0 if cs_in > cin else True
+    assert (fused != 0).any() and ((x == 0) & (plain != 0)).any()            # the mask really removed something
