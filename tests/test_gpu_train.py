@@ -860,7 +860,7 @@ def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, o
 
 
 @pytest.mark.parametrize('dtype_name', ['bf16', 'fp32'])
-@pytest.mark.parametrize('shape', [(64, 128, (3, 3, 3), (1, 1)), (128, 64, (1, 3, 3), (2, 2)), (192, 256, (1, 1, 1), (1, 1))])
+@pytest.mark.parametrize('shape', [(64, 128, (3, 3, 3), (1, 1)), (128, 64, (1, 3, 3), (2, 2)), (200, 256, (1, 1, 1), (1, 1))])
 def test_relu_mask_in_the_data_gradient_epilogue_is_bit_identical_to_the_separate_pass(ops, dtype_name, shape):
     """ADVICE r3 (training.py FUSE_RELU_BWD): the data-gradient conv that applies the ReLU backward of its INPUT blob in its own
     epilogue (`dat_conv3d_fwd` res_mode 3: dx = x > 0 ? dx : 0) must give bit for bit what the two-launch path gives -- the plain data
