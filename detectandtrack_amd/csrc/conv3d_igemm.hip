@@ -611,6 +611,16 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                 }
             } else {
                 *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                if (ODT == DAT_F32 && DT == DAT_BF16 && p.y_split) {
+                    // the same values as hi / lo bf16 halves for the next bf16x3 conv (bit-identical to dat_split_bf16x2 of the stored y):
+                    // 64-channel chunk q of the pixel: line 2q = hi, line 2q + 1 = lo; this lane's 4 channels = 8 bytes in each line
+                    const uint32_t h0 = f2bf2(v[0], v[1]), h1 = f2bf2(v[2], v[3]);
+                    const uint32_t l0 = f2bf2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                    const uint32_t l1 = f2bf2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                    char* sp = p.y_split + ((tile_pos + lpos) * (size_t)(2 * p.out_cs) + (size_t)((c_st >> 6) * 128 + (c_st & 63))) * 2;
+                    *(uint2*)sp = make_uint2(h0, h1);
+                    *(uint2*)(sp + 128) = make_uint2(l0, l1);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -634,7 +644,7 @@ template <int DT>
 __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit, size_t npos, int Cout, int out_cs,
                                      const float* __restrict__ scale, const float* __restrict__ bias,
                                      const char* __restrict__ res, int res_mode, int frames, int Ho, int Wo, int relu,
-                                     char* __restrict__ y) {
+                                     char* __restrict__ y, char* __restrict__ y_split = nullptr) {
     const int c4 = Cout >> 2;
     const size_t total = npos * c4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -675,6 +685,14 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
             *(uint2*)(y + (opos * out_cs + c) * 2) = o;
         } else {
             *(float4*)(y + (opos * out_cs + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            if (y_split) {   // (bf16x3 mode: the hi / lo split of the same values, see the conv kernel's epilogue)
+                const uint32_t h0 = f2bf2(v[0], v[1]), h1 = f2bf2(v[2], v[3]);
+                const uint32_t l0 = f2bf2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = f2bf2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                char* sp = y_split + (opos * (size_t)(2 * out_cs) + (size_t)((c >> 6) * 128 + (c & 63))) * 2;
+                *(uint2*)sp = make_uint2(h0, h1);
+                *(uint2*)(sp + 128) = make_uint2(l0, l1);
+            }
         }
     }
 }
@@ -874,7 +892,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         const size_t tot = npos * (p.Cout >> 2);
         const int blocks = (int)std::min<size_t>((tot + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(splitk_finish_kernel<ODT>, dim3(blocks), dim3(256), 0, st, (const float*)p.part, p.ksplit, npos, p.Cout,
-                           p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y);
+                           p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y, ODT == DAT_F32 && DT == DAT_BF16 ? p.y_split : nullptr);
     }
     DAT_CHECK_LAUNCH(ctx, "conv3d_igemm");
     return DAT_OK;
@@ -904,8 +922,24 @@ double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
     return 2.0 * Cout_real * Cin_real * d->KT * d->KH * d->KW * oframes * Ho * Wo;
 }
 
+static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                           const float* scale, const float* bias, const void* residual, void* y, void* y_split);
+
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
                    const float* scale, const float* bias, const void* residual, void* y) {
+    return conv3d_fwd_impl(ctx, s, d, x, w_packed, scale, bias, residual, y, nullptr);
+}
+
+int dat_conv3d_fwd_x3(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x_split, const void* w_packed,
+                      const float* scale, const float* bias, const void* residual, void* y, void* y_split) {
+    DAT_ENFORCE(ctx, d && d->dtype == DAT_BF16X3, "conv3d_fwd_x3: the descriptor's dtype must be DAT_BF16X3");
+    DAT_ENFORCE(ctx, !y_split || (d->out_cstride % 64 == 0 && d->Cout == d->out_cstride),
+                "conv3d_fwd_x3: a split output needs Cout == out_cstride, a multiple of 64 (got %d / %d)", d->Cout, d->out_cstride);
+    return conv3d_fwd_impl(ctx, s, d, x_split, w_packed, scale, bias, residual, y, y_split);
+}
+
+static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                           const float* scale, const float* bias, const void* residual, void* y, void* y_split) {
     DAT_ENFORCE(ctx, d && x && w_packed && y, "conv3d_fwd: null argument");
     DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16 || d->dtype == DAT_BF16X3, "conv3d_fwd: bad dtype %d", d->dtype);
     const bool x3 = d->dtype == DAT_BF16X3;
@@ -924,7 +958,7 @@ int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const voi
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
-    p.res = (const char*)residual; p.y = (char*)y;
+    p.res = (const char*)residual; p.y = (char*)y; p.y_split = (char*)y_split;
     p.zeros = (const char*)ctx->zeros;
     p.clk = ctx->prof_enabled ? (unsigned long long*)((char*)ctx->zeros + 256) : nullptr;
     p.in_lo = d->in_tn > 0 ? d->in_t0 : 0;

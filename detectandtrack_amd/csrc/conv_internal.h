@@ -31,6 +31,8 @@ struct ConvParams {
     const float* bias;
     const char* res;
     char* y;
+    char* y_split;              // bf16x3 mode only (ODT fp32): also write the hi / lo bf16 split of y (pixel pitch 2 * out_cs bf16, dat_split_bf16x2's layout) -- the
+                                // next conv then needs no split pre-pass; NULL = off
     unsigned long long* dbg;    // DAT_CONV_TRACE builds only: per-phase cycle sums
     unsigned long long* clk;    // profiling only (dat_prof_enable): [0] += shader cycles, [1] += 100-MHz ticks per block
     const char* zeros;          // >= 16 zero bytes (what a halo lane of the patch LDS-DMA fetches)

@@ -259,7 +259,8 @@ class ConvLayer(object):
             b += oframes * (ho // 2) * (wo // 2) * self.cstride * es
         return float(b)
 
-    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None, zero_pad=True):
+    def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None, zero_pad=True,
+                 want_split=False):
         """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored.
         x_split (bf16x3 layers): the hi / lo split of `x` when the caller already has it (a blob read by several convs is split once)."""
         frames, H, W, cin = x.shape
@@ -276,9 +277,19 @@ class ConvLayer(object):
             # (RPN head -> proposal kernels, cls_score / bbox_pred -> softmax / box decode, the deconv -> kps_finalize) -- no fill launch
             alloc = torch.zeros if (self.cstride != self.cout and zero_pad) else torch.empty
             out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
-        xin = (x_split if x_split is not None else split_bf16x2(x)) if self.x3 else x
-        ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(xin), _ptr(self.packed), _ptr(self.scale),
-                   _ptr(self.bias), _ptr(residual), _ptr(out))
+        if not self.x3:
+            ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
+                       _ptr(self.bias), _ptr(residual), _ptr(out))
+            return out
+        # bf16x3: the conv reads the hi / lo split of x; want_split: its epilogue also writes the split of ITS output (out._split) for the
+        # convs that read it -- no pre-pass for them (dat_conv3d_fwd_x3; needs an unpadded channel stride)
+        xin = x_split if x_split is not None else split_bf16x2(x)
+        ysplit = None
+        if want_split and self.cstride == self.cout and self.cstride % 64 == 0:
+            ysplit = torch.empty(tuple(out.shape[:-1]) + (2 * self.cstride,), dtype=torch.bfloat16, device=out.device)
+        ctx().call('dat_conv3d_fwd_x3', _stream(), C.byref(d), _ptr(xin), _ptr(self.packed), _ptr(self.scale),
+                   _ptr(self.bias), _ptr(residual), _ptr(out), _ptr(ysplit))
+        out._split = ysplit
         return out
 
 

@@ -435,8 +435,10 @@ class Executor(object):
         assert xin.keyframe is None or a['kernels'][0] == 1, 'temporal conv on a key-frame-only blob'
         self._log_conv(op.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
                        res_mode=(a['res_mode'] or 1) if res is not None else 0)
-        y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'], x_split=self._split_of(xin, layer))
+        y = layer(xin.t, T=xin.T, residual=res, res_mode=a['res_mode'], x_split=self._split_of(xin, layer),
+                  want_split=layer.x3 and self._read_by_a_conv(op.outputs[0]))
         b = Blob(y, 'fmap', xin.N, xin.T, a['dim_out'], dt, xin.five_d)
+        b.split = getattr(y, '_split', None)      # (bf16x3: written by this conv's epilogue for the convs that read the blob)
         b.keyframe = xin.keyframe
         b.count = xin.count   # per-RoI heads (ResNet3D.py:301-327): the live RoI count travels with the features
         ws.blobs[op.outputs[0]] = b
@@ -452,6 +454,15 @@ class Executor(object):
             readers = [op for net in list(self.ws.nets.values()) + [self.net] for op in net.ops
                        if name in op.inputs or (isinstance(op.args, dict) and op.args.get('residual') == name)]
             hit = self.ws._layers[key] = all(op.type in self._PAD_BLIND for op in readers)
+        return hit
+
+    def _read_by_a_conv(self, name):
+        """Does any op of a registered net read `name` through a conv-type kernel (Conv / FC / ConvTranspose input)?"""
+        key = ('conv_reader', self.net.name, name)
+        hit = self.ws._layers.get(key)
+        if hit is None:
+            hit = self.ws._layers[key] = any(o.type in ('Conv', 'FC', 'ConvTranspose') and o.inputs and o.inputs[0] == name
+                                             for net in list(self.ws.nets.values()) + [self.net] for o in net.ops)
         return hit
 
     @staticmethod

@@ -135,6 +135,12 @@ int dat_conv3d_pack_weights_batch(dat_ctx* ctx, dat_stream s, const dat_pack_ite
  * scale/bias: fp32 [Cout].  residual: same dtype/stride as y. */
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
                    const float* scale, const float* bias, const void* residual, void* y);
+/* bf16x3 mode (d->dtype == DAT_BF16X3) with the operand split fused into the producer: the same launch also writes the
+ * hi / lo bf16 split of y (dat_split_bf16x2's layout, pixel pitch 2 * out_cstride) into y_split, bit-identical to
+ * dat_split_bf16x2(y) -- the next conv reads it without a split pre-pass.  y_split may be NULL (then == dat_conv3d_fwd);
+ * needs Cout == out_cstride, a multiple of 64. */
+int dat_conv3d_fwd_x3(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x_split, const void* w_packed,
+                      const float* scale, const float* bias, const void* residual, void* y, void* y_split);
 /* algorithmic FLOPs of one launch: 2*Cout*Cin*KT*KH*KW*frames*Ho*Wo */
 double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real);
 

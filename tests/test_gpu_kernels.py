@@ -144,6 +144,19 @@ def test_conv3d(ops, case, dtype):
     elif res_mode == 2:
         rd = ops.to_ndhwc(_dev(res_small), dtype, layer.cstride)
     y = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    if x3 and layer.cstride == layer.cout:
+        # the split of the OUTPUT written by the same launch (dat_conv3d_fwd_x3) is bit for bit dat_split_bf16x2 of the stored output --
+        # under the planner's plan and under a forced split-K plan (the finish kernel writes it then)
+        for plan in ((0, 0), (128, 2)):
+            try:
+                assert ops.tune_plan(*plan) == 0
+                y2 = layer(xd, T=T, residual=rd, res_mode=res_mode, want_split=True)
+            finally:
+                ops.tune_plan(0, 0)
+            assert y2._split is not None and y2._split.shape[-1] == 2 * layer.cstride
+            assert torch.equal(y2._split, ops.split_bf16x2(y2)), (name, plan)
+            if plan == (0, 0):
+                assert torch.equal(y2, y)
     got = ops.to_ncdhw(y, dtype, N, Cout, T).cpu().numpy()
     err = np.abs(got - ref).max()
     tol = (5e-4 if x3 else 2e-4) if dtype == 0 else 3e-2 * max(1.0, np.abs(ref).max() / 4)
