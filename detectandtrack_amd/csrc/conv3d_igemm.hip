@@ -267,7 +267,9 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
             for (int ks = 0; ks < 4; ++ks) wa[i][ks] = *(const uint4*)(wcur + i * 4096 + ks * 1024 + lane16);
         const int npat = pi_hi - pi_lo;
         for (int pi = 0; pi < npat; ++pi) {
-            if (!((p.ablate & 1) && pi > 0)) {
+            // (bf16x3: chunk 3q + 1 reads the SAME source line as chunk 3q -- x_hi against W_lo after x_hi against W_hi -- so the patch
+            //  that is in LDS is the one it needs: no reload, no barriers)
+            if (!((p.ablate & 1) && pi > 0) && !(p.x3 && pi > 0 && cc % 3 == 1)) {
                 __syncthreads();                               // all waves finished reading the previous patch
                 const int fin = f_in + kt - p.pt;
                 const char* xbase = p.x + ((size_t)fin * p.H * p.W) * p.Cin * ES + (size_t)(p.x3 ? (cc / 3) * 2 + (cc % 3 == 2) : cc) * CK * ES;
@@ -364,7 +366,9 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
 #define TR_ADD(ACC_)
 #endif
         for (int step = 0; step < total; ++step) {
-            if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0) && !(p.ablate & 8)) {
+            // (bf16x3, one stride plane: chunk 3q + 1 re-uses the patch of chunk 3q, see the unrolled variant)
+            const bool x3_same = p.x3 && p.tab_new == 1u && step > 0 && cc % 3 == 1;
+            if (((p.tab_new >> ti) & 1u) && !((p.ablate & 1) && step > 0) && !(p.ablate & 8) && !x3_same) {
                 __syncthreads();  // all waves finished reading the previous patch
                 // ---- stage the input patch (tile + halo) of (kt, cc, plane): global -> LDS by LDS-DMA, every piece of
                 // the patch in flight at once (no staging registers, no ds_write pass).  Lane (row, phys slot) fetches the
