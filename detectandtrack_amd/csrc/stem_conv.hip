@@ -248,8 +248,10 @@ struct StemPoolParams {
     int sb_off;
 };
 
+// (occupancy window 3..4 waves per SIMD: round 4's same-box A/B at the 4-clip forward -- 2..2: 547 us, 2..3: 464-467, 3..4 / 4..4 / 4..5:
+//  444-446; four blocks per CU is what the 34 KB of LDS per block allow)
 template <int DT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void stem_pool_kernel(const StemPoolParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void stem_pool_kernel(const StemPoolParams p) {
     typedef typename ElemOf<DT>::type E;
     constexpr int ES = ElemOf<DT>::size;
     constexpr int KV = StemCfg<DT>::KV, KPAD = StemCfg<DT>::KPAD;
