@@ -112,6 +112,18 @@ template <> struct ElemOf<DAT_BF16> {
     __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
 };
 
+// element `i` of a small by-value kernel-argument array, chosen with an unrolled compare-and-select: indexing such an array with a
+// run-time `i` makes the compiler copy the whole argument struct to scratch memory first (det_select / det_limit_emit / nms_mask /
+// rpn_select_sort_decode each carried 216-272 bytes of scratch per lane for it)
+template <typename T, int N>
+__device__ __forceinline__ T dat_pick(const T (&a)[N], int i) {
+    T r = a[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k)
+        if (i == k) r = a[k];
+    return r;
+}
+
 // grow the ctx-owned scratch (synchronises + reallocates only when it must grow); defined in c_api.hip
 int dat_ensure_ws(dat_ctx* ctx, size_t bytes);
 

@@ -39,16 +39,21 @@ struct DetParams {
 };
 
 // one tube of class j for roi r: boxes.py:141-183 per frame, then clip (:243-253)
+// (TM: compile-time bound of the tube length -- 1 keeps the box in registers, the general instantiation's array lives in scratch;
+//  see proposals.hip decode_tube)
+template <int TM>
 __device__ void decode_tube(const DetParams& p, int img, int r, int j, float* out) {
-    const int cols = 4 * p.T + 1;
-    const float im_w = p.im_w[img], im_h = p.im_h[img];
+    const int PT = TM == 1 ? 1 : p.T;
+    const int cols = 4 * PT + 1;
+    const float im_w = dat_pick(p.im_w, img), im_h = dat_pick(p.im_h, img);
     const int dcls = p.cls_agnostic ? (p.K - 1) : j;       // CLS_AGNOSTIC_BBOX_REG: the last 4T columns (test.py:224-225)
-    for (int t = 0; t < p.T; ++t) {
+#pragma unroll
+    for (int t = 0; t < (TM == 1 ? 1 : PT); ++t) {
         const float* rb = p.rois + (size_t)r * cols + 1 + 4 * t;
         // `rois[:, 1:] / im_scales[0]`: float32 / float32(scale) under the reference environment's NumPy 1.14 casting
-        const float sc = (float)p.im_scale[img];
+        const float sc = (float)dat_pick(p.im_scale, img);
         const float x1 = rb[0] / sc, y1 = rb[1] / sc, x2 = rb[2] / sc, y2 = rb[3] / sc;
-        const float* d = p.pred + (size_t)r * p.pred_ld + ((size_t)dcls * p.T + t) * 4;
+        const float* d = p.pred + (size_t)r * p.pred_ld + ((size_t)dcls * PT + t) * 4;
         const float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
         const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
         const float dx = d[0] / p.wx, dy = d[1] / p.wy;
@@ -82,11 +87,13 @@ __device__ unsigned block_scan(unsigned v, unsigned* scan, unsigned* total) {
 }
 
 // ---- per class: inds = where(scores[:, j] > thresh); dets_j = [decoded boxes[inds], scores[inds]]  (test.py:759-762), in roi order
+template <int TM>
 __global__ __launch_bounds__(SEL_THREADS) void det_select_kernel(const DetParams p, int j, float* dets, int* n_sel) {
     __shared__ unsigned scan[SEL_THREADS];
     const int img = blockIdx.x;
     const int n = min(p.n_rois[img], p.roi_cap);
-    const int cols = 4 * p.T + 1;
+    const int PT = TM == 1 ? 1 : p.T;
+    const int cols = 4 * PT + 1;
     const int per = (n + SEL_THREADS - 1) / SEL_THREADS;
     const int r0 = img * p.roi_cap;              // this image's first row
     const int lo = r0 + threadIdx.x * per, hi = min(r0 + n, lo + per);
@@ -96,14 +103,15 @@ __global__ __launch_bounds__(SEL_THREADS) void det_select_kernel(const DetParams
     for (int r = lo; r < hi; ++r) local += p.prob[(size_t)r * p.prob_ld + j] > p.score_thresh ? 1u : 0u;
     unsigned total;
     unsigned pos = block_scan(local, scan, &total);
-    float tube[4 * DET_MAX_T];
+    float tube[4 * TM];
     for (int r = lo; r < hi; ++r) {
         const float sc = p.prob[(size_t)r * p.prob_ld + j];
         if (sc > p.score_thresh) {
-            decode_tube(p, img, r, j, tube);
+            decode_tube<TM>(p, img, r, j, tube);
             float* o = dets + (size_t)pos * cols;
-            for (int c = 0; c < 4 * p.T; ++c) o[c] = tube[c];
-            o[4 * p.T] = sc;
+#pragma unroll
+            for (int c = 0; c < (TM == 1 ? 4 : 4 * PT); ++c) o[c] = tube[c];
+            o[4 * PT] = sc;
             ++pos;
         }
     }
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(SEL_THREADS) void det_limit_emit_kernel(const EmitP
         p.kp_rois += (size_t)img * p.out_cap * (4 * p.T + 1);
         p.n_out += 2 * img;
     }
-    const double im_scale = p.im_scale[img];
+    const double im_scale = dat_pick(pin.im_scale, img);
     __shared__ unsigned scan[SEL_THREADS];
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
@@ -271,7 +279,8 @@ int dat_box_results_batch(dat_ctx* ctx, dat_stream s, const float* rois, const i
     const unsigned ni = (unsigned)n_images;
     for (int c = 0; c < nc; ++c) {
         float* dets_c = dets + (size_t)c * roi_cap * cols;
-        hipLaunchKernelGGL(det_select_kernel, dim3(ni), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
+        if (p.T == 1) hipLaunchKernelGGL(det_select_kernel<1>, dim3(ni), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
+        else hipLaunchKernelGGL(det_select_kernel<DET_MAX_T>, dim3(ni), dim3(SEL_THREADS), 0, st, p, c + 1, dets_c, n_sel + c);
         int rc = dat_nms_impl_batch(ctx, st, nms_ws, img_ws, dets_c, img_ws / 4, 0, n_sel + c, (int)(img_ws / 4), roi_cap, T, d->nms_thresh,
                                     0, 0, keep + (size_t)c * roi_cap, (int)(img_ws / 4), n_keep + c, (int)(img_ws / 4), n_images);
         if (rc != DAT_OK) return rc;
