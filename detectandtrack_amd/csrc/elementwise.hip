@@ -1,6 +1,7 @@
 // HBM-bound elementwise / layout kernels of the hot path (gfx950).
 // Each is one pass: read-once + write-once of the logical tensor; 16-byte accesses where the layout allows.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "dat_common.h"
 
@@ -230,6 +231,70 @@ __global__ void kps_finalize_kernel(const void* __restrict__ sub, int R, int Tr,
     }
 }
 
+// The same op with one block per output MAP (roi, frame, keypoint): kps_finalize_kernel spends its time on index arithmetic -- six
+// 64-bit divisions and a strided gather per OUTPUT element (21 M of them per 4-clip forward: 200 us for 85 MB written, ~5x its HBM
+// time).  Here a block unfolds the map's four sub-pixel channels into LDS as the low-resolution map [2S][2S] (fp32); thread
+// (ox, row group) then walks its output column with the x taps fixed, rows in a loop without a division, and the block's ng x M threads
+// store ng complete output rows per step.  Same taps, same order, same fp32 expressions: bit-identical to kps_finalize_kernel.
+template <int DT>
+__global__ void kps_finalize_tile_kernel(const void* __restrict__ sub, int S, int cs, int K, int up, float* __restrict__ out) {
+    extern __shared__ float low[];                 // [L][L]
+    const int L = 2 * S, M = L * up;
+    const int ksz = 2 * up, pad = up / 2;
+    const float factor = (float)((ksz + 1) / 2);
+    const float center = (ksz % 2 == 1) ? factor - 1.f : factor - 0.5f;
+    const int fr = blockIdx.x / K, k = blockIdx.x - fr * K;      // fr = r * Tr + t; output channel t * K + k of roi r = map fr * K + k
+    for (int i = threadIdx.x; i < S * S * 4; i += blockDim.x) {
+        const int cell = i >> 2, ab = i & 3;
+        const int ys = cell / S, xs = cell - ys * S;
+        low[(2 * ys + (ab >> 1)) * L + 2 * xs + (ab & 1)] = ElemOf<DT>::ld(sub, ((size_t)fr * S * S + cell) * cs + ab * K + k);
+    }
+    __syncthreads();
+    const int ox = threadIdx.x % M, og = threadIdx.x / M, ng = blockDim.x / M;     // blockDim = ng * M
+    const int x_hi = (ox + pad) / up;
+    float* const obase = out + (size_t)blockIdx.x * M * M;
+    if (up == 2) {
+        // the configuration every model uses (KRCNN.UP_SCALE 2): exactly two taps per axis -- x_hi, x_hi - 1 -- visited in the general
+        // loop's order; the tap weights of the column are computed once per thread
+        const int xa = x_hi, xb = x_hi - 1;
+        const bool vxa = xa < L, vxb = xb >= 0;
+        const float fxa = 1.f - fabsf((float)(ox + pad - up * xa) - center) / factor;
+        const float fxb = 1.f - fabsf((float)(ox + pad - up * xb) - center) / factor;
+        for (int oy = og; oy < M; oy += ng) {
+            const int ya = (oy + pad) / up, yb = ya - 1;
+            const float fya = 1.f - fabsf((float)(oy + pad - up * ya) - center) / factor;
+            const float fyb = 1.f - fabsf((float)(oy + pad - up * yb) - center) / factor;
+            float acc = 0.f;
+            if (ya < L) {
+                if (vxa) acc += low[ya * L + xa] * (fya * fxa);
+                if (vxb) acc += low[ya * L + xb] * (fya * fxb);
+            }
+            if (yb >= 0) {
+                if (vxa) acc += low[yb * L + xa] * (fyb * fxa);
+                if (vxb) acc += low[yb * L + xb] * (fyb * fxb);
+            }
+            obase[(size_t)oy * M + ox] = acc;
+        }
+        return;
+    }
+    for (int oy = og; oy < M; oy += ng) {
+        const int y_hi = (oy + pad) / up;
+        float acc = 0.f;
+        for (int y = y_hi; y >= 0 && oy + pad - up * y < ksz; --y) {
+            if (y >= L) continue;
+            const int ky = oy + pad - up * y;
+            const float fy = 1.f - fabsf((float)ky - center) / factor;
+            for (int x = x_hi; x >= 0 && ox + pad - up * x < ksz; --x) {
+                if (x >= L) continue;
+                const int kx = ox + pad - up * x;
+                const float fx = 1.f - fabsf((float)kx - center) / factor;
+                acc += low[y * L + x] * (fy * fx);
+            }
+        }
+        obase[(size_t)oy * M + ox] = acc;
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_DT(dtype, KERNEL, grid, block, st, ...)                                                  \
@@ -364,7 +429,19 @@ int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int
     DAT_ENFORCE(ctx, sub && out && up >= 2 && up % 2 == 0, "kps_finalize: up_scale must be even (detector.py:354), got %d", up);
     if (R == 0) return DAT_OK;
     const size_t total = (size_t)R * Tr * K * (2 * S * up) * (2 * S * up);
-    DISPATCH_DT(dtype, kps_finalize_kernel, dim3(grid_for(total)), dim3(TPB), (hipStream_t)s, sub, R, Tr, S, cs, K, up, out);
+    const int M = 2 * S * up;
+    const size_t lds = (size_t)(2 * S) * (2 * S) * sizeof(float);
+    static const bool tile_off = getenv("DAT_KPS_FINALIZE_TILE") && atoi(getenv("DAT_KPS_FINALIZE_TILE")) == 0;   // (A/B switch)
+    if (!tile_off && M <= 256 && lds <= 48 * 1024 && 4 * K <= cs && (long long)R * Tr * K < (1ll << 31) && (long long)R * Tr * K >= 1024) {   // (small jobs: the per-element kernel has more threads)
+        // one block per output map: ng * M threads, ng output rows per step
+        const int ng = std::max(1, std::min(4, 256 / M));
+        if (dtype == DAT_BF16)
+            hipLaunchKernelGGL((kps_finalize_tile_kernel<DAT_BF16>), dim3((unsigned)(R * Tr * K)), dim3(ng * M), lds, (hipStream_t)s, sub, S, cs, K, up, out);
+        else
+            hipLaunchKernelGGL((kps_finalize_tile_kernel<DAT_F32>), dim3((unsigned)(R * Tr * K)), dim3(ng * M), lds, (hipStream_t)s, sub, S, cs, K, up, out);
+    } else {
+        DISPATCH_DT(dtype, kps_finalize_kernel, dim3(grid_for(total)), dim3(TPB), (hipStream_t)s, sub, R, Tr, S, cs, K, up, out);
+    }
     DAT_CHECK_LAUNCH(ctx, "kps_finalize");
     return DAT_OK;
 }
