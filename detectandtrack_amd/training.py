@@ -15,6 +15,7 @@ Gradient semantics follow the reference's ops: AffineChannelNd has no scale/bias
 constants (no gradient through GenerateProposals), biases get 2x gradient and no weight decay (:968-974).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -844,7 +845,9 @@ class Trainer(object):
         ex = TrainExecutor(ws, self.model.net, arena=self.arena, gt_arena=self.gt_arena)
         ex.accumulate_all = not zero_grad
         ex.run()
-        multi = self.dist is not None and self.dist.get_world_size() > 1 and update
+        # (DAT_FORCE_EXCHANGE=1: run the exchange machinery with ONE rank too -- a sum over one rank is the identity -- so that the RCCL path,
+        #  its communication stream and events can be exercised on a one-GPU box: tests/test_gpu_train.py, bench.py --mode train)
+        multi = self.dist is not None and update and (self.dist.get_world_size() > 1 or os.environ.get('DAT_FORCE_EXCHANGE', '0') == '1')
         if multi:
             # every rank reduces the same flat buffer: a parameter without a gradient on this rank contributes its zeros
             xch = self._exchange()
