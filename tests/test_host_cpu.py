@@ -816,6 +816,9 @@ def test_own_configs_load_and_build():
         train = os.path.basename(f).startswith('train_')
         m = model_builder.create(cfg.MODEL.TYPE, train=train)
         assert len(m.net.ops) > 40 and (train or m.keypoint_net is not None), f
+        # what tools/train_net.py asserts before it builds anything (round 4: the shipped training configs inherited the default 2 and
+        # the README's own command line failed)
+        assert not train or cfg.TRAIN.IMS_PER_BATCH == 1, f
         assert cfg.TEST.RPN_PRE_NMS_TOP_N <= 4096 or train
     reset_cfg()
 
