@@ -40,34 +40,65 @@ __device__ __forceinline__ void src_coord(int d, double inv_scale, int n, bool s
     *t = tt;
 }
 
+// One thread = PX horizontally adjacent output pixels (round 4): the one-pixel-per-thread form launched 147 k blocks whose threads
+// each waited out one round of twelve single-byte loads before three 4-byte stores (0.54 ms for a 4-clip batch, 0.9 TB/s of its
+// 484 MB); with four pixels the 48 loads of a thread are in flight together and every plane receives one 16-byte store.  The
+// per-pixel arithmetic is untouched (bit-identical output).
+constexpr int PX = 8;
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int xb = (blockIdx.x * 256 + threadIdx.x) * PX;
     const int y = blockIdx.y;
     const int f = blockIdx.z;
-    if (x >= p.pw) return;
+    if (xb >= p.pw) return;
     const int n = f / p.T, t = f - n * p.T;
     const size_t plane = (size_t)p.ph * p.pw;
-    float* out = p.data + (((size_t)n * 3) * p.T + t) * plane + (size_t)y * p.pw + x;
+    float* out = p.data + (((size_t)n * 3) * p.T + t) * plane + (size_t)y * p.pw + xb;
     const size_t cstep = (size_t)p.T * plane;
-    if (x >= p.ow || y >= p.oh) {              // zero padding up to the stride multiple (blob.py:47-55)
-        out[0] = 0.f; out[cstep] = 0.f; out[2 * cstep] = 0.f;
-        return;
-    }
-    int x0, x1, y0, y1;
-    float tx, ty;
-    src_coord(x, p.inv_fx, p.w, true, &x0, &x1, &tx);
-    src_coord(y, p.inv_fy, p.h, false, &y0, &y1, &ty);
+    float v[3][PX];
+    const bool row_live = y < p.oh;
+    int y0 = 0, y1 = 0;
+    float ty = 0.f;
+    if (row_live) src_coord(y, p.inv_fy, p.h, false, &y0, &y1, &ty);
     const uint8_t* fr = p.frames + (size_t)f * p.h * p.w * 3;
     const uint8_t* r0 = fr + (size_t)y0 * p.w * 3;
     const uint8_t* r1 = fr + (size_t)y1 * p.w * 3;
-    const float ux = 1.f - tx, uy = 1.f - ty;
+    const float uy = 1.f - ty;
+    // ---- all loads first (clamped addresses: unconditional, independent) ----
+    int x0[PX], x1[PX];
+    float tx[PX];
+    uint8_t q[PX][4][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float a00 = (float)((double)r0[x0 * 3 + c] - p.mean[c]), a01 = (float)((double)r0[x1 * 3 + c] - p.mean[c]);
-        const float a10 = (float)((double)r1[x0 * 3 + c] - p.mean[c]), a11 = (float)((double)r1[x1 * 3 + c] - p.mean[c]);
-        const float top = a00 * ux + a01 * tx;      // horizontal pass (two rounded products, one rounded sum)
-        const float bot = a10 * ux + a11 * tx;
-        out[c * cstep] = top * uy + bot * ty;       // vertical blend
+    for (int i = 0; i < PX; ++i) {
+        const int x = min(xb + i, p.ow - 1);          // (columns in the padding are computed on a clamped x and overwritten with 0 below)
+        src_coord(x, p.inv_fx, p.w, true, &x0[i], &x1[i], &tx[i]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            q[i][0][c] = r0[x0[i] * 3 + c]; q[i][1][c] = r0[x1[i] * 3 + c];
+            q[i][2][c] = r1[x0[i] * 3 + c]; q[i][3][c] = r1[x1[i] * 3 + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const float ux = 1.f - tx[i];
+        const bool live = row_live && xb + i < p.ow;   // else: zero padding up to the stride multiple (blob.py:47-55)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a00 = (float)((double)q[i][0][c] - p.mean[c]), a01 = (float)((double)q[i][1][c] - p.mean[c]);
+            const float a10 = (float)((double)q[i][2][c] - p.mean[c]), a11 = (float)((double)q[i][3][c] - p.mean[c]);
+            const float top = a00 * ux + a01 * tx[i];      // horizontal pass (two rounded products, one rounded sum)
+            const float bot = a10 * ux + a11 * tx[i];
+            v[c][i] = live ? top * uy + bot * ty : 0.f;    // vertical blend
+        }
+    }
+    if (xb + PX <= p.pw && (p.pw & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < PX; i += 4) *(float4*)(out + c * cstep + i) = make_float4(v[c][i], v[c][i + 1], v[c][i + 2], v[c][i + 3]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            for (int i = 0; i < PX && xb + i < p.pw; ++i) out[c * cstep + i] = v[c][i];
     }
 }
 
@@ -86,7 +117,7 @@ int dat_preprocess_frames(dat_ctx* ctx, dat_stream s, const unsigned char* frame
     p.frames = frames; p.data = data; p.F = n_frames; p.T = T; p.h = h; p.w = w; p.oh = out_h; p.ow = out_w; p.ph = pad_h; p.pw = pad_w;
     p.inv_fx = 1.0 / fx; p.inv_fy = 1.0 / fy;
     for (int c = 0; c < 3; ++c) p.mean[c] = pixel_means[c];
-    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((pad_w + 255) / 256), (unsigned)pad_h, (unsigned)n_frames), dim3(256), 0,
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((pad_w + 256 * PX - 1) / (256 * PX)), (unsigned)pad_h, (unsigned)n_frames), dim3(256), 0,
                        (hipStream_t)s, p);
     DAT_CHECK_LAUNCH(ctx, "preprocess_frames");
     return DAT_OK;
