@@ -52,7 +52,7 @@ def _check_against_oracle(model, ws, weights, net, pyr, im_info, n_kp, blob_name
     from detectandtrack_amd.utils.precision import set_agreement
     agree = set_agreement(rois[:, 1:], ref_rois[:, 1:], 0.05)
     print('rois: %d, %.2f%% of the device rois are in the oracle set (0.05 px)' % (rois.shape[0], 100 * agree))
-    assert agree > 0.95
+    assert agree >= 0.995       # (measured: 100.00 % in every fp32 / bf16x3 run of rounds 3-4; 0.95 was the gate until round 4)
     # box head + keypoint head on the DEVICE rois (oracle features, oracle heads)
     sub = rois[:200].copy()
     sub[:, 0] = 0                                   # the oracle sees this image as image 0
@@ -305,7 +305,7 @@ def test_2d_r50_fpn_eight_frames_in_one_forward_match_the_oracle_frame_by_frame(
         assert rois.shape == ref_rois.shape, (i, rois.shape, ref_rois.shape)
         agree = set_agreement(rois[:, 1:], ref_rois[:, 1:], 0.05)
         print('frame %d: %d rois, %.2f%% in the oracle set' % (i, rois.shape[0], 100 * agree))
-        assert agree > 0.95
+        assert agree >= 0.995       # (measured: 100.00 % in every fp32 / bf16x3 run of rounds 3-4; 0.95 was the gate until round 4)
         sub = rois[:100].copy()
         sub[:, 0] = 0                                                         # the oracle sees this frame as image 0
         _, per_level, restore = op.distribute(sub, 2, 5)
