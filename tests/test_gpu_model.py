@@ -592,3 +592,49 @@ def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypa
     assert pipe.graphs_captured == 3 and pipe.graphs_evicted == 1 and len(pipe.slots[0].graphs) == 2
     same(run([small[0]])[0], ref_small[0])
     assert pipe.graphs_captured == 3
+
+
+def test_pipeline_graphs_that_read_resident_inputs_in_place():
+    """`ClipPipeline.submit(..., resident=True)` (round 4; what bench.py's `value` runs on): the caller's `data` blob stays where it is
+    and the slot captures ONE graph per (geometry, buffer) that reads it in place -- no device-to-device copy into a private graph
+    input.  Two resident blobs of one geometry on one slot: two graphs, each replay gives the detections of ITS buffer (bit-equal to
+    the copying path and to the eager engine), and re-filling a buffer in place changes what its graph sees."""
+    import torch
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.pipeline import ClipPipeline
+    from detectandtrack_amd.utils import blob as blob_utils
+    T = 2
+    c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)
+    c['TEST'].update(SCALES=(96,), MAX_SIZE=1000, SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+    model, ws, _ = build_product(c)
+    rs = np.random.RandomState(9)
+    clips = [[rs.randint(0, 255, (96, 128, 3)).astype(np.uint8) for _ in range(T)] for _ in range(3)]
+    ref = [engine.im_detect_all(model, clip, None) for clip in clips]
+
+    def blob_of(clip):
+        u8 = torch.from_numpy(np.stack(clip)).cuda()
+        data, _, im_info = blob_utils.frames_to_blob_on_device(u8, T)
+        return data.clone(), im_info
+    (a, info), (b, _), (c3, _) = blob_of(clips[0]), blob_of(clips[1]), blob_of(clips[2])
+    pipe = ClipPipeline(model, ws, depth=1, graph=True)
+
+    def run(data, resident):
+        pipe.submit(data, info, (96, 128, 3), tag='r', resident=resident)
+        (_, out), = pipe.drain()
+        return out[0]
+
+    def same(out, r):
+        np.testing.assert_array_equal(out[0][1], r[0][1])
+        for x, y in zip(out[2][1], r[2][1]):
+            np.testing.assert_array_equal(x, y)
+    same(run(a, True), ref[0])
+    same(run(b, True), ref[1])
+    assert pipe.graphs_captured == 2                    # one per resident buffer
+    same(run(a, True), ref[0])
+    same(run(b, True), ref[1])
+    assert pipe.graphs_captured == 2
+    a.copy_(c3)                                         # the caller re-fills its buffer in place: the graph reads the new clip
+    torch.cuda.synchronize()
+    same(run(a, True), ref[2])
+    same(run(b, False), ref[1])                         # the copying path: a third graph with a private input
+    assert pipe.graphs_captured == 3
