@@ -555,20 +555,32 @@ __global__ __launch_bounds__(NT, 2) void wgrad_direct9_kernel(const Wgrad9Params
 constexpr int W9D_STAGE = 192 * 128;
 constexpr int W9D_STAGES = 3;
 
-__global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p) {
+// SUB = 2 (round 4): one block of EIGHT waves per CU instead of two blocks of four -- two sub-blocks with their own K range and their own three
+// stages work on the same (co, ci, kt) tile and add their accumulators through LDS before the atomics.  The grid is then one block per CU (the
+// ~384 four-wave blocks left half of the CUs with one block and half with two) and a tile's partial sums reach memory from half as many blocks.
+template <int SUB>
+__global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(const Wgrad9Params p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = SUB == 1 ? 0 : wave_all >> 2, wave = wave_all & 3;
     const int wave_m = wave & 1, wave_n = wave >> 1;
     unsigned bid = blockIdx.x;
     const int kt = bid % p.KT; bid /= p.KT;
     const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
     const int co_t = bid % p.n_co_tiles;
-    const int split = bid / p.n_co_tiles;
+    const int split0 = (bid / p.n_co_tiles) * SUB, split = split0 + sub;
     const unsigned per_frame = (unsigned)(p.tiles_h * p.tiles_w);
     const unsigned nchunks = (unsigned)(p.f_end - p.f_begin) * per_frame;
     const unsigned c_lo = (unsigned)((unsigned long long)nchunks * split / p.ksplit), c_hi = (unsigned)((unsigned long long)nchunks * (split + 1) / p.ksplit);
+    // every wave of the block passes the same barriers: iterate over the longer of the sub-blocks' ranges (chunks past a range are fetched as zeros)
+    unsigned n_iter = c_hi - c_lo;
+    if (SUB == 2) {
+        const unsigned o_lo = (unsigned)((unsigned long long)nchunks * (split ^ 1) / p.ksplit), o_hi = (unsigned)((unsigned long long)nchunks * ((split ^ 1) + 1) / p.ksplit);
+        n_iter = max(n_iter, o_hi - o_lo);
+    }
+    char* const sm = smem + sub * (W9D_STAGES * W9D_STAGE);
 
     // ---- this lane's six DMA pieces: stage row (wave + 4 u) * 8 + lane / 8, slot lane % 8 holds data piece slot ^ 4 * bit1(row) ----
     // kind 0: g row (dy, dx) = (row / 8, row % 8); kind 1: patch row (dy, dx) = (xr / 10 - 1, xr % 10 - 1); kind 2: spare (zeros)
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p)
         const int clip = f / p.T, t = f - clip * p.T, ti = t + kt - p.pt;
         const bool tin = live && ti >= 0 && ti < p.T;
         const size_t g_frame = (size_t)f * p.H, x_frame = (size_t)(clip * p.T + (tin ? ti : 0)) * p.H;
-        char* dst0 = smem + stage * W9D_STAGE + wave * 1024;
+        char* dst0 = sm + stage * W9D_STAGE + wave * 1024;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const bool is_g = wave + 4 * u < 8;                         // pieces 0..7 are the g rows (uniform per wave and u)
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p)
     auto tr4 = [&](const char* a) __attribute__((always_inline)) { return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)a)); };
     auto compute = [&](int stage) __attribute__((always_inline)) {
         if (p.ablate & 2) return;
-        const char* sb = smem + stage * W9D_STAGE;
+        const char* sb = sm + stage * W9D_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint2 al = tr4(sb + g_off + ks * 16 * 128), ah = tr4(sb + g_off + ks * 16 * 128 + 4 * 128);
@@ -650,11 +662,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p)
             }
         }
     };
-    if (c_lo < c_hi) {
+    if (n_iter > 0) {
         issue(c_lo, 0);
         issue(c_lo + 1, 1);
         int stage = 0;
-        for (unsigned c = c_lo; c < c_hi; ++c) {
+        for (unsigned it = 0; it < n_iter; ++it) {
+            const unsigned c = c_lo + it;
             // all but the six pieces of chunk c + 1 have landed (mine of chunk c), my LDS reads of chunk c - 1 are done; then the barrier:
             // chunk c is complete for every wave and stage (c - 1) % 3 is free.  A bare s_barrier: __syncthreads() carries a fence that
             // the compiler lowers to vmcnt(0) -- it would wait for chunk c + 1 as well and serialise the pipeline again.
@@ -668,6 +681,49 @@ __global__ __launch_bounds__(NT, 2) void wgrad_dma9_kernel(const Wgrad9Params p)
     }
     const int khalf = lane >> 5;
     const int ci = ci_t * 64 + wave_n * 32 + (lane & 31);
+    if (SUB == 2) {
+        // ---- the two sub-blocks add their tiles through LDS: sub s keeps accumulator rows r = 8 s .. 8 s + 7 of every tap, hands the other eight
+        //      to its partner (wave w of sub 1 - s holds the same 32 x 32 quadrant) -- 72 floats per lane each way, the 147 KB of the stages ----
+        __syncthreads();                                        // every wave is done with the stages
+        float4* mine = (float4*)(smem + (size_t)(sub * 4 + wave) * (18 * 64 * 16));
+        const float4* theirs = (const float4*)(smem + (size_t)((sub ^ 1) * 4 + wave) * (18 * 64 * 16));
+        auto put = [&](auto own_c) __attribute__((always_inline)) {
+            constexpr int OTH = 1 - decltype(own_c)::value;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    mine[(t * 2 + q) * 64 + lane] = make_float4(acc[t][OTH * 8 + q * 4 + 0], acc[t][OTH * 8 + q * 4 + 1], acc[t][OTH * 8 + q * 4 + 2], acc[t][OTH * 8 + q * 4 + 3]);
+        };
+        auto get = [&](auto own_c) __attribute__((always_inline)) {
+            constexpr int OWN = decltype(own_c)::value;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float* Gt = p.G + (size_t)(kt * 9 + t) * p.Cout * p.Cin;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 o = theirs[(t * 2 + q) * 64 + lane];
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = OWN * 8 + q * 4 + e;
+                        const int co = co_t * 64 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                        if (co >= p.Cout) continue;
+                        const float v = acc[t][r] + ov[e];
+                        if (p.atomic) atomicAdd(Gt + (size_t)co * p.Cin + ci, v);
+                        else Gt[(size_t)co * p.Cin + ci] = v;
+                    }
+                }
+            }
+        };
+        if (sub == 0) put(std::integral_constant<int, 0>{});
+        else put(std::integral_constant<int, 1>{});
+        __syncthreads();
+        if (ci >= p.Cin || (p.ablate & 4)) return;
+        if (sub == 0) get(std::integral_constant<int, 0>{});
+        else get(std::integral_constant<int, 1>{});
+        return;
+    }
     if (ci >= p.Cin || (p.ablate & 4)) return;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -1119,20 +1175,31 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
             // beat the 640 (1.25 rounds of the 512 slots) the register-staged kernel liked: res3 (12 tiles) ks 53 -> 32 0.181 -> 0.157 ms,
             // res4 / P3 (48) 13 -> 8 0.192 -> 0.167 / 0.136 -> 0.109, P2 13 -> 8 0.328 -> 0.304; fewer, longer blocks mean fewer atomics and
             // fewer pipeline fills.  Layers with many tiles (res5: 192) want two blocks per CU again: ks 3 -> 4 0.224 -> 0.205.
+            // Eight-wave blocks (DAT_WGRAD_SUB = 2, the default; round 4): one block per CU, two K ranges per block -- ks counts the RANGES, so it
+            // is even; 2 * floor(256 / tiles) was the best of a sweep for every layer with <= 48 tiles (res3 0.164 -> 0.145 ms, res4 0.166 ->
+            // 0.157, P2 0.306 -> 0.274, P3 0.109 -> 0.104).  Layers with more tiles than half the CUs (res5: 192) keep the four-wave blocks
+            // (0.223 vs 0.234-0.237 ms).
+            const int sub = ctx->dbg_wgrad_dma && tiles <= 128 ? ctx->dbg_wgrad_sub : 1;
             long long ks = ctx->dbg_wgrad_dma ? (tiles <= 96 ? (384 + tiles - 1) / tiles : (768 + tiles - 1) / tiles) : 640 / tiles;
+            if (sub == 2) ks = 2 * (256 / tiles);
             if (ks > nchunks / 4) ks = nchunks / 4;             // at least 4 patches per block
             if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
             if (ks > nchunks) ks = nchunks;
+            if (sub == 2) ks &= ~1ll;
+            const bool sub2 = sub == 2 && ks >= 2;
             if (ks < 1) ks = 1;
             q.ksplit = (int)ks;
-            q.atomic = ks > 1 || acc_mode;
+            q.atomic = ks > (sub2 ? 2 : 1) || acc_mode;
             const size_t g_elems = (size_t)Cout_real * Cin_real * d->KT * 9;
-            if (ks > 1 && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+            if (q.atomic && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
                 DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
             q.zeros = (const char*)ctx->zeros;
-            if (ctx->dbg_wgrad_dma) {   // operands by LDS-DMA into three stages (DAT_WGRAD_DMA, default 1)
-                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel, W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
-                hipLaunchKernelGGL(wgrad_dma9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), W9D_STAGES * W9D_STAGE, st, q);
+            if (sub2) {
+                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel<2>, 2 * W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL(wgrad_dma9_kernel<2>, dim3((unsigned)(tiles * ks / 2)), dim3(2 * NT), 2 * W9D_STAGES * W9D_STAGE, st, q);
+            } else if (ctx->dbg_wgrad_dma) {   // operands by LDS-DMA into three stages (DAT_WGRAD_DMA, default 1)
+                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel<1>, W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL(wgrad_dma9_kernel<1>, dim3((unsigned)(tiles * ks)), dim3(NT), W9D_STAGES * W9D_STAGE, st, q);
             } else {
                 if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
                 hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);

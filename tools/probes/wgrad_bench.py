@@ -16,6 +16,8 @@ LAYERS = [  # name, cin, cout, k, stride, T, H, W (input), g frames window (t0, 
     ('r50 res4 2a 1x1 1024->256', 1024, 256, (1, 1, 1), 1, 8, 48, 84, None),
 ]
 
+RESULTS = {}
+
 def run(tag):
     for name, cin, cout, k, st, T, H, W, win in LAYERS:
         g = torch.Generator().manual_seed(1)
@@ -26,8 +28,9 @@ def run(tag):
         w = torch.randn((cout, cin) + k, generator=g).cuda() * 0.05
         cg = ops.ConvGrad(w, None, (st, st), pads, ops.BF16, cin, cout)
         kw = dict(g_frames=win) if win else {}
-        cg.weight(x, gy, T, **kw)
+        dW, _ = cg.weight(x, gy, T, **kw)
         torch.cuda.synchronize()
+        RESULTS.setdefault(name, []).append((tag, dW.clone()))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
@@ -59,6 +62,17 @@ if len(_s.argv) > 1 and _s.argv[1] == 'dma':      # register-staged vs LDS-DMA n
     for rep in range(2):
         fresh({'DAT_WGRAD_DMA': '0'}, 'regs')
         fresh({'DAT_WGRAD_DMA': '1'}, 'dma')
+elif len(_s.argv) > 1 and _s.argv[1] == 'sub':    # four-wave blocks (two per CU) vs eight-wave blocks with two K ranges (DAT_WGRAD_SUB), K-split sweep of the latter
+    LAYERS[:] = LAYERS[:5]
+    fresh({'DAT_WGRAD_SUB': '1'}, 'sub1')
+    fresh({'DAT_WGRAD_SUB': '2'}, 'sub2')
+    for ks in (4, 6, 8, 10, 12, 16, 20, 32, 42, 64):
+        fresh({'DAT_WGRAD_SUB': '2', 'DAT_WGRAD_KS': str(ks)}, 'sub2ks%d' % ks)
+    fresh({'DAT_WGRAD_SUB': '1'}, 'sub1')
+    for name, rs in RESULTS.items():
+        ref = rs[0][1]
+        worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
+        print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
 elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
     for ab in (0, 1, 2, 4, 3, 7):
