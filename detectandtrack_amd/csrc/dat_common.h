@@ -42,6 +42,7 @@ struct dat_ctx {
     int dbg_wgrad_direct;                   // DAT_WGRAD_DIRECT (default 1): bf16 weight gradients straight from the NDHWC tensors (transposing LDS reads), no re-pack passes
     int dbg_ablate_wgrad;                   // DAT_WGRAD_ABLATE (default 0): DEBUG timing ablations of the nine-tap weight-gradient kernel (wrong results)
     int dbg_wgrad_sub;                      // DAT_WGRAD_SUB (default 2): 2 = eight-wave blocks of the nine-tap weight-gradient kernel (two K ranges per block, added through LDS)
+    int dbg_wgrad_ilv;                      // DAT_WGRAD_ILV (default 1): 1 = LDS-DMA pieces of the next-but-one chunk issued between the MFMA groups of the current one
     int dbg_wgrad_dma;                      // DAT_WGRAD_DMA (default 1): nine-tap weight gradient with LDS-DMA operand staging (three stages) instead of register staging
     int dbg_wgrad_ks;                       // DAT_WGRAD_KS (default 0 = heuristic): forced K split of the nine-tap direct weight-gradient kernel
     int dbg_roi_fold;                       // DAT_ROI_BWD_FOLD (default 1): RoIAlign backward folds a bin's samples into one weight per distinct pixel before the atomics

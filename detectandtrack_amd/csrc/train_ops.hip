@@ -558,7 +558,12 @@ constexpr int W9D_STAGES = 3;
 // SUB = 2 (round 4): one block of EIGHT waves per CU instead of two blocks of four -- two sub-blocks with their own K range and their own three
 // stages work on the same (co, ci, kt) tile and add their accumulators through LDS before the atomics.  The grid is then one block per CU (the
 // ~384 four-wave blocks left half of the CUs with one block and half with two) and a tile's partial sums reach memory from half as many blocks.
-template <int SUB>
+// ILV = 1 (round 4, the default): the six LDS-DMA pieces of chunk c + 2 are issued BETWEEN the MFMA groups of chunk c (one piece before every other
+// group of three MFMAs) instead of in one burst behind the barrier: a piece costs its wave 60-185 cycles of issue (MI355X_MICROARCH.md), and
+// behind the barrier every wave of the CU pays them at the same time with no MFMA in flight.  Same box, per layer: res3 0.152 -> 0.147 ms,
+// res4 0.163 -> 0.161, res5 0.221 -> 0.216, P2 0.284 -> 0.274; letting the two sub-blocks take turns (one issues in the first half of the chunk,
+// the other in the second) needs a branch per group, which cuts the chunk's MFMA schedule into basic blocks: 1-2 % slower than the burst.
+template <int SUB, int ILV>
 __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(const Wgrad9Params p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -601,32 +606,46 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
         pk_dy[u] = dy; pk_dx[u] = dx; pk_col[u] = col;
     }
     const char* const zeros = p.zeros;
-    auto issue = [&](unsigned ch, int stage) __attribute__((always_inline)) {
+    struct ChunkAt { bool tin; size_t g_frame, x_frame; int ty, tx; char* dst0; };
+    auto chunk_at = [&](unsigned ch, int stage) __attribute__((always_inline)) {
         // (chunks past the block's range are requested as zeros: the instruction count per chunk stays six, the counted wait stays valid)
         const bool live = ch < c_hi && !(p.ablate & 1);
         const unsigned chc = live ? ch : c_lo;
         const unsigned fr = chc / per_frame, tl = chc - fr * per_frame;
         const int f = p.f_begin + (int)fr;
-        const int ty = (int)(tl / (unsigned)p.tiles_w), tx = (int)tl - ty * p.tiles_w;
+        ChunkAt a;
+        a.ty = (int)(tl / (unsigned)p.tiles_w); a.tx = (int)tl - a.ty * p.tiles_w;
         const int clip = f / p.T, t = f - clip * p.T, ti = t + kt - p.pt;
-        const bool tin = live && ti >= 0 && ti < p.T;
-        const size_t g_frame = (size_t)f * p.H, x_frame = (size_t)(clip * p.T + (tin ? ti : 0)) * p.H;
-        char* dst0 = sm + stage * W9D_STAGE + wave * 1024;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const bool is_g = wave + 4 * u < 8;                         // pieces 0..7 are the g rows (uniform per wave and u)
-            const int y = ty * 8 + pk_dy[u], x = tx * 8 + pk_dx[u];
-            const bool ok = tin && pk_col[u] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const char* src = zeros;
-            if (ok) src = is_g ? p.g + (((g_frame + y) * p.W + x) * (size_t)p.g_cs) * 2 + pk_col[u]
-                               : p.x + (((x_frame + y) * p.W + x) * (size_t)p.x_cs) * 2 + pk_col[u];
-            // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler orders every later ds_read behind an LDS-DMA it can see with
-            //  s_waitcnt vmcnt(0) -- one LDS array, everything may alias -- which would wait for the chunks still in flight; the counted
-            //  wait + barrier at the top of the loop is the ordering this pipeline needs)
-            // (M0 is written without telling the compiler: nothing else in this kernel uses it -- no other LDS-DMA, no s_movrel)
-            const unsigned lds_at = (unsigned)(size_t)(lptr_t)(dst0 + u * 4096);
+        a.tin = live && ti >= 0 && ti < p.T;
+        a.g_frame = (size_t)f * p.H; a.x_frame = (size_t)(clip * p.T + (a.tin ? ti : 0)) * p.H;
+        a.dst0 = sm + stage * W9D_STAGE + wave * 1024;
+        return a;
+    };
+    auto issue_piece = [&](const ChunkAt& a, auto u_c) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_c)::value;
+        const bool is_g = wave + 4 * u < 8;                         // pieces 0..7 are the g rows (uniform per wave and u)
+        const int y = a.ty * 8 + pk_dy[u], x = a.tx * 8 + pk_dx[u];
+        const bool ok = a.tin && pk_col[u] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        // branch-free: the address of a clamped pixel is formed unconditionally and blended with the zero line by a mask (an `if` here
+        // became a branch around every piece, which cut the MFMA schedule of the chunk into basic blocks)
+        const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1), cc = max(pk_col[u], 0);
+        const char* at = is_g ? p.g + (((a.g_frame + yc) * p.W + xc) * (size_t)p.g_cs) * 2 + cc
+                              : p.x + (((a.x_frame + yc) * p.W + xc) * (size_t)p.x_cs) * 2 + cc;
+        const unsigned long long m = ok ? ~0ull : 0ull;
+        const char* src = (const char*)((unsigned long long)zeros + (((unsigned long long)at - (unsigned long long)zeros) & m));
+        // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler orders every later ds_read behind an LDS-DMA it can see with
+        //  s_waitcnt vmcnt(0) -- one LDS array, everything may alias -- which would wait for the chunks still in flight; the counted
+        //  wait + barrier at the top of the loop is the ordering this pipeline needs)
+        // (M0 is written without telling the compiler: nothing else in this kernel uses it -- no other LDS-DMA, no s_movrel)
+        const unsigned lds_at = (unsigned)(size_t)(lptr_t)(a.dst0 + u * 4096);
+        if (ILV)    // no memory clobber: the fragment reads of the chunk being computed may be scheduled across the piece (another stage)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_at));
+        else
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_at) : "memory");
-        }
+    };
+    auto issue = [&](unsigned ch, int stage) __attribute__((always_inline)) {
+        const ChunkAt a = chunk_at(ch, stage);
+        static_for(std::make_integer_sequence<int, 6>{}, [&](auto u_c) __attribute__((always_inline)) { issue_piece(a, u_c); });
     };
     // fragment addressing (see wgrad_direct9_kernel), rows 128 B apart, the piece swizzle as a per-lane XOR
     const int grp = lane >> 4, li = lane & 15;
@@ -641,17 +660,21 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     typedef __attribute__((address_space(3))) wd_v4s* lp_t;
     auto tr4 = [&](const char* a) __attribute__((always_inline)) { return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)a)); };
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        if (p.ablate & 2) return;
+    auto compute = [&](int stage, const ChunkAt& nx) __attribute__((always_inline)) {
+        if (p.ablate & 2) {
+            if (ILV) static_for(std::make_integer_sequence<int, 6>{}, [&](auto u_c) __attribute__((always_inline)) { issue_piece(nx, u_c); });
+            return;
+        }
         const char* sb = sm + stage * W9D_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        static_for(std::make_integer_sequence<int, 4>{}, [&](auto ks_c) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ks_c)::value;
             const uint2 al = tr4(sb + g_off + ks * 16 * 128), ah = tr4(sb + g_off + ks * 16 * 128 + 4 * 128);
             const uint4 a = make_uint4(al.x, al.y, ah.x, ah.y);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
+            static_for(std::make_integer_sequence<int, 3>{}, [&](auto kh_c) __attribute__((always_inline)) {
+                constexpr int kh = decltype(kh_c)::value, grp_i = ks * 3 + kh;      // MFMA group 0..11 of the chunk
                 const char* rb = sb + (kh == 1 ? x_off1 : x_off0) + ((2 * ks + kh) * 10) * 128;
                 const uint2 q0 = tr4(rb), q1 = tr4(rb + 4 * 128), q2 = tr4(rb + 8 * 128);
+                if (ILV && grp_i % 2 == 0) issue_piece(nx, std::integral_constant<int, (grp_i / 2) % 6>{});    // every other group: no branch in the chunk
                 const uint4 b0 = make_uint4(q0.x, q0.y, q1.x, q1.y);
                 const uint4 b2 = make_uint4(q0.y, q1.x, q1.y, q2.x);
                 const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(q0.y, q0.x, 2), __builtin_amdgcn_alignbyte(q1.x, q0.y, 2),
@@ -659,8 +682,8 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
                 MmaT<DAT_BF16>::step(a, b0, acc[kh * 3 + 0]);
                 MmaT<DAT_BF16>::step(a, b1, acc[kh * 3 + 1]);
                 MmaT<DAT_BF16>::step(a, b2, acc[kh * 3 + 2]);
-            }
-        }
+            });
+        });
     };
     if (n_iter > 0) {
         issue(c_lo, 0);
@@ -673,8 +696,9 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
             // the compiler lowers to vmcnt(0) -- it would wait for chunk c + 1 as well and serialise the pipeline again.
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int nstage = stage == 0 ? 2 : stage - 1;      // (c + 2) % 3 == (c - 1) % 3
-            issue(c + 2, nstage);
-            compute(stage);
+            const ChunkAt nx = chunk_at(c + 2, nstage);
+            if (!ILV) static_for(std::make_integer_sequence<int, 6>{}, [&](auto u_c) __attribute__((always_inline)) { issue_piece(nx, u_c); });
+            compute(stage, nx);
             stage = stage == 2 ? 0 : stage + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing zero chunks: nothing may still be writing LDS at exit
@@ -1194,12 +1218,22 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
             if (q.atomic && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
                 DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
             q.zeros = (const char*)ctx->zeros;
+            const bool ilv = ctx->dbg_wgrad_ilv != 0;
+            const void* fn;
             if (sub2) {
-                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel<2>, 2 * W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
-                hipLaunchKernelGGL(wgrad_dma9_kernel<2>, dim3((unsigned)(tiles * ks / 2)), dim3(2 * NT), 2 * W9D_STAGES * W9D_STAGE, st, q);
+                const size_t lds = 2 * W9D_STAGES * W9D_STAGE;
+                const dim3 grid((unsigned)(tiles * ks / 2)), blk(2 * NT);
+                fn = ilv ? (const void*)wgrad_dma9_kernel<2, 1> : (const void*)wgrad_dma9_kernel<2, 0>;
+                if (dat_ensure_lds(ctx, fn, lds) != DAT_OK) return DAT_ERR_LAUNCH;
+                if (ilv) hipLaunchKernelGGL((wgrad_dma9_kernel<2, 1>), grid, blk, lds, st, q);
+                else hipLaunchKernelGGL((wgrad_dma9_kernel<2, 0>), grid, blk, lds, st, q);
             } else if (ctx->dbg_wgrad_dma) {   // operands by LDS-DMA into three stages (DAT_WGRAD_DMA, default 1)
-                if (dat_ensure_lds(ctx, (const void*)wgrad_dma9_kernel<1>, W9D_STAGES * W9D_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
-                hipLaunchKernelGGL(wgrad_dma9_kernel<1>, dim3((unsigned)(tiles * ks)), dim3(NT), W9D_STAGES * W9D_STAGE, st, q);
+                const size_t lds = W9D_STAGES * W9D_STAGE;
+                const dim3 grid((unsigned)(tiles * ks)), blk(NT);
+                fn = ilv ? (const void*)wgrad_dma9_kernel<1, 1> : (const void*)wgrad_dma9_kernel<1, 0>;
+                if (dat_ensure_lds(ctx, fn, lds) != DAT_OK) return DAT_ERR_LAUNCH;
+                if (ilv) hipLaunchKernelGGL((wgrad_dma9_kernel<1, 1>), grid, blk, lds, st, q);
+                else hipLaunchKernelGGL((wgrad_dma9_kernel<1, 0>), grid, blk, lds, st, q);
             } else {
                 if (dat_ensure_lds(ctx, (const void*)wgrad_direct9_kernel, 2 * W9_STAGE) != DAT_OK) return DAT_ERR_LAUNCH;
                 hipLaunchKernelGGL(wgrad_direct9_kernel, dim3((unsigned)(tiles * ks)), dim3(NT), 2 * W9_STAGE, st, q);

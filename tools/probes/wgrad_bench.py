@@ -73,6 +73,14 @@ elif len(_s.argv) > 1 and _s.argv[1] == 'sub':    # four-wave blocks (two per CU
         ref = rs[0][1]
         worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
         print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
+elif len(_s.argv) > 1 and _s.argv[1] == 'ilv':    # LDS-DMA pieces in one burst behind the barrier (0) vs between the MFMA groups (1)
+    LAYERS[:] = LAYERS[:5]
+    for m in (0, 1, 0, 1):
+        fresh({'DAT_WGRAD_ILV': str(m)}, 'ilv%d' % m)
+    for name, rs in RESULTS.items():
+        ref = rs[0][1]
+        worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
+        print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
 elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
     for ab in (0, 1, 2, 4, 3, 7):
