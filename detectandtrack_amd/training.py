@@ -46,6 +46,7 @@ class TrainExecutor(Executor):
         self._deferred = {}      # weight name -> the fused AffineChannelNd scale (tensor or None) its finish multiplies by
         self._sealed = set()     # parameters whose gradient bucket is already on its way to the other ranks (Trainer, overlap)
         self.accumulate_all = False   # the arena already holds gradients of an earlier clip (Trainer.step(zero_grad=False)): add, never overwrite
+        self._iter_cache = {}           # per backward pass: objects several ops build from the same weights (see backward)
         self._last_masked = False       # set by _take_grad: the gradient just taken already carries its producer's ReLU mask
         self._trainable_set = None
         self._readers = {}
@@ -196,12 +197,19 @@ class TrainExecutor(Executor):
         if len(lst) == 1:
             t, l, _ = lst[0]
             return (t if t.dtype == tdt else t.to(tdt)), l
+        # the sum starts as ONE out-of-place add of two full-window contributions (no clone + add pair).  (Adding the fp32 accumulators of
+        # the RoIAlign backward without the .to() pass -- a mixed-dtype in-place add -- measured slower: ATen's casting kernel is not vectorised.)
+        full = [e for e in lst if e[0].shape[0] == hi - lo and not getattr(e[0], '_roi_acc', False)]
+        first = next((e for e in full if e[0].dtype == tdt), None)
         acc = None
-        for t, l, _ in lst:
-            if t.shape[0] == hi - lo and acc is None and t.dtype == tdt and not getattr(t, '_roi_acc', False):
-                acc = t.clone()
-                lst = [e for e in lst if e[0] is not t]
-                break
+        if first is not None:
+            second = next((e for e in full if e is not first and e[0].shape == first[0].shape), None)
+            if second is not None:
+                acc = torch.add(first[0], second[0]) if second[0].dtype == tdt else torch.add(first[0], second[0]).to(tdt)
+                lst = [e for e in lst if e is not first and e is not second]
+            else:
+                acc = first[0].clone()
+                lst = [e for e in lst if e is not first]
         if acc is None:
             acc = torch.zeros((hi - lo,) + tuple(lst[0][0].shape[1:]), dtype=tdt, device=lst[0][0].device)
         for t, l, _ in lst:
@@ -252,6 +260,7 @@ class TrainExecutor(Executor):
     def backward(self, on_op_done=None):
         """on_op_done(i): called after the backward of op i (ops run from the last to the first) -- the Trainer's hook for finishing
         and exchanging gradient buckets while the backward of the earlier layers continues."""
+        self._iter_cache = {}        # objects built from this iteration's weights that several ops share (the RPN heads of the FPN levels)
         for i in range(len(self.net.ops) - 1, -1, -1):
             op = self.net.ops[i]
             skip = (i in self._skip and i not in self._fused) or (op.outputs and all(o in self.no_grad for o in op.outputs))
@@ -388,7 +397,9 @@ class TrainExecutor(Executor):
         A, D = lo.args['dim_out'], do.args['dim_out']
         dbias = torch.zeros(A + D, dtype=torch.float32, device=ws.device)
         g = ops.relu_bias_bwd(dy, y.t, y.dt, A + D, relu=False, dbias=dbias)
-        w = torch.cat([self._master(lo.args['w']).reshape(A, -1), self._master(do.args['w']).reshape(D, -1)], dim=0)
+        w = None
+        if xin.t2c or ('rpnhead', lo.args['w'], do.args['w'], int(xin.t.shape[3]), int(g.shape[3])) not in self._iter_cache:
+            w = torch.cat([self._master(lo.args['w']).reshape(A, -1), self._master(do.args['w']).reshape(D, -1)], dim=0)
         if xin.t2c:
             # heads over time-moved-to-channels (FPN tube RPN, channel index t*C + c): one 1x1 weight slice per input frame;
             # the head has ONE output frame per clip, every input frame gets its own data gradient
@@ -409,8 +420,11 @@ class TrainExecutor(Executor):
             self._pgrad(do.args['b'], dbias[A:])
             self._add_grad(lo.inputs[0], torch.cat(dxs, dim=0))
             return
-        w5 = w.view(A + D, -1, 1, 1, 1)
-        cg = ops.ConvGrad(w5, None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
+        # (the levels above the first share the parameters: one ConvGrad -- one pack of the data-gradient weights -- per iteration)
+        ck = ('rpnhead', lo.args['w'], do.args['w'], int(xin.t.shape[3]), int(g.shape[3]))
+        cg = self._iter_cache.get(ck)
+        if cg is None:
+            cg = self._iter_cache[ck] = ops.ConvGrad(w.view(A + D, -1, 1, 1, 1), None, (1, 1), (0, 0, 0), y.dt, xin.t.shape[3], g.shape[3])
         dW, _ = cg.weight(xin.t, g, xin.T)
         self._pgrad(lo.args['w'], dW[:A])
         self._pgrad(do.args['w'], dW[A:])
@@ -441,7 +455,11 @@ class TrainExecutor(Executor):
         if x.kind == 'fmap':   # flattened RoI features: reference order (c, t, h, w), ours (t, h, w, c)
             f, p, p2, cs = x.t.shape
             xin = x.t.view(1, 1, f // x.T, x.T * p * p2 * cs)
-            wk = w.view(w.shape[0], x.C, x.T, p, p2).permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
+            fwd = ws._layers.get((self.net.name, i))
+            if isinstance(fwd, ops.ConvLayer) and fwd.w_src is not None and fwd.w_src.numel() == w.numel() and not fwd.is_dgrad:
+                wk = fwd.w_src.view(w.shape[0], -1)     # the forward layer of this iteration holds the permuted copy already (51 MB for fc6)
+            else:
+                wk = w.view(w.shape[0], x.C, x.T, p, p2).permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1)
         else:
             xin, wk = x.t, w
         cin_real = wk.shape[1]
@@ -478,16 +496,19 @@ class TrainExecutor(Executor):
         dW3, _ = cg.weight(x.t, g, 1)                  # [4K, Cin, 1, 3, 3]
         # transpose of the sub-pixel weight map (elementwise.hip deconv_k4s2_weights_kernel): every (ky, kx) of the 4x4
         # kernel appears exactly once, at sub-pixel (a, b) = ((ky+1)&1, (kx+1)&1), tap dy = (a + 1 - ky) / 2
-        dw = torch.zeros_like(w)
+        # -- one gather over index tables instead of sixteen strided copies into a zeroed tensor
         d4 = dW3.view(2, 2, K, Cin, 3, 3)
-        for ky in range(4):
-            aa = (ky + 1) & 1
-            ty = (aa + 1 - ky) // 2 + 1
-            for kx in range(4):
-                bb = (kx + 1) & 1
-                tx = (bb + 1 - kx) // 2 + 1
-                dw[:, :, ky, kx] = d4[aa, bb, :, :, ty, tx].t()
-        self._pgrad(a['w'], dw)
+        idx = getattr(self, '_deconv_idx', None)
+        if idx is None or idx[0].device != d4.device:
+            ks = torch.arange(4)
+            sub = (ks + 1) & 1                                              # sub-pixel a (rows) / b (columns) of kernel row / column k
+            tap = torch.div(sub + 1 - ks, 2, rounding_mode='floor') + 1     # tap of the 3 x 3 conv that holds it
+            AA, BB = sub.view(4, 1).expand(4, 4), sub.view(1, 4).expand(4, 4)
+            TY, TX = tap.view(4, 1).expand(4, 4), tap.view(1, 4).expand(4, 4)
+            idx = self._deconv_idx = tuple(t.contiguous().to(d4.device) for t in (AA, BB, TY, TX))
+        AA, BB, TY, TX = idx
+        dw = d4.permute(0, 1, 4, 5, 3, 2)[AA, BB, TY, TX]                  # [4, 4, Cin, K]
+        self._pgrad(a['w'], dw.permute(2, 3, 0, 1))
         f, H, W, _ = x.t.shape
         self._add_grad(op.inputs[0], cg.data(g, 1, H, W))
 

@@ -565,7 +565,10 @@ class Executor(object):
             b = torch.cat([ws.dev_param(lo.args['b']), ws.dev_param(do.args['b'])], dim=0)
             return ops.ConvLayer(w, None, b, stride=(1, 1), pads=(0, 0, 0), relu=False, dtype=dt,
                                  cin_stride=xin.t.shape[3], x3=_x3(self.ws))
-        layer = self._layer(('rpnhead', i), build)
+        # one layer for all the FPN levels that share these parameters (model_builder.py: the RPN heads of the levels above the first
+        # reuse its weights): in training the layer is rebuilt after every update -- once per iteration, not once per level
+        layer = self._layer(('rpnhead', lo.args['w'], do.args['w'], lo.args['b'], do.args['b'], int(xin.t.shape[3]),
+                             (xin.T, xin.C) if xin.t2c else None), build)
         if xin.t2c:
             self._log_conv(lo.outputs[0] + '+' + do.outputs[0], layer, xin.t.shape[0], xin.t.shape[1], xin.t.shape[2],
                            oframes=xin.N)
