@@ -1229,11 +1229,12 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
             // fewer pipeline fills.  Layers with many tiles (res5: 192) want two blocks per CU again: ks 3 -> 4 0.224 -> 0.205.
             // Eight-wave blocks (DAT_WGRAD_SUB = 2, the default; round 4): one block per CU, two K ranges per block -- ks counts the RANGES, so it
             // is even; 2 * floor(256 / tiles) was the best of a sweep for every layer with <= 48 tiles (res3 0.164 -> 0.145 ms, res4 0.166 ->
-            // 0.157, P2 0.306 -> 0.274, P3 0.109 -> 0.104).  Layers with more tiles than half the CUs (res5: 192) keep the four-wave blocks
-            // (0.223 vs 0.234-0.237 ms).
-            const int sub = ctx->dbg_wgrad_dma && tiles <= 128 ? ctx->dbg_wgrad_sub : 1;
+            // 0.157, P2 0.306 -> 0.274, P3 0.109 -> 0.104).  Layers with more tiles than half the CUs (res5: 192) take ONE block per tile with
+            // its two ranges -- no K split across blocks, so no contended atomics at all (plain stores outside the deferred-finish mode):
+            // 0.210 -> 0.192 ms against the four-wave blocks' ks = 4 (768 blocks, 113 MB of atomics); two blocks per tile: 0.230.
+            const int sub = ctx->dbg_wgrad_dma && ctx->dbg_wgrad_sub >= 2 ? 2 : 1;
             long long ks = ctx->dbg_wgrad_dma ? (tiles <= 96 ? (384 + tiles - 1) / tiles : (768 + tiles - 1) / tiles) : 640 / tiles;
-            if (sub == 2) ks = 2 * (256 / tiles);
+            if (sub == 2) ks = tiles <= 128 ? 2 * (256 / tiles) : 2;
             if (ks > nchunks / 4) ks = nchunks / 4;             // at least 4 patches per block
             if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
             if (ks > nchunks) ks = nchunks;

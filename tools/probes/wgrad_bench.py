@@ -81,6 +81,15 @@ elif len(_s.argv) > 1 and _s.argv[1] == 'ilv':    # LDS-DMA pieces in one burst 
         ref = rs[0][1]
         worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
         print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
+elif len(_s.argv) > 1 and _s.argv[1] == 'res5':   # layers with more tiles than half the CUs: four-wave blocks (ks 4) vs eight-wave blocks with two / four K ranges
+    LAYERS[:] = [LAYERS[2], ('kps head 3x3 512 (100 rois x 14 x 14)', 512, 512, (1, 3, 3), 1, 100, 14, 14, None)]
+    for env, tag in (({'DAT_WGRAD_SUB': '1'}, 'four-wave'), ({'DAT_WGRAD_SUB': '2'}, 'sub2 ks2'), ({'DAT_WGRAD_SUB': '2', 'DAT_WGRAD_KS': '4'}, 'sub2 ks4'),
+                     ({'DAT_WGRAD_SUB': '1'}, 'four-wave')):
+        fresh(env, tag)
+    for name, rs in RESULTS.items():
+        ref = rs[0][1]
+        worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
+        print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
 elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
     for ab in (0, 1, 2, 4, 3, 7):
