@@ -942,3 +942,44 @@ def test_clips_given_as_image_files_are_decoded_to_bgr_frames(tmp_path):
     mixed = test_engine.load_clip({'image': [frames[0], paths[1]]})                     # arrays pass through untouched
     assert mixed[0] is frames[0] and mixed[1] is clip_a[1]
     test_engine._FRAME_CACHE = None
+
+
+def test_gradient_contributions_of_a_blob_are_summed_over_their_frame_windows():
+    """TrainExecutor._take_grad (training.py): contributions (tensor, first frame, masked) of one blob -- full-window tensors, shorter
+    windows, another dtype (the fp32 RoIAlign accumulators) -- come back as ONE tensor over the union of the windows; a single
+    contribution is passed through untouched and keeps its `masked` flag; the inputs are not modified."""
+    import types
+    import torch
+    from detectandtrack_amd import training
+    from detectandtrack_amd.ops import hip_ops as ops
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    for dt, tdt in ((ops.F32, torch.float32), (ops.BF16, torch.bfloat16)):
+        ex = types.SimpleNamespace(grads={}, _last_masked=False)
+        take = lambda name: training.TrainExecutor._take_grad(ex, name, dt)
+        assert take('none') == (None, 0)
+        # one contribution: the tensor itself, the mask flag survives
+        t = rnd(3, 2, 2, 4).to(tdt)
+        ex.grads['a'] = [(t, 1, True)]
+        out, lo = take('a')
+        assert out is t and lo == 1 and ex._last_masked and 'a' not in ex.grads
+        # two full windows + a one-frame window + an fp32 accumulator marked as the RoIAlign backward's
+        a, b = rnd(3, 2, 2, 4).to(tdt), rnd(3, 2, 2, 4).to(tdt)
+        c = rnd(1, 2, 2, 4).to(tdt)
+        r = rnd(3, 2, 2, 4)
+        r._roi_acc = True
+        keep = [x.clone() for x in (a, b, c, r)]
+        ex.grads['b'] = [(r, 2, False), (a, 2, False), (c, 3, False), (b, 2, False)]
+        out, lo = take('b')
+        assert lo == 2 and out.dtype == tdt and tuple(out.shape) == (3, 2, 2, 4) and not ex._last_masked
+        ref = a.float() + b.float() + r
+        ref[1:2] += c.float()
+        tol = 1e-6 if tdt == torch.float32 else 0.05
+        assert (out.float() - ref).abs().max() < tol
+        for x, k in zip((a, b, c, r), keep):
+            assert torch.equal(x, k)
+        # windows that only overlap: the union is allocated
+        ex.grads['c'] = [(c, 0, False), (rnd(2, 2, 2, 4).to(tdt), 1, False)]
+        out, lo = take('c')
+        assert lo == 0 and tuple(out.shape) == (3, 2, 2, 4)
+        assert (out[0:1].float() - c.float()).abs().max() < tol
