@@ -68,6 +68,53 @@ def stem_roofline(ws, data_dev, dtype, reps=20):
             'measured': '%d back-to-back launches on the benched `data` blob (%s) between one HIP-event pair' % (reps, 'x'.join(str(v) for v in data.shape))}
 
 
+def conv_back_to_back(model, ws, stream, select, reps=3):
+    """The conv launches of ONE forward whose logged name passes `select`, re-issued in net order `reps` times back to back on `stream`
+    between ONE HIP-event pair -- the real layers (same packed weights, same plan) on the real activations the last eager forward left in
+    `ws`, with no event records between the kernels.  Per-launch event pairs on eager launches each include the gap to the next launch
+    (their sum exceeded the step they were part of); this is how `stem_roofline` has always been timed and it agrees
+    with rocprofv3's kernel durations.  Returns (ms per pass, algorithmic flops per pass, launches per pass, algorithmic bytes per pass)."""
+    from detectandtrack_amd import workspace as wsmod
+    nets = [model.net] + ([model.keypoint_net] if getattr(model, 'keypoint_net', None) is not None else [])
+    plan = []
+    for net in nets:
+        ex = wsmod.Executor(ws, net)
+        ex._plan_rpn_siblings()
+        ex._plan_keyframe_dce()
+        for i, op in enumerate(net.ops):
+            if op.type not in ('Conv', 'FC', 'ConvTranspose') or (i in ex._skip and i not in ex._fused):
+                continue
+            if op.type == 'Conv' and op.inputs[0] == 'data':
+                continue            # the stem is not a conv3d_igemm launch (stem_roofline)
+            name = op.outputs[0]
+            if i in ex._fused:
+                lo, do, _ = ex._fused[i]
+                name = lo.outputs[0] + '+' + do.outputs[0]
+            if select(name):
+                plan.append((ex, i, op))
+
+    def one_pass():
+        for ex, i, op in plan:
+            getattr(ex, 'op_' + op.type)(i, op)
+    prev, wsmod._GLOBAL = wsmod._GLOBAL, ws
+    try:
+        with torch.cuda.stream(stream):
+            ws.conv_log = []
+            one_pass()                      # (also the warm-up: allocator, plan caches)
+            log, ws.conv_log = ws.conv_log, None
+            stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                one_pass()
+            e1.record(stream)
+            stream.synchronize()
+    finally:
+        wsmod._GLOBAL = prev
+        ws.conv_log = None
+    return e0.elapsed_time(e1) / reps, sum(fl for _, fl, _ in log), len(log), sum(b for _, _, b in log)
+
+
 def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
     if tube:    # the declared FPN tube-head extension (SURVEY.md §8 f-1; dead reference design lib/modeling/FPN3D.py:232-330 + tube rois on
         # the 2-MLP head, head_builder.py:29-33, + the 3D keypoint head): the body stays 3D up to the heads (BODY_HEAD_LINK '')
@@ -607,7 +654,7 @@ def main():
     # starts when the hardware queue admits it), so in-region pairs over-state kernel durations ~2x; rocprofv3 (kernel begin -> end)
     # agrees with the one-stream pairs, not with those.  The in-region figures are reported next to them.
     _dbg('profilers stopped')
-    seq_rate, conc = None, None
+    seq_rate, conc, b2b = None, None, None
     graph_on = (not train) and pipe.use_graph and len(pipe.slots[0].graphs) > 0
     if not train and (a.pipeline > 1 or graph_on) and rank == 0:
         conc = (records, conv_log) if records else None     # (graph replays record nothing on the host side)
@@ -643,6 +690,19 @@ def main():
         conv_log, w0.conv_log = w0.conv_log, None
         shader_mhz = getattr(pr, 'shader_mhz', shader_mhz)
         prof_steps = n_seq
+        # the durations the roofline is computed from: the dominant kernel's real layer set (and, separately, every conv launch of a
+        # forward) back to back between ONE event pair, on the activations that eager pass left in the slot's workspace
+        try:
+            tag_ms = {}
+            for (tag, _, ms) in records:
+                tag_ms[tag] = tag_ms.get(tag, 0.0) + ms
+            dtag = max(tag_ms, key=tag_ms.get)
+            dom_names = {name for (tag, _, _), (name, _, _) in zip(records, conv_log) if tag == dtag}
+            b2b = {'dom': conv_back_to_back(model, w0, st0, lambda n: n in dom_names, reps=5),
+                   'all': conv_back_to_back(model, w0, st0, lambda n: True, reps=3), 'tag': dtag, 'fwd': fwd_per_step}
+        except Exception as e:   # noqa: BLE001  (the line then falls back to the per-launch event pairs and says so)
+            b2b = {'error': '%s: %s' % (type(e).__name__, e)}
+        _dbg('back-to-back conv pass done')
     else:
         prof_steps = prof_iters if train else a.steps
     if dist is not None:
@@ -680,6 +740,23 @@ def main():
     # (bf16x3: algorithmic flops counted once, executed as three bf16 MFMAs -- against the bf16 peak its ceiling is 1/3)
     peak = PEAK_F32_TFLOPS if a.dtype == 'fp32' else PEAK_BF16_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    event_pairs = {'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4), 'tflops': round(achieved, 2),
+                   'all_conv_ms_per_step': round(all_ms / max(prof_steps, 1), 3),
+                   'note': 'per-launch HIP-event pairs on eager launches (each pair also spans the gap to the next launch): kept for the per-layer dump, '
+                           'NOT what `achieved` is computed from'}
+    avg_launch_ms = dom_ms / max(dom_n, 1)
+    launches_per_step = dom_n / float(max(prof_steps, 1))
+    dom_tflop_per_step = dom_fl / max(prof_steps, 1) / 1e12
+    all_tflop_per_step, all_ms_per_step = all_fl / max(prof_steps, 1) / 1e12, all_ms / max(prof_steps, 1)
+    use_b2b = b2b is not None and 'dom' in b2b and b2b['tag'] == dom_tag and b2b['dom'][0] > 0 and b2b['dom'][2] > 0
+    if use_b2b:
+        ms_d, fl_d, n_d, by_d = b2b['dom']
+        ms_a, fl_a, n_a, _ = b2b['all']
+        achieved = fl_d / (ms_d * 1e-3) / 1e12
+        avg_launch_ms, launches_per_step, dom_tflop_per_step = ms_d / n_d, n_d * b2b['fwd'], fl_d * b2b['fwd'] / 1e12
+        dom_bytes, dom_n = by_d, n_d
+        all_tflop_per_step, all_ms_per_step = fl_a * b2b['fwd'] / 1e12, ms_a * b2b['fwd']
+        all_fl, all_ms = fl_a, ms_a
     kernel_name = conv_kernel_name(dom_tag, a.dtype)
     traffic = pmc_traffic(a, kernel_name.replace(',tps3', '')) if not (train or two_d) else None
     streams = len(slots)
@@ -702,26 +779,36 @@ def main():
         'frac_at_measured_clock': round(achieved / (peak * shader_mhz / 2400.0), 4) if shader_mhz > 0 else None,
         # the vendor's tuned dense bf16 GEMM on this very box (hipBLASLt 8192^3): the practical, power-capped MFMA ceiling
         'vendor_gemm_tflops_same_box': vendor_gemm_tflops() if a.dtype == 'bf16' else None,
-        'launches_per_step': round(dom_n / float(max(prof_steps, 1)), 2),
-        'avg_launch_ms': round(dom_ms / max(dom_n, 1), 4),
-        'algorithmic_tflop_per_step': round(dom_fl / max(prof_steps, 1) / 1e12, 4),
-        'all_conv_kernels': {'tflop_per_step': round(all_fl / max(prof_steps, 1) / 1e12, 4),
-                             'ms_per_step': round(all_ms / max(prof_steps, 1), 3),
+        'launches_per_step': round(launches_per_step, 2),
+        'avg_launch_ms': round(avg_launch_ms, 4),
+        'algorithmic_tflop_per_step': round(dom_tflop_per_step, 4),
+        'all_conv_kernels': {'tflop_per_step': round(all_tflop_per_step, 4),
+                             'ms_per_step': round(all_ms_per_step, 3),
                              'tflops': round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
                              },
     }
+    if not train:
+        roofline['eager_event_pairs'] = event_pairs
+        if b2b is not None and 'error' in b2b:
+            roofline['back_to_back_error'] = b2b['error']
     if conc is None and (a.pipeline > 1 or graph_on) and not train:
         roofline['measured'] = ('HIP-event pair around every launch on its launch stream, %d clips run EAGERLY one at a time right after the timed '
                                 'region (%d launches of this kernel); the timed region replays captured hipGraphs, whose launches carry no '
                                 'host-side event pairs' % (prof_steps, dom_n))
+    if use_b2b:
+        roofline['measured'] = ('the %d launches of this kernel in one forward (the real layers on the real activations, net order) re-issued back to back '
+                                '5 times between ONE HIP-event pair on the launch stream right after the timed region -- no event records between the '
+                                'kernels; comparable with the rocprofv3 --kernel-trace --stats average of a --pipeline 1 run (profiles/r05); '
+                                'all_conv_kernels: every conv launch of a forward the same way' % n_d)
     if conc is not None:
         c_rec, c_log = conc
         c_fl = sum(fl for (tag, _, ms), (_, fl, _b) in zip(c_rec, c_log) if tag == dom_tag)
         c_ms = sum(ms for (tag, _, ms) in c_rec if tag == dom_tag)
         c_n = sum(1 for (tag, _, ms) in c_rec if tag == dom_tag)
-        roofline['measured'] = ('HIP-event pair around every launch on its launch stream, %d clips run one at a time right after the timed region '
-                                '(%d launches of this kernel); with %d clips in flight an event pair also spans the wait behind other streams\' '
-                                'kernels, see in_region_concurrent' % (prof_steps, dom_n, streams))
+        if not use_b2b:
+            roofline['measured'] = ('HIP-event pair around every launch on its launch stream, %d clips run one at a time right after the timed region '
+                                    '(%d launches of this kernel); with %d clips in flight an event pair also spans the wait behind other streams\' '
+                                    'kernels, see in_region_concurrent' % (prof_steps, dom_n, streams))
         roofline['in_region_concurrent'] = {
             'streams': streams, 'launches': c_n, 'avg_event_pair_ms': round(c_ms / max(c_n, 1), 4),
             'tflops_from_event_pairs': round(c_fl / (c_ms * 1e-3) / 1e12, 2) if c_ms > 0 else 0.0,
@@ -772,6 +859,9 @@ def main():
                    'forwards_in_flight': 1 if train else a.pipeline, 'clips_in_flight': 1 if train else a.pipeline * clips_per_step,
                    'keyframe_dce': bool(a.keyframe_dce),
                    'hip_graph': bool(graph_on),
+                   # since round 4 the benched graphs read the caller's resident input buffers IN PLACE (rounds 1-3 copied the 99 MB
+                   # per clip device-to-device into a private graph input first): `value` is not comparable with rounds 1-3 by that copy
+                   'resident_input': bool(resident_in) if not train else True,
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
         'ranks_seen': ranks_seen,

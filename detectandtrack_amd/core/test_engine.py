@@ -64,7 +64,10 @@ _FRAME_CACHE = None      # path -> decoded BGR uint8 frame, least recently used 
 def read_frame(path, cache_frames=64):
     """One image file -> HxWx3 uint8 BGR (the layout cv2.imread hands the reference, lib/utils/video.py / datasets roidb
     `image` paths, lib/core/test_engine.py:124-204).  Decoded with Pillow (OpenCV is not in the image); an LRU of decoded frames
-    makes a stride-1 sliding window over a video decode every file once."""
+    makes a stride-1 sliding window over a video decode every file once.  The EXIF orientation is applied like cv2.imread does
+    (IMREAD_COLOR honours it since OpenCV 3.1); Pillow's JPEG IDCT / chroma upsampling may still differ from libjpeg-turbo-in-OpenCV by
+    +-1 LSB -- pixel parity on real JPEGs is not claimed.  The cached arrays are shared by every clip that contains the frame and are
+    therefore READ-ONLY: a consumer that flips or augments must copy."""
     global _FRAME_CACHE
     import collections
     if _FRAME_CACHE is None:
@@ -73,10 +76,11 @@ def read_frame(path, cache_frames=64):
     if hit is not None:
         _FRAME_CACHE.move_to_end(path)
         return hit
-    from PIL import Image
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
-        rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+        rgb = np.asarray(ImageOps.exif_transpose(im).convert('RGB'), dtype=np.uint8)
     bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    bgr.setflags(write=False)
     _FRAME_CACHE[path] = bgr
     while len(_FRAME_CACHE) > cache_frames:
         _FRAME_CACHE.popitem(last=False)

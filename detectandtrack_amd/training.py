@@ -58,11 +58,7 @@ class TrainExecutor(Executor):
         self.metrics = {}
         self._cg = {}
         # blobs at or below the StopGradient marker (frozen trunk): no gradient is computed for them or their producers
-        self.no_grad = {'data'}
-        stop = [i for i, op in enumerate(net.ops) if op.type == 'StopGradient']
-        if stop:
-            for op in net.ops[:stop[-1] + 1]:
-                self.no_grad.update(op.outputs)
+        self.no_grad = no_grad_blobs(net)
 
     # ---- forward additions ---------------------------------------------------------------------------------------------
     def op_StopGradient(self, i, op):
@@ -630,6 +626,17 @@ class TrainExecutor(Executor):
         return {k: float(v.item()) for k, v in self.losses.items()}
 
 
+def no_grad_blobs(net):
+    """Blobs no gradient is computed for: the network input and everything produced up to the last StopGradient marker (the frozen
+    conv1 / res2 trunk, ResNet3D.py:273-274).  ONE definition for the executor's backward skip and the Trainer's completion order."""
+    ng = {'data'}
+    stop = [i for i, op in enumerate(net.ops) if op.type == 'StopGradient']
+    if stop:
+        for op in net.ops[:stop[-1] + 1]:
+            ng.update(op.outputs)
+    return ng
+
+
 def param_ready_index(net, fused=None):
     """For every parameter blob a net's ops reference (`w`, `b`): the SMALLEST index of an op that uses it.  The backward pass runs
     the ops from the last to the first, so the parameter's gradient is final once the op of that index has been differentiated
@@ -649,20 +656,20 @@ def param_ready_index(net, fused=None):
                 n = op.args.get(key)
                 if isinstance(n, str) and n:
                     idx[n] = min(idx.get(n, first), first, pos.get(id(op), first))
-    # parameters used only at or below the StopGradient marker (conv1 / res2: ResNet3D.py:273-274) never receive a gradient: their
-    # zeros are final before the backward pass starts
-    stop = [i for i, op in enumerate(net.ops) if op.type == 'StopGradient']
-    if stop:
-        last_use = {}
-        for i, op in enumerate(net.ops):
-            a = op.args if isinstance(op.args, dict) else {}
-            for key in ('w', 'b'):
-                n = a.get(key)
-                if isinstance(n, str) and n:
-                    last_use[n] = max(last_use.get(n, i), i)
-        for n, i in last_use.items():
-            if i <= stop[-1]:
-                idx[n] = len(net.ops)
+    # Parameters that never receive a gradient are final before the backward pass starts.  The rule is the EXECUTOR's own
+    # (TrainExecutor.backward skips an op when all its outputs are in `no_grad_blobs`): a parameter is frozen when every op that uses
+    # it is skipped -- not "last use before the marker", which would seal a parameter that a later op also uses.
+    ng = no_grad_blobs(net)
+    users = {}
+    for i, op in enumerate(net.ops):
+        a = op.args if isinstance(op.args, dict) else {}
+        for key in ('w', 'b'):
+            n = a.get(key)
+            if isinstance(n, str) and n:
+                users.setdefault(n, []).append(op)
+    for n, us in users.items():
+        if all(u.outputs and all(o in ng for o in u.outputs) for u in us):
+            idx[n] = len(net.ops)
     return idx
 
 
@@ -688,6 +695,7 @@ class GradExchange(object):
         self.begin()
 
     def begin(self):
+        self.stats = {}             # (of THIS iteration: finish(timing=True) fills it; never an earlier iteration's numbers)
         self.started = [False] * len(self.buckets)
         self.order = []             # bucket indices in launch order (tests)
         self._works, self._events = [], []

@@ -93,8 +93,16 @@ class Workspace(object):
     def Blobs(self):
         return list(self.blobs.keys())
 
+    # decisions an Executor derives from "which ops of the REGISTERED nets read this blob" and caches in `_layers`
+    _READER_KEYS = ('slice_lazy', 'pad_unread', 'conv_reader')
+
     def CreateNet(self, net):
         self.nets[net.name] = net
+        # a new net may read a blob that so far only pad-blind / frame-addressing ops read: the cached reader scans (lazy SliceKeyFrame,
+        # skipped zero fill of the padding channels, epilogue-written bf16x3 splits) are re-derived on the next forward.  `_layers` is
+        # shared with the forks, so it is edited in place.
+        for k in [k for k in self._layers if isinstance(k, tuple) and k and k[0] in self._READER_KEYS]:
+            del self._layers[k]
         return net
 
     def RunNet(self, name):
@@ -222,6 +230,7 @@ class Executor(object):
     # consumers that read a conv / FC output only up to its real channel count (never the zero padding up to the channel stride)
     _PAD_BLIND = frozenset(['Softmax', 'Sigmoid', 'BilinearInterpolation', 'GenerateProposals', 'TimeMean', 'RpnDeltasPerFrame'])
     training = False            # (TrainExecutor: True -- gradients are taken over whole channel strides)
+    _TSEL_AWARE = frozenset(['Conv', 'RoIFeatureTransform'])    # handlers that understand Blob.tsel
 
     def __init__(self, ws, net):
         self.ws, self.net = ws, net
@@ -232,9 +241,16 @@ class Executor(object):
         self._plan_rpn_siblings()
         self._plan_keyframe_dce()
         start = self._run_cached_trunk()
+        blobs = self.ws.blobs
         for i, op in enumerate(self.net.ops):
             if i < start or i in self._skip:
                 continue
+            if op.type not in self._TSEL_AWARE:
+                # a lazy SliceKeyFrame blob still holds all T frames of every clip: only the handlers that address frame k themselves may
+                # read one (`_slice_readers_address_frames` decides per blob; this catches a reader it was never told about)
+                for n in op.inputs:
+                    b = blobs.get(n)
+                    assert b is None or b.tsel is None, 'op %d (%s) reads the lazily sliced blob %r' % (i, op.type, n)
             getattr(self, 'op_' + op.type)(i, op)
 
     # ---- per-frame trunk cache (cfg.HIP.FRAME_TRUNK_CACHE) -----------------------------------------------------------

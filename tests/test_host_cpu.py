@@ -941,6 +941,15 @@ def test_clips_given_as_image_files_are_decoded_to_bgr_frames(tmp_path):
     assert clip_b[0] is clip_a[1] and len(test_engine._FRAME_CACHE) == 5              # shared frames were not decoded again
     mixed = test_engine.load_clip({'image': [frames[0], paths[1]]})                     # arrays pass through untouched
     assert mixed[0] is frames[0] and mixed[1] is clip_a[1]
+    # the cached arrays are shared between clips: read-only, and the EXIF orientation is applied as cv2.imread applies it
+    assert not clip_a[1].flags.writeable
+    with pytest.raises(ValueError):
+        clip_a[1][0, 0, 0] = 0
+    ex = Image.Exif()
+    ex[0x0112] = 6                                       # "rotate 90 degrees clockwise to display"
+    p = str(tmp_path / 'rotated.png')
+    Image.fromarray(np.ascontiguousarray(frames[0][:, :, ::-1])).save(p, exif=ex)
+    np.testing.assert_array_equal(test_engine.read_frame(p), np.rot90(frames[0], -1))
     test_engine._FRAME_CACHE = None
 
 
@@ -983,3 +992,42 @@ def test_gradient_contributions_of_a_blob_are_summed_over_their_frame_windows():
         out, lo = take('c')
         assert lo == 0 and tuple(out.shape) == (3, 2, 2, 4)
         assert (out[0:1].float() - c.float()).abs().max() < tol
+
+
+def test_create_net_drops_the_cached_reader_scans():
+    """the lazy-SliceKeyFrame / unread-padding / conv-reader decisions are cached per (net, blob) from a scan of the nets
+    registered at that moment; registering another net must invalidate them (a later reader would otherwise see an N*T-frame tensor
+    labelled T = 1, or unzeroed padding channels), packed layers must survive, and forks share the same cache."""
+    from detectandtrack_amd.workspace import Workspace
+
+    class Net(object):
+        def __init__(self, name):
+            self.name, self.ops = name, []
+    ws = Workspace(0)
+    fork = ws.fork()
+    ws._layers[('slice_lazy', 'net', 'fpn_2')] = True
+    ws._layers[('pad_unread', 'net', 'cls_score')] = True
+    ws._layers[('conv_reader', 'net', 'res2_0_sum')] = False
+    ws._layers[('net', 3)] = 'a packed conv layer'
+    ws._layers[('net', ('rpnhead', 'w', 'b'))] = 'a fused head layer'
+    fork.CreateNet(Net('late_reader'))
+    assert sorted(ws._layers, key=str) == sorted([('net', 3), ('net', ('rpnhead', 'w', 'b'))], key=str)
+    assert fork._layers is ws._layers and 'late_reader' in ws.nets
+
+
+def test_reference_affine_op_library_is_built_from_the_reference_source_and_exports_its_entry_points():
+    """oracle/_ref/libref_affine.so = /root/reference/lib/ops/affine_channel_nd_op.cu compiled where it lies by oracle/build_ref.py
+    (hipcc, gfx950, against the Caffe2 stand-in of oracle/ref_affine/shim): loads without a GPU, exports the two C entry points of
+    the test driver and contains the REFERENCE's kernels (caffe2::(anonymous)::ScaleBiasForward<float> / ScaleForward<float>).
+    Test infrastructure only: tracked files hold no copy of the reference source (the driver #includes it by path at build time)."""
+    from oracle import build_ref
+    if os.path.isdir('/root/reference'):
+        assert build_ref.build_affine()
+    lib = build_ref.load_affine()
+    if lib is None:
+        pytest.skip('no /root/reference and no prebuilt oracle/_ref/libref_affine.so')
+    assert hasattr(lib, 'ref_affine_channel_nd_fwd') and hasattr(lib, 'ref_affine_channel_nd_bwd')
+    blob = open(build_ref.AFFINE_SO, 'rb').read()
+    assert b'ScaleBiasForwardIfEE' in blob and b'ScaleForwardIfEE' in blob
+    drv = open(os.path.join(REPO, 'oracle', 'ref_affine', 'ref_affine_driver.hip')).read()
+    assert '#include REF_AFFINE_CU' in drv and 'CUDA_1D_KERNEL_LOOP' not in drv and '__global__' not in drv
