@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE (oracle/): C entry points over the reference's OWN AffineChannelNd translation unit.
 //
 // The reference file is compiled WHERE IT LIES (never copied): the #include below pulls /root/reference/lib/ops/affine_channel_nd_op.cu
-// -- its two __global__ kernels (ScaleBiasForward / ScaleForward, :20-46) and the two RunOnDevice() bodies (:50-92) -- into this
+// -- its two device kernels (ScaleBiasForward / ScaleForward, :20-46) and the two RunOnDevice() bodies (:50-92) -- into this
 // translation unit against the Caffe2 stand-in of oracle/ref_affine/shim.  hipcc compiles the CUDA source unchanged (triple-chevron
 // launches, blockIdx / blockDim are HIP built-ins too).  Built by oracle/build_ref.py into oracle/_ref/libref_affine.so
 // (git-ignored; travels to the GPU box with the snapshot).  tests/test_gpu_kernels.py checks dat_affine_channel_nd_fwd / _bwd and the
