@@ -15,7 +15,7 @@ tag=${1:-t}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 o=$R/gpurun_out/$tag; mkdir -p $o
 cd /tmp && export TMPDIR=/tmp && export PYTHONPATH=$R
-Q="--no-cpu-baseline --no-accuracy --no-other-configs"
+Q="--no-cpu-baseline --no-accuracy --no-other-configs --no-rocprof-check"
 n=0
 for st in "$@"; do
     n=$((n + 1))
@@ -28,7 +28,7 @@ for st in "$@"; do
     bench)  timeout -s KILL 900 python $R/bench.py $args > $o/bench.json 2> $o/bench.err; cut -c1-400 $o/bench.json ;;
     benchq) timeout -s KILL 400 python $R/bench.py $Q $args > $o/benchq_$n.json 2> $o/benchq_$n.err; cut -c1-300 $o/benchq_$n.json ;;
     layers) timeout -s KILL 400 python $R/bench.py $Q --h2d 0 --steps 10 --warmup 3 --pipeline 1 --graph 0 --dump-convs $args > $o/bench_seq_$n.json 2> $o/conv_layers_$n.txt ;;
-    stats)  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/_st -o r1 -- python $R/bench.py $Q --h2d 0 --steps 10 --warmup 3 --pipeline 1 $args > $o/${out}.log 2>&1
+    stats)  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/_st -o r1 -- python $R/bench.py $Q --no-roofline --h2d 0 --steps 10 --warmup 3 --pipeline 1 $args > $o/${out}.log 2>&1
             f=$(ls $o/_st/*/r1_kernel_stats.csv $o/_st/r1_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $o/${out}_kernel_stats.csv; rm -rf $o/_st
             grep -h '"metric"' $o/${out}.log | cut -c1-200; head -8 $o/${out}_kernel_stats.csv | cut -c1-160 ;;
     pmc)    B="python $R/bench.py $Q --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args"
