@@ -263,11 +263,13 @@ def _build_defaults():
     # communication stream while the backward of the earlier layers continues (training.py); False = one exchange after the backward
     # FUSE_RELU_BWD (training): the ReLU backward of a blob with ONE reader is applied in the epilogue of that reader's data-gradient
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
+    # WGRAD_PW_BATCH (training, with DEFER_WGRAD_FINISH): the weight gradients of up to this many POINTWISE convs (1 x 1 x 1) are queued and
+    # run as one grouped launch (dat_conv3d_wgrad_acc_batch; also flushed whenever a gradient bucket completes); 0 = one launch per layer
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
                       'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
                       'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
-                      'OVERLAP_ALLREDUCE': True})
+                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16})
     return c
 
 

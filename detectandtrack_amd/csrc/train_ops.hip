@@ -17,6 +17,9 @@
 #include "dat_common.h"
 
 #include <utility>
+#include <vector>
+
+namespace dat_conv { int ctx_num_cu(dat_ctx* ctx); }      // conv_special.hip: compute units of the device
 
 namespace {
 
@@ -762,6 +765,204 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
     }
 }
 
+// ---- weight gradient of POINTWISE convs (1 x 1 x 1, FC; stride 1 | 2) on the MFMA pipe (round 5) ---------------------------------------
+// wgrad_direct_kernel ran these layers (R-50's bottleneck 1 x 1 x 1 convs and shortcuts, the FPN laterals, the RPN / box heads) at an MFMA duty
+// cycle of 0.11: a (128 co x 128 ci) tile reads 512 bytes per staged position for 32 KFLOP -- 64 FLOP per byte, every operand row
+// fetched once per tile of the other operand (P x (Cout x n_ci + Cin x n_co) x 2 B: 4 x the compulsory traffic of a 128 -> 512 layer) --
+// through a register-staged double buffer with ONE 32-KB chunk in flight per block.  Here:
+//   * one EIGHT-wave block per CU owns a tile of 64 K accumulators -- 128 x 512, 256 x 256 or 512 x 128 (co x ci), whichever moves the
+//     fewest bytes for the layer's channel counts; a wave owns 128 co x 64 ci (8 accumulator tiles, 128 registers): 12 transposing LDS
+//     reads feed 8 MFMAs per 16-k step (the 128 x 128 kernel: 8 reads for 4);
+//   * operands come in by LDS-DMA (`global_load_lds_dwordx4`, no staging registers) as 64-channel PANELS of 32 positions x 128 B into
+//     THREE stages: chunk c computes while c + 1 and c + 2 are in flight (80 KB per CU), one counted `s_waitcnt vmcnt` + bare `s_barrier`
+//     per chunk, the pieces of chunk c + 2 issued between the MFMA groups of chunk c -- the scheme of wgrad_dma9_kernel, whose swizzle
+//     (16-byte piece p of row r in slot p ^ 4 * bit1(r)) keeps the transposing reads of four consecutive 128-byte rows on all 64 banks;
+//   * K (positions) is split over ~one block per CU; partial tiles are added into Gt[co][ci] with float atomics.
+struct WgradPwItem {
+    const char* g;        // [frames * Ho * Wo][g_cs] bf16
+    const char* x;        // [frames * H * W][x_cs] bf16
+    float* G;             // [Cout][Cin] fp32
+    int Cout, Cin, g_cs, x_cs;
+    int H, W, Wo, stride;
+    int wm;               // waves over the co axis: 1 | 2 | 4 -> tile = (128 wm) co x (64 * 8 / wm) ci
+    int ksplit, n_ci_tiles, n_co_tiles;
+    int atomic;
+    unsigned p_begin, p_end;            // output positions [p_begin, p_end) carry a non-zero gradient
+    unsigned how, how_magic, wo_magic;  // Ho * Wo; floor(2^32 / how) (quotient corrected by one step); ceil(2^32 / Wo)
+    unsigned block0;                    // first block of the grid that works on this layer
+};
+// SEVERAL layers per launch (round 5).  Float atomics retire at about one dword per clock and L2 channel on this part (~1.2 TB/s: measured by
+// sweeping the K split, tools/probes/wgrad_bench.py pw), and a layer split over all 256 CUs adds 256 partial tiles of 256 KB = 64 MB -- 50 us
+// of atomics behind 20-30 us of MFMA work, the same for the 128 x 128 kernel this one replaces.  The partial volume is (blocks in flight) x
+// (accumulators per block) whatever the tile, so the only way to shrink it is to give a layer FEWER blocks -- and the other CUs to other
+// layers: the pointwise weight gradients of a whole gradient bucket (10-40 layers) are one grid of ~2 blocks per CU, every block a
+// (layer, tile, K range) with about the same number of chunks.  The table travels in the kernel arguments (no device table to keep alive).
+constexpr int PW_MAX_ITEMS = 24;
+struct WgradPwBatch {
+    const char* zeros;                  // >= 16 zero bytes in global memory
+    int n;
+    WgradPwItem item[PW_MAX_ITEMS];
+};
+
+constexpr int PW_KC = 32;                     // positions per chunk
+constexpr int PW_PANEL = PW_KC * 128;         // one 64-channel panel of a chunk: 4 KB = four 1-KB DMA pieces
+
+template <int PANELS>
+__global__ __launch_bounds__(512, 1) void wgrad_pw_kernel(const WgradPwBatch b) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int STAGE = PANELS * PW_PANEL;
+    constexpr int PPW = PANELS / 2;             // DMA pieces per wave and chunk (PANELS * 4 pieces over 8 waves)
+    static_assert(PANELS == 8 || PANELS == 10, "tile shapes: 256 x 256 (4 + 4 panels), 128 x 512 / 512 x 128 (2 + 8 / 8 + 2)");
+    int job = 0;
+    while (job + 1 < b.n && blockIdx.x >= b.item[job + 1].block0) ++job;
+    const WgradPwItem& p = b.item[job];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = p.wm;
+    const int wm_i = wave & (wm - 1), wn_i = wave / wm;
+    const int ncp = 2 * wm;                     // g panels of a stage; the x panels follow
+    const int TM = 128 * wm, TN = 64 * (8 / wm);
+    unsigned bid = blockIdx.x - p.block0;
+    const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
+    const int co_t = bid % p.n_co_tiles;
+    const int split = bid / p.n_co_tiles;
+    const unsigned p_begin = p.p_begin, p_end = p.p_end;
+    const unsigned nchunks = (p_end - p_begin + (PW_KC - 1)) / PW_KC;
+    const unsigned c_lo = (unsigned)((unsigned long long)nchunks * split / p.ksplit), c_hi = (unsigned)((unsigned long long)nchunks * (split + 1) / p.ksplit);
+    const unsigned n_iter = c_hi - c_lo;
+    const char* const gbase = p.g;
+    const char* const xbase = p.x;
+    const size_t g_pitch = (size_t)p.g_cs * 2, x_pitch = (size_t)p.x_cs * 2;
+    const unsigned how = p.how, how_magic = p.how_magic, wo_magic = p.wo_magic, Wo = (unsigned)p.Wo, Hin = (unsigned)p.H, Win = (unsigned)p.W,
+                   strd = (unsigned)p.stride;
+
+    // ---- this lane's DMA pieces: piece gp = wave + 8 u of a stage covers rows (gp & 3) * 8 .. + 7 of panel gp >> 2; the lane writes
+    //      row (gp & 3) * 8 + lane / 8, slot lane % 8, which holds data piece slot ^ 4 * bit1(row) ----
+    int pk_row[PPW], pk_col[PPW];               // pk_col: byte offset of the piece inside the tensor's channel run, -1 = always zeros
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int gp = wave + 8 * u, panel = gp >> 2;
+        const int row = (gp & 3) * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        int col = -1;
+        if (panel < ncp) {
+            const int ch = co_t * TM + panel * 64 + piece * 8;
+            if (ch < p.g_cs) col = ch * 2;
+        } else {
+            const int ch = ci_t * TN + (panel - ncp) * 64 + piece * 8;
+            if (ch < p.x_cs) col = ch * 2;
+        }
+        pk_row[u] = row; pk_col[u] = col;
+    }
+    const char* const zeros = b.zeros;
+    auto issue_piece = [&](unsigned ch, int stage, auto u_c) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_c)::value;
+        const int gp = wave + 8 * u;
+        const bool is_g = (gp >> 2) < ncp;                              // (uniform per wave and u)
+        const unsigned pos = p_begin + ch * (unsigned)PW_KC + (unsigned)pk_row[u];
+        const bool ok = ch < c_hi && pos < p_end && pk_col[u] >= 0;
+        const unsigned pc = min(pos, p_end - 1u);                       // (a clamped row: the address stays inside the tensor, the mask decides)
+        // output position -> (frame, oy, ox) -> input row (frame, s oy, s ox); stride 1 maps a position onto itself (H x W = Ho x Wo)
+        unsigned f = __umulhi(pc, how_magic);
+        unsigned rem = pc - f * how;
+        if (rem >= how) { rem -= how; ++f; }                            // (floor(2^32 / how) under-estimates the quotient by at most one)
+        const unsigned oy = __umulhi(rem, wo_magic), ox = rem - oy * Wo;
+        const size_t xrow = ((size_t)f * Hin + oy * strd) * Win + ox * strd;
+        const char* at = (is_g ? gbase + (size_t)pc * g_pitch : xbase + xrow * x_pitch) + max(pk_col[u], 0);
+        const unsigned long long m = ok ? ~0ull : 0ull;
+        const char* src = (const char*)((unsigned long long)zeros + (((unsigned long long)at - (unsigned long long)zeros) & m));
+        const unsigned lds_at = (unsigned)(size_t)(lptr_t)(smem + stage * STAGE + gp * 1024);
+        // (inline asm without a memory clobber, M0 written behind the compiler's back: see wgrad_dma9_kernel)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_at));
+    };
+    auto issue = [&](unsigned ch, int stage) __attribute__((always_inline)) {
+        static_for(std::make_integer_sequence<int, PPW>{}, [&](auto u_c) __attribute__((always_inline)) { issue_piece(ch, stage, u_c); });
+        asm volatile("" ::: "memory");
+    };
+    // ---- fragment addressing: a 16-lane group reads the 4 (k) x 16 (channel) block at rows k0 + (grp >> 1) * 8 [+ 4], channels (grp & 1) * 16;
+    //      lane i of the group supplies row i >> 2, channels 4 (i & 3) and receives channel i's four rows ----
+    const int grp = lane >> 4, li = lane & 15;
+    const int f_row = (grp >> 1) * 8 + (li >> 2);
+    const int f_col = (((grp & 1) * 16 + (li & 3) * 4) * 2) ^ (((f_row >> 1) & 1) << 6);
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = (wm_i * 2 + (i >> 1)) * PW_PANEL + f_row * 128 + (f_col ^ ((i & 1) << 6));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_off[j] = (ncp + wn_i) * PW_PANEL + f_row * 128 + (f_col ^ (j << 6));
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typedef __attribute__((address_space(3))) wd_v4s* lp_t;
+    auto frag = [&](const char* a) __attribute__((always_inline)) {
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)a));
+        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(a + 4 * 128)));
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto compute = [&](int stage, unsigned nx_ch, int nx_stage) __attribute__((always_inline)) {
+        const char* sb = smem + stage * STAGE;
+        uint4 a[2][4], bb[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[0][i] = frag(sb + a_off[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bb[0][j] = frag(sb + b_off[j]);
+        static_for(std::make_integer_sequence<int, PW_KC / 16>{}, [&](auto ks_c) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ks_c)::value;
+            if (ks + 1 < PW_KC / 16) {          // the fragments of k-step ks + 1 are requested before the MFMAs of step ks
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[(ks + 1) & 1][i] = frag(sb + a_off[i] + (ks + 1) * 16 * 128);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bb[(ks + 1) & 1][j] = frag(sb + b_off[j] + (ks + 1) * 16 * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for(std::make_integer_sequence<int, 4>{}, [&](auto i_c) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_c)::value, slot = ks * 4 + i;     // MFMA pair 0..7 of the chunk
+                if (slot < PPW) issue_piece(nx_ch, nx_stage, std::integral_constant<int, slot < PPW ? slot : 0>{});
+                MmaT<DAT_BF16>::step(a[ks & 1][i], bb[ks & 1][0], acc[i][0]);
+                MmaT<DAT_BF16>::step(a[ks & 1][i], bb[ks & 1][1], acc[i][1]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    if (n_iter > 0) {
+        issue(c_lo, 0);
+        issue(c_lo + 1, 1);
+        int stage = 0;
+        for (unsigned it = 0; it < n_iter; ++it) {
+            // all but my PPW pieces of chunk c + 1 have landed and my LDS reads of chunk c - 1 are done; behind the barrier chunk c is complete
+            // for every wave and stage (c - 1) % 3 is free for chunk c + 2 (a bare s_barrier: __syncthreads() would wait for vmcnt(0))
+            if (PPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int nstage = stage == 0 ? 2 : stage - 1;
+            compute(stage, c_lo + it + 2, nstage);
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two trailing (zero) chunks: nothing may still be writing LDS at exit
+    }
+    const int khalf = lane >> 5;
+    const int Cout = p.Cout, Cin = p.Cin, atomic = p.atomic;
+    float* const G = p.G;
+    if (n_iter == 0 && atomic) return;          // (nothing to add)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci_t * TN + wn_i * 64 + j * 32 + (lane & 31);
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_t * TM + wm_i * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co >= Cout) continue;
+                if (atomic) atomicAdd(G + (size_t)co * Cin + ci, acc[i][j][r]);
+                else G[(size_t)co * Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // Gt[tap][co][ci] -> dW[co][ci][tap] * scale[co] (the fused AffineChannelNd scale; NULL = 1)
 __global__ void wgrad_finish_kernel(const float* __restrict__ Gt, const float* __restrict__ scale, float* __restrict__ dW, int Cout,
                                     int Cin, int ntaps) {
@@ -1182,6 +1383,89 @@ static bool wgrad_direct_eligible(const dat_ctx* ctx, const dat_conv_desc* d, in
            (long long)Ho * Wo * Wo < (1ll << 32);
 }
 
+// ---- pointwise layers: plan (tile shape, geometry) and grouped launch ------------------------------------------------------------
+struct PwPlan {
+    WgradPwItem it;
+    long long tiles, nchunks;
+};
+
+static bool pw_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    return d->KT == 1 && d->KH == 1 && d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->pad_t == 0 && ctx->dbg_wgrad_pw;
+}
+
+static int pw_plan(dat_ctx* ctx, const dat_conv_desc* d, const void* x, const void* g, int g_cstride, int Cin_real, int Cout_real, float* Gt,
+                   PwPlan* pl) {
+    int Ho, Wo;
+    dat_conv3d_out_shape(d, &Ho, &Wo);
+    const int clips = d->frames / d->T;
+    WgradPwItem& q = pl->it;
+    memset(&q, 0, sizeof(q));
+    q.g = (const char*)g; q.x = (const char*)x; q.G = Gt;
+    q.Cout = Cout_real; q.Cin = Cin_real; q.g_cs = g_cstride; q.x_cs = d->Cin;
+    q.H = d->H; q.W = d->W; q.Wo = Wo; q.stride = d->stride_h;
+    q.how = (unsigned)(Ho * Wo);
+    q.how_magic = q.how == 1 ? 0xffffffffu : (unsigned)(0x100000000ull / q.how);
+    q.wo_magic = Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)Wo - 1) / (unsigned)Wo);
+    q.p_begin = 0; q.p_end = (unsigned)((long long)d->frames * Ho * Wo);
+    if (d->out_tn > 0 && clips == 1) {      // g is non-zero only in frames [out_t0, out_t0 + out_tn) of the clip
+        DAT_ENFORCE(ctx, d->out_t0 >= 0 && d->out_t0 + d->out_tn <= d->T, "conv3d_wgrad: gradient frames [%d, %d) outside T %d",
+                    d->out_t0, d->out_t0 + d->out_tn, d->T);
+        q.p_begin = (unsigned)d->out_t0 * q.how; q.p_end = (unsigned)(d->out_t0 + d->out_tn) * q.how;
+    }
+    // tile shape: least padded MFMA work first, then least operand traffic (every g row is read once per ci tile, every x row once per
+    // co tile); ties go to the squarer tile
+    int best_wm = 2;
+    long long best_work = -1, best_traffic = 0;
+    const int wm_order[3] = {2, 1, 4};
+    for (int k = 0; k < 3; ++k) {
+        const int wm = ctx->dbg_wgrad_pw >= 10 ? ctx->dbg_wgrad_pw / 10 : wm_order[k];      // (DAT_WGRAD_PW = 10 / 20 / 40: forced shape)
+        const long long tm = 128 * wm, tn = 64 * (8 / wm);
+        const long long nco = (Cout_real + tm - 1) / tm, nci = (Cin_real + tn - 1) / tn;
+        const long long work = nco * tm * nci * tn, traffic = (long long)g_cstride * nci + (long long)d->Cin * nco;
+        if (best_work < 0 || work < best_work || (work == best_work && traffic < best_traffic)) {
+            best_work = work; best_traffic = traffic; best_wm = wm;
+        }
+    }
+    q.wm = best_wm;
+    const int tm = 128 * q.wm, tn = 64 * (8 / q.wm);
+    q.n_co_tiles = (Cout_real + tm - 1) / tm; q.n_ci_tiles = (Cin_real + tn - 1) / tn;
+    pl->tiles = (long long)q.n_co_tiles * q.n_ci_tiles;
+    pl->nchunks = ((long long)(q.p_end - q.p_begin) + PW_KC - 1) / PW_KC;
+    return DAT_OK;
+}
+
+// launches the planned items (ksplit / atomic set by the caller): one grid per tile class (8 | 10 panels per stage), <= PW_MAX_ITEMS layers each
+static int pw_launch(dat_ctx* ctx, hipStream_t st, PwPlan* pls, int n) {
+    for (int cls = 0; cls < 2; ++cls) {
+        int i = 0;
+        while (i < n) {
+            WgradPwBatch b;
+            b.zeros = (const char*)ctx->zeros;
+            b.n = 0;
+            unsigned blocks = 0;
+            for (; i < n && b.n < PW_MAX_ITEMS; ++i) {
+                if ((pls[i].it.wm == 2) != (cls == 0)) continue;
+                WgradPwItem& q = b.item[b.n++];
+                q = pls[i].it;
+                q.block0 = blocks;
+                blocks += (unsigned)(pls[i].tiles * q.ksplit);
+            }
+            if (b.n == 0) continue;
+            if (cls == 0) {
+                const size_t lds = 3 * (size_t)8 * PW_PANEL;
+                if (dat_ensure_lds(ctx, (const void*)wgrad_pw_kernel<8>, (int)lds) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL((wgrad_pw_kernel<8>), dim3(blocks), dim3(512), lds, st, b);
+            } else {
+                const size_t lds = 3 * (size_t)10 * PW_PANEL;
+                if (dat_ensure_lds(ctx, (const void*)wgrad_pw_kernel<10>, (int)lds) != DAT_OK) return DAT_ERR_LAUNCH;
+                hipLaunchKernelGGL((wgrad_pw_kernel<10>), dim3(blocks), dim3(512), lds, st, b);
+            }
+        }
+    }
+    DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad pointwise batch");
+    return DAT_OK;
+}
+
 // acc_mode (dat_conv3d_wgrad_acc): `workspace` IS the caller's fp32 accumulator in the kernels' [tap][Cout][Cin] order -- no zeroing, always
 // atomics, no finish launch (the caller zeroes it once per iteration and runs ONE dat_wgrad_finish_batch for all layers)
 static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
@@ -1271,6 +1555,28 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
                 hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
                                    Cout_real, Cin_real, d->KT * 9);
             DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad direct9");
+            return DAT_OK;
+        }
+        if (pw_eligible(ctx, d)) {
+            // pointwise layers (1 x 1 x 1 convs, FC; stride 1 | 2): eight-wave blocks, 64 K accumulators per tile (wgrad_pw_kernel)
+            PwPlan pl;
+            if (int rc = pw_plan(ctx, d, x, g, g_cstride, Cin_real, Cout_real, Gt, &pl)) return rc;
+            const int ncu = dat_conv::ctx_num_cu(ctx);
+            long long ks = pl.tiles >= ncu ? 1 : ncu / pl.tiles;        // one block per CU
+            if (ks > pl.nchunks / 4) ks = pl.nchunks / 4;               // at least 4 chunks per block
+            if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
+            if (ks > pl.nchunks) ks = pl.nchunks;
+            if (ks < 1) ks = 1;
+            pl.it.ksplit = (int)ks;
+            pl.it.atomic = ks > 1 || acc_mode;
+            const size_t g_elems = (size_t)Cout_real * Cin_real;
+            if (ks > 1 && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
+                DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
+            if (int rc = pw_launch(ctx, st, &pl, 1)) return rc;
+            if (!acc_mode)
+                hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid_for((long long)g_elems, 256)), dim3(256), 0, st, (const float*)Gt, scale, dW,
+                                   Cout_real, Cin_real, 1);
+            DAT_CHECK_LAUNCH(ctx, "conv3d_wgrad pointwise");
             return DAT_OK;
         }
         WgradDirectParams wp;
@@ -1395,6 +1701,41 @@ int dat_conv3d_wgrad_acc_supported(dat_ctx* ctx, const dat_conv_desc* d, int g_c
 int dat_conv3d_wgrad_acc(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
                          int Cin_real, int Cout_real, float* Gt) {
     return wgrad_impl(ctx, s, d, x, g, g_cstride, Cin_real, Cout_real, nullptr, Gt, nullptr, 1);
+}
+
+// n deferred-finish weight gradients in one call (same result as n dat_conv3d_wgrad_acc calls): the pointwise layers among them share
+// grouped launches of wgrad_pw_kernel -- ~2 blocks per CU over ALL of them, every block about the same number of 32-position chunks --,
+// the others run one by one.
+int dat_conv3d_wgrad_acc_batch(dat_ctx* ctx, dat_stream s, const dat_wgrad_job* jobs, int n) {
+    DAT_ENFORCE(ctx, jobs || n == 0, "conv3d_wgrad_acc_batch: null argument");
+    std::vector<PwPlan> pls;
+    for (int i = 0; i < n; ++i) {
+        const dat_wgrad_job& j = jobs[i];
+        DAT_ENFORCE(ctx, j.desc && j.x && j.g && j.Gt, "conv3d_wgrad_acc_batch: null member in job %d", i);
+        if (wgrad_direct_eligible(ctx, j.desc, j.g_cstride) && pw_eligible(ctx, j.desc)) {
+            PwPlan pl;
+            if (int rc = pw_plan(ctx, j.desc, j.x, j.g, j.g_cstride, j.Cin_real, j.Cout_real, j.Gt, &pl)) return rc;
+            pls.push_back(pl);
+        } else if (int rc = wgrad_impl(ctx, s, j.desc, j.x, j.g, j.g_cstride, j.Cin_real, j.Cout_real, nullptr, j.Gt, nullptr, 1)) {
+            return rc;
+        }
+    }
+    if (pls.empty()) return DAT_OK;
+    const int ncu = dat_conv::ctx_num_cu(ctx);
+    long long total = 0;
+    for (const PwPlan& pl : pls) total += pl.tiles * pl.nchunks;
+    const long long target = (pls.size() == 1 ? 1 : 2) * (long long)ncu;           // blocks in the grid(s)
+    long long cpb = (total + target - 1) / target;                                  // chunks per block
+    if (cpb < 4) cpb = 4;
+    for (PwPlan& pl : pls) {
+        long long ks = (pl.nchunks + cpb - 1) / cpb;
+        if (ctx->dbg_wgrad_ks > 0) ks = ctx->dbg_wgrad_ks;
+        if (ks > pl.nchunks) ks = pl.nchunks;
+        if (ks < 1) ks = 1;
+        pl.it.ksplit = (int)ks;
+        pl.it.atomic = 1;
+    }
+    return pw_launch(ctx, (hipStream_t)s, pls.data(), (int)pls.size());
 }
 
 // dW[co][ci][tap] (+)= scale[co] * Gt[tap][co][ci] for a table of layers in ONE launch (blocks of 256 threads x 8 elements; an item owns

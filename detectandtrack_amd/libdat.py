@@ -38,6 +38,11 @@ class WFinishItem(C.Structure):
                [(n, C.c_int) for n in ('Cout', 'Cin', 'ntaps', 'accumulate')] + [('block0', C.c_longlong)]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [('desc', C.POINTER(ConvDesc)), ('x', C.c_void_p), ('g', C.c_void_p), ('g_cstride', C.c_int), ('Cin_real', C.c_int),
+                ('Cout_real', C.c_int), ('Gt', C.c_void_p)]
+
+
 class RoiLevel(C.Structure):
     _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
 
@@ -122,6 +127,7 @@ _PROTOS = {
     'dat_conv3d_wgrad_acc_supported': (_i, [_p, C.POINTER(ConvDesc), _i]),
     'dat_conv3d_wgrad_acc': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p]),
     'dat_wgrad_finish_batch': (_i, [_p, _p, _p, _i, C.c_longlong]),
+    'dat_conv3d_wgrad_acc_batch': (_i, [_p, _p, C.POINTER(WgradJob), _i]),
     'dat_relu_bias_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i]),
     'dat_zero_insert2x': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i]),
     'dat_upsample2x_bwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i]),

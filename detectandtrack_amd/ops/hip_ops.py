@@ -366,7 +366,24 @@ class ConvGrad(object):
         ctx().call('dat_conv3d_wgrad_acc', _stream(), C.byref(d), _ptr(x), _ptr(g), self.g_cstride, self.cin, self.cout, _ptr(gt))
         return True
 
-    def data(self, g, T, H, W, accumulate_into=None, g_frames=None, mask=None):
+    def weight_acc_job(self, x, g, T, gt, g_frames=None):
+        """The arguments of `weight_acc` as a job for `wgrad_acc_batch` (None when the layer does not take the direct kernels).  The job holds
+        references to x / g / gt: they stay alive (and must stay unmodified) until the batch has been enqueued."""
+        frames, H, W, _ = x.shape
+        d = self._fwd_desc(frames, T, H, W)
+        if g_frames is not None and frames == T:
+            d.out_t0, d.out_tn = int(g_frames[0]), int(g_frames[1])
+        if not L.lib().dat_conv3d_wgrad_acc_supported(ctx().h, C.byref(d), self.g_cstride):
+            return None
+        assert gt.dtype == torch.float32 and gt.is_contiguous() and gt.numel() == self.w.numel()
+        assert x.is_contiguous() and g.is_contiguous()
+        return (d, x, g, self.g_cstride, self.cin, self.cout, gt)
+
+    @property
+    def pointwise(self):
+        return self.kt == 1 and self.kh == 1 and self.kw == 1 and tuple(self.pads) == (0, 0, 0)
+
+    def data(self, g, T, H, W, accumulate_into=None, g_frames=None, mask=None, inplace=True):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given).  mask: the conv's
         forward input x = relu(...) in the shape of dL/dx -- the ReLU backward of x's producer is applied in this conv's epilogue
         (dL/dx := x > 0 ? dL/dx : 0, res_mode 3), which saves that producer's elementwise mask pass."""
@@ -389,7 +406,9 @@ class ConvGrad(object):
         in_t = g_frames if (g_frames is not None and frames == T) else None   # zero frames of g: their temporal taps are skipped
         if accumulate_into is not None:
             assert mask is None
-            return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into, in_t=in_t)
+            # inplace=False: the sum goes to a NEW tensor (`accumulate_into` is read as the residual and left untouched -- somebody else,
+            # a queued weight-gradient job, still needs its present contents)
+            return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into if inplace else None, in_t=in_t)
         if mask is not None:
             assert mask.is_contiguous() and mask.dtype == gz.dtype
             return lay(gz, T=T, residual=mask, res_mode=3, in_t=in_t)
@@ -467,6 +486,19 @@ class PackBatch(object):
         for l in self.layers:
             if l.bias_src is not None:
                 l.bias[:l.cout_real] = l.bias_src.float()
+
+
+def wgrad_acc_batch(jobs):
+    """dat_conv3d_wgrad_acc_batch: the deferred-finish weight gradients of `jobs` (ConvGrad.weight_acc_job tuples) in one call -- the
+    pointwise layers among them as grouped launches that share the CUs (a tenth of the float-atomic traffic of one launch per layer)."""
+    if not jobs:
+        return
+    arr = (L.WgradJob * len(jobs))()
+    for i, (d, x, g, g_cs, cin, cout, gt) in enumerate(jobs):
+        arr[i].desc = C.pointer(d)
+        arr[i].x, arr[i].g, arr[i].Gt = x.data_ptr(), g.data_ptr(), gt.data_ptr()
+        arr[i].g_cstride, arr[i].Cin_real, arr[i].Cout_real = g_cs, cin, cout
+    ctx().call('dat_conv3d_wgrad_acc_batch', _stream(), arr, len(jobs))
 
 
 class WeightFinishBatch(object):

@@ -44,6 +44,8 @@ class TrainExecutor(Executor):
         # memset + a transposing finish launch around every layer's kernel (46 + 46 launches of an R-18 iteration).
         self.gt_arena = gt_arena if arena is not None else None
         self._deferred = {}      # weight name -> the fused AffineChannelNd scale (tensor or None) its finish multiplies by
+        self._pw_pending = []    # (weight name, ConvGrad.weight_acc_job) of pointwise layers waiting for their grouped launch
+        self._pw_batch = int(cfg.HIP.get('WGRAD_PW_BATCH', 16)) if gt_arena is not None and arena is not None else 0
         self._sealed = set()     # parameters whose gradient bucket is already on its way to the other ranks (Trainer, overlap)
         self.accumulate_all = False   # the arena already holds gradients of an earlier clip (Trainer.step(zero_grad=False)): add, never overwrite
         self._iter_cache = {}           # per backward pass: objects several ops build from the same weights (see backward)
@@ -269,9 +271,17 @@ class TrainExecutor(Executor):
         self._finish_deferred()
         self.grads.clear()
 
+    def _flush_pw(self):
+        """Run the queued pointwise weight gradients (one grouped launch per tile class) and drop the references that kept their operands alive."""
+        if self._pw_pending:
+            ops.wgrad_acc_batch([j for _, j in self._pw_pending])
+            self._pw_pending = []
+
     def _finish_deferred(self, only=None):
         """Turn the deferred weight-gradient accumulators into gradients (one batched launch).  only: restrict to these parameter
         names (one gradient bucket); the others stay deferred."""
+        if self._pw_pending and (only is None or any(n in only for n, _ in self._pw_pending)):
+            self._flush_pw()        # (the accumulators must be complete before they are read)
         names = sorted(n for n in self._deferred if only is None or n in only)
         if not names:
             return
@@ -352,7 +362,17 @@ class TrainExecutor(Executor):
             gt = self.gt_arena.get(a['w']) if (self.gt_arena is not None and a['w'] in self.arena) else None
             if a['w'] in self._sealed:
                 self._pgrad(a['w'], None)       # raises: the bucket of this weight is already being exchanged
-            if gt is not None and cg.weight_acc(x_win, g_emb, Tw, gt, g_frames=gfr):
+            job = None
+            if gt is not None and cg.pointwise and self._pw_batch > 0:
+                # pointwise layers: queued, and run as ONE grouped launch per gradient bucket / per `WGRAD_PW_BATCH` layers (a layer launched
+                # alone is split over all CUs and adds 64 MB of partial tiles with float atomics; a shared grid a tenth of that)
+                job = cg.weight_acc_job(x_win if x_win.is_contiguous() else x_win.contiguous(), g_emb, Tw, gt, g_frames=gfr)
+            if job is not None:
+                self._pw_pending.append((a['w'], job))
+                self._deferred[a['w']] = cg.scale
+                if len(self._pw_pending) >= self._pw_batch:
+                    self._flush_pw()
+            elif gt is not None and cg.weight_acc(x_win, g_emb, Tw, gt, g_frames=gfr):
                 self._deferred[a['w']] = cg.scale
             else:
                 dW, _ = cg.weight(x_win, g_emb, Tw, g_frames=gfr, out=self._pgrad_out(a['w']))
@@ -377,9 +397,14 @@ class TrainExecutor(Executor):
                     isinstance(prod.args, dict) and prod.args.get('relu') and self._readers.get(op.inputs[0], 0) == 1 and
                     not pend and xin.keyframe is None and not xin.t2c and xin.t.shape[3] == ops.round_up(cg.cin, 64)):
                 mask = x_win if x_win.is_contiguous() else None
-            dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None, mask=mask)
+            # a queued pointwise weight gradient may still have to READ the tensor the sum would be written into (the block output's gradient
+            # is both branch2c's `g` and the shortcut contribution of the block input): then the sum goes to a new tensor
+            held = into is not None and any(j[2].data_ptr() == into.data_ptr() for _, j in self._pw_pending)
+            dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None, mask=mask, inplace=not held)
             if into is None:
                 self._add_grad(op.inputs[0], dx, ilo, masked=mask is not None)
+            elif held:
+                self.grads[op.inputs[0]] = [(dx, ilo, False)]
 
     def _bwd_rpn_head(self, i):
         ws = self.ws

@@ -383,6 +383,18 @@ int dat_conv3d_wgrad_acc_supported(dat_ctx* ctx, const dat_conv_desc* d, int g_c
 int dat_conv3d_wgrad_acc(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* g, int g_cstride,
                          int Cin_real, int Cout_real, float* Gt);
 int dat_wgrad_finish_batch(dat_ctx* ctx, dat_stream s, const dat_wfinish_item* items_dev, int n, long long total_blocks);
+/* n deferred-finish weight gradients in ONE call -- the result of n dat_conv3d_wgrad_acc calls (HOST array of jobs; every member as in that
+ * function).  The pointwise layers among them (1 x 1 x 1 convs / FC, stride 1 | 2) are executed as grouped launches: a layer split over all
+ * CUs adds one partial tile per CU with float atomics (~64 MB per layer at ~1.2 TB/s), a grid shared by all the layers of a gradient bucket
+ * a tenth of that.  Reference semantics: the ConvGradient ops AddGradientOperators emits, lib/modeling/model_builder.py:908-951. */
+typedef struct dat_wgrad_job {
+    const dat_conv_desc* desc;
+    const void* x;
+    const void* g;
+    int g_cstride, Cin_real, Cout_real;
+    float* Gt;
+} dat_wgrad_job;
+int dat_conv3d_wgrad_acc_batch(dat_ctx* ctx, dat_stream s, const dat_wgrad_job* jobs, int n);
 /* g = (dy [+ dy2]) * (y > 0 if relu) over [npos][cstride] (channels >= C zeroed); dbias[c] += sum_p g (may be NULL).
  * Relu backward on the fused conv's output + the bias / AffineChannelNd-bias reduction
  * (affine_channel_nd_op.cu:74-92). */

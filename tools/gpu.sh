@@ -10,6 +10,7 @@
 #   pmc[:bench args]        three separate --pmc passes (MFMA busy / FETCH_SIZE / WRITE_SIZE; --kernel-trace only) of a --pipeline 1 run
 #   smoke                   __graft_entry__.smoke()
 #   py:<script;args>        python <script> <args>   (-> py_<n>.log)
+#   env:<NAME=V;NAME2=V2>   export for the stages that follow (A/B pairs inside one call);  unset:<NAME;NAME2>
 # Environment switches (DAT_*) are inherited, so A/B pairs are two stages in one call:  DAT_X=1 bash tools/gpu.sh ...
 tag=${1:-t}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -38,6 +39,8 @@ for st in "$@"; do
             for f in pmc_mfma pmc_fetch pmc_write; do for g in $o/$f/*/r1_*.csv; do [ -f "$g" ] && mv $g $o/$f/; done; done
             ls $o/pmc_mfma | head -3 ;;
     smoke)  (cd $R && timeout -s KILL 600 python -c "import __graft_entry__ as g; g.smoke()" > $o/smoke.log 2>&1; tail -2 $o/smoke.log) ;;
+    env)    for kv in $args; do export "$kv"; done ;;
+    unset)  for kv in $args; do unset "$kv"; done ;;
     py)     (cd $R && timeout -s KILL 900 python $args > $o/py_$n.log 2>&1; echo "rc $?" >> $o/py_$n.log; tail -25 $o/py_$n.log) ;;
     *)      echo "unknown stage $name" ;;
     esac

@@ -90,6 +90,99 @@ elif len(_s.argv) > 1 and _s.argv[1] == 'res5':   # layers with more tiles than 
         ref = rs[0][1]
         worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
         print('%-28s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
+elif len(_s.argv) > 1 and _s.argv[1] == 'pw':     # round 5: pointwise layers of an R-50 FPN3D training iteration -- 128 x 128 per-tap kernel vs wgrad_pw_kernel
+    PW = [  # (res2 is frozen: no weight gradients below res3)
+        ('res3_0 2a 256->128 s2', 256, 128, 2, 8, 192, 336), ('res3_0 sc 256->512 s2', 256, 512, 2, 8, 192, 336),
+        ('res3 2c 128->512', 128, 512, 1, 8, 96, 168), ('res3 2a 512->128', 512, 128, 1, 8, 96, 168),
+        ('res4_0 2a 512->256 s2', 512, 256, 2, 8, 96, 168), ('res4 2c 256->1024', 256, 1024, 1, 8, 48, 84), ('res4 2a 1024->256', 1024, 256, 1, 8, 48, 84),
+        ('res5 2c 512->2048', 512, 2048, 1, 8, 24, 42), ('res5 2a 2048->512', 2048, 512, 1, 8, 24, 42),
+        ('lateral P2 256->256 (3 frames)', 256, 256, 1, 3, 192, 336), ('lateral P3 512->256 (3 frames)', 512, 256, 1, 3, 96, 168),
+        ('lateral P5 2048->256', 2048, 256, 1, 8, 24, 42), ('fc6 12544->1024 (512 rois)', 12544, 1024, 1, 1, 1, 512),
+        ('rpn heads 256->15 P2 key frame', 256, 15, 1, 1, 192, 336),
+    ]
+
+    def run_pw(tag):
+        for name, cin, cout, st, T, H, W in PW:
+            g = torch.Generator().manual_seed(1)
+            Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+            cs_g = ops.round_up(cout, 64)
+            x = torch.randn((T, H, W, cin), generator=g).bfloat16().cuda()
+            gy = torch.randn((T, Ho, Wo, cs_g), generator=g).bfloat16().cuda()
+            gy[..., cout:] = 0
+            w = torch.randn((cout, cin, 1, 1, 1), generator=g).cuda() * 0.05
+            cg = ops.ConvGrad(w, None, (st, st), (0, 0, 0), ops.BF16, cin, cs_g)
+            gt = torch.zeros(cout * cin, dtype=torch.float32, device='cuda')
+            assert cg.weight_acc(x, gy, T, gt)
+            torch.cuda.synchronize()
+            RESULTS.setdefault(name, []).append((tag, gt.clone()))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                cg.weight_acc(x, gy, T, gt)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            fl = 2.0 * cin * cout * T * Ho * Wo
+            byt = 2.0 * T * Ho * Wo * (cin + cs_g)
+            print('%-10s %-34s %7.3f ms  %7.1f TFLOP/s  %6.2f TB/s compulsory' % (tag, name, ms, fl / ms / 1e9, byt / ms / 1e9), flush=True)
+
+    def fresh_pw(env, tag):
+        global run
+        keep, run = run, run_pw
+        try:
+            fresh(env, tag)
+        finally:
+            run = keep
+    def run_batch(tag):
+        # the whole list as ONE dat_conv3d_wgrad_acc_batch call (what the training executor does per gradient bucket) against the sum of the
+        # single launches
+        jobs, fl = [], 0.0
+        for name, cin, cout, st, T, H, W in PW:
+            g = torch.Generator().manual_seed(1)
+            Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+            cs_g = ops.round_up(cout, 64)
+            x = torch.randn((T, H, W, cin), generator=g).bfloat16().cuda()
+            gy = torch.randn((T, Ho, Wo, cs_g), generator=g).bfloat16().cuda()
+            gy[..., cout:] = 0
+            cg = ops.ConvGrad(torch.zeros((cout, cin, 1, 1, 1), device='cuda'), None, (st, st), (0, 0, 0), ops.BF16, cin, cs_g)
+            gt = torch.zeros(cout * cin, dtype=torch.float32, device='cuda')
+            jobs.append(cg.weight_acc_job(x, gy, T, gt))
+            fl += 2.0 * cin * cout * T * Ho * Wo
+        for n in (len(jobs), 8, 4):
+            ops.wgrad_acc_batch(jobs[:n])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                for i in range(0, len(jobs), n):
+                    ops.wgrad_acc_batch(jobs[i:i + n])
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print('%-10s all %d layers in batches of %2d: %7.3f ms  %7.1f TFLOP/s' % (tag, len(jobs), n, ms, fl / ms / 1e9), flush=True)
+
+    def fresh_batch(env, tag):
+        global run
+        keep, run = run, run_batch
+        try:
+            fresh(env, tag)
+        finally:
+            run = keep
+    fresh_batch({'DAT_WGRAD_PW': '1'}, 'batch')
+    fresh_pw({'DAT_WGRAD_PW': '0'}, 'old128')
+    fresh_pw({'DAT_WGRAD_PW': '1'}, 'pw')
+    fresh_batch({'DAT_WGRAD_PW': '1'}, 'batch')
+    if len(_s.argv) > 2 and _s.argv[2] == 'short':
+        raise SystemExit(0)
+    for shape in ('10', '20', '40'):
+        fresh_pw({'DAT_WGRAD_PW': shape}, 'pw' + shape)
+    for ks in (32, 64, 128, 512):
+        fresh_pw({'DAT_WGRAD_PW': '1', 'DAT_WGRAD_KS': str(ks)}, 'pw ks%d' % ks)
+    fresh_pw({'DAT_WGRAD_PW': '0'}, 'old128')
+    for name, rs in RESULTS.items():
+        ref = rs[0][1]
+        worst = max(((r - ref).abs().max() / ref.abs().max()).item() for _, r in rs[1:])
+        print('%-34s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
 elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
     for ab in (0, 1, 2, 4, 3, 7):
