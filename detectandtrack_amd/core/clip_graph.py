@@ -29,16 +29,22 @@ class ClipGraph(object):
     geometry -- blob shape, im_info rows (blob height / width / scale per image) and the unscaled image shapes -- is baked into the
     captured launches (`rpn_proposals` / `dat_box_results` take them by value): `launch` refuses anything else."""
 
-    def __init__(self, model, ws, data_like, im_info, im_shape, stream=None, warmup=2, static_data=None):
+    def __init__(self, model, ws, data_like, im_info, im_shape, stream=None, warmup=2, static_data=None, trunk=None):
+        """trunk = (n_ops, blob name, static tensor [B*T, h, w, Cs], B, T, C, dtype): the net's per-frame prefix (conv1 ... res2) is NOT part
+        of the graph -- the caller fills the static tensor with that prefix's output before every launch (per-frame trunk cache of
+        core/pipeline.py) and the captured forward starts at op n_ops; `data_like` then only names the geometry."""
+        self.trunk = trunk
         assert engine.device_results_supported(), 'graph capture needs the device-side post-processing (cfg.HIP.DEVICE_BOX_RESULTS)'
         self.model, self.ws = model, ws
-        B = int(data_like.shape[0])
+        B = int(trunk[3]) if trunk is not None else int(data_like.shape[0])
         self.im_info = np.asarray(im_info, dtype=np.float32).reshape(-1, 3)
         assert self.im_info.shape[0] == B, 'im_info has %d rows for a blob of %d images' % (self.im_info.shape[0], B)
         self.im_shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
         assert len(self.im_shapes) == B
         self.stream = stream or torch.cuda.current_stream()
-        if static_data is not None:         # the caller's own input buffer (filled in place before every launch)
+        if trunk is not None:
+            self.static_data = None
+        elif static_data is not None:       # the caller's own input buffer (filled in place before every launch)
             self.static_data = static_data
         else:
             self.static_data = torch.empty_like(data_like)
@@ -63,7 +69,10 @@ class ClipGraph(object):
     def _enqueue(self):
         prev, wsmod._GLOBAL = wsmod._GLOBAL, self.ws    # the engine functions talk to the global workspace
         try:
-            self.ws.FeedBlob('data', self.static_data)
+            if self.trunk is not None:
+                self.ws.trunk_ready = self.trunk
+            else:
+                self.ws.FeedBlob('data', self.static_data)
             self.ws.RunNet(self.model.net.name)
             return engine.enqueue_results_on_device(self.model, self.im_shapes, [float(v) for v in self.im_info[:, 2]])
         finally:
@@ -72,6 +81,10 @@ class ClipGraph(object):
     def launch(self, data_dev, im_info=None, im_shape=None):
         """Enqueue one forward (asynchronous): the resident input is copied into the graph's input buffer on the graph's stream
         (unless it IS that buffer).  im_info / im_shape, when given, must be the captured ones."""
+        if self.trunk is not None:          # (the caller has filled the trunk buffer on this stream; nothing to copy)
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+            return self.dev
         assert tuple(data_dev.shape) == tuple(self.static_data.shape), \
             'graph captured for a %s blob, launched with %s' % (tuple(self.static_data.shape), tuple(data_dev.shape))
         if im_info is not None:

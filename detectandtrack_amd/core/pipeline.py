@@ -30,7 +30,7 @@ from detectandtrack_amd import workspace as wsmod
 
 
 class _Slot(object):
-    __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'data')
+    __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'data', 'live', 'gather_event')
 
     def __init__(self, ws):
         self.ws, self.stream = ws, torch.cuda.Stream()
@@ -38,6 +38,116 @@ class _Slot(object):
         self.graphs = collections.OrderedDict()   # geometry key -> ClipGraph, least recently used first (bounded: max_graphs)
         self.pinned = self.dev_u8 = None
         self.data = {}              # geometry key -> the eager path's `data` buffer
+        self.live = {}              # (frame-trunk cache) geometry key -> this slot's static buffer of gathered prefix outputs [B*T, h, w, Cs]
+        self.gather_event = None    # recorded after the slot's last gather out of the trunk pool
+
+
+class FrameTrunkCache(object):
+    """Per-frame cache of the net's frame-wise prefix (conv1 / pool1 / res2: time kernel 1, ResNet3D.py:258-275) for the pipelined engine
+    (round 5; cfg.HIP.FRAME_TRUNK_CACHE frames; the eager engine's version lives in workspace.Executor._run_cached_trunk).
+
+    The reference scores a video with one clip per key frame, stride 1 (lib/utils/video.py:149-201): consecutive clips share T - 1 of T
+    frames and everything is recomputed.  Here a forward of B clips uploads, pre-processes and runs the prefix for its NEW frames only --
+    on a dedicated trunk stream with its own blob namespace, eager launches --, stores their outputs in slots of one pool tensor
+    [capacity, h, w, Cs] (dat_copy_frames), and every slot of the pipeline gathers its B * T frames from the pool into the static input
+    of its captured hipGraph, which starts at the first op AFTER the prefix.  Ordering: a forward's gather waits for the trunk event of
+    its own submit; the trunk stream waits for every slot's last gather before it overwrites pool slots (least recently used first,
+    never a frame of the forward being assembled)."""
+
+    def __init__(self, model, ws, capacity):
+        from detectandtrack_amd.workspace import Executor
+        self.model, self.capacity = model, int(capacity)
+        self.n_ops, self.live = Executor.trunk_split(model.net)
+        assert self.n_ops > 0, 'frame-trunk cache: this net has no per-frame prefix'
+        self.ws = ws.fork()
+        self.stream = torch.cuda.Stream()
+        self.event = torch.cuda.Event()
+        self.copy_event = torch.cuda.Event()
+        self.pool = None                        # [capacity, h, w, Cs] in the activation dtype
+        self.meta = None                        # (C, dtype) of the prefix output
+        self.slot_of = collections.OrderedDict()   # frame id -> pool slot, least recently used first
+        self.free = list(range(self.capacity))
+        self.pinned = self.dev_u8 = None
+        self.frames_computed = self.frames_requested = 0
+
+    def _run_prefix(self, data, im_info):
+        """the prefix ops on `data` [1, 3, n, H, W] (n frames as one clip: the ops are frame-wise) -> the output blob"""
+        from detectandtrack_amd.workspace import Executor
+        ws = self.ws
+        ws.FeedBlob('data', data)
+        ws.FeedBlob('im_info', im_info)
+        ex = Executor(ws, self.model.net)
+        ex._plan_rpn_siblings()
+        ex._plan_keyframe_dce()
+        for i in range(self.n_ops):
+            if i not in ex._skip:
+                getattr(ex, 'op_' + self.model.net.ops[i].type)(i, self.model.net.ops[i])
+        return ws.blobs[self.live]
+
+    def assemble(self, pipe, frames_by_id, ids, T, wait_events):
+        """ids: the B * T frame ids of a forward (clip-major); frames_by_id: id -> uint8 HxWx3 frame for (at least) the ids that are not
+        cached.  Uploads + computes the missing frames on the trunk stream and returns (pool slots of `ids`, im_info rows, geometry)."""
+        import detectandtrack_amd.utils.blob as blob_utils
+        from detectandtrack_amd.ops import hip_ops as ops
+        self.frames_requested += len(ids)
+        need = set(ids)
+        assert len(need) <= self.capacity, 'cfg.HIP.FRAME_TRUNK_CACHE %d < the %d distinct frames of one forward' % (self.capacity, len(need))
+        new = []
+        for fid in ids:
+            if fid not in self.slot_of and fid not in new:
+                new.append(fid)
+        for fid in ids:
+            if fid in self.slot_of:
+                self.slot_of.move_to_end(fid)
+        h, w = frames_by_id[ids[0]].shape[:2] if ids[0] in frames_by_id else self._hw
+        self._hw = (h, w)
+        if new:
+            n = len(new)
+            while len(self.free) < n:           # evict least recently used frames that this forward does not use
+                victim = next(f for f in self.slot_of if f not in need)
+                self.free.append(self.slot_of.pop(victim))
+            if self.pinned is None or self.pinned.shape[0] < n or tuple(self.pinned.shape[1:]) != (h, w, 3):
+                cap = max(n, 8)
+                self.pinned = torch.empty((cap, h, w, 3), dtype=torch.uint8).pin_memory()
+                self.dev_u8 = torch.empty((cap, h, w, 3), dtype=torch.uint8, device=self.ws.device)
+            # (the previous upload out of this pinned buffer must have left it: its copy event)
+            self.copy_event.synchronize()
+            host = self.pinned.numpy()
+            for k, fid in enumerate(new):
+                f = frames_by_id[fid]
+                assert f.dtype == np.uint8 and f.shape == (h, w, 3), 'frames of one size, uint8 HxWx3'
+                np.copyto(host[k], f)
+            with torch.cuda.stream(pipe.copy_stream):
+                pipe.copy_stream.wait_event(self.event)         # the trunk stream is done reading the previous upload
+                self.dev_u8[:n].copy_(self.pinned[:n], non_blocking=True)
+                self.copy_event.record(pipe.copy_stream)
+            pipe.upload_bytes += n * h * w * 3
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(self.copy_event)
+                for ev in wait_events:                          # gathers that still read pool slots about to be overwritten
+                    self.stream.wait_event(ev)
+                prev, wsmod._GLOBAL = wsmod._GLOBAL, self.ws
+                try:
+                    data, _, im_info = blob_utils.frames_to_blob_on_device(self.dev_u8[:n], n)
+                    out = self._run_prefix(data, im_info[:1])
+                finally:
+                    wsmod._GLOBAL = prev
+                assert out.t.shape[0] == n
+                assert self.pool is None or tuple(out.t.shape[1:]) == tuple(self.pool.shape[1:]), \
+                    'frame-trunk cache: frames of another size (%s vs %s): one geometry per pipeline' % (tuple(out.t.shape[1:]), tuple(self.pool.shape[1:]))
+                if self.pool is None:
+                    self.pool = torch.empty((self.capacity,) + tuple(out.t.shape[1:]), dtype=out.t.dtype, device=out.t.device)
+                    self.meta = (out.C, out.dt)
+                    self._info = (float(im_info[0, 0]), float(im_info[0, 1]), float(im_info[0, 2]))
+                slots = [self.free.pop() for _ in new]
+                ops.copy_frames(out.t, list(range(n)), self.pool, slots)
+                self.event.record(self.stream)
+            for fid, sl in zip(new, slots):
+                self.slot_of[fid] = sl
+            self.frames_computed += n
+        B = len(ids) // T
+        im_info = np.tile(np.array([self._info], dtype=np.float32), (B, 1))
+        return [self.slot_of[fid] for fid in ids], im_info
 
 
 class ClipPipeline(object):
@@ -67,6 +177,7 @@ class ClipPipeline(object):
         self._stagers = None
         self.host_path_images = 0   # images that took the host glue (exact score ties beyond the device buffers' spare rows)
         self.finish_times = []      # perf_counter() at every completed forward (steady-state rate of a run: see rate())
+        self.trunk = None           # FrameTrunkCache, made by the first submit_frames(..., frame_ids=...) with cfg.HIP.FRAME_TRUNK_CACHE > 0
         self.device_glue = engine.device_results_supported()
         assert self.device_glue, 'the pipelined engine runs the device post-processing path (cfg.HIP.DEVICE_BOX_RESULTS, hard NMS)'
 
@@ -92,7 +203,7 @@ class ClipPipeline(object):
         return (tuple(int(v) for v in data_shape), tuple(np.asarray(im_info, np.float32).reshape(-1).tolist()),
                 tuple(tuple(int(v) for v in sh[:2]) for sh in im_shapes))
 
-    def _enqueue(self, slot, data_dev, im_info, im_shapes, in_place, resident=False):
+    def _enqueue(self, slot, data_dev, im_info, im_shapes, in_place, resident=False, trunk=None):
         """model.net + device glue + keypoint net + decode of one forward on the slot's stream: a graph replay or eager launches.
         in_place: `data_dev` IS the slot's input buffer of this geometry (already filled on the slot's stream).
         resident: `data_dev` is a caller-owned buffer that stays where it is (and filled) for the life of the pipeline: the graph is
@@ -101,6 +212,8 @@ class ClipPipeline(object):
         key = self._geometry(data_dev.shape, im_info, im_shapes)
         if resident:
             key, in_place = key + (int(data_dev.data_ptr()),), True
+        if trunk is not None:       # (the graph starts behind the per-frame prefix and reads the slot's gathered buffer: its own geometry key)
+            key = key + ('trunk',)
         if self.use_graph:
             g = s.graphs.get(key)
             if g is None:
@@ -110,7 +223,7 @@ class ClipPipeline(object):
                     del old                                 # frees the graph and its memory pool
                     self.graphs_evicted += 1
                 g = s.graphs[key] = ClipGraph(self.model, s.ws, data_dev, im_info, im_shapes, stream=s.stream,
-                                              static_data=data_dev if in_place else None)
+                                              static_data=data_dev if in_place else None, trunk=trunk)
                 self.graphs_captured += 1
             else:
                 s.graphs.move_to_end(key)
@@ -118,7 +231,10 @@ class ClipPipeline(object):
         with torch.cuda.stream(s.stream):
             prev, wsmod._GLOBAL = wsmod._GLOBAL, s.ws          # the engine functions talk to the global workspace
             try:
-                s.ws.FeedBlob('data', data_dev)
+                if trunk is not None:
+                    s.ws.trunk_ready = trunk
+                else:
+                    s.ws.FeedBlob('data', data_dev)
                 s.ws.FeedBlob('im_info', np.asarray(im_info, np.float32))
                 s.ws.RunNet(self.model.net.name)
                 scales = [float(v) for v in np.asarray(im_info, np.float32).reshape(-1, 3)[:, 2]]
@@ -142,10 +258,51 @@ class ClipPipeline(object):
         self.host_enqueue_s += time.perf_counter() - t0       # host time to enqueue one forward (no synchronisation inside)
         self.pending.append((slot, tag, im_info, shapes, dev, None, g))
 
-    def submit_frames(self, clips, tag=None):
+    def _submit_frames_cached(self, clips, tag, frame_ids):
+        """submit_frames through the per-frame trunk cache: only the frames no earlier forward has seen are uploaded and run through
+        conv1 ... res2; the forward itself is the graph behind that prefix on the slot's gathered buffer."""
+        from detectandtrack_amd.ops import hip_ops as ops
+        if self.trunk is None:
+            self.trunk = FrameTrunkCache(self.model, self.slots[0].ws, int(cfg.HIP.FRAME_TRUNK_CACHE))
+        tr = self.trunk
+        slot = self._acquire()
+        s = self.slots[slot]
+        t0 = time.perf_counter()
+        B, T = len(clips), len(clips[0])
+        ids = [tuple(f) if isinstance(f, list) else f for clip_ids in frame_ids for f in clip_ids]
+        assert len(ids) == B * T, 'frame_ids: one id per frame of every clip'
+        frames_by_id = {}
+        for clip, clip_ids in zip(clips, frame_ids):
+            for f, fid in zip(clip, clip_ids):
+                frames_by_id.setdefault(tuple(fid) if isinstance(fid, list) else fid, f)
+        h, w = clips[0][0].shape[:2]
+        slots_idx, im_info = tr.assemble(self, frames_by_id, ids, T, [sl.gather_event for sl in self.slots if sl.gather_event is not None])
+        shapes = [(h, w, 3)] * B
+        gkey = (B * T,) + tuple(tr.pool.shape[1:])
+        with torch.cuda.stream(s.stream):
+            s.stream.wait_event(tr.event)
+            live = s.live.get(gkey)
+            if live is None:
+                live = s.live[gkey] = torch.empty((B * T,) + tuple(tr.pool.shape[1:]), dtype=tr.pool.dtype, device=tr.pool.device)
+            ops.copy_frames(tr.pool, slots_idx, live, list(range(B * T)))
+            if s.gather_event is None:
+                s.gather_event = torch.cuda.Event()
+            s.gather_event.record(s.stream)
+        trunk = (tr.n_ops, tr.live, live, B, T, tr.meta[0], tr.meta[1])
+        geom = torch.empty((B, 3, T, int(im_info[0, 0]), int(im_info[0, 1])), device='meta')      # (names the geometry of the forward: no memory)
+        dev, g = self._enqueue(slot, geom, im_info, shapes, in_place=True, trunk=trunk)
+        s.event.record(s.stream)
+        self.host_enqueue_s += time.perf_counter() - t0
+        self.pending.append((slot, tag, im_info, shapes, dev, clips, g))
+
+    def submit_frames(self, clips, tag=None, frame_ids=None):
         """One forward from HOST frames: `clips` = B entries, each a list of T uint8 BGR frames (HxWx3 arrays of one size).  The
-        frames are staged in the slot's pinned buffer, uploaded on the copy stream as uint8 and prepared on the device."""
+        frames are staged in the slot's pinned buffer, uploaded on the copy stream as uint8 and prepared on the device.
+        frame_ids (B lists of T hashable ids, e.g. (video, frame number)) with cfg.HIP.FRAME_TRUNK_CACHE > 0: frames with an id seen
+        before are neither uploaded nor run through the net's per-frame prefix again (FrameTrunkCache)."""
         import detectandtrack_amd.utils.blob as blob_utils
+        if frame_ids is not None and int(cfg.HIP.FRAME_TRUNK_CACHE) > 0 and cfg.MODEL.VIDEO_ON:
+            return self._submit_frames_cached(clips, tag, frame_ids)
         slot = self._acquire()
         s = self.slots[slot]
         t0 = time.perf_counter()

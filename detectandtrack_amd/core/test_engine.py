@@ -94,13 +94,15 @@ def load_clip(entry):
 
 
 def _pipelined(part):
-    """Can this clip list run on the pipelined engine?  It needs the device post-processing path, frames given as uint8 arrays and
-    no per-frame trunk cache (the sliding-window reuse of cfg.HIP.FRAME_TRUNK_CACHE feeds partial clips: eager path)."""
+    """Can this clip list run on the pipelined engine?  It needs the device post-processing path and frames given as uint8 arrays; with
+    cfg.HIP.FRAME_TRUNK_CACHE > 0 also frame ids on every entry (round 5: core/pipeline.FrameTrunkCache)."""
     from detectandtrack_amd.core import test as engine
     if int(cfg.HIP.get('PIPELINE_DEPTH', 0)) < 1 or not engine.device_results_supported() or cfg.MODEL.MASK_ON:
         return False
-    if cfg.TEST.COMPETITION_MODE or cfg.HIP.FRAME_TRUNK_CACHE > 0 or cfg.HIP.KEYFRAME_DCE:
+    if cfg.TEST.COMPETITION_MODE or cfg.HIP.KEYFRAME_DCE:
         return False
+    if cfg.HIP.FRAME_TRUNK_CACHE > 0 and not (cfg.MODEL.VIDEO_ON and all('frame_ids' in e for e in part)):
+        return False        # (the pipelined engine's per-frame trunk cache needs frame ids on every entry; otherwise: the eager loop)
     first = load_clip(part[0])          # (frame dtypes are checked clip by clip inside the loop: a non-uint8 clip takes the eager path)
     if any(f.dtype != np.uint8 for f in first):
         return False
@@ -126,13 +128,16 @@ def _test_net_pipelined(model, part, all_boxes, all_keyps, timers):
 
     def submit(group):
         clips, tags = [c for _, c in group], [j for j, _ in group]
+        fids = [part[j].get('frame_ids') for j in tags]
+        fids = fids if (cfg.HIP.FRAME_TRUNK_CACHE > 0 and all(f is not None for f in fids)) else None
         if pipe.use_graph and cfg.HIP.get('PAD_TAIL_FORWARD', True) and len(clips) < per and per in batches_seen.get(shape_of(clips[0]), ()):
             # a short group of a geometry whose full-size graph exists: repeat the last clip (results dropped) instead of capturing a
             # second graph -- with its own pool of activations -- for the smaller batch
             pad = per - len(clips)
             clips, tags = clips + [clips[-1]] * pad, tags + [None] * pad
+            fids = fids + [fids[-1]] * pad if fids is not None else None
         batches_seen.setdefault(shape_of(clips[0]), set()).add(len(clips))
-        pipe.submit_frames(clips, tag=tags)
+        pipe.submit_frames(clips, tag=tags, frame_ids=fids)
 
     def shape_of(clip):
         return (len(clip),) + tuple(clip[0].shape)
@@ -187,7 +192,10 @@ def test_net(roidb, ind_range=None, output_dir=None):
         test_net.last_stats = {'clips': len(part), 'seconds': timers['im_detect_bbox'].total_time, 'steady_clips_per_s': rate,
                                'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'host_submit_ms_per_clip': 1e3 * pipe.host_enqueue_s / len(part),
                                'host_staging_ms_per_clip': 1e3 * pipe.stage_s / len(part), 'host_path_images': pipe.host_path_images, 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
-                               'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH)}
+                               'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH),
+                               'frame_trunk_cache': int(cfg.HIP.FRAME_TRUNK_CACHE) if pipe.trunk is not None else 0,
+                               'trunk_frames_computed': pipe.trunk.frames_computed if pipe.trunk is not None else None,
+                               'trunk_frames_requested': pipe.trunk.frames_requested if pipe.trunk is not None else None}
         logger.info('im_detect: range [%d, %d] of %d: %d clips in %.3fs incl. warm-up%s (pipelined: %d in flight, %d per forward, '
                     'hipGraph %s, %.1f MB uploaded per clip)', start + 1, end, len(roidb), len(part), timers['im_detect_bbox'].total_time,
                     ', steady state %.1f clips/s' % rate if rate else '', int(cfg.HIP.PIPELINE_DEPTH), int(cfg.HIP.IMS_PER_FORWARD),

@@ -393,6 +393,47 @@ int dat_maxpool_hw(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y
     return DAT_OK;
 }
 
+// ---- frame gather / scatter: dst frame dst_idx[i] = src frame src_idx[i] (round 5: the per-frame trunk cache of the pipelined engine) ----
+// Frames are contiguous slabs in NDHWC, so "assemble the clips of a forward from cached per-frame trunk outputs" and "store the new frames'
+// trunk outputs in their cache slots" are the same copy with an index table.  The table travels in the kernel arguments (<= 128 pairs: no
+// device-side index buffer, nothing for a hipGraph capture to keep alive); 16-byte accesses, blocks_per_frame blocks walk one frame.
+constexpr int COPY_FRAMES_MAX = 128;
+struct CopyFramesParams {
+    const uint4* src;
+    uint4* dst;
+    long long frame_vec;                 // 16-byte vectors per frame
+    int n, blocks_per_frame;
+    int src_idx[COPY_FRAMES_MAX], dst_idx[COPY_FRAMES_MAX];
+};
+__global__ __launch_bounds__(256) void copy_frames_kernel(const CopyFramesParams p) {
+    const int f = blockIdx.x / p.blocks_per_frame, b = blockIdx.x - f * p.blocks_per_frame;
+    const uint4* s = p.src + (size_t)p.src_idx[f] * p.frame_vec;
+    uint4* d = p.dst + (size_t)p.dst_idx[f] * p.frame_vec;
+    for (long long i = (long long)b * 256 + threadIdx.x; i < p.frame_vec; i += (long long)p.blocks_per_frame * 256) d[i] = s[i];
+}
+
+int dat_copy_frames(dat_ctx* ctx, dat_stream s, const void* src, const int* src_idx, void* dst, const int* dst_idx, int n,
+                    long long frame_bytes) {
+    DAT_ENFORCE(ctx, src && dst && src_idx && dst_idx && n >= 0 && frame_bytes > 0 && frame_bytes % 16 == 0,
+                "copy_frames: bad argument (frame_bytes %lld must be a positive multiple of 16)", frame_bytes);
+    for (int i0 = 0; i0 < n; i0 += COPY_FRAMES_MAX) {
+        CopyFramesParams p;
+        p.src = (const uint4*)src; p.dst = (uint4*)dst; p.frame_vec = frame_bytes / 16;
+        p.n = n - i0 < COPY_FRAMES_MAX ? n - i0 : COPY_FRAMES_MAX;
+        for (int i = 0; i < p.n; ++i) {
+            DAT_ENFORCE(ctx, src_idx[i0 + i] >= 0 && dst_idx[i0 + i] >= 0, "copy_frames: negative frame index");
+            p.src_idx[i] = src_idx[i0 + i]; p.dst_idx[i] = dst_idx[i0 + i];
+        }
+        long long bpf = (p.frame_vec + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
+        if (bpf < 1) bpf = 1;
+        if (bpf > 1024) bpf = 1024;
+        p.blocks_per_frame = (int)bpf;
+        hipLaunchKernelGGL(copy_frames_kernel, dim3((unsigned)(p.n * bpf)), dim3(256), 0, (hipStream_t)s, p);
+    }
+    DAT_CHECK_LAUNCH(ctx, "copy_frames");
+    return DAT_OK;
+}
+
 int dat_time_avg(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int N, int T, long long hwc) {
     DAT_ENFORCE(ctx, x && y && T > 0, "time_avg: bad argument");
     DISPATCH_DT(dtype, time_avg_kernel, dim3(grid_for((size_t)N * hwc)), dim3(TPB), (hipStream_t)s, x, y, N, T, hwc);

@@ -98,6 +98,7 @@ _PROTOS = {
     'dat_split_bf16x2': (_i, [_p, _p, _p, _p, _ll, _i]),
     'dat_maxpool_hw': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i]),
     'dat_time_avg': (_i, [_p, _p, _i, _p, _p, _i, _i, _ll]),
+    'dat_copy_frames': (_i, [_p, _p, _p, C.POINTER(_i), _p, C.POINTER(_i), _i, _ll]),
     'dat_roi_align': (_i, [_p, _p, _i, C.POINTER(RoiLevel), _i, _i, _f, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
     'dat_spatial_mean': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i]),
     'dat_softmax_rows': (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),

@@ -134,6 +134,17 @@ def to_ncdhw(x, dtype, n, c, t):
     return out
 
 
+def copy_frames(src, src_idx, dst, dst_idx):
+    """dst[dst_idx[i]] = src[src_idx[i]] over whole frames (leading axis) of two contiguous tensors with equal frame size (dat_copy_frames)."""
+    n = len(src_idx)
+    assert n == len(dst_idx) and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
+    fb = src[0].numel() * src.element_size()
+    assert fb == dst[0].numel() * dst.element_size() and max(src_idx) < src.shape[0] and max(dst_idx) < dst.shape[0]
+    ctx().call('dat_copy_frames', _stream(), _ptr(src), (C.c_int * n)(*[int(v) for v in src_idx]), _ptr(dst),
+               (C.c_int * n)(*[int(v) for v in dst_idx]), n, C.c_longlong(fb))
+    return dst
+
+
 # ---- fused conv ------------------------------------------------------------------------------------------
 class ConvLayer(object):
     """A conv with packed weights + fused epilogue parameters, ready to launch.

@@ -50,6 +50,7 @@ class Workspace(object):
         self.train_sampler = None   # training: callable(rois, im_info) -> sampled Fast R-CNN blobs (training.py)
         self.trunk_cache = collections.OrderedDict()   # frame id -> (per-frame trunk output, C, dtype)  (cfg.HIP.FRAME_TRUNK_CACHE)
         self.trunk_request = None   # (frame ids of the next clip, ids of the frames in the fed `data` blob)
+        self.trunk_ready = None     # (first op to run, blob name, tensor [N*T,h,w,Cs], N, T, C, dtype): the prefix's output, assembled by the caller
 
     # ---- reference workspace API -------------------------------------------------------------------------------
     def FeedBlob(self, name, arr):
@@ -136,7 +137,7 @@ class Workspace(object):
         w.params, w.nets, w._layers, w._dev_params = self.params, self.nets, self._layers, self._dev_params
         w.conv_log = None
         w.train_sampler = self.train_sampler
-        w.trunk_cache, w.trunk_request = self.trunk_cache, None
+        w.trunk_cache, w.trunk_request, w.trunk_ready = self.trunk_cache, None, None
         return w
 
     # ---- parameters -----------------------------------------------------------------------------------------------
@@ -241,6 +242,13 @@ class Executor(object):
         self._plan_rpn_siblings()
         self._plan_keyframe_dce()
         start = self._run_cached_trunk()
+        ready = getattr(self.ws, 'trunk_ready', None)
+        if ready is not None:
+            # the pipelined engine assembled the per-frame prefix's output itself (core/pipeline.FrameTrunkCache: gathered from per-frame
+            # cache slots into a static buffer): bind it and run the rest of the net
+            self.ws.trunk_ready = None
+            start, live, t, N, T, C, dt = ready
+            self.ws.blobs[live] = Blob(t, 'fmap', N, T, C, dt, True)
         blobs = self.ws.blobs
         for i, op in enumerate(self.net.ops):
             if i < start or i in self._skip:

@@ -162,6 +162,12 @@ int dat_split_bf16x2(dat_ctx* ctx, dat_stream s, const float* x, void* y, long l
 int dat_maxpool_hw(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int frames, int H, int W, int C,
                    int k, int stride, int pad);
 
+/* dst frame dst_idx[i] = src frame src_idx[i], i < n: frames are contiguous slabs of frame_bytes (a multiple of 16) in NDHWC.  HOST index
+ * arrays (they travel in the kernel arguments).  The per-frame trunk cache of the pipelined engine (cfg.HIP.FRAME_TRUNK_CACHE; reference
+ * sliding-window inference lib/utils/video.py:149-201 recomputes conv1 ... res2 for T - 1 of T frames of every clip): scatter of the new
+ * frames' trunk outputs into their cache slots, gather of a forward's clips from the cache. */
+int dat_copy_frames(dat_ctx* ctx, dat_stream s, const void* src, const int* src_idx, void* dst, const int* dst_idx, int n,
+                    long long frame_bytes);
 /* ---- time pooling (detector.py:559-576): avg over T -> frames/T frames ----------------------- */
 int dat_time_avg(dat_ctx* ctx, dat_stream s, int dtype, const void* x, void* y, int N, int T, long long hwc);
 

@@ -523,6 +523,51 @@ def test_pipelined_engine_writes_the_same_detections_as_the_eager_loop(tmp_path)
         assert _boxes_agree(a, b, 0.5) > 0.85, (i, a[:3], b[:3])
 
 
+@pytest.mark.parametrize('per,graph', [(1, True), (2, True), (2, False)])
+def test_pipelined_engine_with_the_frame_trunk_cache_writes_identical_detections(tmp_path, per, graph):
+    """the per-frame trunk cache INSIDE the pipelined / hipGraph engine (core/pipeline.FrameTrunkCache).  A stride-1
+    clip list of two videos (one clip per key frame, border frames replicated: lib/utils/video.py:149-201) through test_net with
+    cfg.HIP.FRAME_TRUNK_CACHE: every video frame is uploaded and run through conv1 ... res2 exactly ONCE (also across the forwards in
+    flight and across clips of one forward), the captured graphs start behind that prefix -- and detections.pkl is bit-identical to
+    the same engine computing every clip whole (same kernels on bit-identical prefix outputs)."""
+    from detectandtrack_amd.core import test_engine
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd import workspace
+    T, H, W, n_frames = 4, 96, 128, 7
+    rs = np.random.RandomState(9)
+    roidb = []
+    for v in range(2):
+        video = [rs.randint(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(n_frames)]
+        for k in range(n_frames):
+            ids = [min(max(k - T // 2 + j, 0), n_frames - 1) for j in range(T)]
+            roidb.append({'image': [video[i] for i in ids], 'frame_ids': [('vid%d' % v, i) for i in ids], 'height': H, 'width': W})
+
+    def run(cache, out):
+        c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)
+        c['TEST'].update(SCALES=(H,), MAX_SIZE=max(H, W), SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+        c['HIP'].update(PIPELINE_DEPTH=3, IMS_PER_FORWARD=per, CLIP_GRAPH=graph, FRAME_TRUNK_CACHE=cache)
+        c['RNG_SEED'] = 3
+        reset_cfg()
+        cfg_from_cfg(c)
+        assert_and_infer_cfg()
+        workspace.ResetWorkspace()
+        os.makedirs(out, exist_ok=True)
+        return test_engine.test_net(roidb, None, out), test_engine.test_net.last_stats
+    plain, st0 = run(0, str(tmp_path / 'plain'))
+    assert st0['frame_trunk_cache'] == 0 and st0['upload_bytes_per_clip'] == T * H * W * 3
+    got, st = run(6 if per == 1 else 10, str(tmp_path / 'cached'))
+    assert st['frame_trunk_cache'] > 0 and st['clips'] == len(roidb) and st['hip_graph'] == graph
+    # padded tail groups repeat a clip whose frames are cached: requested counts the padding, computed never exceeds the real frames
+    assert st['trunk_frames_computed'] == 2 * n_frames, st                    # every frame of both videos exactly once
+    assert st['trunk_frames_requested'] >= len(roidb) * T
+    assert st['upload_bytes_per_clip'] == 2 * n_frames * H * W * 3 / float(len(roidb))
+    for i in range(len(roidb)):
+        np.testing.assert_array_equal(got['all_boxes'][1][i], plain['all_boxes'][1][i], err_msg='clip %d' % i)
+        assert len(got['all_keyps'][1][i]) == len(plain['all_keyps'][1][i]) >= 15
+        for a, b in zip(got['all_keyps'][1][i], plain['all_keyps'][1][i]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypatch):
     """ADVICE r3 (high + medium).  One pipeline slot holds a captured hipGraph per input geometry; the captured launches have the
     C-ABI context's scratch pointer baked in (proposal scratch, split-K partials).  (1) small geometry, then a LARGER one whose

@@ -44,7 +44,9 @@ def main():
     ap.add_argument('--frames', type=int, default=60)
     ap.add_argument('--clips-per-forward', type=int, default=4)
     ap.add_argument('--in-flight', type=int, default=3)
-    ap.add_argument('--trunk-cache', type=int, default=0, help='cfg.HIP.FRAME_TRUNK_CACHE (runs the eager loop: the pipelined engine takes whole clips)')
+    ap.add_argument('--trunk-cache', type=int, default=64,
+                    help='cfg.HIP.FRAME_TRUNK_CACHE: frames whose conv1 ... res2 output the pipelined engine keeps (a stride-1 clip list shares T - 1 of T frames '
+                         'between consecutive clips: only new frames are uploaded and run through that prefix); 0 = every clip computed whole')
     a = ap.parse_args()
     import bench
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
@@ -83,7 +85,8 @@ def main():
         'detector_clips_per_s_incl_warmup': round(n / t_det, 2),
         'engine': {'clips_per_forward': st.get('per_forward'), 'forwards_in_flight': st.get('in_flight'), 'hip_graph': st.get('hip_graph'),
                    'upload_mb_per_clip': round(st.get('upload_bytes_per_clip', 0) / 1e6, 2), 'host_path_images': st.get('host_path_images'),
-                   'frame_trunk_cache': a.trunk_cache},
+                   'frame_trunk_cache': st.get('frame_trunk_cache'),
+                   'trunk_frames_computed': st.get('trunk_frames_computed'), 'trunk_frames_requested': st.get('trunk_frames_requested')},
         'detections_per_frame': round(ndet, 1),
         'tracker_seconds': round(t_trk, 3), 'tracker_frames_per_s': round(n / t_trk, 1), 'tracker_cores': 1,
         'tracker_over_detector': round((n / t_trk) / det_rate, 2),
