@@ -410,6 +410,11 @@ class Executor(object):
         k = (self.net.name, key)
         if k not in self.ws._layers:
             self.ws._layers[k] = build()
+            # the layer's packing kernels were enqueued on THIS stream; the cache is shared by every fork of the workspace (the pipeline's
+            # slots, the frame-trunk stream), whose streams would otherwise be free to launch the layer before its weights are packed.
+            # Layers are built once per model: a host wait per build costs nothing in steady state.
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
         return self.ws._layers[k]
 
     def _log_conv(self, name, layer, frames, H, W, oframes=None, res_mode=0):
