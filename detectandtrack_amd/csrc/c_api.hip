@@ -61,6 +61,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_wgrad_sub = env_int("DAT_WGRAD_SUB", 2);
         c->dbg_wgrad_ilv = env_int("DAT_WGRAD_ILV", 1);
         c->dbg_wgrad_pw = env_int("DAT_WGRAD_PW", 1);
+        c->dbg_kps_sep = env_int("DAT_KPS_DECODE_SEP", 1);
         c->dbg_linear = env_int("DAT_CONV_LINEAR", 1);
         c->dbg_order = env_int("DAT_CONV_ORDER", 0);
         c->dbg_bt = env_int("DAT_CONV_BT", 0);   // opt-in: measured neutral on the full network (the part is power-limited)
