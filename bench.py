@@ -537,18 +537,40 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    ensure_ranks(a.gpus, world, sys.argv[1:])          # N > 1 without a launcher: re-exec under one, or exit non-zero
+    # DAT_BENCH_SHARE_GPU=1 (TEST ONLY; tests/test_gpu_model.py): all ranks on device 0 over gloo -- exercises the N-rank control flow
+    # (barriers, MAX-reduce of the timing, rank-0-only passes, the training exchange) on a one-GPU box.  The line it prints says so
+    # (`shared_gpu_test`) and is not a measurement: RCCL needs one device per rank.
+    share_gpu = os.environ.get('DAT_BENCH_SHARE_GPU', '0') == '1' and world > 1
+    if share_gpu:
+        local_rank = 0
+    else:
+        ensure_ranks(a.gpus, world, sys.argv[1:])      # N > 1 without a launcher: re-exec under one, or exit non-zero
     torch.cuda.set_device(local_rank)
     dist = None
     ranks_seen = [device_identity(rank, local_rank)]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')
+        dist.init_process_group('gloo' if share_gpu else 'nccl')
         seen = [None] * world
         dist.all_gather_object(seen, ranks_seen[0])
         ranks_seen = seen
-        check_ranks_seen(ranks_seen, a.gpus)
+        if not share_gpu:
+            check_ranks_seen(ranks_seen, a.gpus)
+
+    def barrier():
+        if dist is not None:
+            if share_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
+
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     from detectandtrack_amd.ops import hip_ops as ops
     T, H, W = a.frames, a.height, a.width
@@ -633,23 +655,19 @@ def main():
     if not train and not a.no_roofline:
         start_profilers()
     _dbg('profilers started')
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+    barrier()
     torch.cuda.synchronize()
     if not train:
         pipe.host_enqueue_s = 0.0
     t0 = time.perf_counter()
     run_steps(a.steps)
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _dbg('timed region done')
     if a.no_roofline:       # (the rocprofv3 child: its kernel_stats.csv must hold whole graph-replayed forwards and nothing else)
+        elapsed = max_over_ranks(elapsed)
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({'metric': 'clips/sec (8-frame 800px)', 'value': round(a.gpus * a.steps * (1 if train else clips_per_step) / elapsed, 4),
@@ -689,19 +707,13 @@ def main():
             pipe.drain()
         run_h2d(max(a.warmup, a.pipeline + 1))
         pipe.host_enqueue_s, pipe.upload_bytes = 0.0, 0
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+        barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         run_h2d(a.steps)
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+        barrier()
         torch.cuda.synchronize()
-        el_h = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([el_h], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_h = float(t.item())
+        el_h = max_over_ranks(time.perf_counter() - t1)
         h2d = {'value_including_upload': round(a.gpus * a.steps * clips_per_step / el_h, 4), 'unit': 'clips/s',
                'ms_per_step': round(1e3 * el_h / a.steps, 3),
                'upload_mb_per_step': round(pipe.upload_bytes / 1e6 / max(a.steps, 1), 2),
@@ -777,10 +789,7 @@ def main():
         _dbg('back-to-back conv pass done')
     else:
         prof_steps = prof_iters if train else a.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     if rank != 0:
         if dist is not None:
@@ -954,6 +963,7 @@ def main():
                    'parallelism': ('data-parallel x%d, one bucketed RCCL gradient all-reduce per iteration' if train else
                                    'clip-sharded x%d (no data-path collective)') % a.gpus},
         'ranks_seen': ranks_seen,
+        **({'shared_gpu_test': 'DAT_BENCH_SHARE_GPU=1: %d ranks on ONE device over gloo -- a control-flow test, NOT a measurement' % world} if share_gpu else {}),
         'roofline': roofline,
         'roofline_hbm': roofline_hbm,
     }
@@ -967,6 +977,10 @@ def main():
                                 'buckets': xstats[0]['buckets'], 'gradient_mb': round(xstats[0]['bytes'] / 1e6, 1),
                                 'overlap': bool(trainer.exchange.overlap), 'backend': trainer.exchange.backend,
                                 'bucket_mb': round(trainer.BUCKET_BYTES / 1e6, 1)}
+        elif world > 1:     # (gloo on a shared GPU -- the control-flow test: the exchange ran, host-staged and synchronous, and is not timed apart)
+            out['allreduce'] = {'allreduce_ms': None, 'exposed_allreduce_ms': None, 'buckets': len(trainer.buckets),
+                                'gradient_mb': round(4 * trainer.flat_g.numel() / 1e6, 1), 'backend': trainer.exchange.backend,
+                                'overlap': bool(trainer.exchange.overlap), 'note': 'collectives timed with HIP events under RCCL only'}
         else:
             out['allreduce'] = {'allreduce_ms': 0.0, 'exposed_allreduce_ms': 0.0, 'buckets': len(trainer.buckets),
                                 'gradient_mb': round(4 * trainer.flat_g.numel() / 1e6, 1), 'note': 'one rank: no exchange'}

@@ -989,6 +989,37 @@ def test_bench_two_gpus_smoke(mode):
         assert line['allreduce']['backend'] == 'nccl' and line['allreduce']['allreduce_ms'] > 0 and line['allreduce']['buckets'] >= 2
 
 
+@pytest.mark.parametrize('mode', ['infer', 'train'])
+def test_bench_two_ranks_control_flow_on_one_gpu(mode):
+    """The driver's multi-GPU command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 ranks SHARING this box's one GPU over gloo
+    (DAT_BENCH_SHARE_GPU=1, a test-only switch: RCCL needs a device per rank): every barrier, the MAX-reduce of the timing, the
+    rank-0-only roofline passes, the host-frame leg and (train) the bucketed gradient exchange run with two real processes, rank 0
+    prints ONE line with n_gpus 2 that marks itself as a control-flow test.  What only a multi-GPU node can show -- RCCL itself -- is
+    test_two_ranks_nccl / test_bench_two_gpus_smoke, which arm themselves there."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(DAT_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29500 + ((os.getpid() + 211 + (mode == 'train')) % 1000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-accuracy'] + (['--mode', 'train'] if mode == 'train' else [])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and len(line['ranks_seen']) == 2 and {r['rank'] for r in line['ranks_seen']} == {0, 1}
+    assert 'shared_gpu_test' in line and line['value'] > 0 and line['steps'] == 3 and line['scaling'] == 'weak'
+    assert 'cpu_baseline' not in line                  # CPU baselines are timed at N = 1 only
+    if mode == 'train':
+        assert line['allreduce']['buckets'] >= 2 and line['allreduce']['backend'] == 'gloo'
+    else:
+        assert line['roofline']['frac'] > 0 and line['host_frames']['value_including_upload'] > 0
+
+
 @pytest.mark.parametrize('overlap', [True, False])
 def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, overlap):
     """Data-parallel semantics of the training exchange (reference lib/modeling/model_builder.py:908-951 build_data_parallel_model:
