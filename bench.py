@@ -484,7 +484,8 @@ def build_train(arch, T, H, W, dtype, world, rank):
     ws.FeedBlob('data', data)
     for k, v in rpn_data.add_rpn_blobs({}, 1.0, entry, rng).items():
         ws.FeedBlob(k, v)
-    ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+    from detectandtrack_amd.roi_data.device_sampler import make_sampler
+    ws.train_sampler = make_sampler(entry, rng, seed=1000 * rank + 1)      # (device kernel by default: cfg.HIP.DEVICE_ROI_SAMPLING)
     return model, ws
 
 

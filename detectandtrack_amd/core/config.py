@@ -265,11 +265,14 @@ def _build_defaults():
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
     # WGRAD_PW_BATCH (training, with DEFER_WGRAD_FINISH): the weight gradients of up to this many POINTWISE convs (1 x 1 x 1) are queued and
     # run as one grouped launch (dat_conv3d_wgrad_acc_batch; also flushed whenever a gradient bucket completes); 0 = one launch per layer
+    # DEVICE_ROI_SAMPLING (training): GenerateProposalLabels as one device kernel on the device-resident proposals (roi_data/device_sampler.py,
+    # dat_sample_rois: the reference's candidate sets and counts, a counter-based draw instead of NumPy's stream); False = the host restatement
+    # of lib/roi_data/fast_rcnn.py on a copy of the proposals (bit-compatible with the reference's numpy.random stream)
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
                       'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
                       'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
-                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16})
+                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True})
     return c
 
 

@@ -110,6 +110,193 @@ __global__ void scatter_words_kernel(unsigned int* __restrict__ dst, long long d
     }
 }
 
+// ---- GenerateProposalLabels on the device (round 5) -------------------------------------------------------------
+// lib/ops/generate_proposal_labels.py:24-37 -> roi_data/fast_rcnn.py:109-203 (+ json_dataset.py:423-473 merge, keypoint_rcnn.py:32-99,
+// utils/keypoints.py:152-207): the clip's proposals are merged behind its ground-truth boxes, every candidate gets its maximum overlap
+// with the gt boxes, BATCH_SIZE_PER_IM rois are drawn -- up to FG_FRACTION of them foreground (overlap >= FG_THRESH), the rest background
+// ([BG_THRESH_LO, BG_THRESH_HI)) -- and turned into class labels, class-specific box targets and weights; the keypoint branch draws up to
+// the same number of foreground rois that see a visible keypoint of their gt and builds the heatmap cell labels.
+//
+// What cannot be kept is NumPy's Mersenne-Twister stream (`npr.choice`): the device draws with a COUNTER-BASED generator instead.
+// Contract (tests/test_gpu_train.py): the candidate sets (fg / bg / keypoint-fg) and the counts (n_fg, n_bg, n_kp) are the reference's;
+// a draw of n out of a set S is "the n members of S with the smallest (key, index)", key = roi_key(seed, iteration, stream, index) below
+// -- a uniformly random subset in uniformly random order when the keys are i.i.d. uniform, the order being the output row order;
+// labels, targets, weights and heatmap cells of a drawn roi are the reference's arithmetic (float32, its operation order).
+// One block of 1024 threads (<= 4096 candidates): overlaps, flags and keys into LDS, ranks by counting (N x |S| comparisons), rows out.
+__device__ __forceinline__ unsigned roi_key(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned stream, unsigned index) {
+    unsigned h = seed_lo ^ (index * 0x9E3779B9u) ^ (iter * 0x85EBCA6Bu) ^ (stream * 0xC2B2AE35u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;      // murmur3 finaliser
+    h ^= seed_hi;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+struct RoiSampleParams {
+    dat_roi_sample_desc d;
+    const float* props; const int* n_props; int props_cap;
+    const float* gt_boxes; const int* gt_classes; const int* gt_kps; int G;
+    float* rois; int* labels; float* targets; float* w_in; float* w_out;
+    float* kp_rois; int* kp_loc; float* kp_w;
+    int* counts; int* picked;
+};
+
+constexpr int RS_MAXN = 4096;
+
+__global__ __launch_bounds__(1024) void roi_sample_kernel(const RoiSampleParams p) {
+    __shared__ float s_mo[RS_MAXN];
+    __shared__ unsigned s_key[RS_MAXN], s_kkey[RS_MAXN];
+    __shared__ short s_arg[RS_MAXN];
+    __shared__ unsigned char s_flag[RS_MAXN];       // 1 fg, 2 bg, 4 keypoint-fg
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x;
+    const int T = p.d.T, C4 = 4 * T, G = p.G;
+    const int P = min(*p.n_props, p.props_cap);
+    const int N = G + P;
+    const float scale = p.d.im_scale;
+    const int KK = p.d.num_keypoints * T;           // keypoints of a tube
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    // ---- per candidate: box at the image's own scale, max overlap / first arg-max over the gts, flags, keys ----
+    for (int i = tid; i < N; i += 1024) {
+        float box[4 * LAB_MAXT];
+        float mo;
+        int arg;
+        if (i < G) {
+            for (int c = 0; c < C4; ++c) box[c] = p.gt_boxes[(size_t)i * C4 + c];
+            mo = 1.f; arg = i;                      // a gt row: overlap 1 with its own class (json_dataset.py: gt_overlaps one-hot)
+        } else {
+            for (int c = 0; c < C4; ++c) box[c] = p.props[(size_t)(i - G) * (C4 + 1) + 1 + c] / scale;
+            mo = 0.f; arg = -1;
+            for (int g = 0; g < G; ++g) {
+                const float v = tube_iou<LAB_MAXT>(box, p.gt_boxes + (size_t)g * C4, T);
+                if (v > mo) { mo = v; arg = g; }    // first maximum; rows whose maximum is 0 stay unassigned (fast_rcnn merge: `mx > 0`)
+            }
+        }
+        unsigned char fl = 0;
+        if (mo >= p.d.fg_thresh) fl |= 1;
+        if (mo < p.d.bg_thresh_hi && mo >= p.d.bg_thresh_lo) fl |= 2;
+        if ((fl & 1) && p.gt_kps && arg >= 0) {     // keypoint_rcnn.py:88-99: a visible keypoint of the roi's gt inside the roi's FIRST-frame box
+            const int* kp = p.gt_kps + (size_t)arg * 3 * KK;
+            bool vis = false;
+            for (int k = 0; k < KK; ++k) {
+                const float x = (float)kp[k], y = (float)kp[KK + k];
+                vis = vis || (kp[2 * KK + k] > 0 && x >= box[0] && x <= box[2] && y >= box[1] && y <= box[3]);
+            }
+            if (vis) fl |= 4;
+        }
+        s_mo[i] = mo; s_arg[i] = (short)arg; s_flag[i] = fl;
+        s_key[i] = roi_key(p.d.seed_lo, p.d.seed_hi, p.d.iter, 0u, (unsigned)i);
+        s_kkey[i] = roi_key(p.d.seed_lo, p.d.seed_hi, p.d.iter, 1u, (unsigned)i);
+        if (fl & 1) atomicAdd(&s_cnt[0], 1);
+        if (fl & 2) atomicAdd(&s_cnt[1], 1);
+        if (fl & 4) atomicAdd(&s_cnt[2], 1);
+    }
+    __syncthreads();
+    const int all_fg = s_cnt[0], all_bg = s_cnt[1], all_kp = s_cnt[2];
+    const int n_fg = min(p.d.fg_rois_per_im, all_fg);
+    const int n_bg = min(p.d.rois_per_im - n_fg, all_bg);
+    const bool kp_fallback = p.gt_kps && all_kp == 0;                   // keypoint_rcnn.py:47-48: no keypoint-fg roi -> the gt boxes themselves
+    const int n_kp = !p.gt_kps ? 0 : kp_fallback ? min(G, p.d.fg_rois_per_im) : min(p.d.fg_rois_per_im, all_kp);
+    if (tid == 0) {
+        p.counts[0] = n_fg + n_bg; p.counts[1] = n_fg; p.counts[2] = n_kp; p.counts[3] = all_fg; p.counts[4] = all_bg; p.counts[5] = all_kp;
+    }
+    const int Kc = p.d.cls_agnostic ? 2 : p.d.num_classes;
+    const int ld_t = C4 * Kc;
+    const int M = p.d.heatmap_size;
+    for (int i = tid; i < N; i += 1024) {
+        const unsigned char fl = s_flag[i];
+        // rank of this candidate inside each set it belongs to: members with a smaller (key, index)
+        int r_fg = 0, r_bg = 0, r_kp = 0;
+        if (fl & 3) {
+            const unsigned ki = s_key[i];
+            for (int j = 0; j < N; ++j) {
+                const unsigned kj = s_key[j];
+                const bool before = kj < ki || (kj == ki && j < i);
+                const unsigned char fj = s_flag[j];
+                r_fg += (before && (fj & 1)) ? 1 : 0;
+                r_bg += (before && (fj & 2)) ? 1 : 0;
+            }
+        }
+        if (fl & 4) {
+            const unsigned ki = s_kkey[i];
+            for (int j = 0; j < N; ++j) {
+                const unsigned kj = s_kkey[j];
+                r_kp += ((kj < ki || (kj == ki && j < i)) && (s_flag[j] & 4)) ? 1 : 0;
+            }
+        }
+        int row = -1;
+        if ((fl & 1) && r_fg < n_fg) row = r_fg;
+        else if ((fl & 2) && !((fl & 1) && r_fg < n_fg) && r_bg < n_bg) row = n_fg + r_bg;
+        int krow = -1;
+        if (kp_fallback) { if (i < G && i < n_kp) krow = i; }
+        else if ((fl & 4) && r_kp < n_kp) krow = r_kp;
+        if (row < 0 && krow < 0) continue;
+        float box[4 * LAB_MAXT];
+        if (i < G) for (int c = 0; c < C4; ++c) box[c] = p.gt_boxes[(size_t)i * C4 + c];
+        else for (int c = 0; c < C4; ++c) box[c] = p.props[(size_t)(i - G) * (C4 + 1) + 1 + c] / scale;
+        const int arg = s_arg[i];
+        if (row >= 0) {
+            if (p.picked) p.picked[row] = i;
+            float* ro = p.rois + (size_t)row * (C4 + 1);
+            ro[0] = 0.f;
+            for (int c = 0; c < C4; ++c) ro[1 + c] = box[c] * scale;
+            const int cls = row < n_fg ? (arg >= 0 ? p.gt_classes[arg] : 0) : 0;           // fast_rcnn.py:156-158: background rows get label 0
+            p.labels[row] = cls;
+            float* tg = p.targets + (size_t)row * ld_t;
+            float* wi = p.w_in + (size_t)row * ld_t;
+            float* wo = p.w_out + (size_t)row * ld_t;
+            for (int c = 0; c < ld_t; ++c) { tg[c] = 0.f; wi[c] = 0.f; wo[c] = 0.f; }
+            if (cls > 0 && arg >= 0) {
+                const float* gb = p.gt_boxes + (size_t)arg * C4;
+                const int slot = (p.d.cls_agnostic ? 1 : cls) * C4;
+                for (int t = 0; t < T; ++t) {
+                    // utils/boxes.bbox_transform_inv (:205-239), float32, its operation order
+                    const float* e = box + 4 * t;
+                    const float* q = gb + 4 * t;
+                    const float ew = e[2] - e[0] + 1.0f, eh = e[3] - e[1] + 1.0f, gw = q[2] - q[0] + 1.0f, gh = q[3] - q[1] + 1.0f;
+                    tg[slot + 4 * t + 0] = p.d.reg_weights[0] * ((q[0] + 0.5f * gw) - (e[0] + 0.5f * ew)) / ew;
+                    tg[slot + 4 * t + 1] = p.d.reg_weights[1] * ((q[1] + 0.5f * gh) - (e[1] + 0.5f * eh)) / eh;
+                    tg[slot + 4 * t + 2] = p.d.reg_weights[2] * logf(gw / ew);
+                    tg[slot + 4 * t + 3] = p.d.reg_weights[3] * logf(gh / eh);
+                    for (int c = 0; c < 4; ++c) { wi[slot + 4 * t + c] = 1.f; wo[slot + 4 * t + c] = 1.f; }
+                }
+            }
+        }
+        if (krow >= 0) {
+            if (p.picked) p.picked[p.d.rois_per_im + krow] = i;
+            float* ro = p.kp_rois + (size_t)krow * (C4 + 1);
+            ro[0] = 0.f;
+            for (int c = 0; c < C4; ++c) ro[1 + c] = box[c] * scale;
+            int* lo = p.kp_loc + (size_t)krow * KK;
+            float* wt = p.kp_w + (size_t)krow * KK;
+            const int Kf = p.d.num_keypoints;
+            for (int t = 0; t < T; ++t) {
+                // utils/keypoints.py:152-207 keypoints_to_heatmap_labels on frame t's box and keypoints
+                const float x1 = box[4 * t], y1 = box[4 * t + 1], x2 = box[4 * t + 2], y2 = box[4 * t + 3];
+                const float sx = (float)M / (x2 - x1 + 1.0f), sy = (float)M / (y2 - y1 + 1.0f);
+                for (int k = 0; k < Kf; ++k) {
+                    int cell = 0;
+                    float w = 0.f;
+                    if (arg >= 0) {
+                        const int* kp = p.gt_kps + (size_t)arg * 3 * KK;
+                        const float xf = (float)kp[t * Kf + k], yf = (float)kp[KK + t * Kf + k];
+                        const bool vis = kp[2 * KK + t * Kf + k] > 0;
+                        float x = floorf((xf - x1) * sx), y = floorf((yf - y1) * sy);
+                        if (xf == x2) x = (float)(M - 1);
+                        if (yf == y2) y = (float)(M - 1);
+                        if (x >= 0.f && y >= 0.f && x < (float)M && y < (float)M && vis) { cell = (int)(y * (float)M + x); w = 1.f; }
+                    }
+                    lo[t * Kf + k] = cell;
+                    wt[t * Kf + k] = w;
+                    if (w > 0.f) atomicAdd(&s_cnt[3], 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) p.counts[6] = s_cnt[3];       // labelled keypoints of the drawn keypoint rois (the loss normaliser, model_builder.py:873-905)
+}
+
 }  // namespace
 
 extern "C" {
@@ -142,6 +329,28 @@ int dat_scatter_words(dat_ctx* ctx, dat_stream s, void* dst, long long dst_words
     hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, (unsigned int*)dst, dst_words, offsets,
                        (const unsigned int*)values, n);
     DAT_CHECK_LAUNCH(ctx, "scatter_words");
+    return DAT_OK;
+}
+
+int dat_sample_rois(dat_ctx* ctx, dat_stream s, const dat_roi_sample_desc* d, const float* props, const int* n_props, int props_cap,
+                    const float* gt_boxes, const int* gt_classes, const int* gt_kps, int G, float* rois, int* labels, float* targets,
+                    float* w_in, float* w_out, float* kp_rois, int* kp_loc, float* kp_w, int* counts, int* picked) {
+    DAT_ENFORCE(ctx, d && props && n_props && gt_boxes && gt_classes && rois && labels && targets && w_in && w_out && counts,
+                "sample_rois: null argument");
+    DAT_ENFORCE(ctx, d->T >= 1 && d->T <= LAB_MAXT && G >= 1 && props_cap >= 0 && G + props_cap <= RS_MAXN,
+                "sample_rois: T %d (1..%d), %d gts + %d proposals (<= %d candidates)", d->T, LAB_MAXT, G, props_cap, RS_MAXN);
+    DAT_ENFORCE(ctx, d->rois_per_im >= 1 && d->fg_rois_per_im >= 0 && d->fg_rois_per_im <= d->rois_per_im && d->num_classes >= 2,
+                "sample_rois: rois per image %d / %d foreground, %d classes", d->rois_per_im, d->fg_rois_per_im, d->num_classes);
+    DAT_ENFORCE(ctx, !gt_kps || (kp_rois && kp_loc && kp_w && d->num_keypoints >= 1 && d->heatmap_size >= 1 && G <= d->fg_rois_per_im),
+                "sample_rois: keypoint outputs missing (or more gts than foreground rois per image)");
+    RoiSampleParams p;
+    p.d = *d;
+    p.props = props; p.n_props = n_props; p.props_cap = props_cap;
+    p.gt_boxes = gt_boxes; p.gt_classes = gt_classes; p.gt_kps = gt_kps; p.G = G;
+    p.rois = rois; p.labels = labels; p.targets = targets; p.w_in = w_in; p.w_out = w_out;
+    p.kp_rois = kp_rois; p.kp_loc = kp_loc; p.kp_w = kp_w; p.counts = counts; p.picked = picked;
+    hipLaunchKernelGGL(roi_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, p);
+    DAT_CHECK_LAUNCH(ctx, "sample_rois");
     return DAT_OK;
 }
 

@@ -43,6 +43,12 @@ class WgradJob(C.Structure):
                 ('Cout_real', C.c_int), ('Gt', C.c_void_p)]
 
 
+class RoiSampleDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('T', 'num_classes', 'cls_agnostic', 'num_keypoints', 'heatmap_size', 'rois_per_im', 'fg_rois_per_im')] + \
+               [(n, C.c_float) for n in ('fg_thresh', 'bg_thresh_hi', 'bg_thresh_lo')] + [('reg_weights', C.c_float * 4), ('im_scale', C.c_float)] + \
+               [(n, C.c_uint) for n in ('seed_lo', 'seed_hi', 'iter')]
+
+
 class RoiLevel(C.Structure):
     _fields_ = [('feat', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('spatial_scale', C.c_float)]
 
@@ -140,6 +146,7 @@ _PROTOS = {
     'dat_smooth_l1_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p]),
     'dat_anchor_overlaps': (_i, [_p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _p, _p, _p, _p]),
     'dat_scatter_words': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _i]),
+    'dat_sample_rois': (_i, [_p, _p, C.POINTER(RoiSampleDesc), _p, _p, _i, _p, _p, _p, _i] + [_p] * 10),
     'dat_softmax_ce_rows': (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p]),
 }
 EXPORTS = sorted(_PROTOS)

@@ -499,6 +499,57 @@ class PackBatch(object):
                 l.bias[:l.cout_real] = l.bias_src.float()
 
 
+def roi_key(seed, it, stream, index):
+    """The counter-based draw key of dat_sample_rois (csrc/labels.hip roi_key), on NumPy uint32 arrays: two murmur3 finalisers over
+    seed / iteration / stream / candidate index.  Host mirror for tests and for anyone who has to reproduce a draw."""
+    u = np.uint32
+    with np.errstate(over='ignore'):
+        def fmix(h):
+            h = h ^ (h >> u(16)); h = h * u(0x85EBCA6B); h = h ^ (h >> u(13)); h = h * u(0xC2B2AE35); return h ^ (h >> u(16))
+        idx = np.asarray(index, dtype=np.uint32)
+        h = u(seed & 0xffffffff) ^ (idx * u(0x9E3779B9)) ^ (u(it & 0xffffffff) * u(0x85EBCA6B)) ^ (u(stream) * u(0xC2B2AE35))
+        return fmix(fmix(h) ^ u((seed >> 32) & 0xffffffff))
+
+
+def sample_rois(props, n_props, gt_boxes, gt_classes, gt_kps, T, num_classes, cls_agnostic, num_keypoints, heatmap_size, rois_per_im,
+                fg_rois_per_im, fg_thresh, bg_hi, bg_lo, reg_weights, im_scale, seed, it, want_picked=False):
+    """dat_sample_rois on CUDA tensors: props fp32 [cap, 4T+1] + device count (int32[1]), gt_boxes fp32 [G, 4T] (image scale), gt_classes
+    int32 [G], gt_kps int32 [G, 3, K*T] or None.  Returns a dict of capacity-sized device tensors + `counts` (int32[6] on the device)."""
+    dev = props.device
+    G, C4 = int(gt_boxes.shape[0]), 4 * T
+    Kc = 2 if cls_agnostic else num_classes
+    d = L.RoiSampleDesc()
+    d.T, d.num_classes, d.cls_agnostic, d.num_keypoints, d.heatmap_size = T, num_classes, int(bool(cls_agnostic)), int(num_keypoints), int(heatmap_size)
+    d.rois_per_im, d.fg_rois_per_im = int(rois_per_im), int(fg_rois_per_im)
+    d.fg_thresh, d.bg_thresh_hi, d.bg_thresh_lo = float(fg_thresh), float(bg_hi), float(bg_lo)
+    for k in range(4):
+        d.reg_weights[k] = float(reg_weights[k])
+    d.im_scale = float(im_scale)
+    d.seed_lo, d.seed_hi, d.iter = int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff, int(it) & 0xffffffff
+    out = {'rois': torch.empty((rois_per_im, C4 + 1), dtype=torch.float32, device=dev),
+           'labels_int32': torch.empty((rois_per_im,), dtype=torch.int32, device=dev),
+           'bbox_targets': torch.empty((rois_per_im, C4 * Kc), dtype=torch.float32, device=dev),
+           'bbox_inside_weights': torch.empty((rois_per_im, C4 * Kc), dtype=torch.float32, device=dev),
+           'bbox_outside_weights': torch.empty((rois_per_im, C4 * Kc), dtype=torch.float32, device=dev),
+           'counts': torch.zeros((8,), dtype=torch.int32, device=dev)}
+    if gt_kps is not None:
+        KK = num_keypoints * T
+        assert gt_kps.dtype == torch.int32 and tuple(gt_kps.shape) == (G, 3, KK) and gt_kps.is_contiguous()
+        out['keypoint_rois'] = torch.empty((fg_rois_per_im, C4 + 1), dtype=torch.float32, device=dev)
+        out['keypoint_locations_int32'] = torch.empty((fg_rois_per_im, KK), dtype=torch.int32, device=dev)
+        out['keypoint_weights'] = torch.empty((fg_rois_per_im, KK), dtype=torch.float32, device=dev)
+    picked = torch.full((rois_per_im + fg_rois_per_im,), -1, dtype=torch.int32, device=dev) if want_picked else None
+    assert props.dtype == torch.float32 and props.is_contiguous() and props.shape[1] == C4 + 1 and n_props.dtype == torch.int32
+    assert gt_boxes.dtype == torch.float32 and gt_boxes.is_contiguous() and gt_classes.dtype == torch.int32
+    ctx().call('dat_sample_rois', _stream(), C.byref(d), _ptr(props), _ptr(n_props), int(props.shape[0]), _ptr(gt_boxes), _ptr(gt_classes),
+               _ptr(gt_kps), G, _ptr(out['rois']), _ptr(out['labels_int32']), _ptr(out['bbox_targets']), _ptr(out['bbox_inside_weights']),
+               _ptr(out['bbox_outside_weights']), _ptr(out.get('keypoint_rois')), _ptr(out.get('keypoint_locations_int32')),
+               _ptr(out.get('keypoint_weights')), _ptr(out['counts']), _ptr(picked))
+    if want_picked:
+        out['picked'] = picked
+    return out
+
+
 def wgrad_acc_batch(jobs):
     """dat_conv3d_wgrad_acc_batch: the deferred-finish weight gradients of `jobs` (ConvGrad.weight_acc_job tuples) in one call -- the
     pointwise layers among them as grouped launches that share the CUs (a tenth of the float-atomic traffic of one launch per layer)."""

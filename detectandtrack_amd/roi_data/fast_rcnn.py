@@ -83,16 +83,28 @@ def add_keypoint_blobs(blobs, e, fg_rois_per_image, im_scale, batch_idx, rng):
     uses the FIRST frame's box against all T*K keypoints exactly like the reference's _within_box (:88-99), the heatmap
     targets are built per frame and concatenated along the keypoint axis (:62-73)."""
     gt_inds = np.where(e['gt_classes'] > 0)[0]
-    gtk = e['gt_keypoints']
-    ind_kp = gt_inds[e['box_to_gt_ind_map']]
-    within = _within_box(gtk[ind_kp], e['boxes'])
-    visible = np.sum((gtk[ind_kp, 2, :] > 0) & within, axis=1) > 0
-    kp_fg = np.where((e['max_overlaps'] >= cfg.TRAIN.FG_THRESH) & visible)[0]
+    kp_fg = keypoint_fg_candidates(e)
     n = min(fg_rois_per_image, kp_fg.size)
     if kp_fg.size > n:
         kp_fg = rng.choice(kp_fg, size=n, replace=False)
     if kp_fg.shape[0] == 0:
         kp_fg = gt_inds
+    keypoint_blobs_for(blobs, e, kp_fg, im_scale, batch_idx)
+
+
+def keypoint_fg_candidates(e):
+    """roi_data/keypoint_rcnn.py:40-46: foreground rois that see a visible keypoint of their ground-truth box (the set the draw is from)."""
+    gt_inds = np.where(e['gt_classes'] > 0)[0]
+    gtk = e['gt_keypoints']
+    ind_kp = gt_inds[e['box_to_gt_ind_map']]
+    within = _within_box(gtk[ind_kp], e['boxes'])
+    visible = np.sum((gtk[ind_kp, 2, :] > 0) & within, axis=1) > 0
+    return np.where((e['max_overlaps'] >= cfg.TRAIN.FG_THRESH) & visible)[0]
+
+
+def keypoint_blobs_for(blobs, e, kp_fg, im_scale, batch_idx):
+    """The keypoint blobs of the DRAWN keypoint rois `kp_fg` (indices into the merged entry): roi_data/keypoint_rcnn.py:49-86."""
+    gtk = e['gt_keypoints']
     rois = e['boxes'][kp_fg].astype(np.float32)
     b2g = e['box_to_gt_ind_map'][kp_fg]
     kps = -np.ones((len(rois), gtk.shape[1], gtk.shape[2]), dtype=gtk.dtype)
@@ -127,6 +139,14 @@ def sample_rois(e, im_scale, batch_idx, rng):
     if bg.size > 0:
         bg = rng.choice(bg, size=n_bg, replace=False)
     keep = np.append(fg, bg).astype(np.int64)
+    blobs = roi_blobs_for(e, keep, n_fg, im_scale, batch_idx)
+    if cfg.MODEL.KEYPOINTS_ON:
+        add_keypoint_blobs(blobs, e, fg_per_im, im_scale, batch_idx, rng)
+    return blobs
+
+
+def roi_blobs_for(e, keep, n_fg, im_scale, batch_idx):
+    """The Fast R-CNN blobs of the DRAWN rois `keep` (indices into the merged entry, the first n_fg of them foreground): :156-203."""
     labels = e['max_classes'][keep].copy()
     labels[n_fg:] = 0
     boxes = e['boxes'][keep].astype(np.float32)
@@ -142,8 +162,6 @@ def sample_rois(e, im_scale, batch_idx, rng):
     blobs = dict(labels_int32=labels.astype(np.int32),
                  rois=np.hstack((batch_idx * np.ones((len(keep), 1), np.float32), boxes * im_scale)).astype(np.float32),
                  bbox_targets=targets, bbox_inside_weights=w_in, bbox_outside_weights=(w_in > 0).astype(np.float32))
-    if cfg.MODEL.KEYPOINTS_ON:
-        add_keypoint_blobs(blobs, e, fg_per_im, im_scale, batch_idx, rng)
     del gt_boxes
     return blobs
 

@@ -46,8 +46,10 @@ class Minibatch(object):
             ws.FeedBlob(k, v)
         for name, lvl in self.label_levels.items():         # lets the loss normalise without reading the dense blob back
             ws.blobs[name].host = _WindowCounter(self.sparse, lvl)
-        entry, rng = self.entry, self.rng
-        ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+        from detectandtrack_amd.roi_data.device_sampler import make_sampler
+        # (device kernel by default -- cfg.HIP.DEVICE_ROI_SAMPLING; its draw stream is seeded per minibatch from the minibatch's own RNG, so a
+        #  run stays reproducible for any worker count)
+        ws.train_sampler = make_sampler(self.entry, self.rng, seed=int(self.rng.randint(0, 2 ** 31 - 1)))
 
 
 class _WindowCounter(object):

@@ -132,8 +132,11 @@ class TrainExecutor(Executor):
         x = ws.blobs[op.inputs[0]]            # 'mat' fp32 [R, K, M, M]
         loc, wts = ws.blobs[op.inputs[1]], ws.blobs[op.inputs[2]]
         R, K, M, _ = x.t.shape
-        w_host = wts.host if wts.host is not None else wts.t.cpu().numpy()
-        norm = float(np.sum(w_host))
+        if hasattr(wts.host, 'weight_sum'):         # roi_data.device_sampler: the sum came back with the roi counts
+            norm = float(wts.host.weight_sum)
+        else:
+            w_host = wts.host if wts.host is not None else wts.t.cpu().numpy()
+            norm = float(np.sum(w_host))
         loss = self._loss_buf([op.outputs[1]])
         logits = x.t.view(R * K, M * M)
         mult = a['scale'] / norm if norm > 0 else 0.0
@@ -147,25 +150,39 @@ class TrainExecutor(Executor):
         self._run_rpn()
         rois, probs, counts = self._rpn_out
         out, n_out = ops.collect_rois(rois, probs, counts, cfg.TRAIN.RPN_POST_NMS_TOP_N)
-        rois_np = out[:int(n_out.item())].cpu().numpy()
         im_info = ws.blobs['im_info']
         info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
         sampler = getattr(ws, 'train_sampler', None)
         assert sampler is not None, 'training needs ws.train_sampler(rois, im_info) -> dict of sampled blobs ' \
                                     '(roi_data.fast_rcnn.add_fast_rcnn_blobs on the roidb entry of this clip)'
+        if getattr(sampler, 'on_device', False):    # roi_data.device_sampler: the proposals never leave the GPU, the row counts come back
+            self._feed_device_samples(op, sampler(out, n_out, info))
+            return
+        rois_np = out[:int(n_out.item())].cpu().numpy()
         blobs = sampler(rois_np, info)
         for name in op.outputs:
             if name in blobs:
                 ws.FeedBlob(name, np.ascontiguousarray(blobs[name]))
 
+    def _feed_device_samples(self, op, blobs):
+        from detectandtrack_amd.roi_data.device_sampler import WeightSum
+        for name in op.outputs:
+            if name in blobs:
+                self.ws.FeedBlob(name, blobs[name])
+        if 'keypoint_weights' in blobs and 'keypoint_weights' in self.ws.blobs:
+            self.ws.blobs['keypoint_weights'].host = WeightSum(blobs['keypoint_weights_sum'])
+
     def op_GenerateProposalLabels(self, i, op):
         """ops/generate_proposal_labels.py:23-37: sample labelled training rois from the RPN proposals of this clip."""
         ws = self.ws
         r = ws.blobs[op.inputs[0]]
-        rois_np = r.t[:_count(r)].cpu().numpy() if r.count is not None else r.t.cpu().numpy()
         im_info = ws.blobs['im_info']
         info = im_info.host if im_info.host is not None else im_info.t.cpu().numpy()
         assert ws.train_sampler is not None, 'training needs ws.train_sampler(rois, im_info) -> dict of sampled blobs'
+        if getattr(ws.train_sampler, 'on_device', False) and r.count is not None:
+            self._feed_device_samples(op, ws.train_sampler(r.t if r.t.dim() == 2 else r.t.view(-1, r.t.shape[-1]), r.count, info))
+            return
+        rois_np = r.t[:_count(r)].cpu().numpy() if r.count is not None else r.t.cpu().numpy()
         blobs = ws.train_sampler(rois_np, info)
         for name in op.outputs:
             if name in blobs:

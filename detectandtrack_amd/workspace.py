@@ -413,7 +413,8 @@ class Executor(object):
             # the layer's packing kernels were enqueued on THIS stream; the cache is shared by every fork of the workspace (the pipeline's
             # slots, the frame-trunk stream), whose streams would otherwise be free to launch the layer before its weights are packed.
             # Layers are built once per model: a host wait per build costs nothing in steady state.
-            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            # (inference only: a training executor runs on one stream and rebuilds some layers every iteration)
+            if not self.training and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream().synchronize()
         return self.ws._layers[k]
 

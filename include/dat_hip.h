@@ -454,6 +454,29 @@ int dat_anchor_overlaps(dat_ctx* ctx, dat_stream s, const float* anchors, int n,
 /* dst[offsets[i]] = values[i] for 32-bit words (sparse RPN labels -> the dense "wide" label blobs of rpn.py:343-368) */
 int dat_scatter_words(dat_ctx* ctx, dat_stream s, void* dst, long long dst_words, const int* offsets, const void* values, int n);
 
+/* GenerateProposalLabels on the device (lib/ops/generate_proposal_labels.py:24-37 -> lib/roi_data/fast_rcnn.py:109-203, json_dataset.py:423-473,
+ * roi_data/keypoint_rcnn.py:32-99, utils/keypoints.py:152-207).  Candidates = the G gt boxes (image scale) followed by the first *n_props
+ * proposals ([cap, 4T+1], network scale, divided by im_scale); maximum overlap with the gt boxes as the reference's Cython kernel computes it;
+ * rois_per_im rois are drawn, up to fg_rois_per_im foreground (overlap >= fg_thresh) first, then background ([bg_thresh_lo, bg_thresh_hi)):
+ * rois [rows, 4T+1] at network scale, labels, class-specific targets / inside / outside weights [rows, 4T * (cls_agnostic ? 2 : num_classes)].
+ * With gt_kps (int32 [G, 3, num_keypoints * T]): up to fg_rois_per_im keypoint rois (foreground AND a visible keypoint of their gt inside
+ * their first-frame box; none at all: the gt boxes), heatmap cell index / weight per keypoint [rows, num_keypoints * T].
+ * counts (device int32[8]) = rows, n_fg, keypoint rows, |fg|, |bg|, |keypoint-fg|, labelled keypoints of the keypoint rows, 0.  picked (optional int32 [rois_per_im + fg_rois_per_im]):
+ * candidate index (gts first) behind every output row.
+ * The draw replaces NumPy's stream by a counter-based generator: "n of S" = the n members of S with the smallest (key, index),
+ * key = f(seed, iter, stream, index) (csrc/labels.hip roi_key; stream 0: fg / bg, 1: keypoint rois), in that order. */
+typedef struct dat_roi_sample_desc {
+    int T, num_classes, cls_agnostic, num_keypoints, heatmap_size;
+    int rois_per_im, fg_rois_per_im;
+    float fg_thresh, bg_thresh_hi, bg_thresh_lo;
+    float reg_weights[4];
+    float im_scale;
+    unsigned int seed_lo, seed_hi, iter;
+} dat_roi_sample_desc;
+int dat_sample_rois(dat_ctx* ctx, dat_stream s, const dat_roi_sample_desc* d, const float* props, const int* n_props, int props_cap,
+                    const float* gt_boxes, const int* gt_classes, const int* gt_kps, int G, float* rois, int* labels, float* targets,
+                    float* w_in, float* w_out, float* kp_rois, int* kp_loc, float* kp_w, int* counts, int* picked);
+
 #ifdef __cplusplus
 }
 #endif

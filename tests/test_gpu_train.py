@@ -553,9 +553,12 @@ def test_device_anchor_labelling_is_bit_identical_to_the_host(ops, kind, tube_T,
     reset_cfg()
 
 
-def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops):
+@pytest.mark.parametrize('device_sampling', [False, True])
+def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops, device_sampling):
     """tools/train_net.py's two input paths: RoIDataLoader minibatches (device labels, worker streams, sparse loss
-    normaliser) and the synchronous host rpn.add_rpn_blobs feed give the same losses for the same clips and RNG."""
+    normaliser) and the synchronous host rpn.add_rpn_blobs feed give the same losses for the same clips and RNG -- with the roi
+    sampling of GenerateProposalLabels on the host (the reference's numpy.random stream) and on the device (cfg.HIP.DEVICE_ROI_SAMPLING:
+    its counter-based draw is seeded from the minibatch's RNG on both paths)."""
     from tests.model_util import fpn3d_kps_cfg
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
@@ -570,9 +573,11 @@ def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops):
     c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 400, 'RPN_POST_NMS_TOP_N': 200, 'IMS_PER_BATCH': 1, 'MAX_SIZE': 160,
                   'BATCH_SIZE_PER_IM': 64, 'RPN_STRADDLE_THRESH': 0}
     c['NUM_GPUS'] = 1
+    c['HIP']['DEVICE_ROI_SAMPLING'] = bool(device_sampling)
     reset_cfg()
     cfg_from_cfg(c)
     assert_and_infer_cfg()
+    from detectandtrack_amd.roi_data.device_sampler import make_sampler, DeviceRoiSampler
 
     def source(i):
         return synthetic_clip(T, H, W) + np.float32(i), synthetic.synthetic_roidb_entry(H, W, n_persons=2 + i, seed=5 + i), 1.0
@@ -597,7 +602,8 @@ def test_training_from_the_prefetching_loader_equals_synchronous_feeding(ops):
                     ws.FeedBlob('data', data)
                     for k, v in rpn_data.add_rpn_blobs({}, 1.0, entry, rng).items():
                         ws.FeedBlob(k, v)
-                    ws.train_sampler = (lambda e, r: lambda rois, info: frcn_data.sample_training_blobs(e, rois, info, r))(entry, rng)
+                    ws.train_sampler = make_sampler(entry, rng, seed=int(rng.randint(0, 2 ** 31 - 1)))
+                assert isinstance(ws.train_sampler, DeviceRoiSampler) == bool(device_sampling)
                 out.append(trainer.step(lr=0.001).loss_values())
         finally:
             loader.shutdown()
@@ -735,6 +741,179 @@ def test_direct_weight_gradient_over_a_frame_window(ops, k, win):
     assert float((full.cpu() - ref).abs().max()) < 2e-3 * scale
     assert float((part.cpu() - ref).abs().max()) < 2e-3 * scale
     assert float((part - full).abs().max()) < 1e-4 * scale      # (same products; the K split differs, fp32 sums in another order)
+
+
+@pytest.mark.parametrize('T,n_props,n_persons,jitter', [(1, 2000, 8, 400), (1, 300, 3, 20), (2, 1000, 5, 200), (1, 2000, 8, 0), (1, 0, 4, 0)])
+def test_device_roi_sampling_matches_the_reference_semantics(ops, T, n_props, n_persons, jitter):
+    """GenerateProposalLabels as one device kernel (dat_sample_rois; roi_data/device_sampler.py) against the host
+    restatement that is pinned to the REAL reference (roi_data/fast_rcnn.py, tests/golden/reference_roi_data.npz).  The contract, checked
+    piece by piece:  (1) the candidate sets -- foreground, background, keypoint-foreground -- and the counts n_fg / n_bg / n_kp are the
+    reference's;  (2) the draw is "the n members of the set with the smallest (roi_key, index)", in that order (the host mirror
+    ops.roi_key reproduces every picked row), NOT NumPy's Mersenne-Twister stream;  (3) for the picked rows, rois / labels / box targets /
+    weights / keypoint rois / heatmap cells / keypoint weights are what the host code computes for the same rows (targets to float32
+    rounding of log, everything else exact);  (4) different iterations draw different subsets of the same sets."""
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.roi_data import fast_rcnn as frcn, synthetic
+    from detectandtrack_amd.roi_data.device_sampler import DeviceRoiSampler
+    from tests.model_util import fpn3d_kps_cfg
+    reset_cfg()
+    cfg_from_cfg(fpn3d_kps_cfg('18', T=max(T, 2), dtype='fp32'))
+    assert_and_infer_cfg()
+    H, W, scale = 720, 1280, 1.0414
+    rs = np.random.RandomState(17 + n_props + T)
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=n_persons, seed=5, T=T)
+    # proposals at NETWORK scale: random boxes + jittered copies of the gt boxes (so that some are foreground), tubes repeat the jitter
+    x1, y1 = rs.uniform(0, W * 0.8, n_props), rs.uniform(0, H * 0.8, n_props)
+    bw, bh = rs.uniform(20, W * 0.5, n_props), rs.uniform(20, H * 0.6, n_props)
+    boxes = np.stack([x1, y1, np.minimum(x1 + bw, W - 1), np.minimum(y1 + bh, H - 1)], 1)
+    boxes = np.tile(boxes, (1, T))
+    for k in range(min(jitter, n_props)):
+        g = entry['boxes'][k % n_persons] + np.tile(rs.uniform(-25, 25, 4), T) * (1 + (k % 3))
+        boxes[k] = g
+    props = np.hstack((np.zeros((n_props, 1)), boxes * scale)).astype(np.float32)
+    cap = max(n_props, 1) + 7                                                   # rows past the device count are never read
+    props_dev = torch.zeros((cap, 4 * T + 1), dtype=torch.float32, device='cuda')
+    props_dev[:n_props] = torch.from_numpy(props).cuda()
+    props_dev[n_props:] = 1e6
+    n_dev = torch.tensor([n_props], dtype=torch.int32, device='cuda')
+    im_info = np.array([[H * scale, W * scale, scale]], np.float32)
+    per_im = int(cfg.TRAIN.BATCH_SIZE_PER_IM)
+    fg_per_im = int(np.round(cfg.TRAIN.FG_FRACTION * per_im))
+    sampler = DeviceRoiSampler(entry, seed=0x1234567890abcdef)
+    # ---- host side: the merged entry and the reference's candidate sets
+    e = frcn.merge_proposals_into_entry(entry, props[:, 1:] / np.float32(scale))
+    mo = e['max_overlaps']
+    fg = np.where(mo >= cfg.TRAIN.FG_THRESH)[0]
+    bg = np.where((mo < cfg.TRAIN.BG_THRESH_HI) & (mo >= cfg.TRAIN.BG_THRESH_LO))[0]
+    kpc = frcn.keypoint_fg_candidates(e)
+    n_fg = min(fg_per_im, fg.size)
+    n_bg = min(per_im - n_fg, bg.size)
+    n_kp = min(fg_per_im, kpc.size) if kpc.size else n_persons
+    seen = []
+    for it in range(3):
+        got = sampler(props_dev, n_dev, im_info, want_picked=True)
+        c = sampler.last_counts
+        assert (int(c[3]), int(c[4]), int(c[5])) == (fg.size, bg.size, kpc.size), (c, fg.size, bg.size, kpc.size)      # (1) the sets
+        assert (int(c[1]), int(c[0]) - int(c[1]), int(c[2])) == (n_fg, n_bg, n_kp)
+        picked = got['picked'].cpu().numpy()
+        N = e['boxes'].shape[0]
+
+        def draw(cands, n, stream):
+            keys = ops.roi_key(0x1234567890abcdef, it, stream, np.arange(N))
+            order = sorted(cands.tolist(), key=lambda i: (int(keys[i]), i))
+            return np.asarray(order[:n], dtype=np.int64)
+        keep = np.append(draw(fg, n_fg, 0), draw(bg, n_bg, 0))
+        np.testing.assert_array_equal(picked[:n_fg + n_bg], keep)                                                    # (2) the draw
+        kp_keep = draw(kpc, n_kp, 1) if kpc.size else np.arange(n_persons)
+        np.testing.assert_array_equal(picked[per_im:per_im + n_kp], kp_keep)
+        assert np.all(picked[n_fg + n_bg:per_im] == -1) and np.all(picked[per_im + n_kp:] == -1)
+        want = frcn.roi_blobs_for(e, keep, n_fg, scale, 0)                                                           # (3) the rows
+        frcn.keypoint_blobs_for(want, e, kp_keep, scale, 0)
+        for name in ('rois', 'labels_int32', 'bbox_inside_weights', 'bbox_outside_weights', 'keypoint_rois', 'keypoint_locations_int32',
+                     'keypoint_weights'):
+            g_ = got[name].cpu().numpy()
+            assert g_.shape == want[name].shape, (name, g_.shape, want[name].shape)
+            if name.endswith('rois'):
+                np.testing.assert_allclose(g_, want[name], rtol=0, atol=1e-4, err_msg=name)     # (p / s) * s in float32 on both sides
+            else:
+                np.testing.assert_array_equal(g_, want[name], err_msg=name)
+        np.testing.assert_allclose(got['bbox_targets'].cpu().numpy(), want['bbox_targets'], rtol=1e-5, atol=2e-6)
+        assert got['keypoint_weights_sum'] == float(want['keypoint_weights'].sum())
+        if n_fg:
+            assert np.all(got['labels_int32'].cpu().numpy()[:n_fg] == 1) and np.all(got['labels_int32'].cpu().numpy()[n_fg:] == 0)
+        seen.append(tuple(keep.tolist()))
+    if bg.size > n_bg + 5:
+        assert len(set(seen)) == 3                                                                                   # (4) a new draw per iteration
+
+
+def test_device_roi_sampling_is_uniform_without_replacement(ops):
+    """The draw key is a hash, not a proven generator: check what the contract promises -- over 400 iterations every one of 40
+    foreground candidates is picked with frequency n / |S| = 1 / 4 (5-sigma band of the binomial), no roi twice in one draw."""
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.roi_data import synthetic
+    from detectandtrack_amd.roi_data.device_sampler import DeviceRoiSampler
+    from tests.model_util import fpn3d_kps_cfg
+    c = fpn3d_kps_cfg('18', T=2, dtype='fp32')
+    c['TRAIN'] = dict(c.get('TRAIN', {}), BATCH_SIZE_PER_IM=40, FG_FRACTION=0.25)
+    reset_cfg()
+    cfg_from_cfg(c)
+    assert_and_infer_cfg()
+    entry = synthetic.synthetic_roidb_entry(720, 1280, n_persons=4, seed=2, T=1)
+    rs = np.random.RandomState(0)
+    boxes = np.concatenate([entry['boxes'][k % 4][None] + rs.uniform(-6, 6, (1, 4)) for k in range(36)]).astype(np.float32)   # 36 fg proposals + 4 gts
+    props = torch.from_numpy(np.hstack((np.zeros((36, 1), np.float32), boxes))).cuda()
+    n_dev = torch.tensor([36], dtype=torch.int32, device='cuda')
+    sampler = DeviceRoiSampler(entry, seed=99)
+    hits = np.zeros(40)
+    for it in range(400):
+        got = sampler(props, n_dev, np.array([[720, 1280, 1.0]], np.float32), want_picked=True)
+        c_ = sampler.last_counts
+        assert int(c_[3]) == 40 and int(c_[1]) == 10
+        pk = got['picked'].cpu().numpy()[:10]
+        assert len(set(pk.tolist())) == 10
+        hits[pk] += 1
+    p, n = 0.25, 400
+    assert np.all(np.abs(hits - n * p) < 5 * np.sqrt(n * p * (1 - p))), hits
+
+
+def test_training_iteration_with_the_device_roi_sampler_equals_the_host_path_on_the_same_draw(ops):
+    """A whole training iteration (forward, 13 losses, backward) with roi_data.device_sampler.DeviceRoiSampler -- the proposals never
+    leave the GPU -- against the host path (proposals -> host -> roi_data.fast_rcnn -> uploads) FORCED to the rows the device drew:
+    every loss equal to 1e-5, every trainable gradient to the float-atomic noise of the weight-gradient kernels.  Also checks what the
+    device path is for: no proposals cross to the host (the sampler is handed device tensors and returns device tensors)."""
+    from detectandtrack_amd.core.config import cfg
+    from detectandtrack_amd.roi_data import fast_rcnn as frcn, rpn as rpn_data, synthetic
+    from detectandtrack_amd.roi_data.device_sampler import DeviceRoiSampler
+    from detectandtrack_amd.training import Trainer
+    from tests.model_util import synthetic_clip
+    T, H, W = 2, 128, 160
+    entry = synthetic.synthetic_roidb_entry(H, W, n_persons=3, seed=5)
+    data = synthetic_clip(T, H, W, seed=3)
+
+    def run(make_sampler):
+        model, ws = _ddp_model(1)
+        ws.FeedBlob('data', data)
+        for k, v in rpn_data.add_rpn_blobs({}, 1.0, entry, np.random.RandomState(0)).items():
+            ws.FeedBlob(k, v)
+        ws.train_sampler = make_sampler()
+        tr = Trainer(model, ws)
+        ex = tr.step(0.0)
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in ex.loss_values().items()}, {n: tr.arena[n].clone() for n in tr.trainable}
+    record = {}
+
+    class Recording(DeviceRoiSampler):
+        def __call__(self, rois_dev, n_dev, im_info, want_picked=False):
+            assert rois_dev.is_cuda and n_dev.is_cuda
+            out = DeviceRoiSampler.__call__(self, rois_dev, n_dev, im_info, want_picked=True)
+            record.update(rois=rois_dev[:int(n_dev.view(-1)[0])].cpu().numpy(), picked=out['picked'].cpu().numpy(), counts=self.last_counts.copy())
+            assert all(v.is_cuda for k, v in out.items() if hasattr(v, 'is_cuda'))
+            return out
+    dev_losses, dev_grads = run(lambda: Recording(entry, seed=7))
+    per_im = int(cfg.TRAIN.BATCH_SIZE_PER_IM)
+
+    def forced():
+        def sampler(rois, info):
+            np.testing.assert_array_equal(rois, record['rois'])           # the same proposals reach the host path
+            scale = float(info[0, 2])
+            e = frcn.merge_proposals_into_entry(entry, rois[:, 1:] / scale)
+            n, n_fg, m = int(record['counts'][0]), int(record['counts'][1]), int(record['counts'][2])
+            blobs = frcn.roi_blobs_for(e, record['picked'][:n].astype(np.int64), n_fg, scale, 0)
+            frcn.keypoint_blobs_for(blobs, e, record['picked'][per_im:per_im + m].astype(np.int64), scale, 0)
+            return blobs
+        return sampler
+    host_losses, host_grads = run(forced)
+    assert sorted(dev_losses) == sorted(host_losses) and len(dev_losses) >= 10
+    for k in dev_losses:
+        np.testing.assert_allclose(dev_losses[k], host_losses[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    live = 0
+    for n_, g in dev_grads.items():
+        mx = float(host_grads[n_].abs().max())
+        if mx == 0.0:
+            continue
+        live += 1
+        assert float((g - host_grads[n_]).abs().max()) <= 2e-4 * mx + 1e-9, n_
+    assert live > 40
 
 
 PW_CASES = [

@@ -50,7 +50,8 @@ def main():
     ws.FeedBlob('data', data)
     for k, v in blobs.items():
         ws.FeedBlob(k, v)
-    ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+    from detectandtrack_amd.roi_data.device_sampler import make_sampler
+    ws.train_sampler = make_sampler(entry, rng, seed=1)
     trainer = Trainer(model, ws)
     for _ in range(2):
         ex = trainer.step(1e-4)

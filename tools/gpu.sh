@@ -8,6 +8,7 @@
 #   layers[:bench args]     eager sequential per-layer conv table (--pipeline 1 --graph 0 --dump-convs -> conv_layers.txt)
 #   stats[:bench args]      rocprofv3 --kernel-trace --stats of a --pipeline 1 run (-> <name>_kernel_stats.csv; name = stats or NAME= prefix)
 #   pmc[:bench args]        three separate --pmc passes (MFMA busy / FETCH_SIZE / WRITE_SIZE; --kernel-trace only) of a --pipeline 1 run
+#   trace[:bench args]      rocprofv3 --kernel-trace of a short --pipeline 1 run (-> <name>_kernel_trace.csv; tools/probes/trace_iter.py lists one iteration)
 #   smoke                   __graft_entry__.smoke()
 #   py:<script;args>        python <script> <args>   (-> py_<n>.log)
 #   env:<NAME=V;NAME2=V2>   export for the stages that follow (A/B pairs inside one call);  unset:<NAME;NAME2>
@@ -32,6 +33,9 @@ for st in "$@"; do
     stats)  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/_st -o r1 -- python $R/bench.py $Q --no-roofline --h2d 0 --steps 10 --warmup 3 --pipeline 1 $args > $o/${out}.log 2>&1
             f=$(ls $o/_st/*/r1_kernel_stats.csv $o/_st/r1_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $o/${out}_kernel_stats.csv; rm -rf $o/_st
             grep -h '"metric"' $o/${out}.log | cut -c1-200; head -8 $o/${out}_kernel_stats.csv | cut -c1-160 ;;
+    trace)  timeout -s KILL 400 rocprofv3 --kernel-trace --output-format csv -d $o/_tr -o r1 -- python $R/bench.py $Q --no-roofline --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args > $o/${out}_trace.log 2>&1
+            f=$(ls $o/_tr/*/r1_kernel_trace.csv $o/_tr/r1_kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $o/${out}_kernel_trace.csv; rm -rf $o/_tr
+            ls -la $o/${out}_kernel_trace.csv ;;
     pmc)    B="python $R/bench.py $Q --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args"
             timeout -s KILL 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/pmc_mfma -o r1 -- $B > $o/pmc_mfma.log 2>&1
             timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/pmc_fetch -o r1 -- $B > $o/pmc_fetch.log 2>&1

@@ -45,7 +45,8 @@ def feed_clip(ws, data, entry, rng):
     ws.FeedBlob('data', data)
     for k, v in blobs.items():
         ws.FeedBlob(k, v)
-    ws.train_sampler = lambda rois, info: frcn_data.sample_training_blobs(entry, rois, info, rng)
+    from detectandtrack_amd.roi_data.device_sampler import make_sampler
+    ws.train_sampler = make_sampler(entry, rng, seed=int(rng.randint(0, 2 ** 31 - 1)))
 
 
 def main():
