@@ -231,7 +231,7 @@ def enqueue_results_on_device(model, im_shape, im_scale):
         workspace.RunNet(model.keypoint_net.Proto().name)
         heat = ws.blobs['kps_score'].t                       # fp32 [cap, 17 T, M, M] on the device
         assert heat.shape[1] == cfg.KRCNN.NUM_KEYPOINTS * T, 'Heatmaps must be 17xT'
-        xy = ops.heatmaps_to_keypoints(heat.contiguous(), dets[:, :4 * T].contiguous(), T, cfg.KRCNN.NUM_KEYPOINTS,
+        xy = ops.heatmaps_to_keypoints(heat.contiguous(), dets, T, cfg.KRCNN.NUM_KEYPOINTS,     # (box columns of the detection rows, in place)
                                        cfg.KRCNN.INFERENCE_MIN_SIZE)
     return dets, n_out, xy
 

@@ -175,4 +175,13 @@ int dat_prof_read(dat_ctx* ctx, int max_records, int* tags, double* flops, float
     return n;
 }
 
+// zero `bytes` bytes at `ptr` on the stream (hipMemsetAsync; capturable): the zero-initialised outputs of the proposal / collect / detection
+// kernels without a framework fill kernel in between
+int dat_fill_zero(dat_ctx* ctx, dat_stream s, void* ptr, size_t bytes) {
+    DAT_ENFORCE(ctx, ptr || bytes == 0, "fill_zero: null pointer");
+    if (bytes == 0) return DAT_OK;
+    if (hipMemsetAsync(ptr, 0, bytes, (hipStream_t)s) != hipSuccess) DAT_FAIL(ctx, DAT_ERR_LAUNCH, "fill_zero: hipMemsetAsync failed");
+    return DAT_OK;
+}
+
 }  // extern "C"

@@ -21,6 +21,7 @@ struct KpParams {
     const float* boxes;   // [R, 4*T] image-space x1 y1 x2 y2 per frame
     float* out;           // [R, 4, T*K] rows x, y, logit, prob
     int R, T, K, M, min_size;
+    int box_ld;           // floats per row of `boxes` (>= 4 * T: the detection rows [4T boxes | score | class] are read in place)
 };
 
 __device__ __forceinline__ void cubic(float t, float c[4]) {
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void kps_decode_kernel(const KpParams p) {
     for (int i = tid; i < M * M; i += blockDim.x) map[i] = src[i];
     __syncthreads();
 
-    const float* b = p.boxes + ((size_t)r * p.T + t) * 4;
+    const float* b = p.boxes + (size_t)r * p.box_ld + t * 4;
     const float off_x = b[0], off_y = b[1];
     const float width = fmaxf(b[2] - b[0], 1.f), height = fmaxf(b[3] - b[1], 1.f);
     int mw = (int)ceilf(width), mh = (int)ceilf(height);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void kps_decode_sep_kernel(const KpParams p) {
     const float* src = p.maps + ((size_t)r * p.T * p.K + (size_t)t * p.K + k) * M * M;
     for (int i = tid; i < M * M; i += 256) map[i] = src[i];
 
-    const float* b = p.boxes + ((size_t)r * p.T + t) * 4;
+    const float* b = p.boxes + (size_t)r * p.box_ld + t * 4;
     const float off_x = b[0], off_y = b[1];
     const float width = fmaxf(b[2] - b[0], 1.f), height = fmaxf(b[3] - b[1], 1.f);
     int mw = (int)ceilf(width), mh = (int)ceilf(height);
@@ -249,13 +250,21 @@ __global__ __launch_bounds__(256) void kps_decode_sep_kernel(const KpParams p) {
 
 }  // namespace
 
+extern "C" int dat_heatmaps_to_keypoints_ld(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int box_ld, int R, int T,
+                                            int K, int M, int min_size, float* out);
+
 extern "C" int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int R, int T,
                                          int K, int M, int min_size, float* out) {
-    DAT_ENFORCE(ctx, maps && boxes && out, "heatmaps_to_keypoints: null argument");
+    return dat_heatmaps_to_keypoints_ld(ctx, s, maps, boxes, 4 * T, R, T, K, M, min_size, out);
+}
+
+extern "C" int dat_heatmaps_to_keypoints_ld(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int box_ld, int R, int T,
+                                            int K, int M, int min_size, float* out) {
+    DAT_ENFORCE(ctx, maps && boxes && out && box_ld >= 4 * T, "heatmaps_to_keypoints: null argument / box row stride %d < 4 T", box_ld);
     DAT_ENFORCE(ctx, T >= 1 && K >= 1 && M >= 2 && (size_t)M * M * 4 <= 64 * 1024, "heatmaps_to_keypoints: T %d K %d M %d unsupported", T, K, M);
     if (R == 0) return DAT_OK;
     KpParams p;
-    p.maps = maps; p.boxes = boxes; p.out = out; p.R = R; p.T = T; p.K = K; p.M = M; p.min_size = min_size;
+    p.maps = maps; p.boxes = boxes; p.out = out; p.R = R; p.T = T; p.K = K; p.M = M; p.min_size = min_size; p.box_ld = box_ld;
     if (ctx->dbg_kps_sep) {     // (DAT_KPS_DECODE_SEP, default 1; 0 = the per-pixel 4 x 4 kernel)
         const size_t lds = ((((size_t)M * M + 3) & ~(size_t)3) + (size_t)M * KD_HP) * 4;
         hipLaunchKernelGGL(kps_decode_sep_kernel, dim3((unsigned)(R * T * K)), dim3(256), lds, (hipStream_t)s, p);

@@ -77,6 +77,7 @@ _PROTOS = {
     'dat_last_error': (C.c_char_p, [_p]),
     'dat_ws_info': (_i, [_p, C.POINTER(_p), C.POINTER(C.c_size_t), C.POINTER(_i)]),
     'dat_ws_reserve': (_i, [_p, C.c_size_t]),
+    'dat_fill_zero': (_i, [_p, _p, _p, C.c_size_t]),
     'dat_prof_enable': (_i, [_p, _i]),
     'dat_prof_read': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_f)]),
     'dat_prof_clock': (_i, [_p, C.POINTER(_d)]),
@@ -129,6 +130,7 @@ _PROTOS = {
     'dat_stem_conv_pool': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_preprocess_frames': (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _i, _i, _i, C.POINTER(_d), _p]),
     'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'dat_heatmaps_to_keypoints_ld': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc), _i, _i]),
     'dat_conv3d_wgrad': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _i, _i, _i, _p, _p, _p]),
     'dat_conv3d_wgrad_acc_supported': (_i, [_p, C.POINTER(ConvDesc), _i]),

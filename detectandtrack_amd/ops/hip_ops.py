@@ -817,7 +817,8 @@ def zeros_packed(dev, specs):
     """Several zero-initialised 4-byte-element tensors out of ONE zeroed allocation (one fill launch instead of one per tensor):
     specs = [(shape, torch.float32 | torch.int32), ...]; every view starts on a 16-byte boundary."""
     sizes = [(int(np.prod(shp)) + 3) // 4 * 4 for shp, _ in specs]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    ctx().call('dat_fill_zero', _stream(), _ptr(flat), C.c_size_t(flat.numel() * 4))      # (hipMemsetAsync: no ATen fill kernel in a forward)
     out, off = [], 0
     for (shp, dt), n in zip(specs, sizes):
         v = flat[off:off + int(np.prod(shp))]
@@ -961,10 +962,11 @@ def preprocess_frames(frames, T, scale, pixel_means, pad_stride=0, out=None):
 def heatmaps_to_keypoints(maps, boxes, T, K, min_size=0):
     """maps fp32 CUDA [R, T*K, M, M], boxes fp32 CUDA [R, 4T] -> fp32 CUDA [R, 4, T*K] rows (x, y, logit, prob)."""
     R, TK, M, M2 = maps.shape
-    assert TK == T * K and M == M2 and boxes.shape == (R, 4 * T)
+    # boxes: [R, 4T], or wider rows whose first 4T columns are the boxes (the detection rows of dat_box_results: read in place, no slice copy)
+    assert TK == T * K and M == M2 and boxes.dim() == 2 and boxes.shape[0] == R and boxes.shape[1] >= 4 * T
     assert maps.dtype == torch.float32 and boxes.dtype == torch.float32 and maps.is_contiguous() and boxes.is_contiguous()
     out = torch.empty((R, 4, TK), dtype=torch.float32, device=maps.device)
-    ctx().call('dat_heatmaps_to_keypoints', _stream(), _ptr(maps), _ptr(boxes), R, T, K, M, int(min_size), _ptr(out))
+    ctx().call('dat_heatmaps_to_keypoints_ld', _stream(), _ptr(maps), _ptr(boxes), int(boxes.shape[1]), R, T, K, M, int(min_size), _ptr(out))
     return out
 
 

@@ -50,6 +50,8 @@ const char* dat_last_error(dat_ctx* ctx);
 int dat_ws_info(dat_ctx* ctx, void** ptr, size_t* bytes, int* generation);
 /* Make sure the scratch holds at least `bytes` (tests / callers that want the growth outside a timed region). */
 int dat_ws_reserve(dat_ctx* ctx, size_t bytes);
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (capturable): zero-initialised kernel outputs without a framework fill launch */
+int dat_fill_zero(dat_ctx* ctx, dat_stream s, void* ptr, size_t bytes);
 
 /* Per-launch HIP-event timing of the conv kernel (used by bench.py's roofline leg).
  * enable: start recording (capacity launches); read: sync the events and return
@@ -360,6 +362,9 @@ int dat_comm_destroy(dat_comm* comm);
  * KRCNN.INFERENCE_MIN_SIZE), argmax cell centre mapped to the image, spatial-softmax probability of that cell. */
 int dat_heatmaps_to_keypoints(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int R, int T, int K,
                               int M, int min_size, float* out);
+/* the same with `boxes` rows box_ld floats apart (>= 4T): detection rows [4T box | score | class] are read in place */
+int dat_heatmaps_to_keypoints_ld(dat_ctx* ctx, dat_stream s, const float* maps, const float* boxes, int box_ld, int R, int T, int K, int M,
+                                 int min_size, float* out);
 
 /* ---- training: backward of the fused conv and the update ------------------------------ */
 /* Weight gradient of a conv described like dat_conv3d_fwd (same-T, stride 1 or 2):
