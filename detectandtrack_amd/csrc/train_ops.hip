@@ -1237,9 +1237,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiBwdParams p
         const float inv = 1.f / (float)(gh * gw);
         const size_t obase = ((((size_t)r * p.Tr + t) * P + ph) * P + pw) * p.C;
         // The bilinear weights of a bin do not depend on the channel: the gh x gw samples of the bin (2 x 2 at the reference's sampling
-        // ratio) are folded ONCE per wave into a weight per distinct pixel -- they cover at most (gh + 1) x (gw + 1) pixels, often 2 x 2 --
-        // and every lane then issues one atomic per pixel and channel instead of four per SAMPLE and channel (16 -> 4..9 for 2 x 2
-        // samples: the float atomics of overlapping rois serialise on the same lines and were the whole 0.27 ms of a launch).
+        // ratio) are folded into a weight per distinct pixel BEFORE the channel loop -- they cover at most (gh + 1) x (gw + 1) pixels,
+        // often 2 x 2 -- and every lane then issues one atomic per pixel and channel instead of four per SAMPLE and channel (16 -> 4..9
+        // for 2 x 2 samples: the float atomics of overlapping rois serialise on the same lines and were the whole 0.27 ms of a launch).
+        // The fold is wave-uniform work: all 64 lanes execute it in lock step on the same values (one instruction stream per cell, not
+        // one per channel); its two small tables are indexed at run time and therefore live in scratch (~30 scratch accesses
+        // per cell, against 64 x (4..9) atomics saved -- a register-only de-duplication was not worth its code).
         constexpr int MAXPIX = 16;
         int pix[MAXPIX];
         float wgt[MAXPIX];

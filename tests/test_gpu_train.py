@@ -916,6 +916,67 @@ def test_training_iteration_with_the_device_roi_sampler_equals_the_host_path_on_
     assert live > 40
 
 
+@pytest.mark.parametrize('cin,cout,T,H,W', [(64, 70, 3, 9, 11), (130, 200, 2, 17, 13), (128, 64, 5, 8, 8)])
+def test_nine_tap_weight_gradient_variants_agree(ops, monkeypatch, cin, cout, T, H, W):
+    """the default paths of the nine-tap weight-gradient kernel -- eight-wave blocks with two K ranges (DAT_WGRAD_SUB=2), LDS-DMA
+    pieces between the MFMA groups (DAT_WGRAD_ILV=1) -- against the four-wave / burst variants on shapes that make the sub-ranges UNEQUAL
+    (odd chunk counts), channel counts that are not multiples of 64, a forced two-range split (ks = 2: plain stores, no atomics) and a
+    larger forced split: the same gradient to the fp32 summation order, and torch autograd."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((1, cin, T, H, W), generator=g).bfloat16().float()
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05
+    gy = torch.randn((1, cout, T, H, W), generator=g).bfloat16().float()
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, None, stride=1, padding=1).backward(gy)
+    ref = wr.grad
+    mx = float(ref.abs().max())
+    cs_x, cs_g = ops.round_up(cin, 64), ops.round_up(cout, 64)
+    xd, gd = _ndhwc(x, cs_x, torch.bfloat16), _ndhwc(gy, cs_g, torch.bfloat16)
+    outs = {}
+    for name, env in (('sub2 ilv1', {}), ('sub1', {'DAT_WGRAD_SUB': '1'}), ('ilv0', {'DAT_WGRAD_ILV': '0'}), ('sub2 ks2', {'DAT_WGRAD_KS': '2'}),
+                      ('sub2 ks6', {'DAT_WGRAD_KS': '6'}), ('sub1 ks5', {'DAT_WGRAD_SUB': '1', 'DAT_WGRAD_KS': '5'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ops.drop_ctx()
+        cg = ops.ConvGrad(w.cuda(), None, (1, 1), (1, 1, 1), ops.BF16, cs_x, cs_g)
+        outs[name] = cg.weight(xd, gd, T)[0].cpu()
+        for k in env:
+            monkeypatch.delenv(k)
+    ops.drop_ctx()
+    for name, o in outs.items():
+        assert float((o - ref).abs().max()) < 2e-3 * mx, name
+        assert float((o - outs['sub2 ilv1']).abs().max()) < 2e-5 * mx, name
+
+
+@pytest.mark.parametrize('sampling,pooled', [(2, 7), (2, 14), (0, 7)])
+def test_roi_align_backward_fold_equals_the_per_sample_scatter(ops, monkeypatch, sampling, pooled):
+    """DAT_ROI_BWD_FOLD=1 (a bin's samples folded into one weight per distinct pixel before the atomics, the default) against
+    the per-sample scatter (=0) on rois that overlap, leave the map, are smaller than a bin, and -- sampling 0 -- use the adaptive grid
+    (bins of more than four samples take the per-sample path inside the folded kernel): the same fp32 maps to the atomic summation order."""
+    rs = np.random.RandomState(4)
+    R, C = 40, 64
+    feats_hw = [(32, 48), (16, 24)]
+    rois = np.zeros((R, 5), np.float32)
+    x1, y1 = rs.uniform(-20, 150, R), rs.uniform(-20, 100, R)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3], rois[:, 4] = x1 + rs.uniform(0.5, 160, R), y1 + rs.uniform(0.5, 110, R)
+    rois[:5, 3:] = rois[:5, 1:3] + 0.3                                        # smaller than one bin
+    dout = torch.from_numpy(rs.randn(R, pooled, pooled, C).astype(np.float32)).cuda()
+    outs = []
+    for fold in ('1', '0'):
+        monkeypatch.setenv('DAT_ROI_BWD_FOLD', fold)
+        ops.drop_ctx()
+        maps = [torch.zeros((1, h, w, C), dtype=torch.float32, device='cuda') for h, w in feats_hw]
+        ops.roi_align_bwd(maps, [0.25, 0.125], ops.F32, torch.from_numpy(rois).cuda(), dout, T=1, Tr=1, t0=0, pooled=pooled, sampling=sampling)
+        torch.cuda.synchronize()
+        outs.append([m.cpu() for m in maps])
+    monkeypatch.delenv('DAT_ROI_BWD_FOLD')
+    ops.drop_ctx()
+    for a, b in zip(*outs):
+        mx = float(b.abs().max())
+        assert mx > 0 and float((a - b).abs().max()) < 1e-5 * mx
+
+
 PW_CASES = [
     # cin, cout, stride, N, T, H, W, window        (the tile shape the launcher picks: 128 x 512 / 256 x 256 / 512 x 128 co x ci)
     (512, 128, 1, 1, 2, 13, 19, None),             # res3 branch2a: one 128 x 512 tile
