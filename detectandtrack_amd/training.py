@@ -75,8 +75,20 @@ class TrainExecutor(Executor):
                 return lo.outputs[0] + '+' + do.outputs[0], lo, do, gi
         raise KeyError(logits_name)
 
+    def _scalar_pool(self, n):
+        """n zeroed 4-byte words out of ONE buffer zeroed once per forward (hipMemsetAsync): the loss / metric accumulators of an
+        iteration -- 13 losses over ~10 ops -- used to be one fill launch each."""
+        pool = getattr(self, '_pool', None)
+        if pool is None or self._pool_used + n > pool.numel():
+            pool = self._pool = torch.empty(256, dtype=torch.float32, device=self.ws.device)
+            ops.ctx().call('dat_fill_zero', ops._stream(), ops._ptr(pool), ops.C.c_size_t(pool.numel() * 4))
+            self._pool_used = 0
+        t = pool[self._pool_used:self._pool_used + n]
+        self._pool_used += n
+        return t
+
     def _loss_buf(self, names):
-        t = torch.zeros(len(names), dtype=torch.float32, device=self.ws.device)
+        t = self._scalar_pool(len(names))
         for j, n in enumerate(names):
             self.losses[n] = t[j:j + 1]
         return t
@@ -109,7 +121,7 @@ class TrainExecutor(Executor):
         labels = ws.blobs[op.inputs[1]]
         R = x.t.shape[2]
         loss = self._loss_buf([op.outputs[1]])
-        correct = torch.zeros(1, dtype=torch.int32, device=ws.device)
+        correct = self._scalar_pool(1).view(torch.int32)
         d = ops.softmax_ce_rows(x.t, x.dt, x.C, labels.t, None, a['scale'] / max(R, 1), loss, correct)
         self.metrics[op.outputs[2]] = (correct, R)
         self._add_grad(op.inputs[0], d)
@@ -486,7 +498,9 @@ class TrainExecutor(Executor):
         if dy is None:
             return
         x = ws.blobs[op.inputs[0]]
-        dbias = torch.zeros(a['dim_out'], dtype=torch.float32, device=ws.device)
+        # (the kernel ACCUMULATES the bias reduction: straight into the zeroed arena view when there is one -- no fill, no add)
+        dbias = self.arena[a['b']] if (self.arena is not None and a['b'] in self.arena) else \
+            torch.zeros(a['dim_out'], dtype=torch.float32, device=ws.device)
         g = ops.relu_bias_bwd(dy, y.t, y.dt, a['dim_out'], relu=a['relu'], dbias=dbias)
         self._pgrad(a['b'], dbias)
         w = self._master(a['w'])
@@ -505,11 +519,17 @@ class TrainExecutor(Executor):
             wk = torch.nn.functional.pad(wk, (0, xin.shape[3] - cin_real))
         cg = ops.ConvGrad(wk.reshape(wk.shape[0], -1, 1, 1, 1).contiguous(), None, (1, 1), (0, 0, 0), y.dt, xin.shape[3],
                           g.shape[3])
-        dW, _ = cg.weight(xin, g, 1)
-        dW = dW.reshape(dW.shape[0], -1)[:, :cin_real]
-        if x.kind == 'fmap':
-            dW = dW.view(w.shape[0], x.T, p, p2, x.C).permute(0, 4, 1, 2, 3).reshape(w.shape)
-        self._pgrad(a['w'], dW)
+        # a plain FC whose rows are not channel-padded: the kernel's finish writes the gradient where it belongs (first contribution of
+        # the step); fc6 (permuted RoI features) and padded rows go through a temporary
+        direct = self._pgrad_out(a['w']) if (x.kind != 'fmap' and xin.shape[3] == cin_real) else None
+        dW, _ = cg.weight(xin, g, 1, out=direct.view(-1) if direct is not None else None)
+        if direct is not None:
+            self._pgrad(a['w'], direct)
+        else:
+            dW = dW.reshape(dW.shape[0], -1)[:, :cin_real]
+            if x.kind == 'fmap':
+                dW = dW.view(w.shape[0], x.T, p, p2, x.C).permute(0, 4, 1, 2, 3).reshape(w.shape)
+            self._pgrad(a['w'], dW)
         if op.inputs[0] not in self.no_grad:
             dx = cg.data(g, 1, 1, xin.shape[2])
             if x.kind == 'fmap':

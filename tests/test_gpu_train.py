@@ -867,6 +867,7 @@ def test_training_iteration_with_the_device_roi_sampler_equals_the_host_path_on_
     from detectandtrack_amd.training import Trainer
     from tests.model_util import synthetic_clip
     T, H, W = 2, 128, 160
+    _ddp_model(1)                                       # (the synthetic entry reads cfg: configure first)
     entry = synthetic.synthetic_roidb_entry(H, W, n_persons=3, seed=5)
     data = synthetic_clip(T, H, W, seed=3)
 
