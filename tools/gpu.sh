@@ -36,7 +36,7 @@ for st in "$@"; do
     trace)  timeout -s KILL 400 rocprofv3 --kernel-trace --output-format csv -d $o/_tr -o r1 -- python $R/bench.py $Q --no-roofline --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args > $o/${out}_trace.log 2>&1
             f=$(ls $o/_tr/*/r1_kernel_trace.csv $o/_tr/r1_kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $o/${out}_kernel_trace.csv; rm -rf $o/_tr
             ls -la $o/${out}_kernel_trace.csv ;;
-    pmc)    B="python $R/bench.py $Q --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args"
+    pmc)    B="python $R/bench.py $Q --no-roofline --h2d 0 --steps 3 --warmup 1 --pipeline 1 $args"
             timeout -s KILL 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/pmc_mfma -o r1 -- $B > $o/pmc_mfma.log 2>&1
             timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/pmc_fetch -o r1 -- $B > $o/pmc_fetch.log 2>&1
             timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/pmc_write -o r1 -- $B > $o/pmc_write.log 2>&1

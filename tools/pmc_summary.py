@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Summarise the rocprofv3 passes of tools/prof_round.sh into the files kept under profiles/.
+"""Summarise the rocprofv3 passes of `tools/gpu.sh <tag> bench stats pmc` into the files kept under profiles/.
 
-  python tools/pmc_summary.py gpurun_out/r01c profiles/r01c
+  python tools/pmc_summary.py gpurun_out/<tag> profiles/r05 [pmc_traffic.json | -]
 
-Reads  <in>/stats/r1_kernel_stats.csv, <in>/pmc_fetch/r1_counter_collection.csv, <in>/pmc_write/...
+Reads  <in>/stats_kernel_stats.csv (or <in>/stats/r1_kernel_stats.csv), <in>/pmc_fetch/r1_counter_collection.csv, <in>/pmc_write/...
 Writes <out>/kernel_stats.csv (copy), <out>/pmc_hbm.csv (per kernel: launches, FETCH_SIZE, WRITE_SIZE, corrected bytes)
 and profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
 
@@ -81,8 +81,12 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
     mfma_summary(src, dst)
-    if os.path.exists(os.path.join(src, 'stats', 'r1_kernel_stats.csv')):
-        shutil.copy(os.path.join(src, 'stats', 'r1_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
+    for cand in (os.path.join(src, 'stats_kernel_stats.csv'), os.path.join(src, 'stats', 'r1_kernel_stats.csv')):
+        if os.path.exists(cand):
+            shutil.copy(cand, os.path.join(dst, 'kernel_stats_pipeline1.csv'))
+            break
+    if not os.path.exists(os.path.join(src, 'pmc_fetch', 'r1_counter_collection.csv')):
+        return          # (an MFMA-only pass, e.g. of a training workload)
     def by_short(agg):      # template variants of one tile shape (table-driven / unrolled-tap loops) are one bench bucket
         out = collections.OrderedDict()
         for name, (n, v) in agg.items():
@@ -112,8 +116,8 @@ def main():
     wl = bench['config']['workload']
     m = re.search(r'R-(\d+) .* 1x3x(\d+)x(\d+)x(\d+)', wl)
     batch = int(bench['config'].get('images_per_forward', 1))
-    rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python bench.py '
-                     '--steps 3 --warmup 1 --pipeline 1; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
+    rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/gpu.sh pmc), python bench.py '
+                     '--steps 3 --warmup 1 --pipeline 1 --no-roofline; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
            'workload': {'arch': m.group(1), 'frames': int(m.group(2)), 'height': int(m.group(3)),
                         'width': int(m.group(4)), 'dtype': bench['dtype'],
                         'keyframe_dce': bench['config'].get('keyframe_dce', False), 'batch': batch},
