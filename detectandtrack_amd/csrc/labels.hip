@@ -122,7 +122,8 @@ __global__ void scatter_words_kernel(unsigned int* __restrict__ dst, long long d
 // a draw of n out of a set S is "the n members of S with the smallest (key, index)", key = roi_key(seed, iteration, stream, index) below
 // -- a uniformly random subset in uniformly random order when the keys are i.i.d. uniform, the order being the output row order;
 // labels, targets, weights and heatmap cells of a drawn roi are the reference's arithmetic (float32, its operation order).
-// One block of 1024 threads (<= 4096 candidates): overlaps, flags and keys into LDS, ranks by counting (N x |S| comparisons), rows out.
+// Blocks of 1024 threads (<= 4096 candidates): every block computes overlaps, flags and keys of ALL candidates into its LDS; block b then
+// ranks candidates [64 b, 64 b + 64) by counting (16 lanes share a candidate's scan over the N keys) and writes their rows.
 __device__ __forceinline__ unsigned roi_key(unsigned seed_lo, unsigned seed_hi, unsigned iter, unsigned stream, unsigned index) {
     unsigned h = seed_lo ^ (index * 0x9E3779B9u) ^ (iter * 0x85EBCA6Bu) ^ (stream * 0xC2B2AE35u);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;      // murmur3 finaliser
@@ -197,19 +198,24 @@ __global__ __launch_bounds__(1024) void roi_sample_kernel(const RoiSampleParams 
     const int n_bg = min(p.d.rois_per_im - n_fg, all_bg);
     const bool kp_fallback = p.gt_kps && all_kp == 0;                   // keypoint_rcnn.py:47-48: no keypoint-fg roi -> the gt boxes themselves
     const int n_kp = !p.gt_kps ? 0 : kp_fallback ? min(G, p.d.fg_rois_per_im) : min(p.d.fg_rois_per_im, all_kp);
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == 0) {
         p.counts[0] = n_fg + n_bg; p.counts[1] = n_fg; p.counts[2] = n_kp; p.counts[3] = all_fg; p.counts[4] = all_bg; p.counts[5] = all_kp;
     }
     const int Kc = p.d.cls_agnostic ? 2 : p.d.num_classes;
     const int ld_t = C4 * Kc;
     const int M = p.d.heatmap_size;
-    for (int i = tid; i < N; i += 1024) {
-        const unsigned char fl = s_flag[i];
+    // ---- ranks and rows: block b owns candidates [64 b, 64 b + 64), sixteen lanes per candidate share the scan over all N keys ----
+    // (every block has computed the same overlaps / flags / keys above: ~N / 512 candidates per thread, nothing next to the N x N
+    //  comparisons below -- 414 us in one block, the first version; the grid spreads them over N / 64 CUs)
+    {
+        const int i = blockIdx.x * 64 + (tid >> 4), sub = tid & 15;
+        const bool live = i < N;
+        const unsigned char fl = live ? s_flag[i] : 0;
         // rank of this candidate inside each set it belongs to: members with a smaller (key, index)
         int r_fg = 0, r_bg = 0, r_kp = 0;
         if (fl & 3) {
             const unsigned ki = s_key[i];
-            for (int j = 0; j < N; ++j) {
+            for (int j = sub; j < N; j += 16) {
                 const unsigned kj = s_key[j];
                 const bool before = kj < ki || (kj == ki && j < i);
                 const unsigned char fj = s_flag[j];
@@ -219,18 +225,25 @@ __global__ __launch_bounds__(1024) void roi_sample_kernel(const RoiSampleParams 
         }
         if (fl & 4) {
             const unsigned ki = s_kkey[i];
-            for (int j = 0; j < N; ++j) {
+            for (int j = sub; j < N; j += 16) {
                 const unsigned kj = s_kkey[j];
                 r_kp += ((kj < ki || (kj == ki && j < i)) && (s_flag[j] & 4)) ? 1 : 0;
             }
         }
+        for (int off = 8; off > 0; off >>= 1) {
+            r_fg += __shfl_xor(r_fg, off);
+            r_bg += __shfl_xor(r_bg, off);
+            r_kp += __shfl_xor(r_kp, off);
+        }
+        int kvalid = 0;
+        if (live && sub == 0) do {
         int row = -1;
         if ((fl & 1) && r_fg < n_fg) row = r_fg;
         else if ((fl & 2) && !((fl & 1) && r_fg < n_fg) && r_bg < n_bg) row = n_fg + r_bg;
         int krow = -1;
         if (kp_fallback) { if (i < G && i < n_kp) krow = i; }
         else if ((fl & 4) && r_kp < n_kp) krow = r_kp;
-        if (row < 0 && krow < 0) continue;
+        if (row < 0 && krow < 0) break;
         float box[4 * LAB_MAXT];
         if (i < G) for (int c = 0; c < C4; ++c) box[c] = p.gt_boxes[(size_t)i * C4 + c];
         else for (int c = 0; c < C4; ++c) box[c] = p.props[(size_t)(i - G) * (C4 + 1) + 1 + c] / scale;
@@ -288,13 +301,14 @@ __global__ __launch_bounds__(1024) void roi_sample_kernel(const RoiSampleParams 
                     }
                     lo[t * Kf + k] = cell;
                     wt[t * Kf + k] = w;
-                    if (w > 0.f) atomicAdd(&s_cnt[3], 1);
+                    kvalid += w > 0.f ? 1 : 0;
                 }
             }
         }
+        } while (false);
+        // labelled keypoints of the drawn keypoint rois (the loss normaliser, model_builder.py:873-905): counts[6] is zeroed by the caller
+        if (kvalid) atomicAdd(p.counts + 6, kvalid);
     }
-    __syncthreads();
-    if (tid == 0) p.counts[6] = s_cnt[3];       // labelled keypoints of the drawn keypoint rois (the loss normaliser, model_builder.py:873-905)
 }
 
 }  // namespace
@@ -349,7 +363,8 @@ int dat_sample_rois(dat_ctx* ctx, dat_stream s, const dat_roi_sample_desc* d, co
     p.gt_boxes = gt_boxes; p.gt_classes = gt_classes; p.gt_kps = gt_kps; p.G = G;
     p.rois = rois; p.labels = labels; p.targets = targets; p.w_in = w_in; p.w_out = w_out;
     p.kp_rois = kp_rois; p.kp_loc = kp_loc; p.kp_w = kp_w; p.counts = counts; p.picked = picked;
-    hipLaunchKernelGGL(roi_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, p);
+    DAT_ENFORCE(ctx, hipMemsetAsync(counts + 6, 0, 2 * sizeof(int), (hipStream_t)s) == hipSuccess, "sample_rois: memset failed");
+    hipLaunchKernelGGL(roi_sample_kernel, dim3((unsigned)((G + props_cap + 63) / 64)), dim3(1024), 0, (hipStream_t)s, p);
     DAT_CHECK_LAUNCH(ctx, "sample_rois");
     return DAT_OK;
 }
