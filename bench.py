@@ -294,7 +294,7 @@ def vendor_gemm_tflops(n=8192, dtype=torch.bfloat16):
 
 def pmc_traffic(a, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    produced by tools/prof_round.sh + tools/pmc_summary.py on this exact workload); None when the run's workload or
+    produced by `tools/gpu.sh <tag> bench stats pmc` + tools/pmc_summary.py on this exact workload); None when the run's workload or
     dominant kernel differs from the profiled one.  bench.py cannot read PMC counters itself."""
     path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
