@@ -848,8 +848,8 @@ def main():
         'traffic': traffic,
         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload and build; bench.py cannot read PMC counters live)' if traffic else None,
         # (what the ratio to the algorithmic bytes means here: FETCH_SIZE counts L2 misses, Infinity-Cache hits included; per-layer passes
-        #  and the block order that cuts them by 41 % -- and runs 1 % slower -- are in DESIGN.md section 3 / profiles/r03/order_ab/)
-        'traffic_note': 'L2-miss (fabric) bytes incl. Infinity-Cache hits; a weight-stationary block order (DAT_CONV_ORDER=1) cuts them 41 % and is 1 % slower: DESIGN.md section 3' if traffic else None,
+        #  and the block order that cuts them by 41 % -- and runs 1 % slower -- are in docs/history/DESIGN_rounds1-4.md section 3, round 3)
+        'traffic_note': 'L2-miss (fabric) bytes incl. Infinity-Cache hits; a weight-stationary block order (DAT_CONV_ORDER=1) cuts them 41 % and is 1 % slower: DESIGN.md section 3.1' if traffic else None,
         'algorithmic_bytes_per_launch': round(dom_bytes / max(dom_n, 1)) if dom_bytes > 0 else None,
         'measured': ('HIP-event pair around every launch, on its launch stream, in %d extra iterations right after the timed region (the timed '
                      'iterations run without event pairs); %d launches of this kernel' % (prof_iters, dom_n)) if train else

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM rate per kernel instantiation from the separate FETCH_SIZE / WRITE_SIZE passes of `tools/gpu.sh <tag> pmc:<bench args>`:
-   python tools/pmc_by_kernel.py gpurun_out/<tag> > profiles/r03/<name>/hbm_by_kernel.txt
+   python tools/pmc_by_kernel.py gpurun_out/<tag> > profiles/r05/<name>_hbm_by_kernel.txt
 Durations are those of the FETCH_SIZE pass's own kernel trace (counter collection serialises the launches, --pipeline 1); bytes are
 FETCH_SIZE KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB, per launch."""
 import collections
