@@ -995,6 +995,7 @@ def main():
         out['host_frames'] = h2d
     if not train:    # images whose detections went through the host glue (exact score ties beyond the device buffers' spare rows)
         out['host_path_images'] = pipe.host_path_images
+        out['tie_rerun_images'] = pipe.rerun_images     # (detections tied beyond the spare rows: device glue re-run with more rows, no host path)
     if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:
         # what the benched arithmetic costs: bf16 vs the fp32 parity mode of the same model on the benched clip
         from detectandtrack_amd.utils import precision

@@ -175,7 +175,8 @@ class ClipPipeline(object):
         self.upload_bytes = 0
         self.stage_s = 0.0          # host time in the pageable -> pinned staging copies
         self._stagers = None
-        self.host_path_images = 0   # images that took the host glue (exact score ties beyond the device buffers' spare rows)
+        self.rerun_images = 0       # images whose detections tied beyond the device buffers' spare rows: device glue re-run with more rows
+        self.host_path_images = 0   # images that took the reference's host glue (only if that re-run still overflowed)
         self.finish_times = []      # perf_counter() at every completed forward (steady-state rate of a run: see rate())
         self.trunk = None           # FrameTrunkCache, made by the first submit_frames(..., frame_ids=...) with cfg.HIP.FRAME_TRUNK_CACHE > 0
         self.device_glue = engine.device_results_supported()
@@ -351,11 +352,16 @@ class ClipPipeline(object):
         try:
             with torch.cuda.stream(s.stream):
                 res = engine.read_batch_results_from_device(*dev)       # the ONE device -> host transfer of the forward
+                if any(r is None for r in res):
+                    # exact score ties at the detection limit kept more rows than the device buffers hold (the limit rule keeps EVERY score
+                    # tied with the DETECTIONS_PER_IM-th best, core/test.py:795-800): run the device glue + keypoint net again, eagerly, with
+                    # as many rows per image as the rule asked for -- the same kernels, the reference's result, no host post-processing
+                    if g is not None:       # blob names -> the tensors of the graph that was REPLAYED (not of the last captured one)
+                        g.restore_blobs()
+                    res = self._rerun_with_all_tied_rows(res, dev, im_info, shapes)
                 out = []
                 for i, r in enumerate(res):
-                    if r is None:      # exact score ties at the detection limit: this image through the reference's host path
-                        if g is not None:   # blob names -> the tensors of the graph that was REPLAYED (not of the last captured one)
-                            g.restore_blobs()
+                    if r is None:      # (not expected after the re-run; kept as the reference's own glue)
                         out.append(self._host_path(s, i, im_info, shapes, clips))
                         continue
                     cls_boxes, cls_keyps = r
@@ -368,6 +374,14 @@ class ClipPipeline(object):
         self.finish_times.append((time.perf_counter(), len(out)))
         if self.keep_results:
             self.results.append((tag, out))
+
+    def _rerun_with_all_tied_rows(self, res, dev, im_info, shapes):
+        n = dev[1].cpu().numpy().reshape(-1, 2)
+        need = int(n[:, 1].max())
+        scales = [float(v) for v in np.asarray(im_info, np.float32).reshape(-1, 3)[:, 2]]
+        again = engine.read_batch_results_from_device(*engine.enqueue_results_on_device(self.model, list(shapes), scales, out_cap=need))
+        self.rerun_images += sum(1 for r in res if r is None)
+        return [r if r is not None else again[i] for i, r in enumerate(res)]
 
     def _host_path(self, s, i, im_info, shapes, clips):
         """The reference's host glue for ONE image of a finished forward (box_results_with_nms_and_limit keeps every row tied at the

@@ -197,7 +197,7 @@ def device_results_supported():
                 (cfg.HIP.DEVICE_KPS_DECODE or not cfg.MODEL.KEYPOINTS_ON))
 
 
-def enqueue_results_on_device(model, im_shape, im_scale):
+def enqueue_results_on_device(model, im_shape, im_scale, out_cap=None):
     """Everything between `model.net` and the final read-back, enqueued on the current HIP stream WITHOUT a host sync:
     dat_box_results (test.py:215-252 decode + clip, :750-806 score threshold / per-class NMS / DETECTIONS_PER_IM, :78-123 keypoint
     rois), then -- with MODEL.KEYPOINTS_ON -- `model.keypoint_net` on the device-resident rois and the heatmap decode
@@ -218,7 +218,10 @@ def enqueue_results_on_device(model, im_shape, im_scale):
     # rows per image: the limit rule keeps EVERY score tied with the D-th best (test.py:795-800), so D rows are not always enough --
     # frequent with bf16 logits; a few spare rows (cfg.HIP.DET_SPARE_ROWS, default 4: ties at the cut are pairs, and every spare row is a
     # row of keypoint-head work) make the overflow (host path for that image) rare.  No limit: every roi may survive in every class.
-    out_cap = D + max(0, int(cfg.HIP.get('DET_SPARE_ROWS', 4))) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
+    # out_cap (optional): rows per image the caller wants -- the pipelined engine re-runs the glue with exactly as many rows as the
+    # limit rule keeps when an image overflowed the default (core/pipeline.py)
+    if out_cap is None:
+        out_cap = D + max(0, int(cfg.HIP.get('DET_SPARE_ROWS', 4))) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
     dets, kp_rois, n_out = ops.box_results(
         rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,
@@ -350,6 +353,11 @@ def im_detect_all(model, im, box_proposals, timers=None, frame_ids=None):
         im_scales = im_detect_bbox(model, im, None, frame_ids=frame_ids, fetch=False)
         dev = enqueue_results_on_device(model, im[0].shape, im_scales[0])
         res = read_results_from_device(*dev)
+        if res is None:
+            # exact score ties at the DETECTIONS_PER_IM cut beyond the spare rows: the device glue again with as many rows as the limit rule
+            # keeps (n_out[1]) -- the same kernels, every tied row, no host post-processing (the pipelined engine does the same)
+            need = int(dev[1].cpu().numpy().reshape(-1)[1])
+            res = read_results_from_device(*enqueue_results_on_device(model, im[0].shape, im_scales[0], out_cap=need))
         timers['im_detect_bbox'].toc()
         if res is not None:
             cls_boxes, cls_keyps = res

@@ -191,7 +191,7 @@ def test_net(roidb, ind_range=None, output_dir=None):
         rate = pipe.rate()
         test_net.last_stats = {'clips': len(part), 'seconds': timers['im_detect_bbox'].total_time, 'steady_clips_per_s': rate,
                                'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'host_submit_ms_per_clip': 1e3 * pipe.host_enqueue_s / len(part),
-                               'host_staging_ms_per_clip': 1e3 * pipe.stage_s / len(part), 'host_path_images': pipe.host_path_images, 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
+                               'host_staging_ms_per_clip': 1e3 * pipe.stage_s / len(part), 'host_path_images': pipe.host_path_images, 'tie_rerun_images': pipe.rerun_images, 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
                                'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH),
                                'frame_trunk_cache': int(cfg.HIP.FRAME_TRUNK_CACHE) if pipe.trunk is not None else 0,
                                'trunk_frames_computed': pipe.trunk.frames_computed if pipe.trunk is not None else None,

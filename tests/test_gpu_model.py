@@ -631,7 +631,7 @@ def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypa
     orig = engine.read_batch_results_from_device
     monkeypatch.setattr(engine, 'read_batch_results_from_device', lambda *dev: [None] * len(orig(*dev)))
     out = run([small[1]])
-    assert pipe.host_path_images == 1
+    assert pipe.host_path_images == 1 and pipe.rerun_images == 1      # (the forced overflow survives the device re-run too: host glue)
     a, b = out[0][0][1], ref_small[1][0][1]
     assert a.shape == b.shape
     np.testing.assert_allclose(a, b, atol=1e-4)
@@ -645,6 +645,39 @@ def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypa
     assert pipe.graphs_captured == 3 and pipe.graphs_evicted == 1 and len(pipe.slots[0].graphs) == 2
     same(run([small[0]])[0], ref_small[0])
     assert pipe.graphs_captured == 3
+
+
+def test_detections_tied_beyond_the_spare_rows_are_recomputed_on_the_device(monkeypatch):
+    """an image whose detections tie exactly at the DETECTIONS_PER_IM cut beyond the device buffers' spare rows used
+    to take the reference's HOST glue (a silent ~10x slower image).  The pipelined engine now re-runs the device glue + keypoint net with as
+    many rows as the limit rule keeps.  Forced here by giving the first pass ZERO spare rows below the limit (out_cap < what the rule keeps):
+    the overflow is detected from the device counts, the re-run returns the full result -- identical to the eager engine -- and the host
+    path is never entered."""
+    from detectandtrack_amd.core import test as engine
+    from detectandtrack_amd.core.pipeline import ClipPipeline
+    T = 2
+    c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)
+    c['TEST'].update(SCALES=(96,), MAX_SIZE=1000, SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+    model, ws, _ = build_product(c)
+    rs = np.random.RandomState(11)
+    clips = [[rs.randint(0, 255, (96, 128, 3)).astype(np.uint8) for _ in range(T)] for _ in range(2)]
+    ref = [engine.im_detect_all(model, clip, None) for clip in clips]
+    orig = engine.enqueue_results_on_device
+    calls = []
+
+    def starved(model_, im_shape, im_scale, out_cap=None):
+        calls.append(out_cap)
+        return orig(model_, im_shape, im_scale, out_cap=9 if out_cap is None else out_cap)     # 9 rows for a limit of 15: overflow
+    monkeypatch.setattr(engine, 'enqueue_results_on_device', starved)
+    for graph in (False, True):
+        pipe = ClipPipeline(model, ws, depth=1, graph=graph)
+        pipe.submit_frames(clips, tag='x')
+        (_, out), = pipe.drain()
+        assert pipe.rerun_images == 2 and pipe.host_path_images == 0
+        assert calls[-1] is not None and calls[-1] >= 15
+        for o, r in zip(out, ref):
+            assert o[0][1].shape == r[0][1].shape and _boxes_agree(o[0][1], r[0][1], 0.5) > 0.85     # (two clips per forward: other conv plans)
+            assert len(o[2][1]) == len(r[2][1])
 
 
 def test_pipeline_graphs_that_read_resident_inputs_in_place():

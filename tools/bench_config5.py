@@ -84,7 +84,7 @@ def main():
         'clips': n, 'detector_seconds_incl_warmup': round(t_det, 3), 'detector_clips_per_s': round(det_rate, 2),
         'detector_clips_per_s_incl_warmup': round(n / t_det, 2),
         'engine': {'clips_per_forward': st.get('per_forward'), 'forwards_in_flight': st.get('in_flight'), 'hip_graph': st.get('hip_graph'),
-                   'upload_mb_per_clip': round(st.get('upload_bytes_per_clip', 0) / 1e6, 2), 'host_path_images': st.get('host_path_images'),
+                   'upload_mb_per_clip': round(st.get('upload_bytes_per_clip', 0) / 1e6, 2), 'host_path_images': st.get('host_path_images'), 'tie_rerun_images': st.get('tie_rerun_images'),
                    'frame_trunk_cache': st.get('frame_trunk_cache'),
                    'trunk_frames_computed': st.get('trunk_frames_computed'), 'trunk_frames_requested': st.get('trunk_frames_requested')},
         'detections_per_frame': round(ndet, 1),
