@@ -27,7 +27,7 @@ for st in "$@"; do
     case $name in
     tests)  (cd $R && eval "timeout -s KILL 1500 python -m pytest tests -m gpu -q -x $args" > $o/pytest_$n.log 2>&1; echo "pytest rc $?" >> $o/pytest_$n.log)
             grep -E "passed|failed|error|rc " $o/pytest_$n.log | tail -6 ;;
-    bench)  timeout -s KILL 900 python $R/bench.py $args > $o/bench.json 2> $o/bench.err; cut -c1-400 $o/bench.json ;;
+    bench)  DAT_BENCH_KEEP_ROCPROF=$o timeout -s KILL 900 python $R/bench.py $args > $o/bench.json 2> $o/bench.err; cut -c1-400 $o/bench.json ;;
     benchq) timeout -s KILL 400 python $R/bench.py $Q $args > $o/benchq_$n.json 2> $o/benchq_$n.err; cut -c1-300 $o/benchq_$n.json ;;
     layers) timeout -s KILL 400 python $R/bench.py $Q --h2d 0 --steps 10 --warmup 3 --pipeline 1 --graph 0 --dump-convs $args > $o/bench_seq_$n.json 2> $o/conv_layers_$n.txt ;;
     stats)  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/_st -o r1 -- python $R/bench.py $Q --no-roofline --h2d 0 --steps 10 --warmup 3 --pipeline 1 $args > $o/${out}.log 2>&1
