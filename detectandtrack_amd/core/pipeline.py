@@ -376,12 +376,19 @@ class ClipPipeline(object):
             self.results.append((tag, out))
 
     def _rerun_with_all_tied_rows(self, res, dev, im_info, shapes):
+        """Only the images that overflowed are recomputed: their row segment of the forward's blobs through dat_box_results with
+        n_out[i, 1] rows, their boxes through the keypoint net and the decode."""
         n = dev[1].cpu().numpy().reshape(-1, 2)
-        need = int(n[:, 1].max())
-        scales = [float(v) for v in np.asarray(im_info, np.float32).reshape(-1, 3)[:, 2]]
-        again = engine.read_batch_results_from_device(*engine.enqueue_results_on_device(self.model, list(shapes), scales, out_cap=need))
-        self.rerun_images += sum(1 for r in res if r is None)
-        return [r if r is not None else again[i] for i, r in enumerate(res)]
+        info = np.asarray(im_info, np.float32).reshape(-1, 3)
+        out = list(res)
+        for i, r in enumerate(res):
+            if r is not None:
+                continue
+            again = engine.enqueue_results_on_device(self.model, tuple(shapes[i]), float(info[i, 2]), out_cap=int(n[i, 1]),
+                                                     image=i if len(res) > 1 else None)
+            out[i] = engine.read_results_from_device(*again)
+            self.rerun_images += 1
+        return out
 
     def _host_path(self, s, i, im_info, shapes, clips):
         """The reference's host glue for ONE image of a finished forward (box_results_with_nms_and_limit keeps every row tied at the

@@ -197,7 +197,7 @@ def device_results_supported():
                 (cfg.HIP.DEVICE_KPS_DECODE or not cfg.MODEL.KEYPOINTS_ON))
 
 
-def enqueue_results_on_device(model, im_shape, im_scale, out_cap=None):
+def enqueue_results_on_device(model, im_shape, im_scale, out_cap=None, image=None):
     """Everything between `model.net` and the final read-back, enqueued on the current HIP stream WITHOUT a host sync:
     dat_box_results (test.py:215-252 decode + clip, :750-806 score threshold / per-class NMS / DETECTIONS_PER_IM, :78-123 keypoint
     rois), then -- with MODEL.KEYPOINTS_ON -- `model.keypoint_net` on the device-resident rois and the heatmap decode
@@ -212,7 +212,16 @@ def enqueue_results_on_device(model, im_shape, im_scale, out_cap=None):
     ni = int(rois.count.numel())
     prob = workspace.blob_as_matrix(ws.blobs['cls_prob'])
     pred = workspace.blob_as_matrix(ws.blobs['bbox_pred'])
-    cols = int(rois.t.shape[1])
+    rois_t, rois_n = rois.t if rois.t.dim() == 2 else rois.t.view(-1, rois.t.shape[-1]), rois.count
+    if image is not None:
+        # ONE image of a forward of `ni` (the tie-overflow re-run of core/pipeline.py: only the image that overflowed pays for it): its
+        # row segment of the batch blobs; `im_shape` / `im_scale` are that image's; the keypoint rois keep the image's batch index
+        seg = int(rois_t.shape[0]) // ni
+        lo = int(image) * seg
+        rois_t, rois_n = rois_t[lo:lo + seg], rois.count.view(-1)[int(image):int(image) + 1]
+        prob, pred = prob[lo:lo + seg], pred[lo:lo + seg]
+        ni = 1
+    cols = int(rois_t.shape[1])
     T = (cols - 1) // 4
     D = int(cfg.TEST.DETECTIONS_PER_IM)
     # rows per image: the limit rule keeps EVERY score tied with the D-th best (test.py:795-800), so D rows are not always enough --
@@ -221,13 +230,15 @@ def enqueue_results_on_device(model, im_shape, im_scale, out_cap=None):
     # out_cap (optional): rows per image the caller wants -- the pipelined engine re-runs the glue with exactly as many rows as the
     # limit rule keeps when an image overflowed the default (core/pipeline.py)
     if out_cap is None:
-        out_cap = D + max(0, int(cfg.HIP.get('DET_SPARE_ROWS', 4))) if D > 0 else (int(rois.t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
+        out_cap = D + max(0, int(cfg.HIP.get('DET_SPARE_ROWS', 4))) if D > 0 else (int(rois_t.shape[0]) // ni) * (cfg.MODEL.NUM_CLASSES - 1)
     dets, kp_rois, n_out = ops.box_results(
-        rois.t, rois.count, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
+        rois_t, rois_n, prob, pred, cfg.MODEL.NUM_CLASSES, T, im_scale, im_shape, cfg.MODEL.BBOX_REG_WEIGHTS,
         float(np.float32(cfg.BBOX_XFORM_CLIP)), cfg.TEST.SCORE_THRESH, cfg.TEST.NMS, D, out_cap,
         cls_agnostic=cfg.MODEL.CLS_AGNOSTIC_BBOX_REG, n_images=ni)
     xy = None
     if cfg.MODEL.KEYPOINTS_ON:
+        if image is not None:
+            kp_rois[:, 0] = float(image)        # (RoIAlign reads the image's frames of the batch's feature maps)
         b = workspace.Blob(kp_rois, 'mat')
         b.count = n_out[0:1] if ni == 1 else n_out[:, 0]
         ws.blobs['keypoint_rois'] = b

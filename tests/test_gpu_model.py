@@ -629,7 +629,9 @@ def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypa
     assert pipe.graphs_captured == 2 and pipe.graphs_evicted == 0
     # (2) force the host fallback for a SMALL forward while `ws.blobs` still names the large graph's tensors
     orig = engine.read_batch_results_from_device
+    orig_one = engine.read_results_from_device
     monkeypatch.setattr(engine, 'read_batch_results_from_device', lambda *dev: [None] * len(orig(*dev)))
+    monkeypatch.setattr(engine, 'read_results_from_device', lambda *dev: None)        # (the per-image re-run's reader)
     out = run([small[1]])
     assert pipe.host_path_images == 1 and pipe.rerun_images == 1      # (the forced overflow survives the device re-run too: host glue)
     a, b = out[0][0][1], ref_small[1][0][1]
@@ -639,6 +641,7 @@ def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypa
     for x, y in zip(out[0][2][1], ref_small[1][2][1]):
         np.testing.assert_allclose(x[:2], y[:2], atol=1e-3)
     monkeypatch.setattr(engine, 'read_batch_results_from_device', orig)
+    monkeypatch.setattr(engine, 'read_results_from_device', orig_one)
     # (3) a third geometry evicts the least recently used graph (the large one); the small one is still live
     third = [[rs.randint(0, 255, (96, 160, 3)).astype(np.uint8) for _ in range(T)]]
     run(third)
@@ -665,16 +668,16 @@ def test_detections_tied_beyond_the_spare_rows_are_recomputed_on_the_device(monk
     orig = engine.enqueue_results_on_device
     calls = []
 
-    def starved(model_, im_shape, im_scale, out_cap=None):
-        calls.append(out_cap)
-        return orig(model_, im_shape, im_scale, out_cap=9 if out_cap is None else out_cap)     # 9 rows for a limit of 15: overflow
+    def starved(model_, im_shape, im_scale, out_cap=None, image=None):
+        calls.append((out_cap, image))
+        return orig(model_, im_shape, im_scale, out_cap=9 if out_cap is None else out_cap, image=image)     # 9 rows for a limit of 15: overflow
     monkeypatch.setattr(engine, 'enqueue_results_on_device', starved)
     for graph in (False, True):
         pipe = ClipPipeline(model, ws, depth=1, graph=graph)
         pipe.submit_frames(clips, tag='x')
         (_, out), = pipe.drain()
         assert pipe.rerun_images == 2 and pipe.host_path_images == 0
-        assert calls[-1] is not None and calls[-1] >= 15
+        assert calls[-3][0] is None and [c[1] for c in calls[-2:]] == [0, 1] and all(c[0] >= 15 for c in calls[-2:])     # one re-run per image
         for o, r in zip(out, ref):
             assert o[0][1].shape == r[0][1].shape and _boxes_agree(o[0][1], r[0][1], 0.5) > 0.85     # (two clips per forward: other conv plans)
             assert len(o[2][1]) == len(r[2][1])

@@ -27,6 +27,21 @@ def run(cache, per, graph, depth):
     return test_engine.test_net(roidb, None, None)['all_boxes'][1]
 
 
+if len(sys.argv) > 2 and sys.argv[1] == 'loop':
+    # the intermittent eager-launch mismatch: one graph reference, then N x (plain eager, cached eager) -- which side differs, where, by how much
+    ref = run(0, 2, True, 3)
+    for it in range(int(sys.argv[2])):
+        for name, args in (('plain e per2', (0, 2, False, 3)), ('cache e per2', (10, 2, False, 3))):
+            got = run(*args)
+            for k in range(len(roidb)):
+                a, b = got[k], ref[k]
+                if a.shape != b.shape or not np.array_equal(a, b):
+                    d = np.abs(a - b).max() if a.shape == b.shape else float('nan')
+                    rows = int((a != b).any(axis=1).sum()) if a.shape == b.shape else -1
+                    print('iter %d %s: clip %d differs (shapes %s %s, %d rows, max |d| %g)' % (it, name, k, a.shape, b.shape, rows, d), flush=True)
+        print('iter %d done' % it, flush=True)
+    sys.exit(0)
+
 seq = [('plain g per1', (0, 1, True, 3)), ('cache g per1', (6, 1, True, 3)), ('plain g per2', (0, 2, True, 3)), ('cache g per2', (10, 2, True, 3)),
        ('plain e per2', (0, 2, False, 3)), ('cache e per2', (10, 2, False, 3)), ('plain e per2 again', (0, 2, False, 3)), ('cache e per2 again', (10, 2, False, 3))]
 if len(sys.argv) > 1:
