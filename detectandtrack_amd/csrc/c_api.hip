@@ -14,6 +14,11 @@ int dat_ensure_ws(dat_ctx* ctx, size_t bytes) {
         (void)hipGetLastError();
         DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace hipMalloc(%zu) failed", want);
     }
+    if (ctx->dbg_ws_poison && (hipMemset(grown, 0xFF, want) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {   // (the fill runs on the null stream: wait for it)
+        (void)hipGetLastError();
+        hipFree(grown);
+        DAT_FAIL(ctx, DAT_ERR_ALLOC, "workspace poison fill failed");
+    }
     if (ctx->ws) ctx->ws_retired.push_back(ctx->ws);
     ctx->ws = grown;
     ctx->ws_bytes = want;
@@ -66,11 +71,8 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_order = env_int("DAT_CONV_ORDER", 0);
         c->dbg_bt = env_int("DAT_CONV_BT", 0);   // opt-in: measured neutral on the full network (the part is power-limited)
         c->dbg_roi_fold = env_int("DAT_ROI_BWD_FOLD", 1);
+        c->dbg_ws_poison = env_int("DAT_WS_POISON", 0);
         c->num_cu = 0;
-    }
-    if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemset(c->zeros, 0, 512) != hipSuccess) {
-        delete c;
-        return DAT_ERR_ALLOC;
     }
     // a private non-blocking stream + a pinned word buffer for the context's own small device <-> host transfers: the synchronous
     // hipMemcpy / hipMemset entry points are avoided after start-up (measured on ROCm 7.2: a synchronous device -> host hipMemcpy
@@ -80,7 +82,18 @@ int dat_ctx_create(dat_ctx** out, int device) {
     if (hipStreamCreateWithFlags((hipStream_t*)&c->util_stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         if (c->util_stream) hipStreamDestroy((hipStream_t)c->util_stream);
-        hipFree(c->zeros);
+        delete c;
+        return DAT_ERR_ALLOC;
+    }
+    // the all-zero line the conv kernels read for out-of-range patch pieces.  Zeroed on the context's own stream and WAITED for: a
+    // plain hipMemset runs on the null stream, which the caller's non-blocking streams do not order against -- the first conv of a new
+    // context (a pipeline slot's first forward, other forwards keeping the device busy) read the line before the fill had landed and
+    // padded its border tiles with whatever the pages held (round 5: intermittent mismatch of the eager frame-trunk-cache pipeline)
+    if (hipMalloc(&c->zeros, 512) != hipSuccess || hipMemsetAsync(c->zeros, 0, 512, (hipStream_t)c->util_stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)c->util_stream) != hipSuccess) {
+        if (c->zeros) hipFree(c->zeros);
+        hipHostFree(c->pinned);
+        hipStreamDestroy((hipStream_t)c->util_stream);
         delete c;
         return DAT_ERR_ALLOC;
     }

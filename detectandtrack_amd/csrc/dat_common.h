@@ -47,6 +47,7 @@ struct dat_ctx {
     int dbg_wgrad_ks;                       // DAT_WGRAD_KS (default 0 = heuristic): forced K split of the nine-tap direct weight-gradient kernel
     int dbg_wgrad_pw;                       // DAT_WGRAD_PW (default 1): eight-wave 64 K-accumulator kernel for pointwise weight gradients (0: the 128 x 128 per-tap kernel; 10 / 20 / 40: forced tile shape)
     int dbg_kps_sep;                        // DAT_KPS_DECODE_SEP (default 1): separable heatmap decode (horizontal pass per 64-column strip in LDS); 0 = the per-pixel 4 x 4 kernel
+    int dbg_ws_poison;                      // DAT_WS_POISON (default 0): a grown scratch buffer is filled with 0xFF (tests: no kernel may rely on fresh hipMalloc pages reading as zero)
     int dbg_roi_fold;                       // DAT_ROI_BWD_FOLD (default 1): RoIAlign backward folds a bin's samples into one weight per distinct pixel before the atomics
     int num_cu;                             // compute units of the device (persistent-kernel grids)
     int dbg_ntap;                           // DAT_CONV_NTAP (default 1): unrolled-tap variants of the WD kernels (3x3 stride 1, 1x1)

@@ -561,14 +561,6 @@ def test_pipelined_engine_with_the_frame_trunk_cache_writes_identical_detections
     assert st['trunk_frames_computed'] == 2 * n_frames, st                    # every frame of both videos exactly once
     assert st['trunk_frames_requested'] >= len(roidb) * T
     assert st['upload_bytes_per_clip'] == 2 * n_frames * H * W * 3 / float(len(roidb))
-    if os.environ.get('DAT_TRUNK_DBG'):
-        graph_ = graph
-        graph = True
-        ref, _ = run(0, str(tmp_path / 'ref'))
-        graph = graph_
-        bad_p = [i for i in range(len(roidb)) if not np.array_equal(plain['all_boxes'][1][i], ref['all_boxes'][1][i])]
-        bad_c = [i for i in range(len(roidb)) if not np.array_equal(got['all_boxes'][1][i], ref['all_boxes'][1][i])]
-        print('DBG per %d graph %s: plain differs from the graph reference at %s, cached at %s' % (per, graph, bad_p, bad_c))
     for i in range(len(roidb)):
         np.testing.assert_array_equal(got['all_boxes'][1][i], plain['all_boxes'][1][i], err_msg='clip %d' % i)
         assert len(got['all_keyps'][1][i]) == len(plain['all_keyps'][1][i]) >= 15
