@@ -33,6 +33,10 @@ def _poisoned_allocations(monkeypatch):
         t = real(*a, **k)
         if t.is_cuda and t.numel():
             t.view(-1).view(torch.uint8).fill_(0xFF)
+            # the fill runs on the CURRENT stream, the buffer's first writer may be another one (upload buffers: the copy stream):
+            # wait for it, or the poison itself races the product (captures cannot wait and need not: one stream)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
         return t
     monkeypatch.setattr(torch, 'empty', empty)
     yield
