@@ -270,6 +270,87 @@ def device_identity(rank, local_rank):
     return ident
 
 
+def find_hwmon(pci=None, root='/sys/class/drm'):
+    """The amdgpu hwmon directory of the GPU with PCI address `pci` ('0000:bb:dd', function ignored) -- or of the only GPU that has one.
+    None when the container does not expose it."""
+    import glob
+    cands = []
+    for hw in sorted(glob.glob(os.path.join(root, 'card*', 'device', 'hwmon', 'hwmon*'))):
+        if not any(os.path.exists(os.path.join(hw, f)) for f in ('power1_average', 'power1_input')):
+            continue
+        dev = os.path.realpath(os.path.join(hw, '..', '..'))
+        cands.append((os.path.basename(dev), hw))
+    if pci is not None:
+        for name, hw in cands:
+            if name.lower().startswith(pci.lower()):
+                return hw
+    return cands[0][1] if len(cands) == 1 else None
+
+
+class PowerSampler(object):
+    """Package power and shader clock of this rank's GPU WHILE the timed region runs, read from the amdgpu hwmon files by a thread
+    (power1_average | power1_input in microwatts, freq1_input in Hz, power1_cap): VERDICT r4 item 5 asked for the "power ceiling" of the
+    dominant kernel to be shown, not inferred from the clock.  No subprocess, a few microseconds per sample."""
+
+    def __init__(self, hwmon, period_s=0.02):
+        self.hw, self.period = hwmon, period_s
+        self.power_w, self.sclk_mhz = [], []
+        self._stop = self._thread = None
+        self.power_file = None
+        if hwmon is not None:
+            for f in ('power1_average', 'power1_input'):
+                if os.path.exists(os.path.join(hwmon, f)):
+                    self.power_file = f
+                    break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def sample(self):
+        v = self._read(os.path.join(self.hw, self.power_file))
+        if v is not None:
+            self.power_w.append(v * 1e-6)
+        c = self._read(os.path.join(self.hw, 'freq1_input'))
+        if c is not None:
+            self.sclk_mhz.append(c * 1e-6)
+
+    def start(self):
+        if self.power_file is None:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.sample()
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        """-> the report object (None when there is nothing to read here)"""
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        if not self.power_w:
+            return None
+        cap = self._read(os.path.join(self.hw, 'power1_cap'))
+        rep = {'avg_w': round(float(np.mean(self.power_w)), 1), 'max_w': round(float(np.max(self.power_w)), 1),
+               'cap_w': round(cap * 1e-6, 1) if cap else None, 'samples': len(self.power_w),
+               'source': 'amdgpu hwmon %s, %d ms period, over the timed region' % (self.power_file, int(self.period * 1e3))}
+        if self.sclk_mhz:
+            rep['sclk_mhz_avg'] = round(float(np.mean(self.sclk_mhz)), 0)
+            rep['sclk_mhz_min'] = round(float(np.min(self.sclk_mhz)), 0)
+        return rep
+
+
 def check_ranks_seen(seen, n_gpus):
     """N ranks, N distinct (local) devices, N distinct processes -- otherwise no line."""
     ok = (len(seen) == n_gpus and len({s['rank'] for s in seen}) == n_gpus and len({s['pid'] for s in seen}) == n_gpus and
@@ -670,11 +751,13 @@ def main():
     torch.cuda.synchronize()
     if not train:
         pipe.host_enqueue_s = 0.0
+    power = PowerSampler(find_hwmon(device_identity(rank, local_rank).get('pci')) if rank == 0 else None).start()
     t0 = time.perf_counter()
     run_steps(a.steps)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    power = power.stop()
     _dbg('timed region done')
     if a.no_roofline:       # (the rocprofv3 child: its kernel_stats.csv must hold whole graph-replayed forwards and nothing else)
         elapsed = max_over_ranks(elapsed)
@@ -869,6 +952,8 @@ def main():
         'shader_clock_mhz': round(shader_mhz, 1),
         'peak_at_measured_clock': round(peak * shader_mhz / 2400.0, 1),
         'frac_at_measured_clock': round(achieved / (peak * shader_mhz / 2400.0), 4) if shader_mhz > 0 else None,
+        # package power + driver-reported shader clock sampled over the timed region (amdgpu hwmon; None where the container hides it)
+        'power_over_timed_region': power,
         # the vendor's tuned dense bf16 GEMM on this very box (hipBLASLt 8192^3): the practical, power-capped MFMA ceiling
         'vendor_gemm_tflops_same_box': vendor_gemm_tflops() if a.dtype == 'bf16' else None,
         'launches_per_step': round(launches_per_step, 2),

@@ -1031,3 +1031,34 @@ def test_reference_affine_op_library_is_built_from_the_reference_source_and_expo
     assert b'ScaleBiasForwardIfEE' in blob and b'ScaleForwardIfEE' in blob
     drv = open(os.path.join(REPO, 'oracle', 'ref_affine', 'ref_affine_driver.hip')).read()
     assert '#include REF_AFFINE_CU' in drv and 'CUDA_1D_KERNEL_LOOP' not in drv and '__global__' not in drv
+
+
+def test_bench_power_sampler_reads_an_amdgpu_hwmon_tree(tmp_path):
+    """bench.py's `roofline.power_over_timed_region`: the hwmon directory is found by PCI address (or as the only one), power is read from
+    power1_average | power1_input in microwatts, the clock from freq1_input in Hz; a box without the files reports None."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location('bench_for_power_test', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    root = tmp_path / 'drm'
+    devs = tmp_path / 'pci'
+    for card, pci, pf in (('card0', '0000:05:00.0', 'power1_average'), ('card1', '0000:85:00.0', 'power1_input')):
+        hw = devs / pci / 'hwmon' / 'hwmon3'
+        hw.mkdir(parents=True)
+        (hw / pf).write_text('750000000\n' if card == 'card1' else '1000000\n')
+        (hw / 'power1_cap').write_text('1400000000\n')
+        (hw / 'freq1_input').write_text('1780000000\n')
+        (root / card).mkdir(parents=True)
+        os.symlink(str(devs / pci), str(root / card / 'device'))
+    (root / 'card2' / 'device').mkdir(parents=True)        # (a display-only node without hwmon)
+    assert bench.find_hwmon('0000:85:00', root=str(root)).endswith('card1/device/hwmon/hwmon3')
+    assert bench.find_hwmon(None, root=str(root)) is None                 # two candidates and no address: no guess
+    assert bench.find_hwmon('0000:ff:00', root=str(root)) is None
+    ps = bench.PowerSampler(bench.find_hwmon('0000:85:00', root=str(root)), period_s=0.002).start()
+    time.sleep(0.05)
+    rep = ps.stop()
+    assert rep['avg_w'] == 750.0 and rep['max_w'] == 750.0 and rep['cap_w'] == 1400.0 and rep['sclk_mhz_avg'] == 1780.0
+    assert rep['samples'] >= 3 and 'power1_input' in rep['source']
+    assert bench.PowerSampler(None).start().stop() is None
+    assert bench.find_hwmon(None, root=str(tmp_path / 'nothing')) is None
