@@ -106,12 +106,15 @@ class FrameTrunkCache(object):
             while len(self.free) < n:           # evict least recently used frames that this forward does not use
                 victim = next(f for f in self.slot_of if f not in need)
                 self.free.append(self.slot_of.pop(victim))
+            # (the previous upload out of the pinned buffer must have left it: its copy event)
+            self.copy_event.synchronize()
             if self.pinned is None or self.pinned.shape[0] < n or tuple(self.pinned.shape[1:]) != (h, w, 3):
+                # a larger staging pair: the trunk stream may still be reading the old device buffer, and dropping it hands the memory back
+                # to the allocator of THIS thread's stream, which knows nothing about that reader -- wait for the prefix that read it
+                self.event.synchronize()
                 cap = max(n, 8)
                 self.pinned = torch.empty((cap, h, w, 3), dtype=torch.uint8).pin_memory()
                 self.dev_u8 = torch.empty((cap, h, w, 3), dtype=torch.uint8, device=self.ws.device)
-            # (the previous upload out of this pinned buffer must have left it: its copy event)
-            self.copy_event.synchronize()
             host = self.pinned.numpy()
             for k, fid in enumerate(new):
                 f = frames_by_id[fid]

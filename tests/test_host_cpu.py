@@ -1062,3 +1062,23 @@ def test_bench_power_sampler_reads_an_amdgpu_hwmon_tree(tmp_path):
     assert rep['samples'] >= 3 and 'power1_input' in rep['source']
     assert bench.PowerSampler(None).start().stop() is None
     assert bench.find_hwmon(None, root=str(tmp_path / 'nothing')) is None
+
+
+def test_integration_md_names_every_entry_point_of_the_c_abi():
+    """INTEGRATION.md is the map a maintainer of the reference binds from: every function `include/dat_hip.h` declares has a row there
+    (a sizing helper may ride on its function's row as `(+_workspace_bytes)`)."""
+    import re
+    with open(os.path.join(REPO, 'include', 'dat_hip.h')) as f:
+        names = sorted(set(re.findall(r'\b(dat_[a-z0-9_]+|_nms)\s*\(', f.read())))
+    with open(os.path.join(REPO, 'INTEGRATION.md')) as f:
+        text = f.read()
+    assert len(names) >= 70
+    missing = []
+    for n in names:
+        if n in text:
+            continue
+        m = re.match(r'(dat_[a-z0-9_]+?)(_workspace_bytes|_ws_bytes|_weight_bytes)$', n)
+        if m and m.group(1) in text and ('+`%s`' % m.group(2)) in text:
+            continue
+        missing.append(n)
+    assert not missing, 'no row in INTEGRATION.md: %s' % missing
