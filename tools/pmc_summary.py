@@ -111,21 +111,21 @@ def main():
                 'write_bytes,hbm_bytes_per_launch\n')
         for r in rows:
             f.write('%s,%d,%.2f,%.2f,%.0f,%.0f,%.0f\n' % r)
-    with open(os.path.join(src, 'bench.json')) as f:
-        bench = json.loads(f.read().strip().splitlines()[-1])
-    wl = bench['config']['workload']
-    m = re.search(r'R-(\d+) .* 1x3x(\d+)x(\d+)x(\d+)', wl)
-    batch = int(bench['config'].get('images_per_forward', 1))
-    rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/gpu.sh pmc), python bench.py '
-                     '--steps 3 --warmup 1 --pipeline 1 --no-roofline; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
-           'workload': {'arch': m.group(1), 'frames': int(m.group(2)), 'height': int(m.group(3)),
-                        'width': int(m.group(4)), 'dtype': bench['dtype'],
-                        'keyframe_dce': bench['config'].get('keyframe_dce', False), 'batch': batch},
-           'kernels': kernels}
     # (a third argument names another file -- or '-' for none -- when the passes are of a workload other than the bench default,
     #  whose record bench.py reads as profiles/pmc_traffic.json)
     out_json = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(dst.rstrip('/')), 'pmc_traffic.json')
     if out_json != '-':
+        with open(os.path.join(src, 'bench.json')) as f:
+            bench = json.loads(f.read().strip().splitlines()[-1])
+        wl = bench['config']['workload']
+        m = re.search(r'R-(\d+) .* 1x3x(\d+)x(\d+)x(\d+)', wl)
+        batch = int(bench['config'].get('images_per_forward', 1))
+        rec = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/gpu.sh pmc), python bench.py '
+                         '--steps 3 --warmup 1 --pipeline 1 --no-roofline; reads x2 (gfx950 FETCH_SIZE correction), KiB -> bytes',
+               'workload': {'arch': m.group(1), 'frames': int(m.group(2)), 'height': int(m.group(3)),
+                            'width': int(m.group(4)), 'dtype': bench['dtype'],
+                            'keyframe_dce': bench['config'].get('keyframe_dce', False), 'batch': batch},
+               'kernels': kernels}
         with open(out_json, 'w') as f:
             json.dump(rec, f, indent=1, sort_keys=True)
     for r in rows[:8]:
