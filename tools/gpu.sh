@@ -13,6 +13,7 @@
 #   py:<script;args>        python <script> <args>   (-> py_<n>.log)
 #   env:<NAME=V;NAME2=V2>   export for the stages that follow (A/B pairs inside one call);  unset:<NAME;NAME2>
 # Environment switches (DAT_*) are inherited, so A/B pairs are two stages in one call:  DAT_X=1 bash tools/gpu.sh ...
+# Allocation-poison pass of the suite (tests/conftest.py, csrc/c_api.hip):  DAT_POISON=1 DAT_WS_POISON=1 bash tools/gpu.sh <tag> tests
 tag=${1:-t}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 o=$R/gpurun_out/$tag; mkdir -p $o
