@@ -42,7 +42,10 @@ def _write_det_file(dets, path):
 
 
 def _image_path(entry):
-    return entry['image'][0] if isinstance(entry['image'], (list, tuple)) else entry['image']
+    """utils/image.py:44-48: a clip is named by its CENTRE frame (the key frame), a single image by itself -- the key the frames of a video
+    are sorted by (:681) and the directory a video is told apart by (:65-67)."""
+    names = entry['image']
+    return names[len(names) // 2] if isinstance(names, (list, tuple)) else names
 
 
 def _is_same_video(a, b):

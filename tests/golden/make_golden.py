@@ -331,6 +331,83 @@ def golden_posetrack_json(cfg):
     print('wrote reference_posetrack_annorect.json', len(out['cases']), 'cases')
 
 
+def tracker_case(seed, T, frames_per_video, algo):
+    """Seeded detections of a few videos in the detections.pkl layout (test_engine.py:199-204), clip-named roidb entries in SHUFFLED order
+    inside each video (the tracker sorts them by key-frame path, tracking_engine.py:681), with low-confidence, tiny, out-of-image and
+    empty frames in the mix.  Returns (json_data, dets)."""
+    rs = np.random.RandomState(seed)
+    json_data, boxes_all, keyps_all = [], [], []
+    for v, nf in enumerate(frames_per_video):
+        n_p = int(rs.randint(2, 7))
+        pos = np.stack([rs.uniform(50, 1100, n_p), rs.uniform(50, 600, n_p)], axis=1)
+        size = rs.uniform(40, 220, (n_p, 2))
+        vel = rs.uniform(-25, 25, (n_p, 2))
+        order = rs.permutation(nf)                        # entries of one video arrive out of order
+        per_frame = {}
+        for f in range(nf):
+            p = pos + vel * f
+            keep = rs.uniform(size=n_p) > 0.15            # a person is missed now and then
+            if f == nf // 2 and nf > 3:
+                keep[:] = False                           # one frame without any detection
+            rows = []
+            for i in np.where(keep)[0]:
+                tube = []
+                for t in range(T):
+                    j = rs.uniform(-3, 3, 4)
+                    tube += [p[i, 0] + j[0] + 2 * t, p[i, 1] + j[1], p[i, 0] + size[i, 0] + j[2] + 2 * t, p[i, 1] + size[i, 1] + j[3]]
+                score = rs.choice([0.99, 0.95, 0.91, 0.9, 0.89, 0.5])
+                rows.append(tube + [score])
+            if rs.uniform() < 0.3:                        # a tiny box and one hanging out of the image
+                rows.append([10.0, 10.0, 15.0, 16.0] * T + [0.97])
+                rows.append([1250.0, 690.0, 1400.0, 800.0] * T + [0.96])
+            b = np.array(rows, dtype=np.float32).reshape(-1, 4 * T + 1)
+            b = b[rs.permutation(len(b))]
+            k = [rs.uniform(0, 1, (4, 17 * T)).astype(np.float32) for _ in range(len(b))]
+            per_frame[f] = (b, k)
+        for f in order:
+            names = ['/data/vid%02d/%05d.jpg' % (v, min(max(f - T // 2 + j, 0), nf - 1)) for j in range(T)]
+            json_data.append({'image': names if T > 1 else names[0], 'height': 720, 'width': 1280})
+            boxes_all.append(per_frame[f][0])
+            keyps_all.append(per_frame[f][1])
+    dets = {'all_boxes': [[], boxes_all], 'all_keyps': [[], keyps_all], 'all_segms': [[], [None] * len(boxes_all)], 'cfg': None}
+    return json_data, dets
+
+
+def golden_tracker(cfg):
+    """lib/core/tracking_engine.py of the REAL reference (its imports of the drawing module stubbed, py2's list-returning range given
+    back to it): _center_detections (:751-755), _prune_bad_detections (:731-748), compute_matches_tracks (:669-708) with the Hungarian
+    and the greedy matcher on seeded detections -> tests/golden/reference_tracker.json (generator arguments + expected outputs)."""
+    import json
+    sys.modules['utils.vis'] = _Stub('utils.vis')       # matplotlib drawing only: not on the tracker's arithmetic path
+    import core.tracking_engine as ref
+    ref.range = lambda *a: list(range(*a))              # (py2 semantics: `range(...) + [-1]` in _center_boxes)
+    ref.tqdm = lambda it, **k: it
+    ref._summarize_track_stats = lambda *a, **k: None   # (prints only)
+    cases = []
+    for seed, T, frames, algo in ((11, 1, (12, 1, 9), 'hungarian'), (12, 1, (7, 15), 'greedy'), (13, 3, (10, 6, 2), 'hungarian'),
+                                  (14, 1, (40,), 'hungarian'), (20, 4, (9, 8, 3), 'hungarian')):     # (seed 20: naming a clip by its FIRST frame instead of its centre frame changes the ids)
+        cfg.TRACKING.BIPARTITE_MATCHING_ALGO = algo
+        cfg.TRACKING.DISTANCE_METRICS = ('bbox-overlap', 'cnn-cosdist', 'pose-pck')
+        cfg.TRACKING.DISTANCE_METRIC_WTS = (1.0, 0.0, 0.0)
+        cfg.KRCNN.NUM_KEYPOINTS = 17
+        json_data, dets = tracker_case(seed, T, frames, algo)
+        if cfg.TRACKING.KEEP_CENTER_DETS_ONLY:
+            ref._center_detections(dets)
+        centred = [b.copy() for b in dets['all_boxes'][1]]
+        dets = ref._prune_bad_detections(dets, json_data, cfg.TRACKING.CONF_FILTER_INITIAL_DETS)
+        out = ref.compute_matches_tracks(json_data, dets, None)
+        cases.append({'seed': seed, 'T': T, 'frames_per_video': list(frames), 'algo': algo,
+                      'conf': float(cfg.TRACKING.CONF_FILTER_INITIAL_DETS),
+                      'centred_shapes': [list(b.shape) for b in centred],
+                      'pruned_boxes': [np.asarray(b, dtype=np.float64).round(4).tolist() for b in out['all_boxes'][1]],
+                      'pruned_pose_counts': [len(k) for k in out['all_keyps'][1]],
+                      'pose_shapes': [list(k[0].shape) if len(k) else None for k in out['all_keyps'][1]],
+                      'tracks': [[int(t) for t in tr] for tr in out['all_tracks'][1]]})
+    with open(os.path.join(HERE, 'reference_tracker.json'), 'w') as f:
+        json.dump({'cases': cases}, f)
+    print('wrote reference_tracker.json', len(cases), 'cases,', sum(len(c['tracks']) for c in cases), 'frames')
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -380,6 +457,9 @@ def golden_postproc(cfg):
 if __name__ == '__main__':
     if '--only-postproc' in sys.argv:
         golden_postproc(_install_shims())
+    elif '--only-tracker' in sys.argv:
+        golden_tracker(_install_shims())
     else:
         main()
         golden_postproc(sys.modules['core.config'].cfg)
+        golden_tracker(sys.modules['core.config'].cfg)

@@ -1082,3 +1082,47 @@ def test_integration_md_names_every_entry_point_of_the_c_abi():
             continue
         missing.append(n)
     assert not missing, 'no row in INTEGRATION.md: %s' % missing
+
+
+def test_tracker_matches_the_real_reference_golden():
+    """core/tracking_engine.py against lib/core/tracking_engine.py ITSELF (run under the py3 shims of tests/golden/make_golden.py --
+    golden_tracker -- on seeded detections): centre-frame selection of tube detections, confidence / size pruning with in-place clipping,
+    video splitting (entries of a video arrive shuffled and are sorted by their KEY-frame path, utils/image.py:44-48; the last video is
+    taken as it comes, :683-684), Hungarian and greedy matching, track-id assignment.  The test regenerates the inputs from the
+    generator's seeds and compares with the committed outputs."""
+    import json
+    import importlib.util
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.core import tracking_engine as te
+    spec = importlib.util.spec_from_file_location('make_golden_for_tracker', os.path.join(REPO, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_tracker.json')) as f:
+        cases = json.load(f)['cases']
+    assert len(cases) == 5 and {c['algo'] for c in cases} == {'hungarian', 'greedy'} and {c['T'] for c in cases} == {1, 3, 4}
+    reset_cfg()
+    try:
+        for c in cases:
+            cfg.TRACKING.BIPARTITE_MATCHING_ALGO = c['algo']
+            cfg.KRCNN.NUM_KEYPOINTS = 17
+            assert cfg.TRACKING.KEEP_CENTER_DETS_ONLY and float(cfg.TRACKING.CONF_FILTER_INITIAL_DETS) == c['conf']
+            json_data, dets = mg.tracker_case(c['seed'], c['T'], tuple(c['frames_per_video']), c['algo'])
+            te._center_detections(dets)
+            assert [list(b.shape) for b in dets['all_boxes'][1]] == c['centred_shapes']
+            dets = te._prune_bad_detections(dets, json_data, cfg.TRACKING.CONF_FILTER_INITIAL_DETS)
+            out = te.compute_matches_tracks(json_data, dets)
+            assert len(out['all_tracks'][1]) == len(c['tracks']) == sum(c['frames_per_video'])
+            n_rows = 0
+            for i, (b, want) in enumerate(zip(out['all_boxes'][1], c['pruned_boxes'])):
+                want = np.asarray(want, dtype=np.float64)
+                assert len(b) == len(want), (c['seed'], i)
+                if len(want):       # (a frame without detections keeps the shape it came with, :87-88)
+                    assert b.shape == want.shape == (len(want), 5), (c['seed'], i)
+                    np.testing.assert_allclose(b, want, atol=1e-4)
+                n_rows += len(want)
+            assert n_rows > 2 * len(c['tracks'])            # (the cases are not degenerate)
+            assert [len(k) for k in out['all_keyps'][1]] == c['pruned_pose_counts']
+            assert [list(k[0].shape) if len(k) else None for k in out['all_keyps'][1]] == c['pose_shapes']
+            assert [[int(t) for t in tr] for tr in out['all_tracks'][1]] == c['tracks'], 'track ids of case seed %d' % c['seed']
+    finally:
+        reset_cfg()
