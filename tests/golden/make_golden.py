@@ -408,6 +408,49 @@ def golden_tracker(cfg):
     print('wrote reference_tracker.json', len(cases), 'cases,', sum(len(c['tracks']) for c in cases), 'frames')
 
 
+BLOB_CASES = (('b2d_fpn', dict(video=False, fpn=True, T=1, shapes=((37, 50), (40, 45)))),
+              ('b3d_fpn_T4', dict(video=True, fpn=True, T=4, shapes=((20, 40),) * 8)),
+              ('b3d_c4_T3', dict(video=True, fpn=False, T=3, shapes=((33, 41),) * 3)),
+              ('b2d_c4', dict(video=False, fpn=False, T=1, shapes=((20, 31), (25, 30), (25, 31)))))
+PREP_CASES = ((600, 800, 800, 1333), (720, 1280, 800, 1333), (1080, 1920, 800, 1333), (96, 128, 96, 1000), (100, 1000, 800, 1333),
+              (480, 854, 600, 1000), (500, 375, 800, 1333), (333, 500, 500, 833))
+
+
+def blob_case_images(name, shapes):
+    rs = np.random.RandomState(sum(map(ord, name)))
+    return [rs.randint(-120, 130, sh + (3,)).astype(np.float32) for sh in shapes]       # (integer-valued: the fixture compresses)
+
+
+def golden_blob(cfg):
+    """lib/utils/blob.py of the REAL reference: im_list_to_blob (:40-68: common size, FPN.COARSEST_STRIDE padding, NCHW, time axis of video
+    models through utils/image.move_batch_to_time) and the scale rule + argument order of prep_im_for_blob (:71-90; cv2 is absent here, so
+    its resize is replaced by a recorder: the golden holds the (fx, fy, interpolation) it was called with and the mean-subtracted image
+    it was handed) -> tests/golden/reference_blob.npz."""
+    import utils.blob as ref
+    out = {}
+    for name, c in BLOB_CASES:
+        cfg.MODEL.VIDEO_ON, cfg.FPN.FPN_ON, cfg.VIDEO.NUM_FRAMES = c['video'], c['fpn'], c['T']
+        out[name] = ref.im_list_to_blob(blob_case_images(name, c['shapes']))
+    calls = []
+
+    def fake_resize(im, dsize, dst, fx=None, fy=None, interpolation=None):
+        calls.append((fx, fy, interpolation, im.copy()))
+        return im
+    ref.cv2.resize, ref.cv2.INTER_LINEAR = fake_resize, 1
+    rs = np.random.RandomState(5)
+    means = np.array([[[102.9801, 115.9465, 122.7717]]])
+    for k, (h, w, target, max_size) in enumerate(PREP_CASES):
+        im = rs.randint(0, 255, (8, 8, 3)).astype(np.uint8)
+        im = np.ascontiguousarray(np.broadcast_to(im[:1, :1], (h, w, 3)))         # (only the shape matters to the rule; tiny content)
+        del calls[:]
+        _, scales = ref.prep_im_for_blob(im, means, [target], max_size)
+        fx, fy, interp, handed = calls[0]
+        out['prep%d' % k] = np.array([h, w, target, max_size, scales[0], fx, fy, interp], dtype=np.float64)
+        out['prep%d_pixel' % k] = np.concatenate([im[0, 0].astype(np.float64), handed[0, 0].astype(np.float64)])
+    np.savez_compressed(os.path.join(HERE, 'reference_blob.npz'), **out)
+    print('wrote reference_blob.npz', len(out), 'arrays')
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -459,7 +502,10 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-blob' in sys.argv:
+        golden_blob(_install_shims())
     else:
         main()
         golden_postproc(sys.modules['core.config'].cfg)
         golden_tracker(sys.modules['core.config'].cfg)
+        golden_blob(sys.modules['core.config'].cfg)

@@ -1126,3 +1126,39 @@ def test_tracker_matches_the_real_reference_golden():
             assert [[int(t) for t in tr] for tr in out['all_tracks'][1]] == c['tracks'], 'track ids of case seed %d' % c['seed']
     finally:
         reset_cfg()
+
+
+def test_blob_utils_match_the_real_reference_golden():
+    """utils/blob.py against lib/utils/blob.py ITSELF (tests/golden/make_golden.py golden_blob): the `data` blob's layout -- common size,
+    FPN.COARSEST_STRIDE padding, NCHW, clips along a time axis -- and prep_im_for_blob's scale rule, mean subtraction and the (fx, fy,
+    INTER_LINEAR) it hands to the resampler (the resampler itself is pinned by known answers: OpenCV is not in this image)."""
+    import importlib.util
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import blob as blob_utils
+    spec = importlib.util.spec_from_file_location('make_golden_for_blob', os.path.join(REPO, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_blob.npz'))
+    reset_cfg()
+    try:
+        for name, c in mg.BLOB_CASES:
+            cfg.MODEL.VIDEO_ON, cfg.FPN.FPN_ON, cfg.VIDEO.NUM_FRAMES = c['video'], c['fpn'], c['T']
+            got = blob_utils.im_list_to_blob(mg.blob_case_images(name, c['shapes']))
+            assert got.shape == g[name].shape and got.dtype == g[name].dtype == np.float32, (name, got.shape, g[name].shape)
+            np.testing.assert_array_equal(got, g[name])
+        assert g['b3d_fpn_T4'].shape == (2, 3, 4, 32, 64) and g['b2d_fpn'].shape == (2, 3, 64, 64) and g['b3d_c4_T3'].shape == (1, 3, 3, 33, 41)
+        means = np.array([[[102.9801, 115.9465, 122.7717]]])
+        for k, (h, w, target, max_size) in enumerate(mg.PREP_CASES):
+            rec = g['prep%d' % k]
+            assert tuple(rec[:4]) == (h, w, target, max_size)
+            assert rec[5] == rec[6] == rec[4] and rec[7] == 1            # fx = fy = the returned scale, INTER_LINEAR
+            assert blob_utils.test_scale((h, w, 3), target, max_size) == rec[4], (h, w, target, max_size)
+            px = g['prep%d_pixel' % k]
+            im = np.ascontiguousarray(np.broadcast_to(px[:3].astype(np.uint8).reshape(1, 1, 3), (4, 6, 3)))
+            ims, scales = blob_utils.prep_im_for_blob(im, means, [4], 1000)      # (a tiny image: what is checked is the mean subtraction)
+            np.testing.assert_allclose(ims[0][0, 0], px[3:], rtol=0, atol=1e-5)
+            if h * w <= 600 * 800:       # (the NumPy resampler on a full HD frame takes seconds; the rule itself is test_scale above)
+                _, scales = blob_utils.prep_im_for_blob(np.zeros((h, w, 3), np.uint8), means, [target], max_size)
+                assert scales[0] == rec[4]
+    finally:
+        reset_cfg()
