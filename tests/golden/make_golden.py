@@ -451,6 +451,46 @@ def golden_blob(cfg):
     print('wrote reference_blob.npz', len(out), 'arrays')
 
 
+def decode_case_inputs(seed, n, K, M=56):
+    """Seeded heatmaps + rois for the decode golden: rois narrower than a pixel (the max(., 1) clamp), fractional sizes (ceil), a map
+    whose maximum is attained twice (the first position wins) and one that is constant."""
+    rs = np.random.RandomState(seed)
+    maps = (rs.randn(n, K, M, M) * 2).astype(np.float32)
+    maps[0, 1] = np.round(maps[0, 1])                     # plateaus after resampling are rare; ties in the source are not
+    maps[1, 2, :, :] = 0.25                               # a constant map: argmax = first cell
+    xy = rs.uniform(0, 200, (n, 2)).astype(np.float32)
+    wh = rs.uniform(0.3, 90, (n, 2)).astype(np.float32)
+    wh[0] = (0.4, 37.5)
+    wh[1] = (56.0, 0.9)
+    wh[2] = (12.0, 12.0)
+    return maps, np.hstack((xy, xy + wh)).astype(np.float32)
+
+
+def golden_decode(cfg):
+    """lib/utils/keypoints.py:94-149 heatmaps_to_keypoints and :210-216 scores_to_probs of the REAL reference, with cv2.resize -- OpenCV
+    is not in this image -- replaced by the oracle's restatement of INTER_CUBIC (oracle/resize.py, pinned by exact-rational known answers):
+    everything AROUND the resampler is the reference's own code: roi size / ceil / min-size rules, the argmax convention, the
+    (x + 0.5) * correction + offset formula, logit and spatial-softmax probability -> tests/golden/reference_decode.npz."""
+    from oracle import resize as oresize
+    import utils.keypoints as ref
+    ref.cv2.INTER_CUBIC = 2
+
+    def fake_resize(im, dsize, interpolation=None):
+        assert interpolation == 2
+        return oresize.resize_cubic(im, dsize=(int(dsize[0]), int(dsize[1])))
+    ref.cv2.resize = fake_resize
+    out = {}
+    for name, (seed, n, K, min_size) in {'dec_k17': (31, 5, 17, 0), 'dec_k17_min40': (31, 5, 17, 40), 'dec_k3_min8': (32, 4, 3, 8)}.items():
+        cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.INFERENCE_MIN_SIZE = K, min_size
+        maps, rois = decode_case_inputs(seed, n, K)
+        out[name] = ref.heatmaps_to_keypoints(maps, rois)
+        out[name + '_cfg'] = np.array([seed, n, K, min_size])
+    sc = (np.random.RandomState(33).randn(4, 9, 7) * 3).astype(np.float32)
+    out['probs_in'], out['probs_out'] = sc, ref.scores_to_probs(sc.copy())
+    np.savez_compressed(os.path.join(HERE, 'reference_decode.npz'), **out)
+    print('wrote reference_decode.npz', len(out), 'arrays')
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -504,8 +544,11 @@ if __name__ == '__main__':
         golden_tracker(_install_shims())
     elif '--only-blob' in sys.argv:
         golden_blob(_install_shims())
+    elif '--only-decode' in sys.argv:
+        golden_decode(_install_shims())
     else:
         main()
         golden_postproc(sys.modules['core.config'].cfg)
         golden_tracker(sys.modules['core.config'].cfg)
         golden_blob(sys.modules['core.config'].cfg)
+        golden_decode(sys.modules['core.config'].cfg)

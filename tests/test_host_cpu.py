@@ -1162,3 +1162,37 @@ def test_blob_utils_match_the_real_reference_golden():
                 assert scales[0] == rec[4]
     finally:
         reset_cfg()
+
+
+def test_keypoint_decode_matches_the_reference_body_around_the_restated_resampler():
+    """lib/utils/keypoints.py:94-149 / :210-216 ITSELF, run with the oracle's INTER_CUBIC restatement in place of the absent cv2.resize
+    (tests/golden/make_golden.py golden_decode), against the oracle's restatement of that function and the product's host decode: roi
+    clamp / ceil / INFERENCE_MIN_SIZE, first-maximum argmax, the continuous-coordinate formula, logit and spatial-softmax probability
+    are pinned to the reference's own code (the resampler by known answers, tests/test_oracle_golden.py)."""
+    import importlib.util
+    from oracle import resize as R
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import keypoints as ku
+    spec = importlib.util.spec_from_file_location('make_golden_for_decode', os.path.join(REPO, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_decode.npz'))
+    reset_cfg()
+    try:
+        for name in ('dec_k17', 'dec_k17_min40', 'dec_k3_min8'):
+            seed, n, K, min_size = [int(v) for v in g[name + '_cfg']]
+            maps, rois = mg.decode_case_inputs(seed, n, K)
+            want = g[name]
+            assert want.shape == (n, 4, K) and want.dtype == np.float32
+            np.testing.assert_array_equal(R.heatmaps_to_keypoints(maps, rois, min_size), want)
+            cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.INFERENCE_MIN_SIZE = K, min_size
+            np.testing.assert_array_equal(ku.heatmaps_to_keypoints(maps, rois), want)
+        # the constant map decodes to its first cell, the twice-attained maximum to its first position
+        seed, n, K, _ = [int(v) for v in g['dec_k17_cfg']]
+        maps, rois = mg.decode_case_inputs(seed, n, K)
+        w1 = max(rois[1, 2] - rois[1, 0], 1.0)
+        assert abs(g['dec_k17'][1, 0, 2] - (rois[1, 0] + 0.5 * w1 / np.ceil(w1))) < 1e-4
+        np.testing.assert_array_equal(R.scores_to_probs(g['probs_in']), g['probs_out'])
+        np.testing.assert_array_equal(ku.scores_to_probs(g['probs_in'].copy()), g['probs_out'])
+    finally:
+        reset_cfg()
