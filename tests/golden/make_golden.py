@@ -466,6 +466,18 @@ def decode_case_inputs(seed, n, K, M=56):
     return maps, np.hstack((xy, xy + wh)).astype(np.float32)
 
 
+def tube_decode_inputs(seed, n, K, T):
+    rs = np.random.RandomState(seed)
+    maps = (rs.randn(n, K * T, 56, 56) * 2).astype(np.float32)
+    xy = rs.uniform(0, 150, (n, 2)).astype(np.float32)
+    rois = np.zeros((n, 4 * T), np.float32)
+    for t in range(T):
+        j = rs.uniform(-5, 5, (n, 2)).astype(np.float32)
+        rois[:, 4 * t:4 * t + 2] = xy + j
+        rois[:, 4 * t + 2:4 * t + 4] = xy + j + rs.uniform(3, 70, (n, 2)).astype(np.float32)
+    return maps, rois
+
+
 def golden_decode(cfg):
     """lib/utils/keypoints.py:94-149 heatmaps_to_keypoints and :210-216 scores_to_probs of the REAL reference, with cv2.resize -- OpenCV
     is not in this image -- replaced by the oracle's restatement of INTER_CUBIC (oracle/resize.py, pinned by exact-rational known answers):
@@ -487,6 +499,17 @@ def golden_decode(cfg):
         out[name + '_cfg'] = np.array([seed, n, K, min_size])
     sc = (np.random.RandomState(33).randn(4, 9, 7) * 3).astype(np.float32)
     out['probs_in'], out['probs_out'] = sc, ref.scores_to_probs(sc.copy())
+    # core/test.py:865-894 keypoint_results on TUBE detections (T = 2: one decode per frame with that frame's box, rows concatenated along
+    # the keypoint axis) and :77-121 _get_rois_blob (the keypoint net's roi blob: level 0, boxes x the image scale)
+    import core.test as ref_test
+    T, K = 2, 3
+    cfg.KRCNN.NUM_KEYPOINTS, cfg.KRCNN.INFERENCE_MIN_SIZE, cfg.MODEL.NUM_CLASSES, cfg.KRCNN.NMS_OKS = K, 0, 2, False
+    maps, rois = tube_decode_inputs(34, 4, K, T)
+    kps = ref_test.keypoint_results([[], rois], maps, rois)
+    assert len(kps) == 2 and kps[0] == []
+    out['tube_keyps'] = np.stack(kps[1])
+    out['tube_cfg'] = np.array([34, 4, K, T])
+    out['tube_rois_blob'] = ref_test._get_rois_blob(rois, np.array([1.0414]))
     np.savez_compressed(os.path.join(HERE, 'reference_decode.npz'), **out)
     print('wrote reference_decode.npz', len(out), 'arrays')
 
