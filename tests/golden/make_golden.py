@@ -300,6 +300,54 @@ def golden_roi_data(cfg):
     sb = rfr._sample_rois(roidb[0], 1.0, 0)
     for k, v in sb.items():
         out['rd_s_' + k] = np.asarray(v)
+    # ---- the same chain on TUBES (T = 3: boxes n x 4T, keypoints n x 3 x 17T, tube proposals): tube IoU in the merge, 4T-wide class-specific
+    #      targets (fast_rcnn.py:206-229), the first frame's box against all T x 17 keypoints in the visibility test and per-frame heatmap
+    #      cells (keypoint_rcnn.py:62-99) ------------------------------------------------------------------------------------------
+    T, n = 3, 4
+    cfg.MODEL.VIDEO_ON, cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID = True, T, T
+    rs = np.random.RandomState(22)
+    bw, bh = rs.uniform(0.15, 0.5, n) * W, rs.uniform(0.25, 0.8, n) * H
+    x1, y1 = rs.uniform(0, 1, n) * (W - bw - 1), rs.uniform(0, 1, n) * (H - bh - 1)
+    tubes = np.zeros((n, 4 * T), np.float32)
+    tkps = np.zeros((n, 3, 17 * T), np.int32)
+    for t in range(T):
+        dx = 3.0 * t
+        tubes[:, 4 * t:4 * t + 4] = np.stack([x1 + dx, y1, x1 + bw + dx, y1 + bh], axis=1)
+        tkps[:, 0, 17 * t:17 * t + 17] = (x1[:, None] + dx + rs.uniform(-0.1, 1.1, (n, 17)) * bw[:, None]).astype(np.int32)
+        tkps[:, 1, 17 * t:17 * t + 17] = (y1[:, None] + rs.uniform(-0.1, 1.1, (n, 17)) * bh[:, None]).astype(np.int32)
+        tkps[:, 2, 17 * t:17 * t + 17] = rs.randint(0, 3, (n, 17))
+    tov = np.zeros((n, 2), np.float32)
+    tov[:, 1] = 1.0
+    tprops = np.clip(tubes[rs.randint(0, n, 200)] + np.tile(rs.randn(200, 4) * 15, (1, T)), 0, np.tile([W - 1, H - 1, W - 1, H - 1], T)).astype(np.float32)
+    ok = np.all([(tprops[:, 4 * t + 2] > tprops[:, 4 * t] + 2) & (tprops[:, 4 * t + 3] > tprops[:, 4 * t + 1] + 2) for t in range(T)], axis=0)
+    tprops = tprops[ok]
+    out.update(rt_boxes=tubes, rt_kps=tkps, rt_props=tprops)
+    entry = dict(boxes=tubes.copy(), gt_classes=np.ones((n,), np.int32), is_crowd=np.zeros((n,), np.bool_),
+                 gt_overlaps=scipy.sparse.csr_matrix(tov), box_to_gt_ind_map=np.arange(n, dtype=np.int32),
+                 gt_keypoints=tkps.copy(), seg_areas=np.zeros((n,), np.float32), segms=[[] for _ in range(n)], height=H, width=W)
+    roidb = [entry]
+    jd._merge_proposal_boxes_into_roidb(roidb, [tprops])
+    jd._add_class_assignments(roidb)
+    out['rt_merged_max_overlaps'] = roidb[0]['max_overlaps']
+    out['rt_merged_b2g'] = roidb[0]['box_to_gt_ind_map']
+    npr.seed(79)
+    np.random.seed(79)
+    sb = rfr._sample_rois(roidb[0], 1.25, 0)
+    for k, v in sb.items():
+        out['rt_s_' + k] = np.asarray(v)
+    # tube RPN labels: anchors with time_dim T, per-frame visibility of the ground-truth tracks in the inside weights (rpn.py:285-300)
+    rrpn._threadlocal_foa.cache = {}        # (the reference memoises fields by stride / sizes / ratios only -- not by time_dim)
+    tfoas = [rrpn._get_field_of_anchors(2. ** lvl, (cfg.FPN.RPN_ANCHOR_START_SIZE * 2. ** (lvl - cfg.FPN.RPN_MIN_LEVEL),),
+                                        cfg.FPN.RPN_ASPECT_RATIOS, T) for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)]
+    vis = np.array([[1, 1, 1], [1, 0, 1], [1, 1, 0], [1, 1, 1]], dtype=bool)
+    npr.seed(80)
+    tblobs = rrpn._get_rpn_blobs(float(H), float(W), tfoas, np.concatenate([f.field_of_anchors for f in tfoas]), tubes, vis)
+    out['rt_vis'] = vis
+    for i, b in enumerate(tblobs):
+        for k, v in b.items():
+            if 'vis' not in k:
+                out['rt_%s_fpn%d' % (k, i + 2)] = v
+    cfg.MODEL.VIDEO_ON, cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID = False, 1, 1
     np.savez_compressed(os.path.join(HERE, 'reference_roi_data.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_roi_data.npz'), len(out), 'arrays')
     golden_posetrack_json(cfg)
@@ -565,6 +613,8 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-roi-data' in sys.argv:
+        golden_roi_data(_install_shims())
     elif '--only-blob' in sys.argv:
         golden_blob(_install_shims())
     elif '--only-decode' in sys.argv:

@@ -599,6 +599,46 @@ def test_roi_data_matches_the_real_reference_golden():
             np.testing.assert_array_equal(sb[k], ref, err_msg=k)
         else:
             np.testing.assert_allclose(sb[k], ref, rtol=1e-5, atol=1e-6, err_msg=k)
+    # ---- the same chain on tubes (T = 3): tube IoU in the merge, 4T-wide targets, first-frame visibility test, per-frame heatmap cells
+    T = 3
+    tubes, tkps, tprops = g['rt_boxes'], g['rt_kps'], g['rt_props']
+    n = tubes.shape[0]
+    assert tubes.shape == (n, 4 * T) and tkps.shape == (n, 3, 17 * T) and tprops.shape[1] == 4 * T and len(tprops) > 100
+    ov = np.zeros((n, 2), np.float32)
+    ov[:, 1] = 1.0
+    entry = dict(boxes=tubes.copy(), gt_classes=np.ones((n,), np.int32), is_crowd=np.zeros((n,), np.bool_), gt_overlaps=ov,
+                 box_to_gt_ind_map=np.arange(n, dtype=np.int32), gt_keypoints=tkps.copy(), height=H, width=W)
+    e = fast_rcnn.merge_proposals_into_entry(entry, tprops)
+    np.testing.assert_allclose(e['max_overlaps'], g['rt_merged_max_overlaps'], rtol=1e-6)
+    np.testing.assert_array_equal(e['box_to_gt_ind_map'], g['rt_merged_b2g'])
+    npr.seed(79)
+    sb = fast_rcnn.sample_rois(e, 1.25, 0, npr)
+    for k in ('labels_int32', 'rois', 'bbox_targets', 'bbox_inside_weights', 'bbox_outside_weights', 'keypoint_rois',
+              'keypoint_locations_int32', 'keypoint_weights'):
+        ref = g['rt_s_' + k]
+        assert sb[k].shape == ref.shape, (k, sb[k].shape, ref.shape)
+        if sb[k].dtype.kind == 'i':
+            np.testing.assert_array_equal(sb[k], ref, err_msg='tubes: ' + k)
+        else:
+            np.testing.assert_allclose(sb[k], ref, rtol=1e-5, atol=1e-5, err_msg='tubes: ' + k)
+    assert g['rt_s_rois'].shape[1] == 1 + 4 * T and g['rt_s_bbox_targets'].shape[1] == 2 * 4 * T
+    # tube RPN labels: anchors of T frames, per-frame visibility of the tracks in the inside weights (rpn.py:285-300)
+    npr.seed(80)
+    per_level = rpn.get_rpn_blobs(float(H), float(W), rpn.fpn_fields(T), tubes, g['rt_vis'], npr)
+    n_fg = 0
+    for i, b in enumerate(per_level):
+        for k, v in b.items():
+            if 'vis' in k:
+                continue
+            ref = g['rt_%s_fpn%d' % (k, i + 2)]
+            assert v.shape == ref.shape and v.dtype == ref.dtype, ('tubes', k, i, v.shape, ref.shape, v.dtype, ref.dtype)
+            if 'labels' in k:
+                np.testing.assert_array_equal(v, ref)
+                n_fg += int((ref == 1).sum())
+            else:
+                np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-7)
+    assert n_fg >= 4 and g['rt_rpn_bbox_targets_wide_fpn2'].shape[1] == 3 * 4 * T
+    assert g['rt_s_keypoint_locations_int32'].shape[0] == g['rt_s_keypoint_rois'].shape[0] * 17 * T
     reset_cfg()
 
 
