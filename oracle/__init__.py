@@ -9,18 +9,22 @@ Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 import anything from here, and only as the *checker*.  The product package
 `detectandtrack_amd` never imports `oracle` (a test enforces that).
 
-PARITY STATUS
-  * NMS / IoU (`oracle.nms`, `oracle.boxes.bbox_overlaps`): PINNED against the
-    reference's own Cython sources compiled from /root/reference into
-    `oracle/_ref/` (see `oracle/build_ref.py`) and against golden fixtures in
-    `tests/golden/` generated from that build.
-  * anchors (`oracle.anchors`): PINNED against the known-answer table in
-    reference `lib/modeling/generate_anchors.py:16-39`.
-  * bbox_transform: PINNED by the round-trip identity the reference tests use
-    (`tests/test_bbox_transform.py:41-71`).
-  * conv / affine / RoIAlign / deconv / FC graph (`oracle.net3d`): PARITY
-    UNPINNED — the arithmetic lives in Caffe2 @ b4e1588 (+ cuDNN 7.1.2), which is
-    not in /root/reference and cannot be built here.  The
-    restatement follows the public operator semantics and the reference's
-    call sites; there are no golden vectors for it anywhere in the reference.
+PARITY STATUS (what pins each restatement; generators and fixtures are committed under tests/golden/)
+  * NMS / IoU (`oracle.nms`, `oracle.boxes.bbox_overlaps`): PINNED against the reference's own Cython sources compiled from
+    /root/reference into `oracle/_ref/` (`oracle/build_ref.py`) and against golden fixtures generated from that build.
+  * anchors, bbox / tube transforms, GenerateProposals, RoIToBatchFormat, FPN level mapping, collect / distribute, weight
+    inflation, lr policy, detection post-processing (box_results_with_nms_and_limit, soft-NMS, box voting), training labels
+    (RPN labels, proposal merge, roi sampling, bbox / keypoint targets -- boxes and T = 3 tubes), the `data` blob layout and
+    scale rule, the PoseTrack annorect structure and the host tracker: PINNED by golden vectors made by RUNNING the
+    reference's Python (lib/...) under py3 shims -- `tests/golden/make_golden.py`.
+  * AffineChannelNd: PINNED -- the reference's own CUDA operator (lib/ops/affine_channel_nd_op.cu) compiled for gfx950
+    against a stand-in of the Caffe2 API it uses (`oracle/ref_affine`), run on the GPU.
+  * heatmap decode (`oracle.resize.heatmaps_to_keypoints`): the function body is PINNED to lib/utils/keypoints.py:94-149 run
+    with this package's INTER_CUBIC restatement in place of the absent cv2.resize; the OpenCV resamplers themselves
+    (`oracle.resize`) are restated from the published algorithm and pinned by exact-rational known answers.
+  * legacy RoIAlign, ConvTranspose k4 s2 p1: known answers worked by hand (tests/test_oracle_golden.py).
+  * conv / RoIAlign / deconv / FC / loss graph as a whole (`oracle.net3d`, `oracle.train_ref`): PARITY UNPINNED -- the
+    arithmetic lives in Caffe2 @ b4e1588 (+ cuDNN 7.1.2), which is not in /root/reference and cannot be built here
+    (SURVEY.md F1/F7, section 8c).  The restatement follows the public operator semantics at the reference's call sites;
+    there are no golden vectors for it anywhere in the reference.
 """
