@@ -115,7 +115,7 @@ SOLVER:
   SCALE_MOMENTUM_THRESHOLD: 1.1
   LOG_LR_CHANGE_THRESHOLD: 1.1
 FAST_RCNN: {MLP_HEAD_DIM: 1024, ROI_XFORM_METHOD: RoIPoolF, ROI_XFORM_SAMPLING_RATIO: 0, ROI_XFORM_RESOLUTION: 14}
-RPN: {ON: false, SIZES: [64, 128, 256, 512], STRIDE: 16, ASPECT_RATIOS: [0.5, 1, 2]}
+RPN: {'ON': false, SIZES: [64, 128, 256, 512], STRIDE: 16, ASPECT_RATIOS: [0.5, 1, 2]}      # ('ON' quoted: YAML 1.1 reads a bare ON as the boolean true)
 FPN:
   FPN_ON: false
   DIM: 256

@@ -88,6 +88,7 @@ class _Blob(object):
 
 def main():
     cfg = _install_shims()
+    golden_cfg_defaults(cfg)
     from modeling.generate_anchors import generate_anchors
     import utils.boxes as box_utils
     from core.nms_wrapper import nms
@@ -562,6 +563,28 @@ def golden_decode(cfg):
     print('wrote reference_decode.npz', len(out), 'arrays')
 
 
+def golden_cfg_defaults(cfg):
+    """Every key and default of the REAL reference's lib/core/config.py (flattened, JSON) -> tests/golden/reference_cfg_defaults.json.
+    Must run first: the other generators edit cfg."""
+    import json
+
+    def flat(d, pre=''):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, pre + str(k) + '.'))
+            else:
+                if isinstance(v, bytes):
+                    v = v.decode()
+                if isinstance(v, np.ndarray):
+                    v = v.tolist()
+                out[pre + str(k)] = list(v) if isinstance(v, tuple) else v
+        return out
+    with open(os.path.join(HERE, 'reference_cfg_defaults.json'), 'w') as f:
+        json.dump(flat(cfg), f, indent=0, sort_keys=True)
+    print('wrote reference_cfg_defaults.json', len(flat(cfg)), 'keys')
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -613,6 +636,8 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-cfg' in sys.argv:
+        golden_cfg_defaults(_install_shims())
     elif '--only-roi-data' in sys.argv:
         golden_roi_data(_install_shims())
     elif '--only-blob' in sys.argv:

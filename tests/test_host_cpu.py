@@ -1247,3 +1247,35 @@ def test_keypoint_decode_matches_the_reference_body_around_the_restated_resample
         np.testing.assert_array_equal(blob, g['tube_rois_blob'])
     finally:
         reset_cfg()
+
+
+def test_cfg_has_every_key_and_default_of_the_real_reference_config():
+    """core/config.py against lib/core/config.py ITSELF (tests/golden/make_golden.py golden_cfg_defaults: the reference's `cfg` flattened
+    right after import): every reference key exists here under the same name -- a bare `ON` in embedded YAML is the boolean true in
+    YAML 1.1, which once hid RPN.ON -- with the same default; the two site paths of the author's cluster are blank here; the HIP.* keys
+    are this build's additions."""
+    import json
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    reset_cfg()
+
+    def flat(d, pre=''):
+        out = {}
+        for k, v in d.items():
+            assert isinstance(k, str), 'non-string config key %r under %r' % (k, pre)
+            if isinstance(v, dict):
+                out.update(flat(v, pre + k + '.'))
+            else:
+                out[pre + k] = v.tolist() if isinstance(v, np.ndarray) else (list(v) if isinstance(v, tuple) else v)
+        return out
+    mine = flat(cfg)
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_cfg_defaults.json')) as f:
+        ref = json.load(f)
+    assert len(ref) >= 269
+    missing = sorted(set(ref) - set(mine))
+    assert not missing, 'reference config keys without a counterpart: %s' % missing
+    extra = sorted(k for k in set(mine) - set(ref) if not k.startswith('HIP.'))
+    assert not extra, 'keys the reference does not have (outside HIP.*): %s' % extra
+    site_paths = {'EXT_PATHS.POSEVAL_CODE_PATH', 'VOC_DIR'}
+    diff = [(k, ref[k], mine[k]) for k in sorted(ref) if k not in site_paths and json.loads(json.dumps(mine[k])) != ref[k]]
+    assert not diff, 'defaults that differ from the reference: %s' % diff[:10]
+    assert cfg.RPN.ON is False
