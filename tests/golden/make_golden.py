@@ -89,6 +89,7 @@ class _Blob(object):
 def main():
     cfg = _install_shims()
     golden_cfg_defaults(cfg)
+    golden_cfg_files(cfg)
     from modeling.generate_anchors import generate_anchors
     import utils.boxes as box_utils
     from core.nms_wrapper import nms
@@ -585,6 +586,48 @@ def golden_cfg_defaults(cfg):
     print('wrote reference_cfg_defaults.json', len(flat(cfg)), 'keys')
 
 
+def golden_cfg_files(cfg):
+    """The EFFECTIVE configuration of every shipped yaml (configs/video/*/*.yaml) as the REAL reference computes it: cfg_from_file
+    (yaml 1.1 load, type rules of _merge_a_into_b, the TIME_KERNEL_DIM / int-to-dict rules) + assert_and_infer_cfg -> the keys that
+    differ from the defaults, per file -> tests/golden/reference_cfg_files.json.  Must run before any generator that edits cfg."""
+    import copy
+    import glob
+    import json
+    import core.config as rc
+
+    def flat(d, pre=''):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, pre + str(k) + '.'))
+            else:
+                if isinstance(v, bytes):
+                    v = v.decode()
+                if isinstance(v, np.ndarray):
+                    v = v.tolist()
+                out[pre + str(k)] = list(v) if isinstance(v, tuple) else v
+        return out
+    import yaml as _yaml
+    _load = _yaml.load
+    _yaml.load = lambda f, Loader=None: _load(f, Loader=Loader or _yaml.Loader)   # (the PyYAML of the reference's day: no Loader argument = the full Loader)
+    default = copy.deepcopy(rc.cfg)
+    base = flat(default)
+    res = {}
+    for f in sorted(glob.glob('/root/reference/configs/video/*/*.yaml')):
+        for k in list(rc.cfg.keys()):
+            rc.cfg[k] = copy.deepcopy(default[k])
+        rc.cfg_from_file(f)
+        rc.assert_and_infer_cfg()
+        now = flat(rc.cfg)
+        res[os.path.relpath(f, '/root/reference/configs')] = {k: v for k, v in now.items() if k not in base or base[k] != v}
+    for k in list(rc.cfg.keys()):
+        rc.cfg[k] = copy.deepcopy(default[k])
+    _yaml.load = _load
+    with open(os.path.join(HERE, 'reference_cfg_files.json'), 'w') as f:
+        json.dump(res, f, indent=0, sort_keys=True)
+    print('wrote reference_cfg_files.json', len(res), 'files,', sum(len(v) for v in res.values()), 'non-default keys')
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -637,7 +680,9 @@ if __name__ == '__main__':
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
     elif '--only-cfg' in sys.argv:
-        golden_cfg_defaults(_install_shims())
+        _c = _install_shims()
+        golden_cfg_defaults(_c)
+        golden_cfg_files(_c)
     elif '--only-roi-data' in sys.argv:
         golden_roi_data(_install_shims())
     elif '--only-blob' in sys.argv:

@@ -1279,3 +1279,39 @@ def test_cfg_has_every_key_and_default_of_the_real_reference_config():
     diff = [(k, ref[k], mine[k]) for k in sorted(ref) if k not in site_paths and json.loads(json.dumps(mine[k])) != ref[k]]
     assert not diff, 'defaults that differ from the reference: %s' % diff[:10]
     assert cfg.RPN.ON is False
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference configs not mounted')
+def test_every_shipped_yaml_gives_the_effective_config_the_real_reference_computes():
+    """cfg_from_file + assert_and_infer_cfg against lib/core/config.py ITSELF on all 12 shipped configs (tests/golden/make_golden.py
+    golden_cfg_files): yaml load, the type rules of _merge_a_into_b, the TIME_KERNEL_DIM int-to-dict mapping (:826-858) and the inferred
+    keys (RPN.ON, NUM_FRAMES_MID) -- the whole set of keys that differ from the defaults, per file."""
+    import json
+    from detectandtrack_amd.core.config import cfg, cfg_from_file, assert_and_infer_cfg, reset_cfg
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_cfg_files.json')) as f:
+        ref = json.load(f)
+    assert len(ref) == 12
+
+    def flat(d, pre=''):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, pre + str(k) + '.'))
+            else:
+                v = v.tolist() if isinstance(v, np.ndarray) else (list(v) if isinstance(v, tuple) else v)
+                out[pre + str(k)] = json.loads(json.dumps(v))
+        return out
+    reset_cfg()
+    base = flat(cfg)
+    try:
+        for rel, want in sorted(ref.items()):
+            reset_cfg()
+            cfg_from_file(os.path.join('/root/reference/configs', rel))
+            assert_and_infer_cfg()
+            now = flat(cfg)
+            got = {k: v for k, v in now.items() if not k.startswith('HIP.') and (k not in base or base[k] != v)}
+            assert sorted(got) == sorted(want), (rel, sorted(set(got) ^ set(want)))
+            bad = [(k, want[k], got[k]) for k in want if got[k] != want[k]]
+            assert not bad, (rel, bad[:5])
+    finally:
+        reset_cfg()
