@@ -17,6 +17,8 @@ PARITY STATUS (what pins each restatement; generators and fixtures are committed
     (RPN labels, proposal merge, roi sampling, bbox / keypoint targets -- boxes and T = 3 tubes), the `data` blob layout and
     scale rule, the PoseTrack annorect structure and the host tracker: PINNED by golden vectors made by RUNNING the
     reference's Python (lib/...) under py3 shims -- `tests/golden/make_golden.py`.
+  * the model graph (which ops, wired how, with which hyper-parameters): PINNED -- the reference's own builder functions
+    (lib/modeling/*.py) executed on a recorder; `oracle.net3d` follows the same wiring.
   * AffineChannelNd: PINNED -- the reference's own CUDA operator (lib/ops/affine_channel_nd_op.cu) compiled for gfx950
     against a stand-in of the Caffe2 API it uses (`oracle/ref_affine`), run on the GPU.
   * heatmap decode (`oracle.resize.heatmaps_to_keypoints`): the function body is PINNED to lib/utils/keypoints.py:94-149 run

@@ -1315,3 +1315,57 @@ def test_every_shipped_yaml_gives_the_effective_config_the_real_reference_comput
             assert not bad, (rel, bad[:5])
     finally:
         reset_cfg()
+
+
+def test_model_builder_emits_the_graph_the_reference_builders_emit():
+    """modeling/* against the REFERENCE's own builder code (tests/golden/make_golden.py golden_builders: lib/modeling/model_builder.py
+    create() -> build_generic_fast_rcnn_model with ResNet3D / ResNet / FPN3D / FPN / head_builder / keypoint_rcnn_heads and the output
+    functions, executed on a recorder made of this package's helper): for the 3D R-18 / R-50 / R-101 FPN3D and the 2D R-50-FPN keypoint
+    models, inference and training -- the same ops with the same inputs, outputs, kernels, strides, pads and init specs in the same
+    order, the same parameter list, the same split into net / keypoint_net / conv_body_net.  The reference appends its loss ops at the
+    end (:283-303); here they are fused ops next to their heads: their hyper-parameters are compared with the recorded Caffe2 ops'."""
+    import gzip
+    import importlib.util
+    import json
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from tests import model_util
+    spec = importlib.util.spec_from_file_location('make_golden_for_builders', os.path.join(REPO, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    with gzip.open(os.path.join(REPO, 'tests', 'golden', 'reference_builder_nets.json.gz')) as f:
+        ref = json.loads(f.read().decode())
+    assert len(ref) == 8
+    sig = lambda net: json.loads(json.dumps(mg.net_signature(net)))
+    mine_loss = {'SoftmaxLoss', 'SmoothL1Loss', 'KeypointLoss', 'RpnLoss'}
+    try:
+        for name, rec in sorted(ref.items()):
+            reset_cfg()
+            cfg_from_cfg(getattr(model_util, rec['cfg_fn'])(**rec['cfg_kw']))
+            if rec['train']:
+                cfg.TRAIN.DATASET = 'synthetic'
+            assert_and_infer_cfg()
+            model = model_builder.create(cfg.MODEL.TYPE, train=rec['train'])
+            assert [str(p) for p in model.params] == rec['params'], name
+            if not rec['train']:
+                assert sig(model.net) == rec['net'], name
+                assert sig(model.keypoint_net) == rec['keypoint_net'], name
+                assert len(model.conv_body_net.ops) == rec['conv_body_net_ops'], name
+                continue
+            got = sig(model.net)
+            first_loss = [i for i, o in enumerate(rec['net']) if o[0] == 'SoftmaxWithLoss'][0]
+            assert [o for o in got if o[0] not in mine_loss] == rec['net'][:first_loss], name
+            tail = {tuple(o[2]): o for o in rec['net'][first_loss:]}
+            fused = {o[0] + ':' + o[2][-1 if o[0] != 'SoftmaxLoss' else 1]: o for o in got if o[0] in mine_loss}
+            assert fused['SoftmaxLoss:loss_cls'][3]['scale'] == tail[('cls_prob', 'loss_cls')][3]['scale']
+            assert fused['SmoothL1Loss:loss_bbox'][3]['scale'] == tail[('loss_bbox',)][3]['scale'] and fused['SmoothL1Loss:loss_bbox'][3]['beta'] == 1.0
+            assert 'beta' not in tail[('loss_bbox',)][3]                 # (Caffe2's default beta = 1)
+            assert fused['KeypointLoss:loss_kps'][3]['scale'] == tail[('kps_prob', 'loss_kps')][3]['scale']
+            assert tail[('kps_score_reshaped', '_kps_score_old_shape')][3]['shape'] == [-1, cfg.KRCNN.HEATMAP_SIZE ** 2]
+            for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1):
+                mine = fused['RpnLoss:loss_rpn_bbox_fpn%d' % lvl][3]
+                sce, sl1 = tail[('loss_rpn_cls_fpn%d' % lvl,)][3], tail[('loss_rpn_bbox_fpn%d' % lvl,)][3]
+                assert mine['cls_scale'] == sce['scale'] and mine['normalize'] == sce['normalize'] == 0, (name, lvl)
+                assert mine['beta'] == sl1['beta'] and mine['bbox_scale'] == sl1['scale'], (name, lvl)
+    finally:
+        reset_cfg()
