@@ -22,6 +22,7 @@ import torch
 
 from detectandtrack_amd.core.config import cfg
 from detectandtrack_amd.ops import hip_ops as ops
+from detectandtrack_amd.utils import lr_policy
 from detectandtrack_amd.workspace import Executor, _count
 
 logger = logging.getLogger(__name__)
@@ -962,6 +963,11 @@ class Trainer(object):
         if not update:
             return ex
         nw, n = self.n_weights, self.flat_w.numel()
+        # a learning-rate step rescales the update history (detector.py:606-640; a few times per schedule: one elementwise pass)
+        corr = lr_policy.momentum_correction(getattr(self, '_fed_lr', None), float(np.float32(lr)))
+        if corr is not None:
+            self.flat_v.mul_(float(corr))
+        self._fed_lr = float(np.float32(lr))            # (the reference's `lr` blob is float32)
         if nw > 0:
             ops.sgd_momentum(self.flat_w[:nw], self.flat_v[:nw], self.flat_g[:nw], lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, False)
         if n > nw:

@@ -48,3 +48,17 @@ def get_lr_at_iter(it):
             raise KeyError('Unknown SOLVER.WARM_UP_METHOD: {}'.format(cfg.SOLVER.WARM_UP_METHOD))
         lr *= _WARM_UP[cfg.SOLVER.WARM_UP_METHOD](it / n_warm)
     return np.float32(lr)
+
+
+def momentum_correction(cur_lr, new_lr):
+    """The factor the update history V is scaled by when the learning rate changes from cur_lr to new_lr, or None
+    (reference lib/modeling/detector.py:606-616 _SetNewLr / :618-640 _CorrectMomentum): MomentumSGDUpdate keeps V = mu V + lr grad, so V
+    carries the lr it was built with; on a change by more than SOLVER.SCALE_MOMENTUM_THRESHOLD (either way) the reference multiplies V
+    by new_lr / cur_lr -- unless SOLVER.SCALE_MOMENTUM is off or the old lr is (about) zero, which covers the first iteration (its `lr`
+    blob starts at 0, model_builder.py:959)."""
+    if cur_lr is None or cur_lr == new_lr or not cfg.SOLVER.SCALE_MOMENTUM or not cur_lr > 1e-7:
+        return None
+    ratio = float('inf') if new_lr == 0 else max(new_lr / cur_lr, cur_lr / new_lr)
+    if ratio > cfg.SOLVER.SCALE_MOMENTUM_THRESHOLD:
+        return new_lr / cur_lr
+    return None

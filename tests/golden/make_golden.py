@@ -37,6 +37,12 @@ class _Stub(types.ModuleType):
     def __call__(self, *a, **k):
         return _Stub(self.__name__ + '()')
 
+    def __enter__(self):            # (`with core.DeviceScope(...)`, `with core.NameScope(...)`)
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
 
 def _install_shims():
     np.float = float
@@ -237,6 +243,28 @@ def golden_lr_policy(cfg):
         so.LR_POLICY, so.BASE_LR, so.GAMMA, so.STEP_SIZE, so.STEPS, so.LRS = pol, base, gamma, step_size, list(steps), list(lrs)
         so.MAX_ITER, so.WARM_UP_ITERS, so.WARM_UP_FACTOR, so.WARM_UP_METHOD = max_iter, wi, wf, wm
         out['lr_case%d' % i] = np.array([lr_policy.get_lr_at_iter(it) for it in range(max_iter + 10)], dtype=np.float32)
+    # the momentum correction at a learning-rate change: lib/modeling/detector.py:606-616 _SetNewLr ITSELF (unbound, on a dummy whose
+    # _CorrectMomentum records the factor; the Caffe2 FeedBlob it makes first is a stub)
+    import queue
+    sys.modules['Queue'] = queue
+    sys.modules['caffe2.python.cnn'].CNNModelHelper = type('CNNModelHelper', (object,), {})
+    import modeling.detector as rdet
+    pairs = [(0.0, 0.02), (0.02, 0.002), (0.002, 0.02), (0.02, 0.021), (0.02, 0.0225), (0.02, 0.018), (0.02, 0.0181), (1e-8, 0.01),
+             (0.01, 0.0), (0.006666667, 0.007333333), (5e-5, 5e-4), (0.02, 0.02)]
+    rows = []
+    for mode in (True, False):
+        cfg.SOLVER.SCALE_MOMENTUM = mode
+        for cur, new in pairs:
+            calls = []
+
+            class Dummy(object):
+                def _CorrectMomentum(self, c):
+                    calls.append(c)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                rdet.DetectionModelHelper._SetNewLr(Dummy(), np.float32(cur), np.float32(new))
+            rows.append([float(mode), float(np.float32(cur)), float(np.float32(new)), float(len(calls)), float(calls[0]) if calls else 0.0])
+    cfg.SOLVER.SCALE_MOMENTUM = True
+    out['momentum_correction'] = np.array(rows, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, 'reference_lr_policy.npz'), **out)
     print('wrote reference_lr_policy.npz', len(out), 'schedules')
 
@@ -813,6 +841,8 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-lr' in sys.argv:
+        golden_lr_policy(_install_shims())
     elif '--only-builders' in sys.argv:
         golden_builders(_install_shims())
     elif '--only-cfg' in sys.argv:

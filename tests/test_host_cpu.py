@@ -1369,3 +1369,25 @@ def test_model_builder_emits_the_graph_the_reference_builders_emit():
                 assert mine['beta'] == sl1['beta'] and mine['bbox_scale'] == sl1['scale'], (name, lvl)
     finally:
         reset_cfg()
+
+
+def test_momentum_correction_matches_the_reference_set_new_lr():
+    """utils.lr_policy.momentum_correction against lib/modeling/detector.py:606-616 _SetNewLr ITSELF (tests/golden/make_golden.py
+    golden_lr_policy: the method run unbound, its _CorrectMomentum recorded): WHEN the update history is rescaled at a learning-rate
+    change (ratio either way above SOLVER.SCALE_MOMENTUM_THRESHOLD, old lr above 1e-7, switch on) and BY WHAT (new / old)."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import lr_policy
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_lr_policy.npz'))['momentum_correction']
+    assert g.shape == (24, 5) and g[:, 3].sum() >= 6
+    reset_cfg()
+    try:
+        for mode, cur, new, called, factor in g:
+            cfg.SOLVER.SCALE_MOMENTUM = bool(mode)
+            got = lr_policy.momentum_correction(float(cur), float(new))
+            assert (got is not None) == bool(called), (mode, cur, new, got)
+            if called:
+                assert abs(got - factor) <= 1e-6 * max(abs(factor), 1e-12) + 1e-12, (cur, new, got, factor)
+        cfg.SOLVER.SCALE_MOMENTUM = True
+        assert lr_policy.momentum_correction(None, 0.02) is None            # the first iteration
+    finally:
+        reset_cfg()
