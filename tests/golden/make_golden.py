@@ -4,8 +4,13 @@
 Cython NMS/IoU compiled into oracle/_ref (oracle/build_ref.py).
 
 Run in the build container only (needs /root/reference):
-    python tests/golden/make_golden.py
-Writes tests/golden/*.npz.  The shims do not change any arithmetic:
+    python tests/golden/make_golden.py            (everything; or one generator: --only-cfg | --only-roi-data | --only-lr | --only-blob |
+                                                   --only-decode | --only-tracker | --only-builders | --only-postproc)
+Writes tests/golden/: reference_host.npz (anchors, transforms, IoU / NMS, GenerateProposals, RoIToBatchFormat, level mapping, collect /
+distribute, inflation), reference_roi_data.npz (training labels, boxes and tubes), reference_lr_policy.npz (schedules + the momentum
+correction rule), reference_postproc.npz, reference_posetrack_annorect.json, reference_blob.npz, reference_decode.npz,
+reference_tracker.json, reference_cfg_defaults.json / reference_cfg_files.json, reference_builder_nets.json.gz (the graphs the
+reference's builder functions emit).  The shims do not change any arithmetic:
   * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
     cPickle -> pickle, bytes config defaults decoded to str;
   * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
