@@ -787,6 +787,23 @@ def golden_builders(cfg):
                 main.ops = m.net.ops[:len(bbox.ops)]
                 rec['net'], rec['keypoint_net'] = net_signature(main), net_signature(m.keypoint_net)
                 rec['conv_body_net_ops'] = len(m.conv_body_net.ops)
+                # what ONE recorded RoIFeatureTransform stands for: the reference helper's own expansion (detector.py:216-310 run unbound
+                # on a recorder) with the arguments the head builders passed -- per level RoIAlign(level blob, rois_fpnK), Concat,
+                # BatchPermutation with the restore indices
+                import types
+                import modeling.detector as rdet
+                rec['roi_transforms'] = []
+                for o in main.ops + m.keypoint_net.ops:
+                    if o.type != 'RoIFeatureTransform':
+                        continue
+                    n_feat = o.args['n_feat']
+                    r = Recorder(name='r', train=False, num_classes=cfg.MODEL.NUM_CLASSES)
+                    r._do_roi_transform = types.MethodType(rdet.DetectionModelHelper._do_roi_transform, r)
+                    ret = rdet.DetectionModelHelper.RoIFeatureTransform(
+                        r, [str(b) for b in o.inputs[:n_feat]][::-1], str(o.outputs[0]), blob_rois=str(o.inputs[n_feat]), method='RoIAlign',
+                        resolution=o.args['resolution'], spatial_scale=list(o.args['scales'])[::-1], sampling_ratio=o.args['sampling_ratio'])
+                    rec['roi_transforms'].append({'fused': net_signature(types.SimpleNamespace(ops=[o]))[0], 'expansion': net_signature(r.net),
+                                                  'returns': str(ret)})
             out[name + ('_train' if train else '')] = rec
     reset_cfg()
     import gzip

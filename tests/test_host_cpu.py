@@ -1351,6 +1351,23 @@ def test_model_builder_emits_the_graph_the_reference_builders_emit():
                 assert sig(model.net) == rec['net'], name
                 assert sig(model.keypoint_net) == rec['keypoint_net'], name
                 assert len(model.conv_body_net.ops) == rec['conv_body_net_ops'], name
+                # what one RoIFeatureTransform op stands for: the reference helper's own expansion (detector.py:216-310) of the same call
+                mine_rt = [o for o in sig(model.net) + sig(model.keypoint_net) if o[0] == 'RoIFeatureTransform']
+                assert len(mine_rt) == len(rec['roi_transforms']) == 2, name
+                k_min = cfg.FPN.ROI_MIN_LEVEL
+                for o, rt in zip(mine_rt, rec['roi_transforms']):
+                    assert o == rt['fused'], name
+                    n_feat, a = o[3]['n_feat'], o[3]
+                    per_level = [e for e in rt['expansion'] if e[0] == 'RoIAlign']
+                    assert len(per_level) == n_feat == cfg.FPN.ROI_MAX_LEVEL - k_min + 1
+                    for i, e in enumerate(per_level):           # input i of the fused op IS pyramid level k_min + i, with scale i
+                        assert e[1] == [o[1][i], '%s_fpn%d' % (o[1][n_feat], k_min + i)], (name, e)
+                        assert e[3] == {'pooled_h': a['resolution'], 'pooled_w': a['resolution'], 'sampling_ratio': a['sampling_ratio'],
+                                        'spatial_scale': a['scales'][i]}, (name, e)
+                    cat, perm = rt['expansion'][n_feat], rt['expansion'][n_feat + 1]
+                    assert cat[0] == 'Concat' and cat[1] == [e[2][0] for e in per_level] and cat[3] == {'axis': 0}
+                    assert perm[0] == 'BatchPermutation' and perm[1][1] == o[1][n_feat] + '_idx_restore_int32'
+                    assert len(rt['expansion']) == n_feat + 2
                 continue
             got = sig(model.net)
             first_loss = [i for i, o in enumerate(rec['net']) if o[0] == 'SoftmaxWithLoss'][0]
