@@ -8,7 +8,6 @@ config uses), 'center-only-rest-rand'.
 """
 import logging
 import pickle
-import re
 
 import numpy as np
 import yaml
@@ -160,8 +159,10 @@ def initialize_from_weights_file(model, ws, weights_file, momentum=None):
             if name not in ws.params:
                 ws.set_param(name, v)
     kept = []
+    first_init = 'trainedCOCO' in weights_file      # (:165: an ImageNet / COCO initialisation, not a checkpoint: its momentum is not restored)
     for name in model.params:
-        src_name = re.sub(r'^_\[[a-z]*\]_', '', name)
+        # (:186-195) a parameter named `_[xyz]_foo` that the file does not hold under that name is initialised from the file's `foo`
+        src_name = name[name.find(']_') + 2:] if (name.find(']_') >= 0 and name not in src) else name
         if src_name not in src:
             kept.append(name)
             continue
@@ -176,7 +177,7 @@ def initialize_from_weights_file(model, ws, weights_file, momentum=None):
                             np.asarray(src[src_name]).shape, shape)
                 continue
         ws.set_param(name, w)
-        if momentum is not None and src_name + '_momentum' in src:
+        if momentum is not None and not first_init and src_name + '_momentum' in src:
             m = np.asarray(src[src_name + '_momentum'], dtype=np.float32)
             if tuple(m.shape) == shape:
                 momentum[name] = m

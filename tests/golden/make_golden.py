@@ -5,12 +5,12 @@ Cython NMS/IoU compiled into oracle/_ref (oracle/build_ref.py).
 
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py            (everything; or one generator: --only-cfg | --only-roi-data | --only-lr | --only-blob |
-                                                   --only-decode | --only-tracker | --only-builders | --only-postproc)
+                                                   --only-decode | --only-tracker | --only-builders | --only-weights | --only-postproc)
 Writes tests/golden/: reference_host.npz (anchors, transforms, IoU / NMS, GenerateProposals, RoIToBatchFormat, level mapping, collect /
 distribute, inflation), reference_roi_data.npz (training labels, boxes and tubes), reference_lr_policy.npz (schedules + the momentum
 correction rule), reference_postproc.npz, reference_posetrack_annorect.json, reference_blob.npz, reference_decode.npz,
 reference_tracker.json, reference_cfg_defaults.json / reference_cfg_files.json, reference_builder_nets.json.gz (the graphs the
-reference's builder functions emit).  The shims do not change any arithmetic:
+reference's builder functions emit), reference_weights_load.npz (checkpoint loading).  The shims do not change any arithmetic:
   * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
     cPickle -> pickle, bytes config defaults decoded to str;
   * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
@@ -812,6 +812,81 @@ def golden_builders(cfg):
     print('wrote reference_builder_nets.json.gz', {k: len(v['net']) for k, v in out.items()})
 
 
+def weights_case(T=3):
+    """A crafted checkpoint + the model it is loaded into (name -> shape, in model order; name -> initialised value): an exact match, a 2D
+    kernel to inflate into a 3D one, a 2D tensor repeated T times along its output axis, a shape that cannot be inflated, a parameter the
+    file lacks, the `_[xyz]_foo <- foo` sharing rule with and without the full name in the file, momentum blobs, BN statistics and a
+    blob no parameter uses."""
+    rs = np.random.RandomState(41)
+    f32 = lambda *sh: rs.randn(*sh).astype(np.float32)
+    shapes = [('conv1_w', (4, 3, 1, 3, 3)), ('res2_w', (4, 4, 3, 3, 3)), ('res2_b', (4,)), ('pred_w', (6 * T, 8)), ('pred_b', (6 * T,)),
+              ('odd_w', (5, 7)), ('new_head_w', (3, 3)), ('_[pose]_fc_w', (2, 5)), ('_[mask]_fc_w', (2, 5)), ('fc_w', (2, 5))]
+    init = {n: f32(*sh) for n, sh in shapes}
+    blobs = {'conv1_w': f32(4, 3, 1, 3, 3), 'res2_w': f32(4, 4, 3, 3), 'res2_b': f32(4), 'pred_w': f32(6, 8), 'pred_b': f32(6),
+             'odd_w': f32(4, 7), 'fc_w': f32(2, 5), '_[mask]_fc_w': f32(2, 5), 'conv1_w_momentum': f32(4, 3, 1, 3, 3),
+             'res2_b_momentum': f32(4), 'res2_bn_rm': f32(4), 'res2_bn_riv': f32(4), 'unused_w': f32(2, 2)}
+    return shapes, init, blobs
+
+
+def golden_weights(cfg):
+    """lib/utils/net.py:163-249 initialize_gpu_0_from_weights_file ITSELF (with :72-161 inflate_weights) against a dict-backed stand-in
+    of the Caffe2 workspace: which blob of a checkpoint lands in which parameter, inflated how, which momentum blobs are restored, what
+    is preserved -> tests/golden/reference_weights_load.npz (every FeedBlob the reference makes, for both kinds of file name)."""
+    import pickle as _pickle
+    import tempfile
+    import utils.net as rnet
+    shapes, init, blobs = weights_case()
+    store = {}
+
+    class WS(object):
+        @staticmethod
+        def Blobs():
+            return list(store.keys())
+
+        @staticmethod
+        def FetchBlob(name):
+            return store[str(name)]
+
+        @staticmethod
+        def FeedBlob(name, arr):
+            store[str(name)] = np.asarray(arr)
+            fed.append(str(name))
+
+    class Ctx(object):
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    class Core(object):
+        NameScope = DeviceScope = staticmethod(lambda *a, **k: Ctx())
+        DeviceOption = staticmethod(lambda *a, **k: None)
+        ScopedName = staticmethod(lambda n: 'gpu_0/' + str(n))
+
+    class Pickle(object):           # (py2 opened pickles in text mode, :167)
+        load = staticmethod(lambda f: _pickle.load(open(f.name, 'rb')))
+    rnet.workspace, rnet.core, rnet.pickle = WS, Core, Pickle
+    rnet.utils.blob.unscope_name = lambda n: n[n.rfind('/') + 1:]
+    out = {}
+    cfg.VIDEO.WEIGHTS_INFLATE_MODE = 'center-only'
+    d = tempfile.mkdtemp()
+    for tag, fname in (('resume', 'model_iter99.pkl'), ('first', 'R-50_trainedCOCO.pkl')):
+        path = os.path.join(d, fname)
+        with open(path, 'wb') as f:
+            _pickle.dump({'blobs': blobs}, f, protocol=2)
+        store.clear()
+        store.update({'gpu_0/' + n: v.copy() for n, v in init.items()})
+        fed = []
+        model = type('M', (object,), {'params': ['gpu_0/' + n for n, _ in shapes]})()
+        rnet.initialize_gpu_0_from_weights_file(model, path)
+        out[tag + '_fed'] = np.array(fed)
+        for n in fed:
+            out[tag + ':' + n] = store[n]
+    np.savez_compressed(os.path.join(HERE, 'reference_weights_load.npz'), **out)
+    print('wrote reference_weights_load.npz', len(out), 'arrays;', list(out['resume_fed']))
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -863,6 +938,8 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-weights' in sys.argv:
+        golden_weights(_install_shims())
     elif '--only-lr' in sys.argv:
         golden_lr_policy(_install_shims())
     elif '--only-builders' in sys.argv:
@@ -884,3 +961,4 @@ if __name__ == '__main__':
         golden_blob(sys.modules['core.config'].cfg)
         golden_decode(sys.modules['core.config'].cfg)
         golden_builders(sys.modules['core.config'].cfg)
+        golden_weights(sys.modules['core.config'].cfg)

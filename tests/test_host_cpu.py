@@ -1408,3 +1408,50 @@ def test_momentum_correction_matches_the_reference_set_new_lr():
         assert lr_policy.momentum_correction(None, 0.02) is None            # the first iteration
     finally:
         reset_cfg()
+
+
+def test_checkpoint_loading_matches_the_real_reference():
+    """utils.net.initialize_from_weights_file against lib/utils/net.py:163-249 initialize_gpu_0_from_weights_file ITSELF (run on a
+    dict-backed workspace, tests/golden/make_golden.py golden_weights): exact matches, 2D -> 3D inflation, repeat-inflation of a
+    T-times-wider predictor, a shape that cannot be inflated (keeps its initialisation), a parameter the file lacks, `_[xyz]_foo <- foo`
+    only when the file has no `_[xyz]_foo`, momentum restored from a checkpoint but not from a `trainedCOCO` initialisation."""
+    import importlib.util
+    import pickle
+    import types
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import net as net_utils
+    spec = importlib.util.spec_from_file_location('make_golden_for_weights', os.path.join(REPO, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_weights_load.npz'))
+    shapes, init, blobs = mg.weights_case()
+    reset_cfg()
+    cfg.VIDEO.WEIGHTS_INFLATE_MODE = 'center-only'
+    import tempfile
+    d = tempfile.mkdtemp()
+    try:
+        for tag, fname in (('resume', 'model_iter99.pkl'), ('first', 'R-50_trainedCOCO.pkl')):
+            path = os.path.join(d, fname)
+            with open(path, 'wb') as f:
+                pickle.dump({'blobs': blobs}, f, protocol=2)
+            params = {n: v.copy() for n, v in init.items()}
+            ws = types.SimpleNamespace(params=params, set_param=lambda n, v, params=params: params.__setitem__(n, np.asarray(v, np.float32)))
+            model = types.SimpleNamespace(params=[n for n, _ in shapes],
+                                          param_specs={n: {'shape': sh, 'init': ('GaussianFill', {'std': 0.01})} for n, sh in shapes})
+            momentum = {}
+            kept = net_utils.initialize_from_weights_file(model, ws, path, momentum=momentum)
+            fed = [str(n) for n in g[tag + '_fed']]
+            for n, sh in shapes:
+                want = g[tag + ':gpu_0/' + n] if 'gpu_0/' + n in fed else init[n]
+                assert params[n].shape == tuple(sh) == want.shape, (tag, n)
+                np.testing.assert_array_equal(params[n], want, err_msg='%s %s' % (tag, n))
+            assert 'new_head_w' in kept and 'odd_w' in kept
+            np.testing.assert_array_equal(params['odd_w'], init['odd_w'])
+            np.testing.assert_array_equal(params['_[pose]_fc_w'], blobs['fc_w'])            # shared initialisation
+            np.testing.assert_array_equal(params['_[mask]_fc_w'], blobs['_[mask]_fc_w'])    # the file's own entry wins
+            want_m = sorted(n[len('gpu_0/'):-len('_momentum')] for n in fed if n.endswith('_momentum'))
+            assert sorted(momentum) == want_m == (['conv1_w', 'res2_b'] if tag == 'resume' else []), (tag, sorted(momentum), want_m)
+            for n in momentum:
+                np.testing.assert_array_equal(momentum[n], g[tag + ':gpu_0/' + n + '_momentum'])
+    finally:
+        reset_cfg()
