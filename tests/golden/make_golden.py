@@ -5,12 +5,12 @@ Cython NMS/IoU compiled into oracle/_ref (oracle/build_ref.py).
 
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py            (everything; or one generator: --only-cfg | --only-roi-data | --only-lr | --only-blob |
-                                                   --only-decode | --only-tracker | --only-builders | --only-weights | --only-postproc)
+                                                   --only-decode | --only-tracker | --only-builders | --only-weights | --only-clips | --only-postproc)
 Writes tests/golden/: reference_host.npz (anchors, transforms, IoU / NMS, GenerateProposals, RoIToBatchFormat, level mapping, collect /
 distribute, inflation), reference_roi_data.npz (training labels, boxes and tubes), reference_lr_policy.npz (schedules + the momentum
 correction rule), reference_postproc.npz, reference_posetrack_annorect.json, reference_blob.npz, reference_decode.npz,
 reference_tracker.json, reference_cfg_defaults.json / reference_cfg_files.json, reference_builder_nets.json.gz (the graphs the
-reference's builder functions emit), reference_weights_load.npz (checkpoint loading).  The shims do not change any arithmetic:
+reference's builder functions emit), reference_weights_load.npz (checkpoint loading), reference_clips.json (clip assembly).  The shims do not change any arithmetic:
   * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
     cPickle -> pickle, bytes config defaults decoded to str;
   * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
@@ -887,6 +887,32 @@ def golden_weights(cfg):
     print('wrote reference_weights_load.npz', len(out), 'arrays;', list(out['resume_fed']))
 
 
+CLIP_CASES = ((3, 1, (7, 3)), (4, 1, (7, 3)), (8, 1, (10, 2, 1)), (5, 2, (9, 4)), (4, 3, (11,)))
+
+
+def golden_clips(cfg):
+    """lib/utils/video.py:149-201 get_clip ITSELF on synthetic per-frame roidbs (its tube-building _combine_clips replaced by the one
+    line of it that matters to inference: the frame list, :70): which frames make the clip of every key frame, incl. the border
+    replication and VIDEO.TIME_INTERVAL -> tests/golden/reference_clips.json."""
+    import json
+    import types
+    import utils.video as rv
+    rv.tqdm = lambda it, **k: it
+    rv._combine_clips = lambda entry: {'image': [c['image'] for c in entry['clip_ids']]}
+    ds = type('DS', (object,), {'frames_from_video': False})()
+    out = []
+    for T, step, videos in CLIP_CASES:
+        cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID, cfg.VIDEO.TIME_INTERVAL = T, T, step
+        roidb = [{'image': '/data/vid%02d/%06d.jpg' % (v, f + 1), 'dataset': ds, 'flipped': False} for v, n in enumerate(videos) for f in range(n)]
+        clips = rv.get_clip(roidb)
+        out.append({'T': T, 'time_interval': step, 'videos': list(videos),
+                    'clips': [[int(os.path.splitext(os.path.basename(p))[0]) for p in c['image']] for c in clips]})
+    cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID, cfg.VIDEO.TIME_INTERVAL = 1, 1, 1
+    with open(os.path.join(HERE, 'reference_clips.json'), 'w') as f:
+        json.dump(out, f)
+    print('wrote reference_clips.json', [(c['T'], c['time_interval'], len(c['clips'])) for c in out])
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -938,6 +964,8 @@ if __name__ == '__main__':
         golden_postproc(_install_shims())
     elif '--only-tracker' in sys.argv:
         golden_tracker(_install_shims())
+    elif '--only-clips' in sys.argv:
+        golden_clips(_install_shims())
     elif '--only-weights' in sys.argv:
         golden_weights(_install_shims())
     elif '--only-lr' in sys.argv:
@@ -962,3 +990,4 @@ if __name__ == '__main__':
         golden_decode(sys.modules['core.config'].cfg)
         golden_builders(sys.modules['core.config'].cfg)
         golden_weights(sys.modules['core.config'].cfg)
+        golden_clips(sys.modules['core.config'].cfg)

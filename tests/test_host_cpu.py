@@ -1455,3 +1455,22 @@ def test_checkpoint_loading_matches_the_real_reference():
                 np.testing.assert_array_equal(momentum[n], g[tag + ':gpu_0/' + n + '_momentum'])
     finally:
         reset_cfg()
+
+
+def test_clip_assembly_matches_the_reference_get_clip():
+    """utils.video.clip_frame_ids against lib/utils/video.py:149-201 get_clip ITSELF (tests/golden/make_golden.py golden_clips): which
+    frames make the clip of every key frame -- odd and even T (the key frame sits at index T // 2), videos shorter than a clip, border
+    replication towards the key frame, VIDEO.TIME_INTERVAL > 1 -- and the synthetic-video tools build their clips with it."""
+    import json
+    from detectandtrack_amd.utils.video import clip_frame_ids
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_clips.json')) as f:
+        cases = json.load(f)
+    assert len(cases) == 5
+    for c in cases:
+        T, step = c['T'], c['time_interval']
+        got = [clip_frame_ids(k, 1, n, T, step) for n in c['videos'] for k in range(1, n + 1)]
+        assert got == c['clips'], (T, step)
+        assert all(clip[T // 2] == k for clip, k in zip(got, [k for n in c['videos'] for k in range(1, n + 1)]))
+    for tool in ('tools/test_net.py', 'tools/bench_config5.py'):
+        with open(os.path.join(REPO, tool)) as f:
+            assert 'clip_frame_ids(k, 0, n_frames - 1, T)' in f.read(), tool

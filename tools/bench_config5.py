@@ -22,6 +22,7 @@ import numpy as np
 import _path  # noqa
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+from detectandtrack_amd.utils.video import clip_frame_ids  # noqa: E402
 
 
 def video_roidb(n_videos, n_frames, T, h=720, w=1280, seed=3):
@@ -31,7 +32,7 @@ def video_roidb(n_videos, n_frames, T, h=720, w=1280, seed=3):
         base = [rs.randint(0, 255, (h, w, 3)).astype(np.uint8) for _ in range(4)]
         video = [base[i % 4] if i < 4 else np.roll(base[i % 4], 7 * i, axis=1) for i in range(n_frames)]
         for k in range(n_frames):
-            ids = [min(max(k - T // 2 + j, 0), n_frames - 1) for j in range(T)]
+            ids = clip_frame_ids(k, 0, n_frames - 1, T)           # (lib/utils/video.py:149-201: one clip per key frame, borders replicated)
             roidb.append({'image': [video[i] for i in ids], 'frame_ids': [('vid%04d' % v, i) for i in ids], 'height': h, 'width': w,
                           'name': 'images/vid%04d/%06d.jpg' % (v, k)})
     return roidb
