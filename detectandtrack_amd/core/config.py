@@ -268,11 +268,15 @@ def _build_defaults():
     # DEVICE_ROI_SAMPLING (training): GenerateProposalLabels as one device kernel on the device-resident proposals (roi_data/device_sampler.py,
     # dat_sample_rois: the reference's candidate sets and counts, a counter-based draw instead of NumPy's stream); False = the host restatement
     # of lib/roi_data/fast_rcnn.py on a copy of the proposals (bit-compatible with the reference's numpy.random stream)
+    # DECONV_GROUP_IGNORED: the keypoint deconv of a 3D head without KRCNN.NO_3D_DECONV_TIME_TO_CH is recorded with group = T
+    # (model_builder.py:848-856).  False (default): a grouped ConvTranspose in Caffe2's filter layout (C_in, C_out / group, k, k) -- frame t
+    # has its own [C, K, 4, 4] block.  True: what the pinned Caffe2 (b4e1588, Feb 2018: ConvTranspose has no `group` argument yet and brew
+    # creates the full [T*C, T*K, 4, 4] filter) would execute -- the argument is dropped and the deconv is dense over T*C -> T*K channels
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
                       'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
                       'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
-                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True})
+                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True, 'DECONV_GROUP_IGNORED': False})
     return c
 
 

@@ -246,12 +246,16 @@ class DetectionModelHelper(object):
 
     def ConvTranspose(self, blob_in, blob_out, dim_in, dim_out, kernel, pad=0, stride=1, group=1, weight_init=None,
                       bias_init=None, **kw):
-        assert kernel == 4 and stride == 2 and pad == 1 and group == 1, \
-            'only the k4/s2/p1 keypoint deconv is on the hot path (model_builder.py:848-856)'
+        assert kernel == 4 and stride == 2 and pad == 1, 'only the k4/s2/p1 keypoint deconv is on the hot path (model_builder.py:848-856)'
+        assert group >= 1 and dim_in % group == 0 and dim_out % group == 0, (dim_in, dim_out, group)
         blob_out = str(blob_out)
-        w = self._param(blob_out + '_w', [dim_in, dim_out, kernel, kernel], weight_init or ('XavierFill', {}), 'w')
+        # filter layout: Caffe2's (C_in, C_out / group, kH, kW); with cfg.HIP.DECONV_GROUP_IGNORED the full [dim_in, dim_out, k, k] blob
+        # that brew.conv_transpose creates whatever the group (see workspace.Executor.op_ConvTranspose)
+        per_group = dim_out // group if (group > 1 and not cfg.HIP.get('DECONV_GROUP_IGNORED', False)) else dim_out
+        w = self._param(blob_out + '_w', [dim_in, per_group, kernel, kernel], weight_init or ('XavierFill', {}), 'w')
         b = self._param(blob_out + '_b', [dim_out], bias_init or ('ConstantFill', {'value': 0.}), 'b')
-        return self.net.add(Op('ConvTranspose', [str(blob_in)], [blob_out], w=w, b=b, dim_in=dim_in, dim_out=dim_out))
+        extra = {'group': int(group)} if group > 1 else {}
+        return self.net.add(Op('ConvTranspose', [str(blob_in)], [blob_out], w=w, b=b, dim_in=dim_in, dim_out=dim_out, **extra))
 
     def BilinearInterpolation(self, blob_in, blob_out, dim_in, dim_out, up_scale):
         """detector.py:348-380: fixed (non-trainable) bilinear ConvTranspose, kernel 2*up, stride up, pad up/2."""
@@ -270,6 +274,10 @@ class DetectionModelHelper(object):
     def MoveTimeToBatchDim(self, blob_in, blob_out=None):
         blob_out = blob_out or str(blob_in) + '_MovedTimeToBatchDim'
         return self.net.add(Op('TimeToBatch', [str(blob_in)], [str(blob_out)]))
+
+    def GetTemporalDim(self, blob_in):
+        """detector.py:440-465 makes a shape blob; here the frame count travels with the blob (workspace.Blob.T): a symbolic handle."""
+        return ('T', str(blob_in))
 
     def MoveTimeToBatchDimInverse(self, blob_in, blob_out, temporal_dim):
         blob_out = blob_out or str(blob_in) + '_MovedTimeToBatchDimInv'

@@ -246,22 +246,37 @@ def add_rpn_losses(model, time_dim=1):
 # ---- keypoint heatmap outputs (:755-870) ----------------------------------------------------------------------------------
 def add_heatmap_outputs(model, blob_in, dim, time_dim, is_head_3d):
     """Trunk output -> ConvTranspose k4 s2 (K maps, 2x) -> fixed bilinear ConvTranspose (UP_SCALE x).  With a 3D
-    head the deconvs run per frame (NO_3D_DECONV_TIME_TO_CH: time -> batch, :760-764) and the K maps of the T frames
-    end up channel-concatenated as t*K + k (:864-868)."""
+    head the deconvs run per frame, either with shared weights (NO_3D_DECONV_TIME_TO_CH: time -> batch, :760-764; what the
+    shipped 3D configs set) or -- the reference default -- with one weight block per frame (time -> channels + group = T,
+    :765-767, :848-856); either way the K maps of the T frames end up channel-concatenated as t*K + k (:864-868)."""
     if is_head_3d and cfg.KRCNN.USE_3D_DECONV:
         raise NotImplementedError('ConvTranspose3D is unavailable in the reference too (utils/net.py:55-56)')
-    if is_head_3d and not cfg.KRCNN.NO_3D_DECONV_TIME_TO_CH:
-        raise NotImplementedError('time->channel grouped deconv variant: use KRCNN.NO_3D_DECONV_TIME_TO_CH True '
-                                  '(what the shipped 3D configs set)')
     if cfg.KRCNN.USE_DECONV:
         raise NotImplementedError('KRCNN.USE_DECONV intermediate deconv is not used by any shipped config')
     if cfg.KRCNN.UP_SCALE == 1 or not cfg.KRCNN.USE_DECONV_OUTPUT:
         raise NotImplementedError('shipped configs use USE_DECONV_OUTPUT True with UP_SCALE 2')
     K = cfg.KRCNN.NUM_KEYPOINTS
     pad = int(cfg.KRCNN.DECONV_KERNEL / 2 - 1)
+    winit, binit = (cfg.KRCNN.CONV_INIT, {'std': 0.001}), ('ConstantFill', {'value': 0.})
+    if is_head_3d and not cfg.KRCNN.NO_3D_DECONV_TIME_TO_CH:
+        # the reference DEFAULT (core/config.py:472, :765-767 / :848-868): time -> channels (index t*C + c), ONE grouped deconv with
+        # group = time_dim -- frame t has its own [C, K, 4, 4] weight block and its own K biases -- and the fixed bilinear deconv on
+        # the T*K maps; `kps_score` comes out as (R, T*K, M, M) directly
+        blob_in = model.MoveTimeToChannelDim(blob_in, None)
+        low = model.ConvTranspose(blob_in, 'kps_score_lowres', dim * time_dim, K * time_dim, cfg.KRCNN.DECONV_KERNEL, pad=pad, stride=2,
+                                  group=time_dim, weight_init=winit, bias_init=binit)
+        return model.BilinearInterpolation(low, 'kps_score', K * time_dim, K * time_dim, cfg.KRCNN.UP_SCALE)
     if is_head_3d:
+        original_time_dim = model.GetTemporalDim(blob_in)
         blob_in = model.MoveTimeToBatchDim(blob_in, None)
     low = model.ConvTranspose(blob_in, 'kps_score_lowres', dim, K, cfg.KRCNN.DECONV_KERNEL, pad=pad, stride=2,
-                              weight_init=(cfg.KRCNN.CONV_INIT, {'std': 0.001}),
-                              bias_init=('ConstantFill', {'value': 0.}))
-    return model.BilinearInterpolation(low, 'kps_score', K, K, cfg.KRCNN.UP_SCALE)
+                              weight_init=winit, bias_init=binit)
+    if not is_head_3d:
+        return model.BilinearInterpolation(low, 'kps_score', K, K, cfg.KRCNN.UP_SCALE)
+    # :858-868: the up-sampled maps of the R*T frames, then batch -> time and time -> channels: (R*T, K, M, M) -> (R, K, T, M, M) ->
+    # (R, T*K, M, M).  The executor's output kernel writes that last layout directly; the two moves are views of it.  (Like the reference,
+    # the function returns the pre-move blob.)
+    blob_out = model.BilinearInterpolation(low, 'kps_score_prefinal', K, K, cfg.KRCNN.UP_SCALE)
+    model.MoveTimeToBatchDimInverse('kps_score_prefinal', 'kps_score_prefinal2', original_time_dim)
+    model.MoveTimeToChannelDim('kps_score_prefinal2', 'kps_score')
+    return blob_out

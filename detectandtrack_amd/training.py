@@ -545,6 +545,8 @@ class TrainExecutor(Executor):
         if dy is None:
             return
         x = ws.blobs[op.inputs[0]]
+        if x.t2c:
+            return self._bwd_deconv_over_time_channels(op, x, y, dy)
         K, Cin = a['dim_out'], a['dim_in']
         dbias4 = torch.zeros(4 * K, dtype=torch.float32, device=ws.device)
         g = ops.relu_bias_bwd(dy, y.t, y.dt, 4 * K, relu=False, dbias=dbias4)
@@ -553,9 +555,15 @@ class TrainExecutor(Executor):
         w3 = ops.deconv_k4s2_as_conv3x3(w)             # [4K, Cin, 1, 3, 3]
         cg = ops.ConvGrad(w3, None, (1, 1), (0, 1, 1), y.dt, x.t.shape[3], g.shape[3])
         dW3, _ = cg.weight(x.t, g, 1)                  # [4K, Cin, 1, 3, 3]
-        # transpose of the sub-pixel weight map (elementwise.hip deconv_k4s2_weights_kernel): every (ky, kx) of the 4x4
-        # kernel appears exactly once, at sub-pixel (a, b) = ((ky+1)&1, (kx+1)&1), tap dy = (a + 1 - ky) / 2
-        # -- one gather over index tables instead of sixteen strided copies into a zeroed tensor
+        self._pgrad(a['w'], self._deconv_filter_grad(dW3, K, Cin))
+        f, H, W, _ = x.t.shape
+        self._add_grad(op.inputs[0], cg.data(g, 1, H, W))
+
+    def _deconv_filter_grad(self, dW3, K, Cin):
+        """Gradient of the sub-pixel conv weight [4K, Cin, 1, 3, 3] -> gradient of the ConvTranspose filter [Cin, K, 4, 4]: the transpose of
+        the sub-pixel weight map (elementwise.hip deconv_k4s2_weights_kernel) -- every (ky, kx) of the 4x4 kernel appears exactly once,
+        at sub-pixel (a, b) = ((ky+1)&1, (kx+1)&1), tap dy = (a + 1 - ky) / 2: one gather over index tables instead of sixteen strided
+        copies into a zeroed tensor."""
         d4 = dW3.view(2, 2, K, Cin, 3, 3)
         idx = getattr(self, '_deconv_idx', None)
         if idx is None or idx[0].device != d4.device:
@@ -567,9 +575,41 @@ class TrainExecutor(Executor):
             idx = self._deconv_idx = tuple(t.contiguous().to(d4.device) for t in (AA, BB, TY, TX))
         AA, BB, TY, TX = idx
         dw = d4.permute(0, 1, 4, 5, 3, 2)[AA, BB, TY, TX]                  # [4, 4, Cin, K]
-        self._pgrad(a['w'], dw.permute(2, 3, 0, 1))
-        f, H, W, _ = x.t.shape
-        self._add_grad(op.inputs[0], cg.data(g, 1, H, W))
+        return dw.permute(2, 3, 0, 1)
+
+    def _bwd_deconv_over_time_channels(self, op, x, y, dy):
+        """Backward of workspace.Executor._deconv_over_time_channels (the reference-default keypoint deconv over time-moved-to-channels,
+        model_builder.py:765-767 / :848-856): the head has ONE output frame per roi and T input frames, so every input frame t gets its own
+        data gradient through its own [4*T*K, C] filter slice -- T plain sub-pixel-conv gradients (the FPN tube RPN head does the same,
+        _bwd_rpn_head).  With group = T only the diagonal [C, K] blocks are parameters: the gradient of block t is read off frame t's
+        slice."""
+        ws, a = self.ws, op.args
+        T, C = x.T, x.C
+        TK = a['dim_out']
+        R = x.N
+        dbias4 = torch.zeros(4 * TK, dtype=torch.float32, device=ws.device)
+        g = ops.relu_bias_bwd(dy, y.t, y.dt, 4 * TK, relu=False, dbias=dbias4)
+        self._pgrad(a['b'], dbias4.view(4, TK).sum(0))
+        w = self._master(a['w'])
+        group = self._deconv_group(a, w)
+        dense = self.deconv_dense_filter(w, T, group)                   # [T*C, T*K, 4, 4]
+        w3 = ops.deconv_k4s2_as_conv3x3(dense).view(4 * TK, T, C, 1, 3, 3)
+        f, H, W, cs = x.t.shape
+        xv = x.t.view(R, T, H, W, cs)
+        dxs, dWs = [], []
+        for t in range(T):
+            cg = ops.ConvGrad(w3[:, t].contiguous(), None, (1, 1), (0, 1, 1), y.dt, cs, g.shape[3])
+            dW_t, _ = cg.weight(xv[:, t].contiguous(), g, 1)            # [4TK, C, 1, 3, 3]
+            dWs.append(self._deconv_filter_grad(dW_t, TK, C))           # [C, T*K, 4, 4]: rows t*C.. of the dense filter's gradient
+            if op.inputs[0] not in self.no_grad:
+                dxs.append(cg.data(g, 1, H, W))
+        if group == 1:
+            self._pgrad(a['w'], torch.cat(dWs, dim=0))
+        else:
+            k = TK // T
+            self._pgrad(a['w'], torch.cat([dWs[t][:, t * k:(t + 1) * k] for t in range(T)], dim=0).contiguous())
+        if dxs:
+            self._add_grad(op.inputs[0], torch.stack(dxs, dim=1).reshape(f, H, W, dxs[0].shape[3]))
 
     def bwd_BilinearInterpolation(self, i, op):
         ws = self.ws
@@ -630,6 +670,7 @@ class TrainExecutor(Executor):
             self.grads.setdefault(op.inputs[0], []).extend(self.grads.pop(op.outputs[0]))
 
     bwd_Alias = bwd_TimeToBatch
+    bwd_BatchToTime = bwd_TimeToBatch       # (views of the keypoint maps in the order they were written: the gradient passes through as it is)
 
     def bwd_RoIFeatureTransform(self, i, op):
         ws, a = self.ws, op.args

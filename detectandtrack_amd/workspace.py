@@ -673,6 +673,12 @@ class Executor(object):
 
     def op_TimeToChannel(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
+        if x.kind == 'mat':     # (R, K, T, M, M) keypoint maps (op_BatchToTime) -> (R, T*K, M, M): back to the memory order they were written in
+            assert x.five_d and x.t.dim() == 5
+            v = x.t.permute(0, 2, 1, 3, 4)
+            assert v.is_contiguous()
+            self.ws.blobs[op.outputs[0]] = Blob(v.reshape(v.shape[0], v.shape[1] * v.shape[2], v.shape[3], v.shape[4]), 'mat')
+            return
         b = Blob(x.t, 'fmap', x.N, x.T, x.C, x.dt, False)
         b.t2c = True
         self.ws.blobs[op.outputs[0]] = b
@@ -843,6 +849,9 @@ class Executor(object):
     def op_ConvTranspose(self, i, op):
         ws, a, dt = self.ws, op.args, _dt(self.ws)
         x = ws.blobs[op.inputs[0]]
+        if x.t2c:
+            return self._deconv_over_time_channels(i, op, x)
+        assert a.get('group', 1) == 1, 'a grouped ConvTranspose reads a time -> channel blob (model_builder.py:765-767)'
 
         def build():
             w3 = ops.deconv_k4s2_as_conv3x3(ws.dev_param(a['w']))
@@ -857,11 +866,71 @@ class Executor(object):
         b = Blob(y, 'fmap', x.N, x.T, 4 * a['dim_out'], dt, x.five_d)
         ws.blobs[op.outputs[0]] = b
 
+    @staticmethod
+    def deconv_dense_filter(w, T, group):
+        """The [T*C, T*K, 4, 4] filter of the deconv over time-moved-to-channels: `w` itself when it already has that shape (group
+        dropped, cfg.HIP.DECONV_GROUP_IGNORED), else the block-diagonal expansion of the grouped filter [T*C, K, 4, 4] -- block t
+        (input channels t*C.., output maps t*K..) = w[t*C:(t+1)*C]."""
+        tc, kk = int(w.shape[0]), int(w.shape[1])
+        if group == 1:
+            return w
+        assert group == T and tc % T == 0, (tuple(w.shape), T, group)
+        c = tc // T
+        dense = torch.zeros((tc, T * kk) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+        for t in range(T):
+            dense[t * c:(t + 1) * c, t * kk:(t + 1) * kk] = w[t * c:(t + 1) * c]
+        return dense
+
+    def _deconv_group(self, a, w):
+        """The group count the op EXECUTES with: the recorded one when the filter is in the grouped layout, 1 when it is the full brew blob."""
+        g = int(a.get('group', 1))
+        return g if (g > 1 and int(w.shape[1]) * g == a['dim_out']) else 1
+
+    def _deconv_over_time_channels(self, i, op, x):
+        """ConvTranspose k4 s2 on a blob whose T frames were moved into channels (index t*C + c; model_builder.py:765-767, :848-856 --
+        the reference default KRCNN.NO_3D_DECONV_TIME_TO_CH False): the sub-pixel 3 x 3 conv with KT = T temporal taps, no temporal
+        padding, output frame 0 only -- ONE launch per forward, the transposed copy never exists.  group = T (one [C, K, 4, 4] block per
+        frame) runs as the block-diagonal case of the same launch (T = 3: 0.3 GFLOP per 100 rois either way).  Output: one frame per
+        roi with 4*T*K sub-pixel channels, map index t*K + k."""
+        ws, a, dt = self.ws, op.args, _dt(self.ws)
+        T, C = x.T, x.C
+        assert a['dim_in'] == T * C and a['dim_out'] % T == 0, (a['dim_in'], a['dim_out'], T, C)
+
+        def build():
+            w = ws.dev_param(a['w'])
+            dense = self.deconv_dense_filter(w, T, self._deconv_group(a, w))        # [T*C, T*K, 4, 4]
+            w3 = ops.deconv_k4s2_as_conv3x3(dense)                                    # [4*T*K, T*C, 1, 3, 3]
+            w3 = w3.reshape(w3.shape[0], T, C, 3, 3).permute(0, 2, 1, 3, 4).contiguous()
+            bias = ws.dev_param(a['b']).repeat(4)
+            return ops.ConvLayer(w3, None, bias, stride=(1, 1), pads=(0, 1, 1), relu=False, dtype=dt,
+                                 cin_stride=x.t.shape[3], x3=_x3(self.ws))
+        layer = self._layer(i, build)
+        if ws.conv_log is not None:
+            g = self._deconv_group(a, ws.dev_param(a['w']))
+            ws.conv_log.append((op.outputs[0], 2.0 * a['dim_in'] * a['dim_out'] / g * 16 * x.N * x.t.shape[1] * x.t.shape[2],
+                                layer.hbm_bytes(x.t.shape[0], x.t.shape[1], x.t.shape[2], oframes=x.N)))
+        y = layer(x.t, T=T, out_t=(0, 1), zero_pad=not self._pad_unread(op.outputs[0]))
+        b = Blob(y, 'fmap', x.N, 1, 4 * a['dim_out'], dt, False)
+        b.count = x.count
+        ws.blobs[op.outputs[0]] = b
+
     def op_BilinearInterpolation(self, i, op):
         x = self.ws.blobs[op.inputs[0]]
         K = op.args['dim']
-        out = ops.kps_finalize(x.t, x.dt, x.N, x.T, K, op.args['up_scale'])
-        self.ws.blobs[op.outputs[0]] = Blob(out, 'mat')
+        out = ops.kps_finalize(x.t, x.dt, x.N, x.T, K, op.args['up_scale'])        # (R, T*K, M, M), map index t*K + k
+        # a 3D head whose frames sit in the batch axis (model_builder.py:760-764): the blob the reference has here is (R*T, K, M, M) -- the
+        # same memory; BatchToTime / TimeToChannel (:864-868) are views that end at the (R, T*K, M, M) the kernel wrote.  (T = 1: the same)
+        self.ws.blobs[op.outputs[0]] = Blob(out.view(x.N * x.T, K, out.shape[2], out.shape[3]), 'mat', x.N, x.T, K)
+
+    def op_BatchToTime(self, i, op):
+        """detector.py:513-534 on the up-sampled keypoint maps: (R*T, K, M, M) -> (R, K, T, M, M), a strided view (FetchBlob copies it out
+        in the reference's order; the TimeToChannel that follows undoes the transpose)."""
+        x = self.ws.blobs[op.inputs[0]]
+        assert x.kind == 'mat' and x.t.dim() == 4 and x.T >= 1 and x.t.shape[0] == x.N * x.T, 'BatchToTime: keypoint maps of a 3D head only'
+        v = x.t.view((x.N, x.T) + tuple(x.t.shape[1:])).permute(0, 2, 1, 3, 4)
+        b = Blob(v, 'mat', x.N, x.T, x.C)
+        b.five_d = True
+        self.ws.blobs[op.outputs[0]] = b
 
     def __getattr__(self, name):
         if name.startswith('op_'):

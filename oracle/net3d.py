@@ -266,12 +266,32 @@ class Net(object):
         x = _t(roi_align_tube(feat.numpy(), kp_rois, o['kps_res'], 1. / 16., o['kps_sampling']))
         for i in range(o['kps_num_convs']):
             x = F.relu(self.conv_nd(x, 'conv_fcn%d' % (i + 1), [kt, 3, 3], [1, 1, 1], [kt // 2, 1, 1]))
+        return self.kps_outputs_tube(x)
+
+    def kps_outputs_tube(self, x):
+        """model_builder.py:755-870 on a 3D head output (R, C, T, H, W).  o['kps_time_to_ch'] False: KRCNN.NO_3D_DECONV_TIME_TO_CH True
+        (:760-764 time -> batch, the 2D deconvs with shared weights, :864-868 batch -> time, time -> channel).  True: the reference default
+        (:765-767 MoveTimeToChannelDim = detector.py:480-491 Transpose(0,2,1,3,4) + Reshape: channel t*C + c; :848-856 ConvTranspose
+        dim*T -> K*T with group = T; :858-863 the bilinear deconv over K*T maps).  The filter decides what `group` means: Caffe2's grouped
+        layout (T*C, K, 4, 4) -> groups = T; the full (T*C, T*K, 4, 4) blob brew.conv_transpose creates -> the argument dropped (dense), which
+        is what a Caffe2 without ConvTranspose group support executes."""
         R, C, T, H, W = x.shape
-        xb = x.permute(0, 2, 1, 3, 4).reshape(R * T, C, H, W)
-        y = self.kps_outputs_2d(xb)  # (R*T, 17, 56, 56)
-        K, M = y.shape[1], y.shape[2]
-        # batch->time: (R, T, K, M, M) -> (R, K, T, M, M); time->channel: -> (R, T*K, M, M)
-        return y.reshape(R, T, K, M, M).reshape(R, T * K, M, M)
+        if not self.o.get('kps_time_to_ch', False):
+            xb = x.permute(0, 2, 1, 3, 4).reshape(R * T, C, H, W)
+            y = self.kps_outputs_2d(xb)  # (R*T, 17, 56, 56)
+            K, M = y.shape[1], y.shape[2]
+            # batch->time: (R, T, K, M, M) -> (R, K, T, M, M); time->channel: -> (R, T*K, M, M)
+            return y.reshape(R, T, K, M, M).reshape(R, T * K, M, M)
+        x2 = x.permute(0, 2, 1, 3, 4).reshape(R, T * C, H, W)
+        w = _t(self.w['kps_score_lowres_w'])
+        b = _t(self.w['kps_score_lowres_b'])
+        assert w.shape[0] == T * C and b.shape[0] % T == 0, (w.shape, b.shape, T, C)
+        groups = T if w.shape[1] * T == b.shape[0] else 1
+        assert w.shape[1] * groups == b.shape[0]
+        low = F.conv_transpose2d(x2, w, b, stride=2, padding=1, groups=groups)
+        self.blobs['kps_score_lowres'] = low
+        up = self.o['kps_up_scale']
+        return F.conv_transpose2d(low, _t(bilinear_kernel(low.shape[1], up)), None, stride=up, padding=up // 2)
 
 
     # ---- FPN tube path (declared extension, SURVEY.md §8 f-1) -----------------------------------------------
@@ -330,10 +350,7 @@ class Net(object):
         x = _t(roi_feat)
         for i in range(o['kps_num_convs']):
             x = F.relu(self.conv_nd(x, 'conv_fcn%d' % (i + 1), [kt, 3, 3], [1, 1, 1], [kt // 2, 1, 1]))
-        R, C, T, H, W = x.shape
-        y = self.kps_outputs_2d(x.permute(0, 2, 1, 3, 4).reshape(R * T, C, H, W))
-        K, M = y.shape[1], y.shape[2]
-        return y.reshape(R, T * K, M, M)
+        return self.kps_outputs_tube(x)
 
 
 def bilinear_kernel(dim, up_scale):
@@ -354,7 +371,7 @@ DEFAULT_OPTS = dict(
     rpn_anchor_start=32, rpn_aspect_ratios=(0.5, 1, 2), pre_nms_topn=1000, post_nms_topn=1000,
     rpn_nms_thresh=0.7, rpn_min_size=0, rpn_sizes=(64, 128, 256, 512), rpn_c4_aspect_ratios=(0.5, 1, 2),
     frcn_res=7, frcn_sampling=2, kps_res=14, kps_sampling=2, kps_num_convs=8, kps_up_scale=2,
-    res5_blocks=2, res5_dim=512,
+    res5_blocks=2, res5_dim=512, kps_time_to_ch=False,
 )
 
 

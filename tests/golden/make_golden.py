@@ -10,7 +10,7 @@ Writes tests/golden/: reference_host.npz (anchors, transforms, IoU / NMS, Genera
 distribute, inflation), reference_roi_data.npz (training labels, boxes and tubes), reference_lr_policy.npz (schedules + the momentum
 correction rule), reference_postproc.npz, reference_posetrack_annorect.json, reference_blob.npz, reference_decode.npz,
 reference_tracker.json, reference_cfg_defaults.json / reference_cfg_files.json, reference_builder_nets.json.gz (the graphs the
-reference's builder functions emit), reference_weights_load.npz (checkpoint loading), reference_clips.json (clip assembly).  The shims do not change any arithmetic:
+reference's builder functions emit) + reference_heatmap_outputs.json (the keypoint output function on a 3D head, both deconv variants), reference_weights_load.npz (checkpoint loading), reference_clips.json (clip assembly).  The shims do not change any arithmetic:
   * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
     cPickle -> pickle, bytes config defaults decoded to str;
   * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
@@ -805,6 +805,23 @@ def golden_builders(cfg):
                     rec['roi_transforms'].append({'fused': net_signature(types.SimpleNamespace(ops=[o]))[0], 'expansion': net_signature(r.net),
                                                   'returns': str(ret)})
             out[name + ('_train' if train else '')] = rec
+    # the keypoint OUTPUT function on a 3D head, both settings of KRCNN.NO_3D_DECONV_TIME_TO_CH (model_builder.py:755-870 run on the
+    # recorder with the arguments build_generic_fast_rcnn_model passes for a T = 3 tube head): False is the reference DEFAULT
+    # (core/config.py:472) -- time -> channels, ConvTranspose with group = time_dim over dim*T -> K*T channels, the bilinear deconv on
+    # K*T maps; True is what the shipped 3D configs set (time -> batch ... batch -> time, time -> channels)
+    heat = {}
+    for no_t2c in (False, True):
+        reset_cfg()
+        cfg_from_cfg(model_util.c4_tube_kps_cfg(T=3, deconv='time_to_batch' if no_t2c else 'grouped'))
+        assert_and_infer_cfg()
+        mirror(cfg, my_cfg)
+        assert cfg.KRCNN.NO_3D_DECONV_TIME_TO_CH == no_t2c
+        r = Recorder(name='heat', train=False, num_classes=cfg.MODEL.NUM_CLASSES)
+        ret = rmb.add_heatmap_outputs(r, 'conv_fcn8', cfg.KRCNN.CONV_HEAD_DIM, 3, True)
+        heat['no_3d_deconv_time_to_ch_%s' % no_t2c] = {'ops': net_signature(r.net), 'returns': str(ret), 'params': [str(p) for p in r.params]}
+    with open(os.path.join(HERE, 'reference_heatmap_outputs.json'), 'w') as f:
+        json.dump(heat, f, sort_keys=True, indent=1)
+    print('wrote reference_heatmap_outputs.json', {k: [o[0] for o in v['ops']] for k, v in heat.items()})
     reset_cfg()
     import gzip
     with gzip.GzipFile(os.path.join(HERE, 'reference_builder_nets.json.gz'), 'wb', mtime=0) as f:

@@ -59,14 +59,18 @@ def oracle_opts(arch, T, kt, link, pre, post):
                     post_nms_topn=post)
 
 
-def c4_tube_kps_cfg(T=3, kt=3, pre=300, post=60, dtype='fp32'):
+def c4_tube_kps_cfg(T=3, kt=3, pre=300, post=60, dtype='fp32', deconv='time_to_batch'):
     """The shipped 3D configuration (configs/video/3d/04_R-18-3D_PTFromImNet.yaml): ResNet-18 3D C4 body, tube RPN,
-    per-RoI res5 head, 3D keypoint head."""
+    per-RoI res5 head, 3D keypoint head.  deconv: 'time_to_batch' (KRCNN.NO_3D_DECONV_TIME_TO_CH True, what the shipped configs
+    set) | 'grouped' (the reference default: time -> channels + ConvTranspose group = T) | 'group_ignored' (the same graph with the
+    full brew filter and the group argument dropped, cfg.HIP.DECONV_GROUP_IGNORED)."""
     d = fpn3d_kps_cfg('18', T=T, kt=kt, link='', pre=pre, post=post, dtype=dtype)
     d['MODEL'].update(CONV_BODY='ResNet3D.add_ResNet18_conv4_body', ROI_HEAD='ResNet3D.add_ResNet18_roi_conv5_head')
     d['FPN'] = {'FPN_ON': False, 'MULTILEVEL_ROIS': False, 'MULTILEVEL_RPN': False}
+    assert deconv in ('time_to_batch', 'grouped', 'group_ignored')
     d['KRCNN'].update(ROI_KEYPOINTS_HEAD='keypoint_rcnn_heads.add_roi_pose_head_v1convX_3d',
-                      NO_3D_DECONV_TIME_TO_CH=True)
+                      NO_3D_DECONV_TIME_TO_CH=(deconv == 'time_to_batch'))
+    d['HIP']['DECONV_GROUP_IGNORED'] = (deconv == 'group_ignored')
     return d
 
 

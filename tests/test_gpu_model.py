@@ -209,22 +209,29 @@ def test_frame_trunk_cache_gives_identical_sliding_window_results(dtype):
             np.testing.assert_array_equal(a, b)
 
 
-def test_c4_tube_forward_matches_oracle():
+@pytest.mark.parametrize('deconv,T', [('time_to_batch', 3), ('grouped', 3), ('group_ignored', 3), ('grouped', 2)])
+def test_c4_tube_forward_matches_oracle(deconv, T):
     """The shipped 3D configuration (configs/video/3d/04_R-18-3D_*.yaml): 3D C4 body -> tube RPN (logits averaged
     over T, per-frame deltas) -> tube RoIAlign -> per-RoI res5 -> T-averaged class scores / per-frame box deltas,
-    and the 3D keypoint head with per-frame deconvs (heatmap channels t*K + k)."""
+    and the 3D keypoint head with per-frame deconvs (heatmap channels t*K + k) -- with the shipped configs' time -> batch deconv
+    (shared weights) and with the reference DEFAULT, KRCNN.NO_3D_DECONV_TIME_TO_CH False (model_builder.py:765-767, :848-868: time ->
+    channels, ConvTranspose group = T on T*C -> T*K channels, bilinear deconv over T*K maps), in both readings of `group`."""
     from oracle.net3d import Net, opts_for
     from tests.model_util import c4_tube_kps_cfg
-    T, H, W = 3, 96, 128
+    H, W = 96, 128
     pre, post = 300, 60
-    model, ws, weights = build_product(c4_tube_kps_cfg(T=T, pre=pre, post=post))
+    model, ws, weights = build_product(c4_tube_kps_cfg(T=T, pre=pre, post=post, deconv=deconv))
+    Ck = 512
+    assert weights['kps_score_lowres_w'].shape == {'time_to_batch': (Ck, 17, 4, 4), 'grouped': (T * Ck, 17, 4, 4),
+                                                   'group_ignored': (T * Ck, T * 17, 4, 4)}[deconv]
+    assert weights['kps_score_lowres_b'].shape == ((17,) if deconv == 'time_to_batch' else (T * 17,))
     data = synthetic_clip(T, H, W)
     im_info = np.array([[H, W, 1.0]], dtype=np.float32)
     ws.FeedBlob('data', data)
     ws.FeedBlob('im_info', im_info)
     ws.RunNet(model.net.name)
     net = Net(weights, opts_for('R18', block_counts=(2, 2, 2), kt_body=3, kt_rpn=3, kt_kps=3, body_head_link='',
-                                num_frames_mid=T, pre_nms_topn=pre, post_nms_topn=post))
+                                num_frames_mid=T, pre_nms_topn=pre, post_nms_topn=post, kps_time_to_ch=deconv != 'time_to_batch'))
     feat = net.body(torch.from_numpy(data))
     got = ws.FetchBlob('res4_1_sum')
     assert got.shape == tuple(feat.shape)

@@ -431,10 +431,12 @@ def test_deferred_weight_gradient_finish_gives_the_immediate_gradients(ops):
     assert np.median(list(errs.values())) < 2e-4 and errs[worst] < 2e-2, (worst, errs[worst])
 
 
-def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
+@pytest.mark.parametrize('deconv', ['time_to_batch', 'grouped', 'group_ignored'])
+def test_c4_tube_train_step_gradients_match_oracle_autograd(ops, deconv):
     """The shipped 3D configuration (configs/video/3d/04_R-18-3D_*.yaml) in TRAINING mode: tube RPN losses on the per-frame head
     (T-averaged logits), tube RoIAlign, per-RoI res5, T-averaged class scores, regrouped tube deltas, 3D keypoint head: all
-    losses and the gradient of every trainable parameter vs autograd on the oracle."""
+    losses and the gradient of every trainable parameter vs autograd on the oracle.  deconv: the shipped time -> batch keypoint deconv
+    and the reference default (time -> channels, group = T; model_builder.py:765-767, :848-868) in both readings of `group`."""
     from tests.model_util import c4_tube_kps_cfg, synthetic_clip
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
@@ -445,7 +447,7 @@ def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
     from oracle import train_ref
     from oracle.net3d import opts_for
     T, H, W = 3, 96, 128
-    c = c4_tube_kps_cfg(T=T, dtype='fp32', pre=200, post=60)
+    c = c4_tube_kps_cfg(T=T, dtype='fp32', pre=200, post=60, deconv=deconv)
     c['TRAIN'] = {'RPN_PRE_NMS_TOP_N': 200, 'RPN_POST_NMS_TOP_N': 60, 'IMS_PER_BATCH': 1, 'MAX_SIZE': 128, 'BATCH_SIZE_PER_IM': 24,
                   'RPN_STRADDLE_THRESH': -1}
     c['NUM_GPUS'] = 1
@@ -479,7 +481,8 @@ def test_c4_tube_train_step_gradients_match_oracle_autograd(ops):
     assert fixed['rois'].shape[1] == 4 * T + 1 and fixed['keypoint_locations_int32'].shape[0] == fixed['keypoint_rois'].shape[0] * 17 * T
     wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True) for k, v in weights.items()}
     ref = train_ref.training_losses_c4_tube(
-        wt, opts_for('R18', block_counts=(2, 2, 2), kt_body=3, kt_rpn=3, kt_kps=3, body_head_link='', num_frames_mid=T),
+        wt, opts_for('R18', block_counts=(2, 2, 2), kt_body=3, kt_rpn=3, kt_kps=3, body_head_link='', num_frames_mid=T,
+                     kps_time_to_ch=deconv != 'time_to_batch'),
         data, labels, fixed, dict(num_gpus=1, kps_loss_weight=cfg.KRCNN.LOSS_WEIGHT))
     sum(ref.values()).backward()
     for k in sorted(ref):

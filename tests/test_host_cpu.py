@@ -1388,6 +1388,40 @@ def test_model_builder_emits_the_graph_the_reference_builders_emit():
         reset_cfg()
 
 
+def test_heatmap_outputs_of_a_3d_head_emit_what_the_reference_function_emits():
+    """model_builder.add_heatmap_outputs on a T = 3 tube head against the REFERENCE's own function run on the recorder
+    (tests/golden/make_golden.py golden_builders -> reference_heatmap_outputs.json; lib/modeling/model_builder.py:755-870).
+    KRCNN.NO_3D_DECONV_TIME_TO_CH False -- the reference default, core/config.py:472 -- : op for op the same (time -> channels,
+    ConvTranspose dim*T -> K*T with group = T, bilinear deconv on K*T maps).  True (the shipped 3D configs): time -> batch, the 2D
+    deconvs, batch -> time and time -> channels (views of what dat_kps_finalize wrote).  Both op for op, parameter for parameter."""
+    import json
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd.modeling import model_builder
+    from detectandtrack_amd.modeling.detector import DetectionModelHelper
+    from tests import model_util
+    with open(os.path.join(REPO, 'tests', 'golden', 'reference_heatmap_outputs.json')) as f:
+        ref = json.load(f)
+    sig = lambda net: json.loads(json.dumps([[o.type, [str(b) for b in o.inputs], [str(b) for b in o.outputs], dict(o.args)] for o in net.ops]))
+    try:
+        for no_t2c in (False, True):
+            reset_cfg()
+            cfg_from_cfg(model_util.c4_tube_kps_cfg(T=3, deconv='time_to_batch' if no_t2c else 'grouped'))
+            assert_and_infer_cfg()
+            m = DetectionModelHelper(name='heat', train=False, num_classes=cfg.MODEL.NUM_CLASSES)
+            ret = model_builder.add_heatmap_outputs(m, 'conv_fcn8', cfg.KRCNN.CONV_HEAD_DIM, 3, True)
+            rec = ref['no_3d_deconv_time_to_ch_%s' % no_t2c]
+            assert [str(p) for p in m.params] == rec['params'] and str(ret) == rec['returns']
+            got = sig(m.net)
+            assert got == rec['ops'], no_t2c
+            if not no_t2c:
+                assert got[1][3]['group'] == 3 and got[1][3]['dim_in'] == 3 * 512 and got[1][3]['dim_out'] == got[2][3]['dim'] == 3 * 17
+            else:
+                assert [o[0] for o in got] == ['TimeToBatch', 'ConvTranspose', 'BilinearInterpolation', 'BatchToTime', 'TimeToChannel']
+                assert got[-1][2] == ['kps_score'] and str(ret) == 'kps_score_prefinal'     # (the reference returns the pre-move blob)
+    finally:
+        reset_cfg()
+
+
 def test_momentum_correction_matches_the_reference_set_new_lr():
     """utils.lr_policy.momentum_correction against lib/modeling/detector.py:606-616 _SetNewLr ITSELF (tests/golden/make_golden.py
     golden_lr_policy: the method run unbound, its _CorrectMomentum recorded): WHEN the update history is rescaled at a learning-rate
