@@ -11,7 +11,7 @@ the WIRING follows the reference builders line by line:
   FPN RPN     lib/modeling/FPN.py:205-279
   proposals   oracle.proposals (generate_proposals.py, collect_and_distribute...)
   box head    lib/modeling/head_builder.py:17-38, model_builder.py:426-478
-  C4 RPN      lib/modeling/model_builder.py:500-609 (tube path, nd=True)
+  C4 RPN      lib/modeling/model_builder.py:500-609 (tube path, nd=True; 2D path, nd=False)
   C4 box head lib/modeling/ResNet3D.py:301-327, model_builder.py:427-473
   kps head    lib/modeling/keypoint_rcnn_heads.py:39-73,
               model_builder.py:755-870, detector.py:348-380
@@ -218,6 +218,35 @@ class Net(object):
         up = self.o['kps_up_scale']
         K = low.shape[1]
         return F.conv_transpose2d(low, _t(bilinear_kernel(K, up)), None, stride=up, padding=up // 2)
+
+    # ---- C4 path of the 2D models (configs/video/3d/01_R-18_*.yaml, 02_R-18_*.yaml) ------------------------------
+    def rpn_c4_2d(self, feat2d, im_info):
+        # model_builder.py:500-609 with nd=False: Conv 3x3 + Relu, 1x1 logits (A) and deltas (4A), Sigmoid, GenerateProposals
+        o = self.o
+        anchors = generate_anchors(stride=16., sizes=o['rpn_sizes'], aspect_ratios=o['rpn_c4_aspect_ratios'], time_dim=1)
+        h = F.relu(self.conv2d(feat2d, 'conv_rpn', 3, 1, 1))
+        probs = torch.sigmoid(self.conv2d(h, 'rpn_cls_logits', 1))
+        deltas = self.conv2d(h, 'rpn_bbox_pred', 1)
+        self.blobs['rpn_cls_probs'] = probs
+        self.blobs['rpn_bbox_pred'] = deltas
+        return prop.generate_proposals(probs.numpy(), deltas.numpy(), im_info, anchors, 1. / 16., o['pre_nms_topn'],
+                                       o['post_nms_topn'], o['rpn_nms_thresh'], o['rpn_min_size'])
+
+    def box_head_c4_2d(self, feat2d, rois):
+        # ResNet.py:268-287 (RoIAlign, res5 per RoI, AveragePool 7) + model_builder.py:426-478 (2D branch: FC scores / deltas)
+        o = self.o
+        pooled = o['frcn_res']
+        x = _t(roi_align_2d(feat2d.numpy(), rois, pooled, 1. / 16., o['frcn_sampling']))[:, :, None]
+        dims = o['feat_dims']
+        x = self._stage(x, 4, 'res5', o['res5_blocks'], dims[3], o['res5_dim'], 1, stride_init=int(pooled / 7))
+        x = x[:, :, 0].mean(dim=3).mean(dim=2)
+        self.blobs['res5_pool'] = x
+        return F.softmax(self.fc(x, 'cls_score'), dim=1).numpy(), self.fc(x, 'bbox_pred').numpy()
+
+    def kps_head_c4_2d(self, feat2d, kp_rois):
+        # keypoint_rcnn_heads.py:39-69 (nd=False) on the C4 feature map
+        o = self.o
+        return self.kps_head_2d(roi_align_2d(feat2d.numpy(), kp_rois, o['kps_res'], 1. / 16., o['kps_sampling']))
 
     # ---- C4 tube path ----------------------------------------------------------------
     def rpn_c4_tube(self, feat, im_info):

@@ -101,3 +101,54 @@ def oracle_weights_2d(weights):
             v = v[:, :, None]
         out[k] = v
     return out
+
+
+def check_c4_tube_against_oracle(model, ws, weights, T, H, W, pre, post, kps_time_to_ch=False, im_scale=1.0, n_kp=5, max_box_rois=None):
+    """The 3D C4 tube model (ResNet-18 3D C4 body -> tube RPN -> tube RoIAlign -> per-RoI res5 -> 3D keypoint head) in fp32 parity mode
+    against the oracle graph on one synthetic clip of T x H x W: res4 features, the fused RPN head (T-averaged logits, per-frame deltas),
+    proposals (same count, device tubes found in the oracle set), box head on the device tubes, kps_score < 1e-3 on the first tubes."""
+    import torch
+    from oracle.net3d import Net, opts_for
+    data = synthetic_clip(T, H, W)
+    im_info = np.array([[H, W, im_scale]], dtype=np.float32)
+    ws.FeedBlob('data', data)
+    ws.FeedBlob('im_info', im_info)
+    ws.RunNet(model.net.name)
+    net = Net(weights, opts_for('R18', block_counts=(2, 2, 2), kt_body=3, kt_rpn=3, kt_kps=3, body_head_link='',
+                                num_frames_mid=T, pre_nms_topn=pre, post_nms_topn=post, kps_time_to_ch=kps_time_to_ch))
+    feat = net.body(torch.from_numpy(data))
+    got = ws.FetchBlob('res4_1_sum')
+    assert got.shape == tuple(feat.shape)
+    assert np.abs(got - feat.numpy()).max() < 1e-3 * max(1.0, float(feat.abs().max()))
+    ref_rois, _ = net.rpn_c4_tube(feat, im_info)[:2]
+    # fused head: A objectness logits + 4A deltas per frame
+    head = ws.FetchBlob('rpn_cls_logits_1+rpn_bbox_pred_1')          # (1, 5A, T, h, w)
+    A = 12
+    assert head.shape[1] == 5 * A and head.shape[2] == T
+    probs = 1.0 / (1.0 + np.exp(-head[:, :A].mean(axis=2)))
+    np.testing.assert_allclose(probs, net.blobs['rpn_cls_probs'].numpy(), atol=1e-4)
+    d = head[:, A:].reshape(1, A, 4, T, head.shape[3], head.shape[4]).transpose(0, 1, 3, 2, 4, 5)
+    np.testing.assert_allclose(d.reshape(1, A * T * 4, head.shape[3], head.shape[4]),
+                               net.blobs['rpn_bbox_pred'].numpy(), atol=1e-3)
+    rois = ws.FetchBlob('rois')
+    assert rois.shape[1] == 4 * T + 1 and rois.shape[0] == ref_rois.shape[0]
+    dd = np.abs(rois[:, None, 1:] - ref_rois[None, :, 1:]).max(axis=2).min(axis=1)
+    assert (dd < 0.05).mean() > 0.95, 'only %.1f%% of device tubes found in the oracle set' % (100 * (dd < 0.05).mean())
+    # per-RoI res5 head on the DEVICE tubes (max_box_rois: the oracle's per-RoI res5 on the first rows only)
+    nb = rois.shape[0] if max_box_rois is None else min(max_box_rois, rois.shape[0])
+    cls_prob, bbox_pred = net.box_head_c4_tube(feat, rois[:nb])
+    np.testing.assert_allclose(ws.FetchBlob('cls_prob')[:nb], cls_prob, atol=1e-4)
+    got_bp = ws.FetchBlob('bbox_pred')
+    assert got_bp.shape == (rois.shape[0], 2 * T * 4) and bbox_pred.shape == (nb, 2 * T * 4)
+    np.testing.assert_allclose(got_bp[:nb], bbox_pred, atol=1e-3)
+    # 3D keypoint head
+    kp_rois = rois[:n_kp].copy()
+    ws.FeedBlob('keypoint_rois', kp_rois)
+    ws.RunNet(model.keypoint_net.name)
+    kps = ws.FetchBlob('kps_score')
+    ref = net.kps_head_tube(feat, kp_rois).numpy()
+    assert kps.shape == ref.shape == (n_kp, T * 17, 56, 56)
+    err = np.abs(kps - ref).max()
+    print('tube kps_score max-abs %.3e (ref max %.2f)' % (err, np.abs(ref).max()))
+    assert err < 1e-3
+    return err
