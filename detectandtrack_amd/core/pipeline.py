@@ -69,6 +69,21 @@ class FrameTrunkCache(object):
         self.free = list(range(self.capacity))
         self.pinned = self.dev_u8 = None
         self.frames_computed = self.frames_requested = 0
+        self._hw = self._info = None
+        self.resets = 0
+
+    def reset(self, capacity=None):
+        """Forget every cached frame (and the pool: the next forward allocates one for ITS geometry).  The caller has finished every forward
+        in flight -- they read the pool or a buffer gathered from it.  PoseTrack videos differ in resolution: a frame of another size starts
+        a new pool (frames of the previous video are not asked for again: clips never cross a video, utils/video.py:149-201)."""
+        self.event.synchronize()
+        if capacity is not None:
+            self.capacity = int(capacity)
+        self.pool = self.meta = None
+        self._hw = self._info = None
+        self.slot_of.clear()
+        self.free = list(range(self.capacity))
+        self.resets += 1
 
     def _run_prefix(self, data, im_info):
         """the prefix ops on `data` [1, 3, n, H, W] (n frames as one clip: the ops are frame-wise) -> the output blob"""
@@ -266,20 +281,29 @@ class ClipPipeline(object):
         """submit_frames through the per-frame trunk cache: only the frames no earlier forward has seen are uploaded and run through
         conv1 ... res2; the forward itself is the graph behind that prefix on the slot's gathered buffer."""
         from detectandtrack_amd.ops import hip_ops as ops
+        B, T = len(clips), len(clips[0])
+        h, w = clips[0][0].shape[:2]
+        # capacity: the configured frame count, but never less than two forwards' worth of frames (a forward must fit next to the frames the
+        # forwards in flight still gather; ADVICE r5: was a hard assert inside assemble)
+        want = max(int(cfg.HIP.FRAME_TRUNK_CACHE), 2 * B * T)
         if self.trunk is None:
-            self.trunk = FrameTrunkCache(self.model, self.slots[0].ws, int(cfg.HIP.FRAME_TRUNK_CACHE))
+            self.trunk = FrameTrunkCache(self.model, self.slots[0].ws, want)
         tr = self.trunk
+        if (tr.pool is not None and (h, w) != tr._hw) or want > tr.capacity:
+            # frames of another size (the next video) or a larger forward: one pool holds one geometry.  Finish what is in flight (results are
+            # kept), then start over with an empty cache -- mixed-resolution datasets run through the cached engine (ADVICE r5; before: an assert
+            # AFTER the upload and the prefix had run)
+            self._finish_pending()
+            tr.reset(capacity=max(want, tr.capacity))
         slot = self._acquire()
         s = self.slots[slot]
         t0 = time.perf_counter()
-        B, T = len(clips), len(clips[0])
         ids = [tuple(f) if isinstance(f, list) else f for clip_ids in frame_ids for f in clip_ids]
         assert len(ids) == B * T, 'frame_ids: one id per frame of every clip'
         frames_by_id = {}
         for clip, clip_ids in zip(clips, frame_ids):
             for f, fid in zip(clip, clip_ids):
                 frames_by_id.setdefault(tuple(fid) if isinstance(fid, list) else fid, f)
-        h, w = clips[0][0].shape[:2]
         slots_idx, im_info = tr.assemble(self, frames_by_id, ids, T, [sl.gather_event for sl in self.slots if sl.gather_event is not None])
         shapes = [(h, w, 3)] * B
         gkey = (B * T,) + tuple(tr.pool.shape[1:])
@@ -417,12 +441,16 @@ class ClipPipeline(object):
         n = sum(c for _, c in ft[skip + 1:])
         return n / max(ft[-1][0] - ft[skip][0], 1e-9)
 
-    def drain(self):
-        """Finish everything in flight (submission order); returns the accumulated (tag, per-image results) list and clears it."""
+    def _finish_pending(self):
+        """Finish everything in flight (submission order); the results stay in `self.results`."""
         while self.pending:
             item = self.pending.pop(0)
             self._finish(item)
             self.free.append(item[0])
+
+    def drain(self):
+        """Finish everything in flight (submission order); returns the accumulated (tag, per-image results) list and clears it."""
+        self._finish_pending()
         torch.cuda.synchronize()
         out, self.results = self.results, []
         return out

@@ -193,7 +193,8 @@ def test_net(roidb, ind_range=None, output_dir=None):
                                'upload_bytes_per_clip': pipe.upload_bytes / float(len(part)), 'host_submit_ms_per_clip': 1e3 * pipe.host_enqueue_s / len(part),
                                'host_staging_ms_per_clip': 1e3 * pipe.stage_s / len(part), 'host_path_images': pipe.host_path_images, 'tie_rerun_images': pipe.rerun_images, 'in_flight': int(cfg.HIP.PIPELINE_DEPTH),
                                'per_forward': int(cfg.HIP.IMS_PER_FORWARD), 'hip_graph': bool(cfg.HIP.CLIP_GRAPH),
-                               'frame_trunk_cache': int(cfg.HIP.FRAME_TRUNK_CACHE) if pipe.trunk is not None else 0,
+                               'frame_trunk_cache': int(pipe.trunk.capacity) if pipe.trunk is not None else 0,
+                               'trunk_resets': pipe.trunk.resets if pipe.trunk is not None else None,
                                'trunk_frames_computed': pipe.trunk.frames_computed if pipe.trunk is not None else None,
                                'trunk_frames_requested': pipe.trunk.frames_requested if pipe.trunk is not None else None}
         logger.info('im_detect: range [%d, %d] of %d: %d clips in %.3fs incl. warm-up%s (pipelined: %d in flight, %d per forward, '

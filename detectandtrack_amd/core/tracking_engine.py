@@ -247,14 +247,41 @@ def synthetic_detections(n_videos=50, n_frames=100, n_persons=8, seed=3, T=1):
     return json_data, {'all_boxes': [[], boxes_all], 'all_keyps': [[], keyps_all]}
 
 
-def benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3):
-    json_data, dets = synthetic_detections(n_videos, n_frames, n_persons, seed)
+def benchmark_tracking(json_data, dets):
+    """Time the tracking path proper (centre-frame selection, pruning, per-video matching) on prepared detections."""
     t0 = time.time()
     _center_detections(dets)
     dets = _prune_bad_detections(dets, json_data, cfg.TRACKING.CONF_FILTER_INITIAL_DETS)
     dets = compute_matches_tracks(json_data, dets)
-    el = time.time() - t0
-    n = len(json_data)
+    return {'seconds': time.time() - t0, 'frames': len(json_data)}
+
+
+def benchmark_synthetic(n_videos=50, n_frames=100, n_persons=8, seed=3):
+    json_data, dets = synthetic_detections(n_videos, n_frames, n_persons, seed)
+    r = benchmark_tracking(json_data, dets)
+    el, n = r['seconds'], r['frames']
     return {'value': n / el, 'unit': 'frames/s', 'cores': 1, 'kind': 'port', 'seconds': el,
             'sample': '%d videos x %d frames x ~%d persons (synthetic detections, seed %d), Hungarian matching, '
                       'sequential over videos as reference tracking_engine.py:689-694' % (n_videos, n_frames, n_persons, seed)}
+
+
+def _bench_worker_main(argv):
+    """`python -m detectandtrack_amd.core.tracking_engine --bench-worker SEED N_VIDEOS N_FRAMES`: one persistent worker of bench.py's all-cores
+    tracker leg.  Builds its videos' synthetic detections, prints 'ready', waits for a line on stdin, tracks, prints '<seconds> <frames>'."""
+    import sys
+    seed, n_videos, n_frames = int(argv[0]), int(argv[1]), int(argv[2])
+    json_data, dets = synthetic_detections(n_videos, n_frames, 8, seed)
+    benchmark_tracking(*synthetic_detections(1, 20, 8, seed))            # (first-call costs outside the clock)
+    sys.stdout.write('ready\n')
+    sys.stdout.flush()
+    if not sys.stdin.readline():
+        return
+    r = benchmark_tracking(json_data, dets)
+    sys.stdout.write('%.6f %d\n' % (r['seconds'], r['frames']))
+    sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    import sys
+    if len(sys.argv) >= 5 and sys.argv[1] == '--bench-worker':
+        _bench_worker_main(sys.argv[2:5])

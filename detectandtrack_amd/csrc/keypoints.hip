@@ -265,9 +265,14 @@ extern "C" int dat_heatmaps_to_keypoints_ld(dat_ctx* ctx, dat_stream s, const fl
     if (R == 0) return DAT_OK;
     KpParams p;
     p.maps = maps; p.boxes = boxes; p.out = out; p.R = R; p.T = T; p.K = K; p.M = M; p.min_size = min_size; p.box_ld = box_ld;
-    if (ctx->dbg_kps_sep) {     // (DAT_KPS_DECODE_SEP, default 1; 0 = the per-pixel 4 x 4 kernel)
-        const size_t lds = ((((size_t)M * M + 3) & ~(size_t)3) + (size_t)M * KD_HP) * 4;
-        hipLaunchKernelGGL(kps_decode_sep_kernel, dim3((unsigned)(R * T * K)), dim3(256), lds, (hipStream_t)s, p);
+    // the separable kernel's dynamic LDS = the map + M rows of the horizontal pass (+ 4 KB static): above the 64-KB default limit the
+    // attribute is raised (160 KB per CU on gfx950); a map whose separable footprint does not fit at all takes the per-pixel kernel, whose
+    // need (M * M * 4, checked above) is what this entry point always accepted
+    const size_t lds_sep = ((((size_t)M * M + 3) & ~(size_t)3) + (size_t)M * KD_HP) * 4;
+    bool sep = ctx->dbg_kps_sep && lds_sep + 4096 <= 160 * 1024;     // (DAT_KPS_DECODE_SEP, default 1; 0 = the per-pixel 4 x 4 kernel)
+    if (sep && lds_sep + 4096 > 64 * 1024 && dat_ensure_lds(ctx, (const void*)kps_decode_sep_kernel, 160 * 1024) != DAT_OK) sep = false;
+    if (sep) {
+        hipLaunchKernelGGL(kps_decode_sep_kernel, dim3((unsigned)(R * T * K)), dim3(256), lds_sep, (hipStream_t)s, p);
     } else
         hipLaunchKernelGGL(kps_decode_kernel, dim3((unsigned)(R * T * K)), dim3(256), (size_t)M * M * 4, (hipStream_t)s, p);
     DAT_CHECK_LAUNCH(ctx, "heatmaps_to_keypoints");

@@ -18,22 +18,34 @@ from detectandtrack_amd.ops import hip_ops as ops
 
 class DeviceRoiSampler(object):
     on_device = True
+    MAX_CANDIDATES, MAX_T = 4096, 8         # RS_MAXN / LAB_MAXT of csrc/labels.hip
 
     def __init__(self, entry, seed=0, device=None):
+        """seed: an int, or a zero-argument callable that is asked for one only when the device sampler is really built (the host sampler's
+        numpy.random stream must not lose a draw to a sampler that is never used)."""
         gt = np.where(entry['gt_classes'] > 0)[0]
         # the device path covers what every clip of the training set looks like here: all rows of the entry are ground-truth boxes
         # (no crowd regions, no pre-computed proposals); anything else keeps the host sampler
         assert len(gt) == len(entry['gt_classes']) and not np.any(entry['is_crowd']), 'entry with non-gt rows: use the host sampler'
         assert np.array_equal(entry['box_to_gt_ind_map'], np.arange(len(gt))), 'gt rows must map to themselves'
         assert cfg.TRAIN.FG_THRESH >= cfg.TRAIN.BG_THRESH_HI, 'overlapping fg / bg ranges are not supported on the device'
-        dev = device or torch.device('cuda', torch.cuda.current_device())
+        # the kernel's own limits (csrc/labels.hip dat_sample_rois: RS_MAXN candidates, LAB_MAXT frames per tube, every gt a keypoint roi), checked
+        # HERE against the configuration so that make_sampler falls back to the host restatement instead of a launch error mid-iteration
+        # (ADVICE r5): the proposal blob holds at most RPN_POST_NMS_TOP_N rows (collect, one image per GPU)
+        G = len(gt)
         self.T = entry['boxes'].shape[1] // 4
+        fg_per_im = int(np.round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE_PER_IM))
+        assert 1 <= self.T <= self.MAX_T, 'tubes of %d frames: the device sampler holds up to %d' % (self.T, self.MAX_T)
+        assert G >= 1 and G + int(cfg.TRAIN.RPN_POST_NMS_TOP_N) <= self.MAX_CANDIDATES, \
+            '%d gt boxes + %d proposals exceed the device sampler\'s %d candidates' % (G, cfg.TRAIN.RPN_POST_NMS_TOP_N, self.MAX_CANDIDATES)
+        assert not cfg.MODEL.KEYPOINTS_ON or G <= fg_per_im, '%d persons for %d foreground rois per image' % (G, fg_per_im)
+        dev = device or torch.device('cuda', torch.cuda.current_device())
         self.gt_boxes = torch.from_numpy(np.ascontiguousarray(entry['boxes'], dtype=np.float32)).to(dev)
         self.gt_classes = torch.from_numpy(np.ascontiguousarray(entry['gt_classes'], dtype=np.int32)).to(dev)
         self.gt_kps = None
         if cfg.MODEL.KEYPOINTS_ON:
             self.gt_kps = torch.from_numpy(np.ascontiguousarray(entry['gt_keypoints'], dtype=np.int32)).to(dev)
-        self.seed, self.iter = int(seed), 0
+        self.seed, self.iter = int(seed() if callable(seed) else seed), 0
         self.last_counts = None
 
     def __call__(self, rois_dev, n_dev, im_info, want_picked=False):
@@ -70,8 +82,9 @@ class WeightSum(object):
 
 
 def make_sampler(entry, rng, seed=0):
-    """The roi sampler of one clip for `Workspace.train_sampler`: on the device (cfg.HIP.DEVICE_ROI_SAMPLING, entries made of gt rows only)
-    or the host restatement driven by `rng` (the reference's numpy.random stream)."""
+    """The roi sampler of one clip for `Workspace.train_sampler`: on the device (cfg.HIP.DEVICE_ROI_SAMPLING, entries made of gt rows only,
+    within the kernel's limits) or the host restatement driven by `rng` (the reference's numpy.random stream).  seed: int or callable, see
+    DeviceRoiSampler: with a callable the host path consumes NOTHING from `rng` here, i.e. it stays bit-compatible with the reference's stream."""
     from detectandtrack_amd.roi_data import fast_rcnn as frcn_data
     if cfg.HIP.get('DEVICE_ROI_SAMPLING', True) and torch.cuda.is_available():
         try:

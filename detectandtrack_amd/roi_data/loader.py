@@ -49,7 +49,7 @@ class Minibatch(object):
         from detectandtrack_amd.roi_data.device_sampler import make_sampler
         # (device kernel by default -- cfg.HIP.DEVICE_ROI_SAMPLING; its draw stream is seeded per minibatch from the minibatch's own RNG, so a
         #  run stays reproducible for any worker count)
-        ws.train_sampler = make_sampler(self.entry, self.rng, seed=int(self.rng.randint(0, 2 ** 31 - 1)))
+        ws.train_sampler = make_sampler(self.entry, self.rng, seed=lambda: int(self.rng.randint(0, 2 ** 31 - 1)))      # (drawn only if the device sampler is built)
 
 
 class _WindowCounter(object):

@@ -429,7 +429,9 @@ class TrainExecutor(Executor):
                 mask = x_win if x_win.is_contiguous() else None
             # a queued pointwise weight gradient may still have to READ the tensor the sum would be written into (the block output's gradient
             # is both branch2c's `g` and the shortcut contribution of the block input): then the sum goes to a new tensor
-            held = into is not None and any(j[2].data_ptr() == into.data_ptr() for _, j in self._pw_pending)
+            # (byte-range overlap with BOTH operands of every queued job -- an offset view or the x operand would have slipped past
+            #  an equality test of the g operand's start pointer)
+            held = into is not None and any(_bytes_overlap(into, j[1]) or _bytes_overlap(into, j[2]) for _, j in self._pw_pending)
             dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None, mask=mask, inplace=not held)
             if into is None:
                 self._add_grad(op.inputs[0], dx, ilo, masked=mask is not None)
@@ -728,6 +730,12 @@ class TrainExecutor(Executor):
     # ---- update ---------------------------------------------------------------------------------------------------------------
     def loss_values(self):
         return {k: float(v.item()) for k, v in self.losses.items()}
+
+
+def _bytes_overlap(a, b):
+    """Do the memory extents of two (dense) tensors intersect?"""
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
 
 
 def no_grad_blobs(net):

@@ -534,6 +534,49 @@ def test_pipelined_engine_with_the_frame_trunk_cache_writes_identical_detections
             np.testing.assert_array_equal(a, b)
 
 
+def test_frame_trunk_cache_follows_a_mixed_resolution_clip_list(tmp_path):
+    """PoseTrack videos differ in size.  A stride-1 clip list over THREE videos of two resolutions (A, B, A again) through
+    the pipelined engine with cfg.HIP.FRAME_TRUNK_CACHE -- set smaller than one forward's frames on purpose: the pool of cached prefix outputs
+    holds one geometry, so a frame of another size finishes what is in flight and starts an empty pool (before: an assert after the upload),
+    and the capacity is raised to two forwards' worth of frames (before: a hard assert).  detections.pkl must be bit-identical to the same
+    engine computing every clip whole; every frame still runs the prefix exactly once."""
+    from detectandtrack_amd.core import test_engine
+    from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
+    from detectandtrack_amd import workspace
+    T, n_frames = 4, 5
+    sizes = [(96, 128), (80, 144), (96, 128)]
+    rs = np.random.RandomState(11)
+    roidb = []
+    for v, (H, W) in enumerate(sizes):
+        video = [rs.randint(0, 255, (H, W, 3)).astype(np.uint8) for _ in range(n_frames)]
+        for k in range(n_frames):
+            ids = [min(max(k - T // 2 + j, 0), n_frames - 1) for j in range(T)]
+            roidb.append({'image': [video[i] for i in ids], 'frame_ids': [('vid%d' % v, i) for i in ids], 'height': H, 'width': W})
+
+    def run(cache, out):
+        c = fpn3d_kps_cfg('18', T=T, dtype='fp32', pre=300, post=100)
+        c['TEST'].update(SCALES=(96,), MAX_SIZE=160, SCORE_THRESH=0.0, DETECTIONS_PER_IM=15)
+        c['HIP'].update(PIPELINE_DEPTH=3, IMS_PER_FORWARD=2, CLIP_GRAPH=True, FRAME_TRUNK_CACHE=cache)
+        c['RNG_SEED'] = 3
+        reset_cfg()
+        cfg_from_cfg(c)
+        assert_and_infer_cfg()
+        workspace.ResetWorkspace()
+        os.makedirs(out, exist_ok=True)
+        return test_engine.test_net(roidb, None, out), test_engine.test_net.last_stats
+    plain, st0 = run(0, str(tmp_path / 'plain'))
+    assert st0['frame_trunk_cache'] == 0
+    got, st = run(3, str(tmp_path / 'cached'))
+    assert st['clips'] == len(roidb) and st['frame_trunk_cache'] >= 2 * 2 * T       # (capacity raised from 3 to two forwards' worth)
+    assert st['trunk_resets'] == 2, st                                               # A -> B and B -> A
+    assert st['trunk_frames_computed'] == len(sizes) * n_frames, st
+    for i in range(len(roidb)):
+        np.testing.assert_array_equal(got['all_boxes'][1][i], plain['all_boxes'][1][i], err_msg='clip %d' % i)
+        assert len(got['all_keyps'][1][i]) == len(plain['all_keyps'][1][i]) >= 15
+        for a, b in zip(got['all_keyps'][1][i], plain['all_keyps'][1][i]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_pipeline_graphs_survive_workspace_growth_and_a_second_geometry(monkeypatch):
     """ADVICE r3 (high + medium).  One pipeline slot holds a captured hipGraph per input geometry; the captured launches have the
     C-ABI context's scratch pointer baked in (proposal scratch, split-K partials).  (1) small geometry, then a LARGER one whose

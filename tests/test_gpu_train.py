@@ -1264,6 +1264,34 @@ def test_bench_two_ranks_control_flow_on_one_gpu(mode):
         assert line['roofline']['frac'] > 0 and line['host_frames']['value_including_upload'] > 0
 
 
+@pytest.mark.parametrize('mode', ['infer', 'train'])
+def test_bench_eight_ranks_control_flow_on_one_gpu(mode):
+    """World-8 readiness: the driver's `torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8` command line with
+    EIGHT real ranks sharing this box's one GPU over gloo (DAT_BENCH_SHARE_GPU=1): rendezvous, per-rank contexts, barriers, the MAX-reduce
+    of the timing and -- train -- the Trainer's bucketed, overlapped gradient exchange (bucket completion order, seal, deferred finish)
+    with eight participants; rank 0 prints ONE line with n_gpus 8 whose value is the sum over the eight ranks.  One clip per forward and
+    one forward in flight per rank keep eight model copies inside one device's memory."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(DAT_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29500 + ((os.getpid() + 617 + (mode == 'train')) % 1000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(repo, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-accuracy', '--no-other-configs', '--h2d', '0'] + (['--mode', 'train'] if mode == 'train' else ['--batch', '1', '--pipeline', '1'])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and len(line['ranks_seen']) == 8 and {r['rank'] for r in line['ranks_seen']} == set(range(8))
+    assert 'shared_gpu_test' in line and line['value'] > 0 and line['steps'] == 2 and line['scaling'] == 'weak'
+    assert 'cpu_baseline' not in line
+    if mode == 'train':
+        assert line['allreduce']['buckets'] >= 2 and line['allreduce']['backend'] == 'gloo'
+
+
 @pytest.mark.parametrize('overlap', [True, False])
 def test_two_ranks_with_one_clip_each_equal_one_rank_over_both_clips(tmp_path, overlap):
     """Data-parallel semantics of the training exchange (reference lib/modeling/model_builder.py:908-951 build_data_parallel_model:

@@ -1508,3 +1508,33 @@ def test_clip_assembly_matches_the_reference_get_clip():
     for tool in ('tools/test_net.py', 'tools/bench_config5.py'):
         with open(os.path.join(REPO, tool)) as f:
             assert 'clip_frame_ids(k, 0, n_frames - 1, T)' in f.read(), tool
+
+
+def test_device_roi_sampler_checks_the_kernel_limits_up_front_and_draws_its_seed_lazily():
+    """(1) the limits of dat_sample_rois (4096 candidates, every person a keypoint roi, 8 frames per tube) are checked against
+    cfg and the entry in DeviceRoiSampler.__init__ -- where make_sampler's fallback to the host restatement catches them -- not by a launch
+    error in the middle of an iteration; (2) the seed of the device draw is taken from the minibatch RNG only when the device sampler is
+    really built: the host path, documented as bit-compatible with the reference's numpy.random stream, loses no draw."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.roi_data import synthetic
+    from detectandtrack_amd.roi_data.device_sampler import DeviceRoiSampler, make_sampler
+    reset_cfg()
+    try:
+        cfg.MODEL.KEYPOINTS_ON, cfg.MODEL.NUM_CLASSES = True, 2
+        entry = synthetic.synthetic_roidb_entry(128, 160, n_persons=5, seed=2)
+        asked = []
+        seed = lambda: asked.append(1) or 7
+        cfg.TRAIN.RPN_POST_NMS_TOP_N = 4092                      # 5 + 4092 > 4096 candidates
+        with pytest.raises(AssertionError, match='candidates'):
+            DeviceRoiSampler(entry, seed=seed)
+        cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000
+        cfg.TRAIN.BATCH_SIZE_PER_IM = 16                         # 4 foreground rois per image for 5 persons
+        with pytest.raises(AssertionError, match='persons'):
+            DeviceRoiSampler(entry, seed=seed)
+        assert not asked
+        rng = np.random.RandomState(5)
+        state = rng.get_state()[1].copy()
+        s = make_sampler(entry, rng, seed=lambda: int(rng.randint(0, 2 ** 31 - 1)))       # (no GPU here: the host sampler)
+        assert not isinstance(s, DeviceRoiSampler) and np.array_equal(rng.get_state()[1], state)
+    finally:
+        reset_cfg()

@@ -46,7 +46,7 @@ def feed_clip(ws, data, entry, rng):
     for k, v in blobs.items():
         ws.FeedBlob(k, v)
     from detectandtrack_amd.roi_data.device_sampler import make_sampler
-    ws.train_sampler = make_sampler(entry, rng, seed=int(rng.randint(0, 2 ** 31 - 1)))
+    ws.train_sampler = make_sampler(entry, rng, seed=lambda: int(rng.randint(0, 2 ** 31 - 1)))
 
 
 def main():
