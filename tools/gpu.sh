@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/gpu.sh <tag> <stage> [<stage> ...]'        results -> gpurun_out/<tag>/
 # A stage is NAME or NAME:ARGS (ARGS: extra command-line arguments, ';' instead of spaces).  Stages:
 #   tests[:pytest args]     pytest -m gpu (-> pytest_<n>.log; args are eval'ed)   e.g.  'tests:-k;"affine;or;known_answer"'
+#   testsall[:pytest args]  the same without -x (every failure listed)
 #   bench[:bench args]      python bench.py (-> bench.json / bench.err)        e.g.  bench:--no-other-configs
 #   benchq[:bench args]     bench.py without the CPU baselines / other configs / accuracy leg (quick A/B runs; -> benchq_<n>.json)
 #   layers[:bench args]     eager sequential per-layer conv table (--pipeline 1 --graph 0 --dump-convs -> conv_layers.txt)
@@ -28,6 +29,8 @@ for st in "$@"; do
     case $name in
     tests)  (cd $R && eval "timeout -s KILL 1500 python -m pytest tests -m gpu -q -x $args" > $o/pytest_$n.log 2>&1; echo "pytest rc $?" >> $o/pytest_$n.log)
             grep -E "passed|failed|error|rc " $o/pytest_$n.log | tail -6 ;;
+    testsall) (cd $R && eval "timeout -s KILL 2400 python -m pytest tests -m gpu -q $args" > $o/pytest_$n.log 2>&1; echo "pytest rc $?" >> $o/pytest_$n.log)
+            grep -E "passed|failed|error|rc |^FAILED|^ERROR" $o/pytest_$n.log | tail -40 ;;
     bench)  DAT_BENCH_KEEP_ROCPROF=$o timeout -s KILL 900 python $R/bench.py $args > $o/bench.json 2> $o/bench.err; cut -c1-400 $o/bench.json ;;
     benchq) timeout -s KILL 400 python $R/bench.py $Q $args > $o/benchq_$n.json 2> $o/benchq_$n.err; cut -c1-300 $o/benchq_$n.json ;;
     layers) timeout -s KILL 400 python $R/bench.py $Q --h2d 0 --steps 10 --warmup 3 --pipeline 1 --graph 0 --dump-convs $args > $o/bench_seq_$n.json 2> $o/conv_layers_$n.txt ;;
