@@ -1,9 +1,9 @@
 """Dataset-level inference engine — mirror of reference lib/core/test_engine.py (model init :50-74, the clip loop
 :124-204, per-GPU fan-out :278-308, detections.pkl layout :199-204).
 
-The clip list is an in-memory "roidb": a list of dicts with `image` (list of T frame paths or arrays) — the COCO-json /
-PoseTrack dataset layer (lib/datasets, needs pycocotools + the dataset files) is outside the hot-path scope, so the
-entry points accept either a pickled roidb or a synthetic one.
+The clip list is a "roidb": a list of dicts with `image` (list of T frame paths or arrays).  It comes from cfg.TEST.DATASET through
+`get_roidb_and_dataset` (datasets/json_dataset.py: a pycocotools-free reader of the COCO-format lists; utils/video.get_clip), or -- the
+PoseTrack files are not available offline -- from a pickled / synthetic clip list handed in by the tools.
 """
 import logging
 import os
@@ -43,6 +43,27 @@ def initialize_model_from_cfg():
     if cfg.MODEL.KEYPOINTS_ON:
         ws.CreateNet(model.keypoint_net)
     return model
+
+
+def get_roidb_and_dataset(ind_range, include_gt=False):
+    """(:77-103) the clip list of cfg.TEST.DATASET: the COCO-format annotation file -> roidb (datasets/json_dataset.py), video models ->
+    one clip per key frame (utils/video.get_clip).  Entries whose frames are files carry their paths as `frame_ids`, so the per-frame trunk
+    cache (cfg.HIP.FRAME_TRUNK_CACHE) recognises the frames that consecutive clips share."""
+    from detectandtrack_amd.datasets.json_dataset import JsonDataset
+    from detectandtrack_amd.utils import video as video_utils
+    dataset = JsonDataset(cfg.TEST.DATASET)
+    if cfg.MODEL.FASTER_RCNN:
+        roidb = dataset.get_roidb(gt=include_gt)
+    else:
+        roidb = dataset.get_roidb(gt=include_gt, proposal_file=cfg.TEST.PROPOSAL_FILE, proposal_limit=cfg.TEST.PROPOSAL_LIMIT)
+    if cfg.MODEL.VIDEO_ON:
+        roidb = video_utils.get_clip(roidb, remove_imperfect=False)
+        for e in roidb:
+            if all(isinstance(p, str) for p in e['image']):
+                e['frame_ids'] = list(e['image'])
+    total = len(roidb)
+    start, end = (0, total) if ind_range is None else ind_range
+    return roidb[start:end] if ind_range is not None else roidb, dataset, start, end, total
 
 
 def empty_results(num_classes, num_images):

@@ -1,10 +1,11 @@
-"""Clip assembly for video models -- the rule of reference lib/utils/video.py:149-201 (get_clip).
+"""Clip assembly for video models -- reference lib/utils/video.py.
 
 The reference scores a video with ONE clip per key frame: the clip of key frame k holds the frames at offsets
 floor(-(T-1)/2) ... floor((T-1)/2) around it, VIDEO.TIME_INTERVAL apart -- for even T one more frame before the key frame than after it, the
 key frame always at index T // 2 -- and a position whose frame does not exist (before the first / after the last frame of the video) takes
-the nearest clip position towards the key frame that does (:183-196): border frames are replicated.  The dataset layer that builds tube
-ground truth around this (:66-147) is out of scope."""
+the nearest clip position towards the key frame that does (:183-196): border frames are replicated.  `clip_frame_ids` is that rule on frame
+NUMBERS (the synthetic-video tools); `get_clip` / `combine_clip` are the roidb form (:38-201) with the tube ground truth of :66-147 -- both
+pinned to the reference's own functions (tests/golden/reference_clips.json, reference_json_dataset.npz)."""
 import math
 
 
@@ -24,3 +25,103 @@ def clip_frame_ids(key_frame, first_frame, last_frame, num_frames, time_interval
                 break
         ids.append(f)
     return ids
+
+
+# ---- roidb -> clips with tube ground truth (lib/utils/video.py:38-201) ---------------------------------------------------------------------
+def get_video_info(roidb):
+    """:38-54: entry index -> (video, key frame number, flipped).  Image datasets: the video is the directory of the frame file, the frame
+    number its basename; video-file datasets carry `frame_id`."""
+    import os
+    info = {}
+    for i, e in enumerate(roidb):
+        if e['dataset'].frames_from_video:
+            info[i] = (e['image'], e['frame_id'], e['flipped'])
+        else:
+            info[i] = (os.path.dirname(e['image']), int(os.path.splitext(os.path.basename(e['image']))[0]), e['flipped'])
+    return info
+
+
+def _fill_towards_key_frame(slots):
+    """:183-196: a clip position without a frame takes the nearest filled position between it and the key frame (index len // 2)."""
+    mid = len(slots) // 2
+    for rng in (range(mid, -1, -1), range(mid, len(slots))):
+        last = None
+        for k in rng:
+            if slots[k] is not None:
+                last = slots[k]
+            else:
+                slots[k] = last
+    assert all(s is not None for s in slots)
+    return slots
+
+
+def get_clip(roidb, remove_imperfect=False):
+    """:149-201: one clip per roidb entry (= key frame): the entries of the frames at offsets floor(-(T-1)/2) .. floor((T-1)/2) times
+    VIDEO.TIME_INTERVAL in the same video (and flip state), missing ones replaced towards the key frame (or the clip dropped:
+    remove_imperfect, training), merged into ONE entry with tube ground truth by `combine_clip`."""
+    from detectandtrack_amd.core.config import cfg
+    T = cfg.VIDEO.NUM_FRAMES
+    info = get_video_info(roidb)
+    where = {v: i for i, v in info.items()}
+    half = (T - 1) / 2.0
+    offsets = list(range(int(math.floor(-half)), int(math.floor(half)) + 1))
+    assert len(offsets) == T and offsets[T // 2] == 0
+    out = []
+    for i, entry in enumerate(roidb):
+        video, key, flipped = info[i]
+        slots = [None] * T
+        for k, dt in enumerate(offsets):
+            j = where.get((video, key + dt * cfg.VIDEO.TIME_INTERVAL, flipped))
+            if j is not None:
+                slots[k] = roidb[j]
+        if remove_imperfect and any(s is None for s in slots):
+            continue
+        out.append(combine_clip(entry, _fill_towards_key_frame(slots), cfg.VIDEO.NUM_FRAMES_MID))
+    return out
+
+
+def combine_clip(entry, frames, num_frames_mid):
+    """:66-147 (_combine_clips): the key-frame entry + the T frame entries of its clip -> the clip entry.  `image` lists all T frames; the
+    ground truth covers the centre `num_frames_mid` frames: one row per track id seen in them -- boxes (n, 4 * T'), keypoints
+    (n, 3, K * T') with map index t * K + k, track_visible (n, T'); a track missing in a frame leaves zeros there."""
+    import numpy as np
+    import scipy.sparse
+    assert num_frames_mid <= len(frames)
+    new = {'image': [f['image'] for f in frames]}
+    start = len(frames) // 2 - num_frames_mid // 2
+    mid = frames[start:start + num_frames_mid]
+    assert len(mid) == num_frames_mid and mid[len(mid) // 2] is frames[len(frames) // 2]
+    for k in ('dataset', 'has_visible_keypoints', 'id', 'nframes', 'width', 'head_boxes', 'is_labeled', 'frame_id', 'height', 'flipped'):
+        if k in entry:
+            new[k] = entry[k]
+    ids = [f['tracks'].reshape(-1).tolist() for f in mid]
+    tracks = np.array(list(set(t for per in ids for t in per)), dtype=entry['tracks'].dtype)      # (set order, like the reference)
+    n, Tm = len(tracks), len(mid)
+    K = entry['gt_keypoints'].shape[-1]
+    new['tracks'] = tracks
+    new['all_frame_ids'] = [f['frame_id'] for f in mid]
+    if 'original_file_name' in entry:
+        new['original_file_name'] = [f['original_file_name'] for f in mid]
+    kps = np.zeros((n, Tm, entry['gt_keypoints'].shape[-2], K), dtype=entry['gt_keypoints'].dtype)
+    new['boxes'] = np.zeros((n, 4 * Tm), dtype=entry['boxes'].dtype)
+    new['is_crowd'] = np.zeros((n,), dtype=entry['is_crowd'].dtype)
+    overlaps = np.zeros((n, entry['gt_overlaps'].shape[1]), dtype=entry['gt_overlaps'].dtype)
+    new['gt_classes'] = np.zeros((n,), dtype=entry['gt_classes'].dtype)
+    new['track_visible'] = np.full((n, Tm), False)
+    new['segms'] = [[]] * n
+    new['box_to_gt_ind_map'] = np.arange(n, dtype=entry['box_to_gt_ind_map'].dtype)
+    new['max_classes'] = np.ones((n,), dtype=entry['max_classes'].dtype)           # one class: person; all rows are ground truth
+    new['max_overlaps'] = np.ones((n,), dtype=entry['max_overlaps'].dtype)
+    new['seg_areas'] = np.ones((n,), dtype=entry['seg_areas'].dtype)
+    for r, tid in enumerate(tracks.tolist()):
+        for t, f in enumerate(mid):
+            if tid in ids[t]:
+                p = ids[t].index(tid)
+                new['boxes'][r, 4 * t:4 * t + 4] = f['boxes'][p]
+                kps[r, t] = f['gt_keypoints'][p]
+                new['track_visible'][r, t] = True
+                new['gt_classes'][r] = f['gt_classes'][p]
+                overlaps[r, 1] = 1.0
+    new['gt_overlaps'] = scipy.sparse.csr_matrix(overlaps)
+    new['gt_keypoints'] = kps.transpose((0, 2, 1, 3)).reshape((n, 3, Tm * K))
+    return new

@@ -5,12 +5,12 @@ Cython NMS/IoU compiled into oracle/_ref (oracle/build_ref.py).
 
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py            (everything; or one generator: --only-cfg | --only-roi-data | --only-lr | --only-blob |
-                                                   --only-decode | --only-tracker | --only-builders | --only-weights | --only-clips | --only-postproc)
+                                                   --only-decode | --only-tracker | --only-builders | --only-weights | --only-clips | --only-postproc | --only-dataset)
 Writes tests/golden/: reference_host.npz (anchors, transforms, IoU / NMS, GenerateProposals, RoIToBatchFormat, level mapping, collect /
 distribute, inflation), reference_roi_data.npz (training labels, boxes and tubes), reference_lr_policy.npz (schedules + the momentum
 correction rule), reference_postproc.npz, reference_posetrack_annorect.json, reference_blob.npz, reference_decode.npz,
 reference_tracker.json, reference_cfg_defaults.json / reference_cfg_files.json, reference_builder_nets.json.gz (the graphs the
-reference's builder functions emit) + reference_heatmap_outputs.json (the keypoint output function on a 3D head, both deconv variants), reference_weights_load.npz (checkpoint loading), reference_clips.json (clip assembly).  The shims do not change any arithmetic:
+reference's builder functions emit) + reference_heatmap_outputs.json (the keypoint output function on a 3D head, both deconv variants), reference_weights_load.npz (checkpoint loading), reference_clips.json (clip assembly), synthetic_posetrack.json + reference_json_dataset.npz / .json (the dataset layer: JsonDataset.get_roidb and get_clip's tube ground truth on a synthetic COCO-format file).  The shims do not change any arithmetic:
   * removed NumPy aliases (np.float/np.int), py2 builtins (basestring, unicode),
     cPickle -> pickle, bytes config defaults decoded to str;
   * caffe2 / cv2 / pycocotools are replaced by inert stub modules so that pure
@@ -930,6 +930,185 @@ def golden_clips(cfg):
     print('wrote reference_clips.json', [(c['T'], c['time_interval'], len(c['clips'])) for c in out])
 
 
+KPT_NAMES = ['nose', 'head_bottom', 'head_top', 'left_ear', 'right_ear', 'left_shoulder', 'right_shoulder', 'left_elbow', 'right_elbow',
+             'left_wrist', 'right_wrist', 'left_hip', 'right_hip', 'left_knee', 'right_knee', 'left_ankle', 'right_ankle']
+
+
+def synthetic_posetrack_json(seed=23):
+    """A small COCO-format annotation file shaped like the PoseTrack lists the reference reads (lib/datasets/lists/PoseTrack/v1.0/*.json):
+    three videos (5, 4 -- frame 3 missing -- and 3 frames), persons with track ids, 17 keypoints, head boxes; plus the records the
+    reference's sanitiser drops or treats specially: `ignore`, zero area, a one-pixel box, a box that leaves the image, an area below
+    TRAIN.GT_MIN_AREA is not used (default -1), a crowd region (RLE dict), a polygon with fewer than three points, an image without
+    annotations, image ids out of order in the file."""
+    rs = np.random.RandomState(seed)
+    images, anns = [], []
+    sizes = {'bonn_000001': (480, 640), 'mpii_000002': (360, 540), 'bonn_000003': (480, 854)}
+    frames = {'bonn_000001': [1, 2, 3, 4, 5], 'mpii_000002': [1, 2, 4, 5], 'bonn_000003': [7, 8, 9]}
+    img_id = 1000
+    ann_id = 1
+    for vi, (vid, fr) in enumerate(sorted(frames.items())):
+        h, w = sizes[vid]
+        persons = {tid: (rs.uniform(0.1, 0.6) * w, rs.uniform(0.1, 0.4) * h, rs.uniform(0.1, 0.3) * w, rs.uniform(0.3, 0.55) * h)
+                   for tid in range(3 + vi)}
+        for f in fr:
+            img_id += 7 if f % 2 else -3             # (ids neither contiguous nor monotonic in file order)
+            iid = img_id + 100 * vi
+            images.append({'id': iid, 'file_name': 'images/%s/%06d.jpg' % (vid, f), 'width': w, 'height': h, 'nframes': len(fr), 'frame_id': f,
+                           'is_labeled': bool(f % 2), 'original_file_name': 'images/%s/%08d.jpg' % (vid, f), 'license': 1})
+            if vid == 'bonn_000003' and f == 8:
+                continue                              # an image without annotations
+            for tid, (x, y, bw, bh) in persons.items():
+                if (tid + f) % 4 == 0:
+                    continue                          # the person is not in this frame
+                dx, dy = rs.uniform(-6, 6, 2)
+                bx = [float(np.round(x + dx * f, 2)), float(np.round(y + dy, 2)), float(np.round(bw, 2)), float(np.round(bh, 2))]
+                kp = []
+                for k in range(17):
+                    v = int(rs.randint(0, 3))
+                    kp += [int(bx[0] + rs.uniform(0, 1) * bx[2]) if v else 0, int(bx[1] + rs.uniform(0, 1) * bx[3]) if v else 0, v]
+                anns.append({'id': ann_id, 'image_id': iid, 'category_id': 1, 'bbox': bx, 'area': float(np.round(bx[2] * bx[3], 2)), 'iscrowd': 0,
+                             'keypoints': kp, 'num_keypoints': int(sum(1 for q in kp[2::3] if q > 0)), 'track_id': tid,
+                             'head_box': [bx[0] + 2, bx[1] + 1, bx[0] + bx[2] / 3, bx[1] + bx[3] / 5],
+                             'segmentation': [[bx[0], bx[1], bx[0] + bx[2], bx[1], bx[0] + bx[2], bx[1] + bx[3]], [1.0, 2.0, 3.0, 4.0]]})
+                ann_id += 1
+        # the special records, on the video's first image
+        first = [im for im in images if ('/%s/' % vid) in im['file_name']][0]['id']
+        zero_kp = [0] * 51
+        specials = [dict(bbox=[10., 10., 50., 80.], area=4000., ignore=1), dict(bbox=[20., 20., 40., 40.], area=0.),
+                    dict(bbox=[30., 30., 1., 60.], area=60.), dict(bbox=[w - 30., h - 40., 90., 120.], area=10800.),
+                    dict(bbox=[5., 5., 200., 150.], area=30000., iscrowd=1, segmentation={'counts': 'abc', 'size': [h, w]}),
+                    dict(bbox=[-15., -8., 60., 70.], area=4200.)]
+        for k, sp in enumerate(specials):
+            a = {'id': ann_id, 'image_id': first, 'category_id': 1, 'iscrowd': 0, 'keypoints': list(zero_kp), 'num_keypoints': 0, 'track_id': 50 + k,
+                 'segmentation': []}
+            a.update(sp)
+            anns.append(a)
+            ann_id += 1
+    cats = [{'id': 1, 'name': 'person', 'supercategory': 'person', 'keypoints': KPT_NAMES, 'skeleton': [[1, 2], [2, 3]]}]
+    return {'images': images, 'annotations': anns, 'categories': cats}
+
+
+class _StubCOCO(object):
+    """The slice of pycocotools.coco.COCO that lib/datasets/json_dataset.py calls (pycocotools is absent): a plain index over the JSON,
+    written here independently of the package's CocoIndex."""
+
+    def __init__(self, annotation_file):
+        import json
+        with open(annotation_file) as f:
+            d = json.load(f)
+        self._imgs = [(im['id'], im) for im in d['images']]
+        self._cats = [(c['id'], c) for c in d['categories']]
+        self._anns = d['annotations']
+
+    def getImgIds(self):
+        return [i for i, _ in self._imgs]
+
+    def loadImgs(self, ids):
+        m = dict(self._imgs)
+        return [m[i] for i in ids]
+
+    def getCatIds(self):
+        return [i for i, _ in self._cats]
+
+    def loadCats(self, ids):
+        m = dict(self._cats)
+        return [m[i] for i in ids]
+
+    def getAnnIds(self, imgIds=(), iscrowd=None):
+        want = set(imgIds if isinstance(imgIds, (list, tuple)) else [imgIds])
+        return [a['id'] for a in self._anns if a['image_id'] in want and (iscrowd is None or a['iscrowd'] == iscrowd)]
+
+    def loadAnns(self, ids):
+        m = {a['id']: a for a in self._anns}
+        return [m[i] for i in ids]
+
+
+ROIDB_ARRAYS = ('boxes', 'tracks', 'head_boxes', 'gt_classes', 'seg_areas', 'is_crowd', 'box_to_gt_ind_map', 'gt_keypoints', 'max_classes',
+                'max_overlaps', 'track_visible')
+ROIDB_SCALARS = ('id', 'width', 'height', 'nframes', 'frame_id', 'is_labeled', 'flipped', 'has_visible_keypoints')
+
+
+def roidb_record(roidb, out, prefix):
+    """Flatten a roidb into named arrays (npz) + a JSON-able list of the non-array fields."""
+    meta = []
+    for i, e in enumerate(roidb):
+        for k in ROIDB_ARRAYS:
+            if k in e:
+                out['%s/%d/%s' % (prefix, i, k)] = np.asarray(e[k])
+        out['%s/%d/gt_overlaps' % (prefix, i)] = e['gt_overlaps'].toarray()
+        m = {k: (bool(e[k]) if isinstance(e[k], (bool, np.bool_)) else int(e[k])) for k in ROIDB_SCALARS if k in e and not isinstance(e[k], np.ndarray)}
+        m['image'] = e['image']
+        m['keys'] = sorted(str(k) for k in e.keys())
+        m['n_segms'] = [len(s) for s in e['segms']]
+        for k in ('all_frame_ids', 'original_file_name'):
+            if k in e:
+                m[k] = e[k]
+        meta.append(m)
+    return meta
+
+
+DATASET_CLIP_CASES = ((3, 3, 1, False), (3, 1, 1, False), (2, 2, 1, False), (3, 3, 2, False), (3, 3, 1, True), (1, 1, 1, False))
+
+
+def golden_dataset(cfg):
+    """lib/datasets/json_dataset.py ITSELF (JsonDataset.__init__, get_roidb with and without ground truth, proposals from a file) and
+    lib/utils/video.py:38-201 (get_video_info, get_clip, _combine_clips -- the tube ground truth) run on tests/golden/synthetic_posetrack.json
+    through a stub of the four pycocotools.COCO calls it makes -> tests/golden/reference_json_dataset.npz / .json.  Not pinned: the crowd
+    filter (:479-497 calls pycocotools.mask.iou, C code that is not in the tree)."""
+    import json
+    import pickle as pkl
+    sys.modules['pycocotools.coco'].COCO = _StubCOCO
+    sys.modules['tqdm'] = types.ModuleType('tqdm')
+    sys.modules['tqdm'].tqdm = lambda it, **k: it
+    import datasets.json_dataset as rj
+    import utils.video as rv
+    rv.tqdm = lambda it, **k: it
+    ann = os.path.join(HERE, 'synthetic_posetrack.json')
+    with open(ann, 'w') as f:
+        json.dump(synthetic_posetrack_json(), f, sort_keys=True)
+    rj.DATASETS['synthetic_posetrack'] = {rj.IM_DIR: '/data/PoseTrack/', rj.ANN_FN: ann, rj.ANN_DN: '/data/annots'}
+    ds = rj.JsonDataset('synthetic_posetrack')
+    out, meta = {}, {}
+    meta['dataset'] = {'classes': ds.classes, 'num_classes': ds.num_classes, 'keypoints': ds.keypoints, 'num_keypoints': ds.num_keypoints,
+                       'keypoint_flip_map': ds.keypoint_flip_map, 'category_to_id_map': ds.category_to_id_map,
+                       'person_cat_info_keys': sorted(ds.person_cat_info), 'image_directory': ds.image_directory,
+                       'annotation_directory': ds.annotation_directory, 'frames_from_video': bool(ds.frames_from_video)}
+    meta['gt'] = roidb_record(ds.get_roidb(gt=True), out, 'gt')
+    meta['nogt'] = roidb_record(ds.get_roidb(gt=False), out, 'nogt')
+    # proposals from a file (:303-331, :424-476): duplicates, tiny boxes, boxes outside the image, file order != id order
+    rs = np.random.RandomState(5)
+    base = ds.get_roidb(gt=True)
+    props = {'boxes': [], 'ids': [], 'scores': []}
+    for e in base[::-1]:
+        n = 12
+        xy = np.stack([rs.uniform(-20, e['width'] - 40, n), rs.uniform(-20, e['height'] - 40, n)], axis=1)
+        b = np.hstack([xy, xy + rs.uniform(0.5, 220, (n, 2))]).astype(np.float32)
+        b[3] = b[2]
+        if len(e['boxes']):
+            b[5] = e['boxes'][0] + 1.5
+        props['boxes'].append(b)
+        props['ids'].append(e['id'])
+        props['scores'].append(rs.uniform(0, 1, n).astype(np.float32))
+    pfile = os.path.join(HERE, 'synthetic_posetrack_proposals.pkl')
+    with open(pfile, 'wb') as f:
+        pkl.dump(props, f, protocol=2)
+    rj.pickle = types.SimpleNamespace(load=lambda f: pkl.load(open(pfile, 'rb'), encoding='latin1'))     # (py2 text-mode open(..., 'r'))
+    meta['props'] = roidb_record(ds.get_roidb(gt=True, proposal_file=pfile, min_proposal_size=2, proposal_limit=8), out, 'props')
+    # clips with tube ground truth
+    meta['clips'] = []
+    for ci, (T, mid, step, imperfect) in enumerate(DATASET_CLIP_CASES):
+        cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID, cfg.VIDEO.TIME_INTERVAL = T, mid, step
+        clips = rv.get_clip(ds.get_roidb(gt=True), remove_imperfect=imperfect)
+        meta['clips'].append({'T': T, 'mid': mid, 'time_interval': step, 'remove_imperfect': imperfect,
+                              'entries': roidb_record(clips, out, 'clips%d' % ci)})
+    cfg.VIDEO.NUM_FRAMES, cfg.VIDEO.NUM_FRAMES_MID, cfg.VIDEO.TIME_INTERVAL = 1, 1, 1
+    np.savez_compressed(os.path.join(HERE, 'reference_json_dataset.npz'), **out)
+    with open(os.path.join(HERE, 'reference_json_dataset.json'), 'w') as f:
+        json.dump(meta, f, sort_keys=True)
+    print('wrote synthetic_posetrack.json, synthetic_posetrack_proposals.pkl, reference_json_dataset.npz (%d arrays) / .json; roidb %d entries, clips %s'
+          % (len(out), len(meta['gt']), [len(c['entries']) for c in meta['clips']]))
+
+
 def golden_postproc(cfg):
     """Detection post-processing of the REAL reference: core/test.py:750-806 box_results_with_nms_and_limit (with the reference's
     compiled Cython NMS), utils/boxes.py:294-310 box_voting, and the Cython soft_nms (utils/cython_nms.pyx:98-203) in its three
@@ -989,6 +1168,8 @@ if __name__ == '__main__':
         golden_lr_policy(_install_shims())
     elif '--only-builders' in sys.argv:
         golden_builders(_install_shims())
+    elif '--only-dataset' in sys.argv:
+        golden_dataset(_install_shims())
     elif '--only-cfg' in sys.argv:
         _c = _install_shims()
         golden_cfg_defaults(_c)
@@ -1008,3 +1189,4 @@ if __name__ == '__main__':
         golden_builders(sys.modules['core.config'].cfg)
         golden_weights(sys.modules['core.config'].cfg)
         golden_clips(sys.modules['core.config'].cfg)
+        golden_dataset(sys.modules['core.config'].cfg)

@@ -3,9 +3,9 @@
 
     python tools/test_net.py --cfg configs/x.yaml [--range s e] [--multi-gpu-testing] [--roidb clips.pkl] [KEY VAL ...]
 
-Differences forced by the offline environment: the clip list comes from `--roidb` (a pickled list of
-{'image': [T frame arrays], 'height', 'width'}) or `--synthetic N` instead of the PoseTrack JSON (needs pycocotools
-and the dataset).  `--multi-gpu-testing` shards clips over the ranks of a torch.distributed launch
+The clip list is cfg.TEST.DATASET read through datasets/json_dataset.py (COCO-format lists, no pycocotools; a dataset mounted elsewhere:
+DAT_DATASET_ROOT / DAT_DATASET_CATALOG), like the reference; offline it can also come from `--roidb` (a pickled list of
+{'image': [T frame arrays or paths], 'height', 'width'}) or `--synthetic N` / `--synthetic-video N`.  `--multi-gpu-testing` shards clips over the ranks of a torch.distributed launch
 (`python -m torch.distributed.run --nproc-per-node N tools/test_net.py ...`), the reference's one-process-per-GPU
 `--range` protocol (lib/utils/subprocess.py:38-63) also works unchanged.
 """
@@ -70,8 +70,12 @@ def main():
             roidb = pickle.load(f)
     elif args.synthetic_video:
         roidb = synthetic_video_roidb(args.synthetic_video, max(cfg.VIDEO.NUM_FRAMES, 1))
-    else:
+    elif args.synthetic:
         roidb = synthetic_roidb(max(args.synthetic, 1), max(cfg.VIDEO.NUM_FRAMES, 1))
+    else:       # the reference's own path (tools/test_net.py:66-143 -> core/test_engine.py:77-103): cfg.TEST.DATASET through the dataset layer
+        from detectandtrack_amd.datasets.json_dataset import load_catalog_from_env
+        load_catalog_from_env()
+        roidb = test_engine.get_roidb_and_dataset(None)[0]
     if args.synthetic_weights:
         test_engine.SYNTHETIC_WEIGHTS = True
     out = get_output_dir(training=False)
