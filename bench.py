@@ -183,7 +183,7 @@ def rocprof_same_box(a, B, kernel_name, flops_per_launch, peak):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
+def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False, kt=3):
     if tube:    # the declared FPN tube-head extension (dead reference design lib/modeling/FPN3D.py:232-330 + tube rois on
         # the 2-MLP head, head_builder.py:29-33, + the 3D keypoint head): the body stays 3D up to the heads (BODY_HEAD_LINK '')
         c = model_cfg(arch, T, dtype)
@@ -205,7 +205,7 @@ def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
                   'NUM_KEYPOINTS': 17, 'USE_DECONV_OUTPUT': True, 'CONV_INIT': 'MSRAFill', 'CONV_HEAD_DIM': 512,
                   'UP_SCALE': 2, 'HEATMAP_SIZE': 56, 'ROI_XFORM_METHOD': 'RoIAlign', 'ROI_XFORM_RESOLUTION': 14,
                   'ROI_XFORM_SAMPLING_RATIO': 2},
-        'VIDEO': {'NUM_FRAMES': T, 'TIME_KERNEL_DIM': 3, 'BODY_HEAD_LINK': 'slice-center',
+        'VIDEO': {'NUM_FRAMES': T, 'TIME_KERNEL_DIM': kt, 'BODY_HEAD_LINK': 'slice-center',
                   'WEIGHTS_INFLATE_MODE': 'center-only'},
         'TEST': {'RPN_PRE_NMS_TOP_N': 1000, 'RPN_POST_NMS_TOP_N': 1000, 'COMPETITION_MODE': False, 'NMS': 0.5,
                  'SCALES': (800,), 'MAX_SIZE': 1333},
@@ -412,13 +412,13 @@ def synthetic_clip(T, H, W, seed):
     return (data - means).contiguous()
 
 
-def build(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False):
+def build(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False, kt=3):
     from detectandtrack_amd.core.config import cfg, cfg_from_cfg, assert_and_infer_cfg, reset_cfg
     from detectandtrack_amd.modeling import model_builder
     from detectandtrack_amd.utils import net as net_utils
     from detectandtrack_amd import workspace
     reset_cfg()
-    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce, two_d, tube))
+    cfg_from_cfg(model_cfg(arch, T, dtype, keyframe_dce, two_d, tube, kt=kt))
     assert_and_infer_cfg()
     model = model_builder.create(cfg.MODEL.TYPE, train=False)
     workspace.ResetWorkspace()
@@ -611,8 +611,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn', '3d_r18_fpn3d_tube'],
-                    help='default 3d_r18_fpn3d (BASELINE config 3); 2d_r50_fpn = config 2 (a step = 8 frames, one forward per frame)')
+    ap.add_argument('--workload', default=None, choices=['3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d', '2d_r50_fpn', '3d_r18_fpn3d_tube', '2d_best_r101'],
+                    help='default 3d_r18_fpn3d (BASELINE config 3); 2d_r50_fpn = config 2 (a step = 8 frames, one forward per frame); 2d_best_r101 = the '
+                         'shipped configs/video/2d_best/01_R101_best_hungarian.yaml model (R-101 FPN3D body, NUM_FRAMES 1, TIME_KERNEL_DIM 1: the one the '
+                         'reference publishes accuracy for), a step = one forward of 8 single-frame clips, value in frames/s')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'], help='train: one training iteration per step (config 4)')
     ap.add_argument('--arch', default=None, choices=['18', '50', '101'], help='shorthand for --workload 3d_r<arch>_fpn3d')
     ap.add_argument('--frames', type=int, default=8)
@@ -648,7 +650,10 @@ def main():
         a.pipeline = 3 if a.workload in ('3d_r18_fpn3d', '3d_r50_fpn3d', '3d_r101_fpn3d') and a.mode == 'infer' and not a.batch else 4 if not a.workload.endswith('_tube') else 2
     two_d = a.workload == '2d_r50_fpn'
     tube = a.workload.endswith('_tube')
-    a.arch = '50' if two_d else a.workload.split('_')[1][1:]
+    best2d = a.workload == '2d_best_r101'
+    if best2d:      # single-frame clips, no temporal kernels: 8 of them per forward unless told otherwise
+        a.frames, a.batch = 1, a.batch or 8
+    a.arch = '50' if two_d else '101' if best2d else a.workload.split('_')[1][1:]
     train = a.mode == 'train'
     assert not (train and (two_d or tube)), '--mode train benches the 3D FPN models with 2D heads (BASELINE config 4)'
 
@@ -721,7 +726,7 @@ def main():
             torch.cuda.synchronize()
         n_det = 512
     else:
-        model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d, tube)
+        model, ws = build(a.arch, T, a.dtype, a.keyframe_dce, two_d, tube, kt=1 if best2d else 3)
         # every rank gets its own clips (weak scaling): seed by rank.  2D: the frames of a clip are fed one by one.
         from detectandtrack_amd.core.pipeline import ClipPipeline
         if two_d:   # a step = T frames in T / B forwards of B frames
@@ -1080,6 +1085,10 @@ def main():
         workload = ('2D R-%s-FPN keypoint R-CNN inference, a step = %d frames of 1x3x%dx%d run as %d forward(s) of %d frame(s) '
                     '(per frame: 1000 proposals, %d detections in the last frame -> kps_score -> decoded keypoints)'
                     % (a.arch, T, H, W, fwd_per_step, B, n_det))
+    elif best2d:
+        workload = ('configs/video/2d_best/01_R101_best_hungarian.yaml model (R-101 FPN3D body with NUM_FRAMES 1 / TIME_KERNEL_DIM 1, slice-center, 2-MLP box head, '
+                    '2D keypoint head): %d frames of 1x3x1x%dx%d per step (= per forward) per GPU; `value` counts FRAMES/s (per frame: 1000 proposals, %d '
+                    'detections -> kps_score -> decoded keypoints)' % (B, H, W, n_det))
     elif tube:
         workload = ('3D R-%s FPN3D keypoint R-CNN with TUBE heads (declared extension of the reference\'s dead FPN3D RPN design), %d clip(s) of '
                     '1x3x%dx%dx%d per step per GPU (kT=3 body+FPN kept 3D to the heads, tube RPN per level, tube rois on the 2-MLP head, 3D keypoint '
@@ -1193,7 +1202,8 @@ def other_configs():
             ('config4_3d_r50_fpn3d_training', ['--workload', '3d_r50_fpn3d', '--mode', 'train']),
             ('config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
             ('config3_3d_r18_fpn3d_training', ['--mode', 'train']),
-            ('extension_3d_r18_fpn3d_tube_heads_inference', ['--workload', '3d_r18_fpn3d_tube'])]
+            ('extension_3d_r18_fpn3d_tube_heads_inference', ['--workload', '3d_r18_fpn3d_tube']),
+            ('reference_2d_best_r101', ['--workload', '2d_best_r101'])]
     res = {}
     try:    # config 5 END TO END: detector over a video-shaped clip list (host frames) -> detections.pkl -> host Hungarian tracker
         p = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bench_config5.py')], env=env, stdout=subprocess.PIPE,

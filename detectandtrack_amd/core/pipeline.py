@@ -29,11 +29,33 @@ from detectandtrack_amd.core import test as engine
 from detectandtrack_amd import workspace as wsmod
 
 
+def _cu_masked_stream(spec):
+    """EXPERIMENT (DAT_SLOT_CUS): a HIP stream restricted to a CU subset (hipExtStreamCreateWithCUMask), wrapped for torch.
+    spec: 'lo-hi[+lo-hi...]' bit ranges of the CU mask (256 CUs on MI355X; the driver spreads mask bits round-robin over the 8 XCDs)."""
+    import ctypes
+    bits = 0
+    for part in spec.split('+'):
+        lo, hi = [int(v) for v in part.split('-')]
+        for b in range(lo, hi + 1):
+            bits |= 1 << b
+    words = (ctypes.c_uint32 * 8)(*[(bits >> (32 * i)) & 0xffffffff for i in range(8)])
+    hip = ctypes.CDLL('libamdhip64.so')
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    assert rc == 0, 'hipExtStreamCreateWithCUMask failed: %d' % rc
+    return torch.cuda.ExternalStream(st.value)
+
+
 class _Slot(object):
     __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'data', 'live', 'gather_event')
+    _made = 0
 
     def __init__(self, ws):
-        self.ws, self.stream = ws, torch.cuda.Stream()
+        spec = os.environ.get('DAT_SLOT_CUS', '')          # e.g. '0-127,128-255': slot i takes entry i % n ('all' = an ordinary stream)
+        parts = [p for p in spec.split(',') if p]
+        mine = parts[_Slot._made % len(parts)] if parts else 'all'
+        _Slot._made += 1
+        self.ws, self.stream = ws, (torch.cuda.Stream() if mine == 'all' else _cu_masked_stream(mine))
         self.event, self.copy_event = torch.cuda.Event(), torch.cuda.Event()
         self.graphs = collections.OrderedDict()   # geometry key -> ClipGraph, least recently used first (bounded: max_graphs)
         self.pinned = self.dev_u8 = None
