@@ -620,8 +620,8 @@ def main():
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--height', type=int, default=768)
     ap.add_argument('--width', type=int, default=1344)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'bf16x3'],
-                    help="arithmetic mode (cfg.HIP.DTYPE): bf16 = the benched performance mode; fp32 = v_mfma_f32 parity mode; bf16x3 = fp32 activations, convs on "
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32', 'bf16x3'],
+                    help="arithmetic mode (cfg.HIP.DTYPE): bf16 = the benched performance mode; fp16 = IEEE-half operands at the bf16 MFMA rate (libdat_hip_f16.so; this process is re-run with DAT_H16=fp16); fp32 = v_mfma_f32 parity mode; bf16x3 = fp32 activations, convs on "
                          "hi / lo bf16 splits of both operands (three bf16 MFMAs per k-slice): the parity bar at several times the fp32 rate")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -644,6 +644,11 @@ def main():
                     help='opt-in cfg.HIP.KEYFRAME_DCE: compute only the centre frame of the FPN outputs that slice-center keeps '
                          '(identical detections; NOT the default, the default materialises every frame like the reference)')
     a = ap.parse_args()
+    if a.dtype == 'fp16' and os.environ.get('DAT_H16', 'bf16') != 'fp16':
+        # the 16-bit format is a property of the library build, chosen when it is loaded: the same command line again with the fp16 build
+        # (under a launcher every rank does this for itself)
+        os.environ['DAT_H16'] = 'fp16'
+        os.execv(sys.executable, [sys.executable] + sys.argv)
     if a.workload is None:
         a.workload = '3d_r%s_fpn3d' % (a.arch or '18')
     if a.pipeline is None:
@@ -739,7 +744,7 @@ def main():
 
         # the input blobs are resident in HBM (the contract of `value`); in the benched bf16 mode the graphs read them where they
         # lie -- one captured graph per (slot, input buffer) -- instead of copying 99 MB per clip into a private graph input first
-        resident_in = a.dtype == 'bf16' and bool(a.graph) and os.environ.get('DAT_BENCH_RESIDENT', '1') != '0'   # (env: A/B switch)
+        resident_in = a.dtype in ('bf16', 'fp16') and bool(a.graph) and os.environ.get('DAT_BENCH_RESIDENT', '1') != '0'   # (env: A/B switch)
 
         def run_steps(n):
             for i in range(n):
@@ -986,7 +991,7 @@ def main():
         # package power + driver-reported shader clock sampled over the timed region (amdgpu hwmon; None where the container hides it)
         'power_over_timed_region': power,
         # the vendor's tuned dense bf16 GEMM on this very box (hipBLASLt 8192^3): the practical, power-capped MFMA ceiling
-        'vendor_gemm_tflops_same_box': vendor_gemm_tflops() if a.dtype == 'bf16' else None,
+        'vendor_gemm_tflops_same_box': vendor_gemm_tflops(dtype=torch.float16 if a.dtype == 'fp16' else torch.bfloat16) if a.dtype in ('bf16', 'fp16') else None,
         'launches_per_step': round(launches_per_step, 2),
         'avg_launch_ms': round(avg_launch_ms, 4),
         'algorithmic_tflop_per_step': round(dom_tflop_per_step, 4),
@@ -1146,7 +1151,7 @@ def main():
     if not train:    # images whose detections went through the host glue (exact score ties beyond the device buffers' spare rows)
         out['host_path_images'] = pipe.host_path_images
         out['tie_rerun_images'] = pipe.rerun_images     # (detections tied beyond the spare rows: device glue re-run with more rows, no host path)
-    if a.dtype == 'bf16' and not train and not a.no_accuracy and not a.keyframe_dce:
+    if a.dtype in ('bf16', 'fp16') and not train and not a.no_accuracy and not a.keyframe_dce:
         # what the benched arithmetic costs: bf16 vs the fp32 parity mode of the same model on the benched clip
         from detectandtrack_amd.utils import precision
         out['accuracy_vs_fp32'] = precision.bf16_vs_fp32(model, slots[0][0], clips[0][0][:1].contiguous(), im_info[:1], n_kp=100, trail=True)
@@ -1163,6 +1168,11 @@ def main():
         out['bf16x3_mode'] = precision_mode_run('bf16x3')
         if 'value' in out['fp32_mode'] and 'value' in out['bf16x3_mode']:
             out['bf16x3_mode']['speedup_over_fp32_mode'] = round(out['bf16x3_mode']['value'] / out['fp32_mode']['value'], 3)
+        # fp16-operand mode: the same workload on libdat_hip_f16.so -- IEEE-half activations / weights, v_mfma_f32_32x32x16_f16
+        # (the bf16 MFMA rate, three more mantissa bits) -- with its own accuracy_vs_fp32, next to the bf16 headline
+        out['fp16_mode'] = fp16_mode_run()
+        if 'value' in out['fp16_mode']:
+            out['fp16_mode']['rate_vs_bf16'] = round(out['fp16_mode']['value'] / value, 4)
         out['other_configs'] = other_configs()
     print(json.dumps(out), flush=True)
     if dist is not None:
@@ -1188,6 +1198,29 @@ def precision_mode_run(dtype, steps=5, warmup=2):
                 'sequential_clips_per_s': d.get('sequential_clips_per_s'),
                 'all_conv_tflops': d['roofline']['all_conv_kernels']['tflops'],
                 'parity': 'kps_score max-abs < 1e-3 vs the oracle at this shape (tests/test_gpu_parity_full.py, 1 and 4 clips per forward)'}
+    except Exception as e:   # noqa: BLE001
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
+def fp16_mode_run(steps=20, warmup=5):
+    """The headline workload with fp16 operands (child run of this script with --dtype fp16): clips/s, the dominant kernel's rate, and what
+    the arithmetic costs against the fp32 parity mode of the same model on the benched clip -- the figures `accuracy_vs_fp32` gives for bf16."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', str(steps), '--warmup', str(warmup), '--dtype', 'fp16',
+           '--no-cpu-baseline', '--no-other-configs', '--no-rocprof-check', '--h2d', '0']
+    try:
+        p = subprocess.run(cmd, env=_child_env(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+        d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        acc = d.get('accuracy_vs_fp32') or {}
+        rl = d['roofline']
+        return {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'dtype': d['dtype'], 'steps': steps,
+                'sequential_clips_per_s': d.get('sequential_clips_per_s'),
+                'dominant_kernel': {'kernel': rl['kernel'], 'tflops': rl['achieved'], 'frac': rl['frac'], 'avg_launch_ms': rl['avg_launch_ms'],
+                                    'measured': 'hip_events_back_to_back of the child run'},
+                'all_conv_tflops': rl['all_conv_kernels']['tflops'], 'power_over_timed_region': rl.get('power_over_timed_region'),
+                'accuracy_vs_fp32': {k: acc.get(k) for k in ('kps_score_max_abs_err', 'kps_score_mean_abs_err', 'kps_score_ref_max_abs',
+                                                             'kps_argmax_cell_identical', 'keypoints_within_1px', 'keypoint_mean_px_err',
+                                                             'rois_matched_iou_0.9', 'worst_blob_rel_err')}}
     except Exception as e:   # noqa: BLE001
         return {'error': '%s: %s' % (type(e).__name__, e)}
 

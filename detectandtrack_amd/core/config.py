@@ -233,7 +233,8 @@ def _build_defaults():
     c.BBOX_XFORM_CLIP = np.log(1000. / 16.)                          # config.py:672
     c.PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])     # config.py:677 (BGR)
     c.ROOT_DIR = os.getcwd()
-    # extension (not in the reference): arithmetic mode of the HIP path, 'bf16' (performance) | 'fp32' (parity: v_mfma_f32) |
+    # extension (not in the reference): arithmetic mode of the HIP path, 'bf16' (performance) | 'fp16' (round 6: IEEE-half operands at the
+    # bf16 MFMA rate, libdat_hip_f16.so, process started with DAT_H16=fp16) | 'fp32' (parity: v_mfma_f32) |
     # 'bf16x3' (inference: fp32 activations, every conv on hi / lo bf16 splits of both operands -- x_hi*W_hi + x_hi*W_lo + x_lo*W_hi,
     # fp32 accumulate, ~2^-16 relative: the 1e-3 parity bar at several times the fp32-MFMA rate)
     # KEYFRAME_DCE (opt-in): with BODY_HEAD_LINK 'slice-center' the heads read only the centre frame of every FPN

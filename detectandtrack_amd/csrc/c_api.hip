@@ -29,6 +29,7 @@ int dat_ensure_ws(dat_ctx* ctx, size_t bytes) {
 extern "C" {
 
 int dat_version(void) { return 1; }
+int dat_h16_format(void) { return DAT_H16_FORMAT; }
 
 int dat_ctx_create(dat_ctx** out, int device) {
     if (!out) return DAT_ERR_ARG;

@@ -947,6 +947,7 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     DAT_ENFORCE(ctx, d && x && w_packed && y, "conv3d_fwd: null argument");
     DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16 || d->dtype == DAT_BF16X3, "conv3d_fwd: bad dtype %d", d->dtype);
     const bool x3 = d->dtype == DAT_BF16X3;
+    DAT_ENFORCE(ctx, !x3 || DAT_H16_FORMAT == 0, "conv3d_fwd: DAT_BF16X3 needs the bf16 build of the library (this one holds IEEE half in its 16-bit tensors)");
     DAT_ENFORCE(ctx, !x3 || weights_direct(ctx, d), "conv3d_fwd: the bf16x3 mode runs on the weights-direct kernel variants (DAT_CONV_WD)");
     DAT_ENFORCE(ctx, d->Cin % 64 == 0, "conv3d_fwd: Cin (channel stride) %d must be a multiple of 64", d->Cin);
     DAT_ENFORCE(ctx, d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_cstride >= d->Cout,

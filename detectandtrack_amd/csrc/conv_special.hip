@@ -64,9 +64,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                     if (tp < VT) wv[tp][mb][ks] = v; else wg[tp - VT][mb][ks] = v;
                 }
     }
-#define WS_MFMA0_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(ACC_) : "v"(A_), "v"(B_) : "memory")
-#define WS_MFMA_V(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
-#define WS_MFMA_A(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "a"(A_), "v"(B_) : "memory")
+#define WS_MFMA0_V(ACC_, A_, B_) asm volatile(DAT_MFMA16_OP " %0, %1, %2, 0" : "=&a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_V(ACC_, A_, B_) asm volatile(DAT_MFMA16_OP " %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define WS_MFMA_A(ACC_, A_, B_) asm volatile(DAT_MFMA16_OP " %0, %1, %2, %0" : "+a"(ACC_) : "a"(A_), "v"(B_) : "memory")
     // ---- swizzled LDS address (k-slice 0) of the B fragment of every (tap, position sub-tile), two per register ----
     // sub-tile j of this wave: 8 x 32 tiles: output row 2*wave + j, column n; 16 x 16 tiles: rows 4*wave + 2*j + (n >> 4), column n & 15
     unsigned qp[9];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
             asm volatile("ds_read_b128 %0, %1" : "=v"(bq[(S_) % 2][j_]) : "v"(ba[j_] ^ (unsigned)(((S_) % 4) << 5)) : "memory"); \
     }
-#define BT_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
+#define BT_MFMA(ACC_, A_, B_) asm volatile(DAT_MFMA16_OP " %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
 
     f32x16_t acc[4][4];
 #pragma unroll

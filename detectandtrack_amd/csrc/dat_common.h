@@ -91,6 +91,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+// ---- the 16-bit element format of this BUILD --------------------------------------------------------------------------------------------
+// libdat_hip.so: bfloat16 (the benched performance mode).  libdat_hip_f16.so (-DDAT_H16_IS_FP16, round 6): IEEE half -- the same enum value
+// DAT_BF16 ("the 16-bit activation / weight type"), the same kernels, tiles and layouts; only the conversions below and the MFMA opcode
+// differ (v_mfma_f32_32x32x16_f16 runs at the bf16 rate on gfx950).  Three more mantissa bits for activations that are O(1 - 1000) after
+// the affine layers; the range shrinks to 65504 (values beyond saturate to +-inf).  One flavour per process (dat_h16_format()).
+#ifdef DAT_H16_IS_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
+typedef _Float16 dat_h16x2_t __attribute__((ext_vector_type(2)));
+typedef float dat_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }       // round to nearest even
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    const dat_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dat_h16x2_t));
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+#define DAT_MFMA16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, A_), __builtin_bit_cast(h16x8_t, B_), C_, 0, 0, 0)
+#define DAT_MFMA16_OP "v_mfma_f32_32x32x16_f16"
+#define DAT_H16_FORMAT 1
+#else
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer-arithmetic
 // version it replaces cost ~8 VALU operations per element and dominated the epilogue of the memory-bound layers
 typedef __bf16 dat_bf16x2_t __attribute__((ext_vector_type(2)));
@@ -102,6 +121,10 @@ __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dat_bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+#define DAT_MFMA16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A_), __builtin_bit_cast(bf16x8_t, B_), C_, 0, 0, 0)
+#define DAT_MFMA16_OP "v_mfma_f32_32x32x16_bf16"
+#define DAT_H16_FORMAT 0
+#endif
 
 template <int DT> struct ElemOf;
 template <> struct ElemOf<DAT_F32> {

@@ -488,6 +488,7 @@ int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int
 }
 
 int dat_split_bf16x2(dat_ctx* ctx, dat_stream s, const float* x, void* y, long long npos, int C) {
+    DAT_ENFORCE(ctx, DAT_H16_FORMAT == 0, "split_bf16x2: needs the bf16 build of the library");
     DAT_ENFORCE(ctx, x && y && npos >= 0 && C > 0 && C % 64 == 0, "split_bf16x2: C %d must be a positive multiple of 64", C);
     const long long n8 = npos * (C / 8);
     if (n8 == 0) return DAT_OK;

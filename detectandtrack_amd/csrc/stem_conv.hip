@@ -34,7 +34,7 @@ struct StemParams {
 
 template <int DT> __device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x16_t& c);
 template <> __device__ __forceinline__ void mma_step<DAT_BF16>(const uint4& a, const uint4& b, f32x16_t& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    c = DAT_MFMA16(a, b, c);
 }
 template <> __device__ __forceinline__ void mma_step<DAT_F32>(const uint4& a, const uint4& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);

@@ -37,7 +37,7 @@ template <int DT> struct MmaT;
 template <> struct MmaT<DAT_BF16> {
     static constexpr int CK = 64;
     __device__ static __forceinline__ void step(const uint4& a, const uint4& b, f32x16_t& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+        c = DAT_MFMA16(a, b, c);
     }
 };
 template <> struct MmaT<DAT_F32> {

@@ -12,7 +12,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('DAT_LIB', os.path.join(_HERE, 'libdat_hip.so'))
+# DAT_H16=fp16 selects the IEEE-half build of the same sources (cfg.HIP.DTYPE 'fp16'; one 16-bit flavour per process)
+H16 = os.environ.get('DAT_H16', 'bf16')
+assert H16 in ('bf16', 'fp16'), 'DAT_H16: bf16 | fp16'
+LIB_PATH = os.environ.get('DAT_LIB', os.path.join(_HERE, 'libdat_hip_f16.so' if H16 == 'fp16' else 'libdat_hip.so'))
 
 DAT_F32, DAT_BF16, DAT_BF16X3 = 0, 1, 2
 DAT_OK = 0
@@ -72,6 +75,7 @@ _lib = C.CDLL(LIB_PATH)
 _p, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
 _PROTOS = {
     'dat_version': (_i, []),
+    'dat_h16_format': (_i, []),
     'dat_ctx_create': (_i, [C.POINTER(_p), _i]),
     'dat_ctx_destroy': (None, [_p]),
     'dat_last_error': (C.c_char_p, [_p]),

@@ -14,8 +14,13 @@ from .. import libdat as L
 F32, BF16 = L.DAT_F32, L.DAT_BF16
 
 
+# the 16-bit element format of the LOADED library build (libdat.H16: 'bf16' = libdat_hip.so, 'fp16' = libdat_hip_f16.so, the same sources
+# compiled with -DDAT_H16_IS_FP16): the C ABI's DAT_BF16 tag then means IEEE half, and the torch tensors that carry it are float16
+H16_DTYPE = torch.float16 if L.H16 == 'fp16' else torch.bfloat16
+
+
 def tdtype(dt):
-    return torch.bfloat16 if dt == BF16 else torch.float32
+    return H16_DTYPE if dt == BF16 else torch.float32
 
 
 def _ptr(t):

@@ -201,14 +201,19 @@ def _valid_rows(b, arr):
 
 def _mode(ws=None):
     mode = (getattr(ws, 'dtype', None) if ws is not None else None) or cfg.HIP.DTYPE
-    assert mode in ('bf16', 'fp32', 'bf16x3'), 'cfg.HIP.DTYPE %r: bf16 | fp32 | bf16x3' % (mode,)
+    assert mode in ('bf16', 'fp16', 'fp32', 'bf16x3'), 'cfg.HIP.DTYPE %r: bf16 | fp16 | fp32 | bf16x3' % (mode,)
+    if mode in ('bf16', 'fp16', 'bf16x3'):
+        # the 16-bit format is a property of the loaded library build (one per process: DAT_H16 selects libdat_hip.so / libdat_hip_f16.so)
+        want = 'fp16' if mode == 'fp16' else 'bf16'
+        assert ops.L.H16 == want, ('cfg.HIP.DTYPE %r needs the %s build of the library: start the process with DAT_H16=%s (loaded: %s)'
+                                   % (mode, want, want, ops.L.H16))
     return mode
 
 
 def _dt(ws=None):
     """element type of the activations: bf16 in the performance mode; fp32 in the parity mode AND in 'bf16x3', whose convs split
     their fp32 operands into bf16 hi / lo parts on the fly (ops.ConvLayer x3)"""
-    return ops.BF16 if _mode(ws) == 'bf16' else ops.F32
+    return ops.BF16 if _mode(ws) in ('bf16', 'fp16') else ops.F32       # (ops.BF16 = the library's 16-bit tag: IEEE half in the fp16 build)
 
 
 def _x3(ws=None):

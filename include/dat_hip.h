@@ -41,6 +41,10 @@ enum { DAT_OK = 0, DAT_ERR_ARG = -1, DAT_ERR_LAUNCH = -2, DAT_ERR_ALLOC = -3, DA
 
 /* ---- context ------------------------------------------------------------------------- */
 int dat_version(void);
+/* The 16-bit element format of THIS build of the library: 0 = bfloat16 (libdat_hip.so, the benched performance mode), 1 = IEEE half
+ * (libdat_hip_f16.so, the same sources compiled with -DDAT_H16_IS_FP16: every tensor or packed weight tagged DAT_BF16 then holds fp16 and the
+ * conv kernels issue v_mfma_f32_32x32x16_f16 -- the bf16 MFMA rate with three more mantissa bits; DAT_BF16X3 is not available there). */
+int dat_h16_format(void);
 int dat_ctx_create(dat_ctx** out, int device);
 void dat_ctx_destroy(dat_ctx* ctx);
 const char* dat_last_error(dat_ctx* ctx);

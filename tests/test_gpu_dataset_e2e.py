@@ -2,7 +2,8 @@
 dataset layer (datasets/json_dataset.py -> utils/video.get_clip), decodes frame FILES, runs the pipelined engine (mixed resolutions, per-frame
 trunk cache), `tools/compute_tracks.py` reads the same dataset with its ground truth and writes detections_withTracks.pkl -- end to end
 on a synthetic COCO-format dataset DIRECTORY (annotation JSON + image files), and equal to the reference-shaped eager loop
-(cfg.HIP.PIPELINE_DEPTH 0: one clip at a time through im_detect_all)."""
+(cfg.HIP.PIPELINE_DEPTH 0: one clip at a time through im_detect_all) -- bit for bit with one clip per forward (the same kernels on the
+same grids; several clips per forward change the summation order of the conv grids, tests/test_gpu_model.py)."""
 import json
 import os
 import pickle
@@ -88,7 +89,7 @@ def test_tools_run_a_shipped_config_on_a_dataset_directory(tmp_path, rel):
         with open(os.path.join(sub, 'detections_withTracks.pkl'), 'rb') as f:
             return pickle.load(f), (stats[0] if stats else None)
     three_d = '-3D_' in rel
-    piped, st = run('pipelined', ['HIP.PIPELINE_DEPTH', '3', 'HIP.IMS_PER_FORWARD', '2'] + (['HIP.FRAME_TRUNK_CACHE', '8'] if three_d else []))
+    piped, st = run('pipelined', ['HIP.PIPELINE_DEPTH', '3', 'HIP.IMS_PER_FORWARD', '1'] + (['HIP.FRAME_TRUNK_CACHE', '8'] if three_d else []))
     eager, st0 = run('eager', ['HIP.PIPELINE_DEPTH', '0'])
     assert st is not None and st['clips'] == n_images and st0 is None
     if three_d:

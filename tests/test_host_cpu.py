@@ -23,7 +23,11 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(REPO, 'detectandtrack_amd', 'libdat_hip.so'))
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.dat_version() >= 1
+    assert lib.dat_version() >= 1 and lib.dat_h16_format() == 0
+    # the IEEE-half flavour of the same sources (cfg.HIP.DTYPE 'fp16'): the same exports, the other 16-bit format
+    lib16 = ctypes.CDLL(os.path.join(REPO, 'detectandtrack_amd', 'libdat_hip_f16.so'))
+    assert not [n for n in declared if not hasattr(lib16, n)]
+    assert lib16.dat_version() == lib.dat_version() and lib16.dat_h16_format() == 1
     from detectandtrack_amd import libdat
     assert sorted(libdat.EXPORTS) == declared, set(declared) ^ set(libdat.EXPORTS)
 
