@@ -37,6 +37,9 @@ class ClipGraph(object):
         assert engine.device_results_supported(), 'graph capture needs the device-side post-processing (cfg.HIP.DEVICE_BOX_RESULTS)'
         self.model, self.ws = model, ws
         B = int(trunk[3]) if trunk is not None else int(data_like.shape[0])
+        # the image scale reaches the device glue as the DOUBLE the reference divides the boxes by (core/test.py:224-231: im_scales from
+        # prep_im_for_blob); the `im_info` blob holds its float32 rounding (round 6: the graph path used the rounded one for both)
+        self.scales = [float(v) for v in np.asarray(im_info, dtype=np.float64).reshape(-1, 3)[:, 2]]
         self.im_info = np.asarray(im_info, dtype=np.float32).reshape(-1, 3)
         assert self.im_info.shape[0] == B, 'im_info has %d rows for a blob of %d images' % (self.im_info.shape[0], B)
         self.im_shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
@@ -74,7 +77,7 @@ class ClipGraph(object):
             else:
                 self.ws.FeedBlob('data', self.static_data)
             self.ws.RunNet(self.model.net.name)
-            return engine.enqueue_results_on_device(self.model, self.im_shapes, [float(v) for v in self.im_info[:, 2]])
+            return engine.enqueue_results_on_device(self.model, self.im_shapes, list(self.scales))
         finally:
             wsmod._GLOBAL = prev
 

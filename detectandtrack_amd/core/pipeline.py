@@ -112,7 +112,7 @@ class FrameTrunkCache(object):
         from detectandtrack_amd.workspace import Executor
         ws = self.ws
         ws.FeedBlob('data', data)
-        ws.FeedBlob('im_info', im_info)
+        ws.FeedBlob('im_info', np.asarray(im_info, np.float32))
         ex = Executor(ws, self.model.net)
         ex._plan_rpn_siblings()
         ex._plan_keyframe_dce()
@@ -186,7 +186,7 @@ class FrameTrunkCache(object):
                 self.slot_of[fid] = sl
             self.frames_computed += n
         B = len(ids) // T
-        im_info = np.tile(np.array([self._info], dtype=np.float32), (B, 1))
+        im_info = np.tile(np.array([self._info], dtype=np.float64), (B, 1))
         return [self.slot_of[fid] for fid in ids], im_info
 
 
@@ -278,7 +278,7 @@ class ClipPipeline(object):
                     s.ws.FeedBlob('data', data_dev)
                 s.ws.FeedBlob('im_info', np.asarray(im_info, np.float32))
                 s.ws.RunNet(self.model.net.name)
-                scales = [float(v) for v in np.asarray(im_info, np.float32).reshape(-1, 3)[:, 2]]
+                scales = [float(v) for v in np.asarray(im_info, np.float64).reshape(-1, 3)[:, 2]]      # (the exact double, see ClipGraph)
                 return engine.enqueue_results_on_device(self.model, list(im_shapes), scales), None
             finally:
                 wsmod._GLOBAL = prev
@@ -291,7 +291,7 @@ class ClipPipeline(object):
         slot = self._acquire()
         t0 = time.perf_counter()
         B = int(data_dev.shape[0])
-        im_info = np.asarray(im_info, np.float32).reshape(-1, 3)
+        im_info = np.asarray(im_info, np.float64).reshape(-1, 3)        # (float64: the scale column is used as the reference's double)
         assert im_info.shape[0] == B, (im_info.shape, B)
         shapes = [tuple(im_shape)] * B if not isinstance(im_shape[0], (tuple, list)) else [tuple(sh) for sh in im_shape]
         dev, g = self._enqueue(slot, data_dev, im_info, shapes, in_place=False, resident=resident and self.use_graph)
@@ -428,7 +428,7 @@ class ClipPipeline(object):
         """Only the images that overflowed are recomputed: their row segment of the forward's blobs through dat_box_results with
         n_out[i, 1] rows, their boxes through the keypoint net and the decode."""
         n = dev[1].cpu().numpy().reshape(-1, 2)
-        info = np.asarray(im_info, np.float32).reshape(-1, 3)
+        info = np.asarray(im_info, np.float64).reshape(-1, 3)
         out = list(res)
         for i, r in enumerate(res):
             if r is not None:

@@ -60,7 +60,9 @@ def frames_to_blob_on_device(frames_u8, num_frames, out=None):
     T = int(num_frames) if cfg.MODEL.VIDEO_ON else 1
     data, _ = ops.preprocess_frames(frames_u8, T, scale, cfg.PIXEL_MEANS, int(cfg.FPN.COARSEST_STRIDE) if cfg.FPN.FPN_ON else 0, out=out)
     n = data.shape[0]
-    im_info = np.tile(np.array([[data.shape[-2], data.shape[-1], scale]], dtype=np.float32), (n, 1))
+    # (float64 rows: the `im_info` BLOB is their float32 rounding -- whoever feeds it converts --, the scale column also travels to the device
+    #  glue, which divides the boxes by the double like the reference)
+    im_info = np.tile(np.array([[data.shape[-2], data.shape[-1], scale]], dtype=np.float64), (n, 1))
     if not cfg.MODEL.VIDEO_ON:
         data = data.view(n, 3, data.shape[-2], data.shape[-1])
     return data, scale, im_info
