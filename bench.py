@@ -440,6 +440,8 @@ def conv_kernel_name(tag, dtype):
         return 'conv1x1_k64_c256_ws_kernel<%s>' % dtype     # weights-stationary 1x1 kernel (64 -> 256: the FPN P2 lateral)
     if bn == 256 and bp == 33:
         return 'conv1x1_lw_kernel<%s>' % dtype              # weights-in-LDS persistent 1x1 kernel (HBM-bound bottleneck / lateral layers)
+    if bn == 256 and bp == 34:
+        return 'conv1x1_ks_kernel<%s>' % dtype              # K-streaming 1x1 kernel (K >= 1024: res4 / res5 branch2a, res5 shortcut, P4 / P5 laterals)
     if bn == 256 and bp == 256:
         return 'conv3x3_bt_kernel<%s,256,256>' % dtype      # big-tile kernel (one wave per SIMD)
     tps = {3: ',tps3', 4: ',tps3'}.get(tag % 10, '')
@@ -1048,7 +1050,8 @@ def main():
     # ---- the HBM-bound kernel class, scored in GB/s against the 8 TB/s HBM3E peak (1x1x1 convs, conv1, pooling are
     # HBM-bound): the persistent 1x1 kernels from the same per-launch event pairs, the fused stem from its own timed launches ----
     roofline_hbm = []
-    for tags_, kname in (((2560331,), 'conv1x1_lw_kernel<%s>' % a.dtype), ((2560321,), 'conv1x1_k64_c256_ws_kernel<%s>' % a.dtype)):
+    for tags_, kname in (((2560331,), 'conv1x1_lw_kernel<%s>' % a.dtype), ((2560321,), 'conv1x1_k64_c256_ws_kernel<%s>' % a.dtype),
+                         ((2560341,), 'conv1x1_ks_kernel<%s>' % a.dtype)):
         sel = [(ms, nb) for (tag, _, ms), (_, _fl, nb) in zip(records, conv_log) if tag in tags_ and nb > 0]
         if sel:
             tms, tb = sum(m for m, _ in sel), sum(b for _, b in sel)
@@ -1236,7 +1239,10 @@ def other_configs():
             ('config5_3d_r50_fpn3d_inference', ['--workload', '3d_r50_fpn3d']),
             ('config3_3d_r18_fpn3d_training', ['--mode', 'train']),
             ('extension_3d_r18_fpn3d_tube_heads_inference', ['--workload', '3d_r18_fpn3d_tube']),
-            ('reference_2d_best_r101', ['--workload', '2d_best_r101'])]
+            ('reference_2d_best_r101', ['--workload', '2d_best_r101']),
+            # OPT-IN mode, reported for information only (never `value`): the FPN outputs' frames that 'slice-center' drops are not computed
+            # (cfg.HIP.KEYFRAME_DCE: identical rois / scores / heat maps; the default materialises every frame like the reference does)
+            ('config3_with_keyframe_dce_opt_in', ['--keyframe-dce'])]
     res = {}
     try:    # config 5 END TO END: detector over a video-shaped clip list (host frames) -> detections.pkl -> host Hungarian tracker
         p = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bench_config5.py')], env=env, stdout=subprocess.PIPE,

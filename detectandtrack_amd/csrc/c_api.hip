@@ -60,6 +60,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_pack_simple = env_int("DAT_PACK_SIMPLE", 0) != 0;
         c->dbg_ws64 = env_int("DAT_CONV_WS64", 1);
         c->dbg_pwlw = env_int("DAT_CONV_PWLW", 1);
+        c->dbg_pwks = env_int("DAT_CONV_PWKS", 8);
         c->dbg_wgrad_direct = env_int("DAT_WGRAD_DIRECT", 1);
         c->dbg_wgrad_ks = env_int("DAT_WGRAD_KS", 0);
         c->dbg_wgrad_dma = env_int("DAT_WGRAD_DMA", 1);

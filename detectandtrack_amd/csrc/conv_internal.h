@@ -121,6 +121,8 @@ bool pw256_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp);
 bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_conv_desc* d);
+bool pwks_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
+int launch_pwks(dat_ctx* ctx, hipStream_t st, const ConvParams& cp);
 bool bt_eligible(const dat_ctx* ctx, const dat_conv_desc* d);
 int bt_tile_twl(const ConvParams& p, long long* nblocks);
 int launch_bt(dat_ctx* ctx, hipStream_t st, ConvParams& p);

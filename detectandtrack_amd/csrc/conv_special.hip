@@ -539,6 +539,198 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef LW_LOAD
 }
 
+// ---- K-streaming 1x1 kernel (round 6): 1x1x1 convs whose weights do NOT fit LDS (K >= 512 with 256-channel cout blocks: R-50 / R-101 res4 /
+// res5 `branch2a`, the res4 / res5 shortcuts, res5 `branch2c`, the P3 - P5 laterals, and the data gradients of the `branch2c` layers) --------
+// These ran on the generic implicit-GEMM kernel, whose 128 x 128 tile re-fetches a 16-KB input patch AND 16 KB of weights per 2 MFLOP: with
+// one tap there is nothing to reuse a patch for, and the layers sat at 1.5-2.4 TB/s of their compulsory traffic.  Here a block of EIGHT waves
+// owns 256 positions x 256 output channels (64 K fp32 accumulators: a wave = 128 positions x 64 channels) and streams K in 64-channel
+// chunks: the chunk of the input rows (32 KB, each row read from HBM exactly once per cout block) and the chunk of the packed weights (32 KB,
+// L2-resident, already in MFMA-fragment order) go global -> LDS by LDS-DMA -- rows two chunks ahead into three buffers, weights one chunk
+// ahead into two --, one barrier per chunk; a chunk is 32 MFMAs per wave for 24 fragment reads.  Blocks that share an input tile (the cout
+// blocks of a layer) are neighbours in the grid.  The epilogue is the 1x1 kernels' per-wave LDS transpose: affine, residual (same-shape or
+// nearest-2x top-down), ReLU, 16-byte channel-contiguous stores of complete 128-byte runs.
+struct PwKsParams {
+    const char* x;
+    const char* w;              // MFMA-fragment order: [64-channel chunk][32-row block][k-slice][lane][16 B]
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    unsigned npos;              // output positions: frames * Ho * Wo
+    int Ho, Wo, H, W, stride;
+    int in_cs, out_cs, cout;
+    int relu, res_mode;
+    int ncb;                    // cout blocks of 256
+    int kchunks, mb_total;      // Cin / 64; Cout_pad / 32
+    unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo)
+};
+
+constexpr int KS_THREADS = 512;
+constexpr int KS_XBYTES = 256 * 128, KS_WBYTES = 8 * 4 * 1024;      // one K chunk of the input tile / of the weights of a cout block
+
+__global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams p) {
+    constexpr int EPITCH = 64 * 4 + 16;                 // fp32 transpose row of one position: 64 channels + pad
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xb = smem;                              // [3][256 rows x 128 B], XOR-swizzled 16-byte slots
+    char* const wb = smem + 3 * KS_XBYTES;              // [2][8 row blocks][4 k-slices][64 lanes][16 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, n = lane & 31;
+    const int cb = blockIdx.x % p.ncb;
+    const unsigned pos0 = (blockIdx.x / p.ncb) * 256u;
+    const int wq = wave & 3, ph = wave >> 2;            // cout quarter (row blocks 2 wq, 2 wq + 1) / position half (tiles 4 ph .. 4 ph + 3)
+    // ---- chunk copies by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass; one wave instruction lands 64 x 16 B =
+    // 8 input rows, lane-linear, so the XOR swizzle of the fragment reads is applied on the SOURCE side: lane (row, physical slot) fetches the
+    // row's logical slot phys ^ ((row >> 1) & 7)).  Wave w copies rows 32 w .. 32 w + 31 (4 pieces) and 4 of the 32 1-KB weight pieces ----
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const char* xsrc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = wave * 32 + u * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        const unsigned pos = min(pos0 + (unsigned)row, p.npos - 1u);
+        unsigned ip = pos;
+        if (p.stride == 2) {
+            const unsigned f = pos / p.how, rem = pos - f * p.how;
+            const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
+            ip = (f * (unsigned)p.H + 2u * oh) * (unsigned)p.W + 2u * ow;
+        }
+        xsrc[u] = p.x + (size_t)ip * (unsigned)p.in_cs * 2u + slot * 16;
+    }
+    const char* wsrc = p.w + (size_t)cb * 8 * 4096 + (size_t)(wave * 4) * 1024 + lane * 16;
+    const size_t wstep = (size_t)p.mb_total * 4096;     // bytes between consecutive K chunks of the packed weights
+    char* const xdma = xb + wave * (32 * 128);          // this wave's rows inside an input buffer
+    char* const wdma = wb + wave * 4096;                // this wave's pieces inside a weight buffer
+#define KS_DMA_X(KC_, BUF_)                                                                                  \
+    {                                                                                                        \
+        const size_t ko_ = (size_t)min((KC_), p.kchunks - 1) * 128;      /* (past the end: the last chunk again, into a buffer nobody reads) */ \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[u_] + ko_), (lptr_t)(xdma + (BUF_) * KS_XBYTES + u_ * 1024), 16, 0, 0); \
+    }
+#define KS_DMA_W(KC_, BUF_)                                                                                  \
+    {                                                                                                        \
+        const char* ws_ = wsrc + (size_t)min((KC_), p.kchunks - 1) * wstep;                                  \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ws_ + u_ * 1024), (lptr_t)(wdma + (BUF_) * KS_WBYTES + u_ * 1024), 16, 0, 0); \
+    }
+#define KS_COMPUTE(XBUF_, WBUF_)                                                                             \
+    {                                                                                                        \
+        const char* xc_ = xb + (XBUF_) * KS_XBYTES + b_base;                                                 \
+        const char* wc_ = wb + (WBUF_) * KS_WBYTES + a_off;                                                  \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                \
+            uint4 a_[2], b_[4];                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) a_[i_] = *(const uint4*)(wc_ + (i_ * 4 + ks_) * 1024); \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) b_[j_] = *(const uint4*)(xc_ + j_ * 4096 + b_slot[ks_]); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                 \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) Mma<DAT_BF16>::step(a_[i_], b_[j_], acc[i_][j_]); \
+        }                                                                                                    \
+    }
+    KS_DMA_W(0, 0);
+    KS_DMA_X(0, 0);
+    KS_DMA_X(1, 1);
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_off = (2 * wq) * 4096 + lane * 16;
+    // B fragment of (position tile j, k-slice ks): row ph * 128 + j * 32 + n, logical slot 2 ks + khalf; the swizzle term (row >> 1) & 7 only
+    // depends on n, so the offset is  b_base + j * 4096 + b_slot[ks]
+    const int b_base = (ph * 128 + n) * 128;
+    int b_slot[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_slot[ks] = (((ks * 2 + khalf) ^ (n >> 1)) & 7) << 4;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // chunk 0 (weights + rows) has landed; the rows of chunk 1 may still be on their way
+    __syncthreads();
+    // chunk kc lives in input buffer kc % 3 and weight buffer kc & 1.  Iteration kc requests the weights of chunk kc + 1 (L2-resident: one
+    // iteration ahead) and the input rows of chunk kc + 2 (HBM: two iterations ahead -- an iteration of 32 MFMAs per wave is shorter than the
+    // memory latency under load), computes chunk kc, then waits until only the four row pieces it has just requested are outstanding
+    // (vmcnt counts in issue order) and publishes chunk kc + 1 with the barrier.  The buffers a request overwrites were last read in
+    // iteration kc - 1, behind the previous barrier.
+    int xi = 0;                                         // kc % 3
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        const int x2 = xi >= 1 ? xi - 1 : 2;            // (kc + 2) % 3
+        KS_DMA_W(kc + 1, (kc + 1) & 1);
+        KS_DMA_X(kc + 2, x2);
+        KS_COMPUTE(xi, kc & 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        xi = xi == 2 ? 0 : xi + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing may land in LDS once the epilogue reuses it
+    __syncthreads();
+#undef KS_DMA_X
+#undef KS_DMA_W
+#undef KS_COMPUTE
+    // ---- epilogue ----
+    char* const est = smem + wave * (32 * EPITCH);
+    const int sq = lane & 7, spl = lane >> 3;           // store phase: lane = 8 channels (sq) of one of 8 positions per round
+    const int c0 = cb * 256 + wq * 64 + sq * 8;         // first of this lane's 8 output channels
+    float sc[8], bi[8];                                 // channels past the stored Cout: 0 / 0 (their zero weight rows give zeros)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool ok = c0 + e < p.cout;
+        const int c = ok ? c0 + e : 0;
+        sc[e] = ok ? (p.scale ? p.scale[c] : 1.f) : 0.f;
+        bi[e] = (ok && p.bias) ? p.bias[c] : 0.f;
+    }
+    const unsigned cres = (unsigned)min(c0, p.out_cs - 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned tile0 = pos0 + (unsigned)(ph * 128 + j * 32);
+        uint4 rr[4];
+        if (p.res_mode) {                               // residual rows of the tile requested before the transpose
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned pc = min(tile0 + (unsigned)(r * 8 + spl), p.npos - 1u);
+                unsigned rpos = pc;
+                if (p.res_mode == 2) {                  // nearest-2x up-sampled coarser map (FPN top-down, FPN3D.py:186-222)
+                    const unsigned fr = pc / p.how, rem = pc - fr * p.how;
+                    const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
+                    rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
+                }
+                rr[r] = *(const uint4*)(p.res + ((size_t)rpos * (unsigned)p.out_cs + cres) * 2u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(est + n * EPITCH + (i * 32 + g * 8 + khalf * 4) * 4) =
+                    make_float4(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pl = r * 8 + spl;
+            const float4 t0 = *(const float4*)(est + pl * EPITCH + sq * 32);
+            const float4 t1 = *(const float4*)(est + pl * EPITCH + sq * 32 + 16);
+            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+            if (p.res_mode) {
+                const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                    v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const unsigned pos = tile0 + (unsigned)pl;
+            if (pos < p.npos && c0 < p.cout)
+                *(uint4*)(p.y + ((size_t)pos * (unsigned)p.out_cs + (unsigned)c0) * 2u) =
+                    make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- big-tile 3x3 kernel: 256 output channels x 256 positions per block, one block per CU, one wave per SIMD ---------------------
 // The 128 x 256 kernel above feeds 8 MFMAs per k-slice from 6 operand fragments per wave, two blocks per CU: the CU's operand
 // delivery (L1 64 B/clk for the weight fragments, LDS for the patch) is what holds it at ~55 % of the matrix peak (DESIGN.md
@@ -962,6 +1154,43 @@ int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_co
 #undef LW_CASE
     if (rc != DAT_OK) DAT_FAIL(ctx, rc, "conv1x1_lw: no instantiation for K chunks %d x %d row blocks x %d passes", kc, mbw, npass);
     DAT_CHECK_LAUNCH(ctx, "conv1x1_lw");
+    return DAT_OK;
+}
+
+// K-streaming 1x1 kernel: K >= 512 (DAT_CONV_PWKS chunks of 64; same-box A/B of the R-50 forward, round 6: off 175.6, K >= 1024 179.0, K >= 512
+// 180.8 clips/s -- the K = 512 layers it takes from the weights-in-LDS kernel are the ones that needed two cout parts there), cout a multiple
+// of 256 after padding, enough 256-position tiles to give most CUs a block (one block per CU at a time: all 160 KB of LDS)
+bool pwks_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
+    if (!(ctx->dbg_pwks > 0 && d->dtype == DAT_BF16 && d->KT == 1 && d->KH == 1 && d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->pad_t == 0 &&
+          d->out_tn <= 0 && d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && weights_direct(ctx, d)))
+        return false;
+    if (d->Cin % 64 || d->Cin / 64 < ctx->dbg_pwks || cout_pad_of(d) % 256) return false;
+    if (d->out_cstride % 8 || d->out_cstride < d->Cout || d->out_cstride < 8) return false;
+    int Ho, Wo;
+    dat_conv3d_out_shape(d, &Ho, &Wo);
+    const long long npos = (long long)d->frames * Ho * Wo;
+    if ((long long)Ho * Wo < 1 || (long long)Ho * Wo * Wo >= (1ll << 32)) return false;
+    if (npos >= (1ll << 31) || (long long)d->frames * d->H * d->W >= (1ll << 31)) return false;
+    const long long blocks = cdiv_ll(npos, 256) * (cout_pad_of(d) / 256);
+    return npos >= 256 && blocks * 4 >= 3ll * ctx->num_cu;
+}
+
+int launch_pwks(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
+    ctx_num_cu(ctx);
+    PwKsParams p;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.npos = (unsigned)((long long)cp.frames * cp.Ho * cp.Wo);
+    p.Ho = cp.Ho; p.Wo = cp.Wo; p.H = cp.H; p.W = cp.W; p.stride = cp.sh;
+    p.in_cs = cp.Cin; p.out_cs = cp.out_cs; p.cout = cp.Cout; p.relu = cp.relu; p.res_mode = cp.res_mode;
+    p.ncb = cp.Cout_pad / 256; p.kchunks = cp.Cin / 64; p.mb_total = cp.Cout_pad / 32;
+    p.how = (unsigned)(cp.Ho * cp.Wo);
+    p.wo_magic = cp.Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.Wo - 1) / (unsigned)cp.Wo);
+    const long long blocks = cdiv_ll(p.npos, 256) * p.ncb;
+    DAT_ENFORCE(ctx, blocks > 0 && blocks < (1ll << 31), "conv1x1_ks: grid of %lld blocks unsupported", blocks);
+    const size_t lds = (size_t)3 * KS_XBYTES + 2 * KS_WBYTES;     // 160 KB: three input buffers, two weight buffers (the epilogue reuses them)
+    if (dat_ensure_lds(ctx, (const void*)conv1x1_ks_kernel, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv1x1_ks_kernel, dim3((unsigned)blocks), dim3(KS_THREADS), lds, st, p);
+    DAT_CHECK_LAUNCH(ctx, "conv1x1_ks");
     return DAT_OK;
 }
 

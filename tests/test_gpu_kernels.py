@@ -1486,3 +1486,63 @@ def test_conv1x1_weights_in_lds_kernel(ops, case):
     assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4)
     if layer.cstride > Cout:          # the padding channels of the blob stay zero
         assert not y[..., Cout:].any()
+
+
+KS_CASES = [
+    # name, T, H, W (input), Cin, Cout, stride, relu, res_mode, affine: layers the K-streaming 1x1 kernel (conv1x1_ks_kernel, round 6) takes
+    ('k1024_c256', 2, 192, 200, 1024, 256, 1, True, 0, True),                # res4_x_branch2a (R-50 / R-101)
+    ('k2048_c512', 2, 128, 200, 2048, 512, 1, True, 0, True),                # res5_x_branch2a: two cout blocks share the input tiles
+    ('k1024_c2048_s2', 2, 192, 200, 1024, 2048, 2, False, 0, True),          # res5_0_branch1: stride 2, eight cout blocks
+    ('k1024_c256_up2', 2, 192, 200, 1024, 256, 1, False, 2, False),          # FPN P4 lateral + nearest-2x top-down Sum
+    ('k1024_c512_sum', 2, 160, 168, 1024, 512, 1, True, 1, True),            # data gradient of a branch2c-shaped layer: Sum + ReLU epilogue
+    ('k1088_c200_ragged', 2, 191, 201, 1088, 200, 1, True, 1, True),         # K not a power of two, Cout padded to 256, ragged last tile
+]
+
+
+@pytest.mark.parametrize('case', KS_CASES, ids=[c[0] for c in KS_CASES])
+def test_conv1x1_k_streaming_kernel(ops, case):
+    """conv1x1_ks_kernel (round 6: the 1x1x1 layers whose weights do not fit LDS, K >= 1024 -- R-50's res4 / res5 `branch2a`, the res5
+    shortcut, the P4 / P5 laterals; ResNet3D.py:21-55, :89-101, FPN3D.py:111-134) against torch on the same bf16 operands and -- bit for
+    bit -- against the generic kernel it replaces (forced plan): stride 2, both residual modes, several cout blocks, Cout padding,
+    a ragged last tile."""
+    name, T, H, W, Cin, Cout, stride, relu, res_mode, affine = case
+    rs = np.random.RandomState(abs(hash(name)) % 1000)
+    q = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    x = q(rs.randn(1, Cin, T, H, W).astype(np.float32))
+    w = q((rs.randn(Cout, Cin, 1, 1, 1) * np.sqrt(2.0 / Cin)).astype(np.float32))
+    scale = rs.uniform(0.5, 1.5, Cout).astype(np.float32) if affine else None
+    bias = (rs.randn(Cout) * 0.1).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = res_small = None
+    if res_mode == 1:
+        res = q(rs.randn(1, Cout, T, Ho, Wo).astype(np.float32))
+    elif res_mode == 2:
+        res_small = q(rs.randn(1, Cout, T, Ho // 2, Wo // 2).astype(np.float32))
+        res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    ref = _conv_ref(x, w, scale, bias, res, (stride, stride), (0, 0, 0), relu)
+    layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(stride, stride), pads=(0, 0, 0),
+                          relu=relu, dtype=1)
+    xd = ops.to_ndhwc(_dev(x), 1)
+    rd = None
+    if res_mode == 1:
+        rd = ops.to_ndhwc(_dev(res), 1, layer.cstride)
+    elif res_mode == 2:
+        rd = ops.to_ndhwc(_dev(res_small), 1, layer.cstride)
+    prof = ops.ConvProfiler(capacity=8)
+    prof.start()
+    y = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    rec = prof.stop()
+    assert [t for t, _, _ in rec] == [2560341], 'the layer did not take the K-streaming kernel: tags %r' % ([t for t, _, _ in rec],)
+    try:
+        assert ops.tune_plan(128, 1) == 0
+        y_gen = layer(xd, T=T, residual=rd, res_mode=res_mode)
+    finally:
+        ops.tune_plan(0, 0)
+    assert torch.equal(y, y_gen), 'differs from the generic kernel in %d elements' % int((y != y_gen).sum())
+    got = ops.to_ncdhw(y, 1, 1, Cout, T).cpu().numpy()
+    err = np.abs(got - ref).max()
+    print('ks %s max-abs err %.3e (ref max %.2f), %.1f us' % (name, err, np.abs(ref).max(), 1e3 * rec[0][2]))
+    assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4)
+    if layer.cstride > Cout:          # the padding channels of the blob stay zero
+        assert not y[..., Cout:].any()
