@@ -210,7 +210,8 @@ def model_cfg(arch, T, dtype, keyframe_dce=False, two_d=False, tube=False, kt=3)
         'TEST': {'RPN_PRE_NMS_TOP_N': 1000, 'RPN_POST_NMS_TOP_N': 1000, 'COMPETITION_MODE': False, 'NMS': 0.5,
                  'SCALES': (800,), 'MAX_SIZE': 1333},
         'HIP': {'DTYPE': dtype, 'KEYFRAME_DCE': bool(keyframe_dce),
-                'FUSE_STEM_POOL': os.environ.get('DAT_FUSE_STEM_POOL', '1') != '0'},   # (A/B switch for tools/)
+                'FUSE_STEM_POOL': os.environ.get('DAT_FUSE_STEM_POOL', '1') != '0',   # (A/B switches for tools/)
+                'STEM_FROM_UINT8': os.environ.get('DAT_STEM_FROM_UINT8', '1') != '0'},
     }
 
 

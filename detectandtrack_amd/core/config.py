@@ -269,6 +269,9 @@ def _build_defaults():
     # DEVICE_ROI_SAMPLING (training): GenerateProposalLabels as one device kernel on the device-resident proposals (roi_data/device_sampler.py,
     # dat_sample_rois: the reference's candidate sets and counts, a counter-based draw instead of NumPy's stream); False = the host restatement
     # of lib/roi_data/fast_rcnn.py on a copy of the proposals (bit-compatible with the reference's numpy.random stream)
+    # STEM_FROM_UINT8: on the host-frame path of the pipelined engine the fused stem (conv1 + affine + ReLU + pool1) reads the UPLOADED uint8
+    # frames and evaluates prep_im_for_blob / im_list_to_blob (resize, mean, padding) in its patch loader (dat_stem_conv_pool_u8, bit-identical):
+    # the fp32 `data` blob -- 99 MB per 720p clip -- is never written; False = dat_preprocess_frames writes it first
     # DECONV_GROUP_IGNORED: the keypoint deconv of a 3D head without KRCNN.NO_3D_DECONV_TIME_TO_CH is recorded with group = T
     # (model_builder.py:848-856).  False (default): a grouped ConvTranspose in Caffe2's filter layout (C_in, C_out / group, k, k) -- frame t
     # has its own [C, K, 4, 4] block.  True: what the pinned Caffe2 (b4e1588, Feb 2018: ConvTranspose has no `group` argument yet and brew
@@ -277,7 +280,7 @@ def _build_defaults():
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
                       'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'DET_SPARE_ROWS': 4,
                       'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
-                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True, 'DECONV_GROUP_IGNORED': False})
+                      'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True, 'DECONV_GROUP_IGNORED': False, 'STEM_FROM_UINT8': True})
     return c
 
 

@@ -47,7 +47,7 @@ def _cu_masked_stream(spec):
 
 
 class _Slot(object):
-    __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'data', 'live', 'gather_event')
+    __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'u8', 'data', 'live', 'gather_event')
     _made = 0
 
     def __init__(self, ws):
@@ -59,7 +59,8 @@ class _Slot(object):
         self.event, self.copy_event = torch.cuda.Event(), torch.cuda.Event()
         self.graphs = collections.OrderedDict()   # geometry key -> ClipGraph, least recently used first (bounded: max_graphs)
         self.pinned = self.dev_u8 = None
-        self.data = {}              # geometry key -> the eager path's `data` buffer
+        self.u8 = {}                # geometry key (frames, h, w) -> (pinned staging tensor, device uint8 tensor)
+        self.data = {}              # geometry key -> the forward's input: the fp32 `data` buffer, or the FrameBlob over the slot's uint8 buffer
         self.live = {}              # (frame-trunk cache) geometry key -> this slot's static buffer of gathered prefix outputs [B*T, h, w, Cs]
         self.gather_event = None    # recorded after the slot's last gather out of the trunk pool
 
@@ -168,7 +169,8 @@ class FrameTrunkCache(object):
                     self.stream.wait_event(ev)
                 prev, wsmod._GLOBAL = wsmod._GLOBAL, self.ws
                 try:
-                    data, _, im_info = blob_utils.frames_to_blob_on_device(self.dev_u8[:n], n)
+                    # (lazy: with cfg.HIP.STEM_FROM_UINT8 the fused stem of the prefix reads the uploaded frames themselves)
+                    data, _, im_info = blob_utils.frames_to_blob_on_device(self.dev_u8[:n], n, lazy=True)
                     out = self._run_prefix(data, im_info[:1])
                 finally:
                     wsmod._GLOBAL = prev
@@ -359,9 +361,12 @@ class ClipPipeline(object):
         B, T = len(clips), len(clips[0])
         h, w = clips[0][0].shape[:2]
         n = B * T
-        if s.pinned is None or tuple(s.pinned.shape) != (n, h, w, 3):
-            s.pinned = torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory()
-            s.dev_u8 = torch.empty((n, h, w, 3), dtype=torch.uint8, device=s.ws.device)
+        gkey = (n, h, w)
+        if gkey not in s.u8:
+            # one staging pair per input geometry: a captured graph reads ITS device buffer (the frames are the forward's input since
+            # round 6 -- the fused stem evaluates the pre-processing itself --, so the buffer a graph was captured on must stay where it is)
+            s.u8[gkey] = (torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory(), torch.empty((n, h, w, 3), dtype=torch.uint8, device=s.ws.device))
+        s.pinned, s.dev_u8 = s.u8[gkey]
         host = s.pinned.numpy()
         frames = [f for clip in clips for f in clip]
         assert len(frames) == n and all(f.dtype == np.uint8 and f.shape == (h, w, 3) for f in frames), 'clips of one frame size, uint8 HxWx3'
@@ -383,8 +388,10 @@ class ClipPipeline(object):
             s.stream.wait_event(s.copy_event)
             prev, wsmod._GLOBAL = wsmod._GLOBAL, s.ws
             try:
-                gkey = (n, h, w)
-                data, _, im_info = blob_utils.frames_to_blob_on_device(s.dev_u8, T, out=s.data.get(gkey))
+                data, _, im_info = blob_utils.frames_to_blob_on_device(s.dev_u8, T, out=s.data.get(gkey) if torch.is_tensor(s.data.get(gkey)) else None,
+                                                                     lazy=True)
+                if not torch.is_tensor(data) and gkey in s.data and not torch.is_tensor(s.data[gkey]):
+                    data = s.data[gkey]         # the SAME FrameBlob object for a geometry: the graph was captured on it
                 s.data[gkey] = data
             finally:
                 wsmod._GLOBAL = prev

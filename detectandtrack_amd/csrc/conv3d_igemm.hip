@@ -1059,7 +1059,7 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     } else if (pw256_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 320 + d->dtype;     // (256 channels x 32 positions per wave: the weights-stationary 1x1 kernel)
         rc = launch_pw256(ctx, st, p);
-    } else if (pwks_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode && !x3) {
+    } else if (pwks_eligible(ctx, d) && !force_bp && !force_ks && !x3) {       // (its epilogue knows the masking combine too)
         tag = 256 * 10000 + 340 + d->dtype;     // (the K-streaming 1x1 kernel: 256 positions x 256 channels per block)
         rc = launch_pwks(ctx, st, p);
     } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {

@@ -710,12 +710,12 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
             float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-            if (p.res_mode) {
+            if (p.res_mode) {                           // modes 1 / 2: Sum; mode 3: MASK by the forward input of the conv whose data gradient this is
                 const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
-                    v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
-                    v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                    v[2 * e2] = res_combine(v[2 * e2], bf2f((uint16_t)(ru[e2] & 0xffff)), p.res_mode);
+                    v[2 * e2 + 1] = res_combine(v[2 * e2 + 1], bf2f((uint16_t)(ru[e2] >> 16)), p.res_mode);
                 }
             }
             if (p.relu) {

@@ -117,6 +117,158 @@ __device__ __forceinline__ void stem_fill_lds(const float* __restrict__ data, co
     }
 }
 
+// ---- the same prologue fed from the UPLOADED uint8 frames (round 6) -------------------------------------------------------------------
+// On the host-frame path the clip is in HBM as uint8 HWC frames of the SOURCE resolution (3 bytes per source pixel); dat_preprocess_frames
+// turned them into the fp32 NC(T)HW `data` blob (resize x scale, mean subtraction, padding: 12 bytes per network pixel, 99 MB per 720p clip
+// written and read again).  Here the patch loader computes the value of `data` at (c, ih, iw) ITSELF, in the arithmetic of that kernel
+// (preprocess.hip; OpenCV's float32 bilinear path in the order of the host restatement): source coordinate formed in double and rounded to
+// float32, horizontal pass first (columns outside the image snap onto the border pixel with weights (1, 0)), then the vertical blend (weights
+// kept, row indices clamped), the mean subtracted in double and rounded once -- every product and sum rounded to float32 (contraction off
+// inside the function), so the patch and therefore pool1 are BIT-IDENTICAL to dat_preprocess_frames + dat_stem_conv_pool, and the blob never
+// exists.  The six bytes a pixel needs per source row (two BGR pixels) come as three aligned dwords.
+struct U8Src {
+    const uint8_t* frames;       // [F][h][w][3]
+    int h, w;                    // source frame
+    int oh, ow;                  // resized image inside the (padded) blob
+    double inv_fx, inv_fy;       // 1 / scale
+    double mean[3];
+    long long last_dword;        // byte offset of the dword that holds the last byte of the frames buffer (loads are clamped onto it)
+};
+
+__device__ __forceinline__ void u8_src_coord(int d, double inv_scale, int n, bool snap, int* i0, int* i1, float* t) {
+#pragma clang fp contract(off)
+    const float f = (float)(((double)d + 0.5) * inv_scale - 0.5);
+    const float fl = floorf(f);
+    int s = (int)fl;
+    float tt = f - fl;
+    if (snap) {                     // x: out-of-range columns read the border pixel with weights (1, 0)
+        if (s < 0 || s >= n - 1) tt = 0.f;
+        s = min(max(s, 0), n - 1);
+        *i0 = s;
+        *i1 = min(s + 1, n - 1);
+    } else {                        // y: weights kept, the two row indices clamped
+        *i0 = min(max(s, 0), n - 1);
+        *i1 = min(max(s + 1, 0), n - 1);
+    }
+    *t = tt;
+}
+
+template <int DT, int ROWS_L, int COLS_L, int ROWS_Z>
+__device__ __forceinline__ void stem_fill_lds_u8(const U8Src& src, const char* __restrict__ w, const float* __restrict__ scale,
+                                                 const float* __restrict__ bias, char* wl, typename ElemOf<DT>::type* patch, float* sb,
+                                                 int f, int H, int W, int ih0, int iw0, int tid) {
+#pragma clang fp contract(off)
+    constexpr int ES = ElemOf<DT>::size;
+    constexpr int KPAD = StemCfg<DT>::KPAD;
+    constexpr int WPITCH = KPAD * ES + 16;
+    constexpr int PCS = KPAD * ES / 16;
+    constexpr int NW = 64 * PCS, WIT = (NW + 255) / 256;
+    uint4 wv[WIT];
+#pragma unroll
+    for (int u = 0; u < WIT; ++u) {
+        const int i = min(tid + u * 256, NW - 1);
+        wv[u] = *(const uint4*)(w + (size_t)i * 16);
+    }
+    const float* sp = tid < 64 ? scale : bias;
+    const bool has = sp != nullptr;
+    const float one = 1.f;
+    const float sx = (has ? sp : &one)[has ? (tid & 63) : 0];
+    constexpr int ITEMS = ROWS_L * COLS_L, PIT = (ITEMS + 255) / 256;
+    const uint8_t* fr = src.frames + (size_t)f * src.h * src.w * 3;
+    const long long fr_off = (long long)f * src.h * src.w * 3;
+    // ---- all loads first: per pixel 2 source rows x 3 aligned dwords (unconditional, clamped addresses) ----
+    uint32_t q[PIT][2][3];
+#pragma unroll
+    for (int u = 0; u < PIT; ++u) {
+        const int i = tid + u * 256;
+        const int r = i / COLS_L, col = i - r * COLS_L;
+        const int y = min(max(ih0 + r, 0), src.oh - 1), x = min(max(iw0 + col, 0), src.ow - 1);
+        int y0, y1, x0, x1;
+        float ty, tx;
+        u8_src_coord(y, src.inv_fy, src.h, false, &y0, &y1, &ty);
+        u8_src_coord(x, src.inv_fx, src.w, true, &x0, &x1, &tx);
+        const int xl = min(x0, src.w - 2);                  // the run starts at pixel xl: (xl, xl + 1) hold (x0, x1) -- or x0 twice at the right border
+        const int yy[2] = {y0, y1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long long o = fr_off + ((long long)yy[k] * src.w + xl) * 3;
+            const long long b = o & ~3ll;
+            const uint8_t* base = src.frames + b;
+            q[u][k][0] = *(const uint32_t*)base;
+            q[u][k][1] = *(const uint32_t*)(src.frames + min(b + 4, src.last_dword));
+            q[u][k][2] = *(const uint32_t*)(src.frames + min(b + 8, src.last_dword));
+        }
+    }
+    (void)fr;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < WIT; ++u) {
+        const int i = min(tid + u * 256, NW - 1);
+        const int row = i / PCS, pc = i - row * PCS;
+        *(uint4*)(wl + row * WPITCH + pc * 16) = wv[u];
+    }
+    if (tid < 128) sb[tid] = has ? sx : (tid < 64 ? 1.f : 0.f);
+#pragma unroll
+    for (int u = 0; u < PIT; ++u) {
+        const int i = tid + u * 256;
+        const int r = i / COLS_L, col = i - r * COLS_L;
+        const int ih = ih0 + r, iw = iw0 + col;
+        const bool live = (u + 1) * 256 <= ITEMS || i < ITEMS;
+        // inside the blob AND inside the resized image (the rest of the blob is the zero padding up to the stride multiple)
+        const bool in = live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && ih < src.oh && iw < src.ow;
+        const int y = min(max(ih, 0), src.oh - 1), x = min(max(iw, 0), src.ow - 1);
+        int y0, y1, x0, x1;
+        float ty, tx;
+        u8_src_coord(y, src.inv_fy, src.h, false, &y0, &y1, &ty);
+        u8_src_coord(x, src.inv_fx, src.w, true, &x0, &x1, &tx);
+        const int xl = min(x0, src.w - 2);
+        const bool second = x0 != xl;                        // x0 is the SECOND pixel of the run (right border: x0 = x1 = w - 1)
+        const float ux = 1.f - tx, uy = 1.f - ty;
+        uint32_t lo[2], hi[2];                               // bytes 0-3 / 4-7 of the run of each row
+        const int yy[2] = {y0, y1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long long o = fr_off + ((long long)yy[k] * src.w + xl) * 3;
+            const long long b = o & ~3ll;
+            const unsigned sh = (unsigned)(o - b);
+            // (a dword whose address was clamped is one the six bytes of the run do not reach into: both pixels of a run lie inside the frame)
+            lo[k] = __builtin_amdgcn_alignbyte(q[u][k][1], q[u][k][0], sh);
+            hi[k] = __builtin_amdgcn_alignbyte(q[u][k][2], q[u][k][1], sh);
+        }
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t p0 = (lo[k] >> (8 * c)) & 0xffu;                                          // pixel xl, channel c
+                const uint32_t p1 = c == 0 ? (lo[k] >> 24) : ((hi[k] >> (8 * (c - 1))) & 0xffu);        // pixel xl + 1
+                a[k][0] = (float)((double)(second ? p1 : p0) - src.mean[c]);
+                a[k][1] = (float)((double)p1 - src.mean[c]);
+            }
+            const float top = a[0][0] * ux + a[0][1] * tx;   // horizontal pass (two rounded products, one rounded sum)
+            const float bot = a[1][0] * ux + a[1][1] * tx;
+            v[c] = in ? top * uy + bot * ty : 0.f;           // vertical blend
+        }
+        if (live) {
+            const int dst = r * PP + col * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (DT == DAT_BF16) ((uint16_t*)patch)[dst + c] = f2bf(v[c]);
+                else ((float*)patch)[dst + c] = v[c];
+            }
+        }
+    }
+    constexpr int ZT = PP - COLS_L * 3;
+    constexpr int NZ = ROWS_L * ZT + (ROWS_Z - ROWS_L) * PP;
+    for (int i = tid; i < NZ; i += 256) {
+        int at;
+        if (i < ROWS_L * ZT) { const int r = i / ZT; at = r * PP + COLS_L * 3 + (i - r * ZT); }
+        else at = ROWS_L * PP + (i - ROWS_L * ZT);
+        patch[at] = 0;
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void stem_conv_kernel(const StemParams p) {
     typedef typename ElemOf<DT>::type E;
@@ -239,6 +391,7 @@ constexpr int SPITCH_PAD = 8;                    // staging: bytes added to a po
 
 struct StemPoolParams {
     const float* data;
+    U8Src u8;            // SRC = 1: the uploaded frames instead of `data`
     const char* w;
     const float* scale;
     const float* bias;
@@ -250,7 +403,7 @@ struct StemPoolParams {
 
 // (occupancy window 3..4 waves per SIMD: round 4's same-box A/B at the 4-clip forward -- 2..2: 547 us, 2..3: 464-467, 3..4 / 4..4 / 4..5:
 //  444-446; four blocks per CU is what the 34 KB of LDS per block allow)
-template <int DT>
+template <int DT, int SRC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void stem_pool_kernel(const StemPoolParams p) {
     typedef typename ElemOf<DT>::type E;
     constexpr int ES = ElemOf<DT>::size;
@@ -271,7 +424,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int oh0 = 2 * ph0 - 1, ow0 = 2 * pw0 - 1;        // conv coordinate of the region's corner (may be -1: never read back)
     const int ih0 = 2 * oh0 - 3, iw0 = 2 * ow0 - 3;
     float* sb = (float*)__builtin_assume_aligned(smem + p.sb_off, 16);   // scale[64], bias[64] (beyond the staging area)
-    stem_fill_lds<DT, 2 * FTH + 5, 2 * (2 * FPW + 1) + 5, 2 * FTH + 6>(p.data, p.w, p.scale, p.bias, wl, patch, sb, n, t, p.T, p.H, p.W, ih0, iw0, tid);
+    if (SRC == 1)
+        stem_fill_lds_u8<DT, 2 * FTH + 5, 2 * (2 * FPW + 1) + 5, 2 * FTH + 6>(p.u8, p.w, p.scale, p.bias, wl, patch, sb, f, p.H, p.W, ih0, iw0, tid);
+    else
+        stem_fill_lds<DT, 2 * FTH + 5, 2 * (2 * FPW + 1) + 5, 2 * FTH + 6>(p.data, p.w, p.scale, p.bias, wl, patch, sb, n, t, p.T, p.H, p.W, ih0, iw0, tid);
     __syncthreads();
 
     const int khalf = lane >> 5, nl = lane & 31;
@@ -493,6 +649,44 @@ int dat_stem_conv_pool(dat_ctx* ctx, dat_stream s, int dtype, const float* data,
         hipLaunchKernelGGL(stem_pool_kernel<DAT_F32>, dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)s, p);
     }
     DAT_CHECK_LAUNCH(ctx, "stem_conv_pool");
+    return DAT_OK;
+}
+
+int dat_stem_conv_pool_u8(dat_ctx* ctx, dat_stream s, int dtype, const unsigned char* frames, int n_frames, int h, int w, double fx, double fy,
+                          int out_h, int out_w, int pad_h, int pad_w, const double* pixel_means, const void* w_packed, const float* scale,
+                          const float* bias, int relu, void* out_pool) {
+    DAT_ENFORCE(ctx, frames && pixel_means && w_packed && out_pool, "stem_conv_pool_u8: null argument");
+    DAT_ENFORCE(ctx, dtype == DAT_BF16 || dtype == DAT_F32, "stem_conv_pool_u8: bad dtype %d", dtype);
+    DAT_ENFORCE(ctx, n_frames > 0 && h > 0 && w >= 2 && out_h > 0 && out_w > 0 && pad_h >= out_h && pad_w >= out_w && fx > 0 && fy > 0,
+                "stem_conv_pool_u8: bad geometry %dx%d -> %dx%d (pad %dx%d)", h, w, out_h, out_w, pad_h, pad_w);
+    StemPoolParams p;
+    p.data = nullptr; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias; p.out = (char*)out_pool;
+    p.N = n_frames; p.T = 1; p.H = pad_h; p.W = pad_w; p.relu = relu;
+    p.u8.frames = frames; p.u8.h = h; p.u8.w = w; p.u8.oh = out_h; p.u8.ow = out_w; p.u8.inv_fx = 1.0 / fx; p.u8.inv_fy = 1.0 / fy;
+    for (int c = 0; c < 3; ++c) p.u8.mean[c] = pixel_means[c];
+    const long long total = (long long)n_frames * h * w * 3;
+    p.u8.last_dword = ((total + 3) & ~3ll) - 4;
+    p.Ho = (p.H + 6 - 7) / 2 + 1; p.Wo = (p.W + 6 - 7) / 2 + 1;
+    p.Hp = (p.Ho + 2 - 3) / 2 + 1; p.Wp = (p.Wo + 2 - 3) / 2 + 1;
+    DAT_ENFORCE(ctx, p.Ho >= 1 && p.Wo >= 1 && p.Hp >= 1 && p.Wp >= 1, "stem_conv_pool_u8: input %dx%d too small", p.H, p.W);
+    p.tiles_h = (p.Hp + FPH - 1) / FPH; p.tiles_w = (p.Wp + FPW - 1) / FPW;
+    const size_t es = dat_esize(dtype);
+    const int kpad = dtype == DAT_BF16 ? StemCfg<DAT_BF16>::KPAD : StemCfg<DAT_F32>::KPAD;
+    size_t lds = (size_t)64 * (kpad * es + 16) + (size_t)FPR * PP * es;
+    const size_t stage = (size_t)FTH * 32 * (64 * es + SPITCH_PAD);
+    if (lds < stage) lds = stage;
+    lds = (lds + 15) & ~(size_t)15;
+    p.sb_off = (int)lds; lds += 128 * sizeof(float);
+    const long long nblocks = (long long)n_frames * p.tiles_h * p.tiles_w;
+    DAT_ENFORCE(ctx, nblocks > 0 && nblocks < (1ll << 31), "stem_conv_pool_u8: grid of %lld blocks unsupported", nblocks);
+    if (dtype == DAT_BF16) {
+        if (dat_ensure_lds(ctx, (const void*)stem_pool_kernel<DAT_BF16, 1>, 64 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL((stem_pool_kernel<DAT_BF16, 1>), dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)s, p);
+    } else {
+        if (dat_ensure_lds(ctx, (const void*)stem_pool_kernel<DAT_F32, 1>, 96 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL((stem_pool_kernel<DAT_F32, 1>), dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)s, p);
+    }
+    DAT_CHECK_LAUNCH(ctx, "stem_conv_pool_u8");
     return DAT_OK;
 }
 

@@ -133,6 +133,7 @@ _PROTOS = {
     'dat_stem_conv': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_stem_conv_pool': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_preprocess_frames': (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _i, _i, _i, _i, C.POINTER(_d), _p]),
+    'dat_stem_conv_pool_u8': (_i, [_p, _p, _i, _p, _i, _i, _i, _d, _d, _i, _i, _i, _i, C.POINTER(_d), _p, _p, _p, _i, _p]),
     'dat_heatmaps_to_keypoints': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dat_heatmaps_to_keypoints_ld': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dat_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc), _i, _i]),

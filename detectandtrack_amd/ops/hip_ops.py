@@ -761,6 +761,25 @@ class StemConv(object):
         return out
 
 
+def _stem_pooled_u8(self, fb):
+    """conv1 + affine + ReLU + pool1 straight from uploaded uint8 frames (dat_stem_conv_pool_u8): `fb` = utils.blob.FrameBlob -- the `data`
+    blob that was never materialised.  Bit-identical to `pooled(fb.materialise())`."""
+    frames = fb.frames
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4 and frames.shape[3] == 3
+    F, h, w, _ = [int(v) for v in frames.shape]
+    (oh, ow), (ph, pw) = fb.out_hw, fb.pad_hw
+    ho, wo = (ph - 1) // 2 + 1, (pw - 1) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    out = torch.empty((F, hp, wp, 64), dtype=tdtype(self.dtype), device=frames.device)
+    means = (C.c_double * 3)(*[float(v) for v in np.asarray(fb.pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    ctx().call('dat_stem_conv_pool_u8', _stream(), self.dtype, _ptr(frames), F, h, w, C.c_double(fb.scale), C.c_double(fb.scale), oh, ow, ph, pw,
+               means, _ptr(self.packed), _ptr(self.scale), _ptr(self.bias), int(self.relu), _ptr(out))
+    return out
+
+
+StemConv.pooled_u8 = _stem_pooled_u8
+
+
 def maxpool_hw(x, dtype, k, stride, pad):
     f, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1

@@ -49,7 +49,43 @@ def test_scale(frame_shape, target_size, max_size):
     return scale
 
 
-def frames_to_blob_on_device(frames_u8, num_frames, out=None):
+class FrameBlob(object):
+    """The `data` blob of a forward that has NOT been materialised (round 6, cfg.HIP.STEM_FROM_UINT8): the uploaded uint8 frames [F, h, w, 3]
+    plus the geometry prep_im_for_blob / im_list_to_blob would give them.  The fused stem reads the frames directly
+    (dat_stem_conv_pool_u8 evaluates the pre-processing arithmetic in its patch loader, bit-identical); anything else that wants the blob
+    -- an unfused stem, FetchBlob('data') -- calls materialise() (dat_preprocess_frames).  `shape` is the blob's."""
+
+    def __init__(self, frames_u8, T, scale, out_hw, pad_hw, five_d, pixel_means):
+        self.frames, self.T, self.scale = frames_u8, int(T), float(scale)
+        self.out_hw, self.pad_hw, self.five_d = tuple(out_hw), tuple(pad_hw), bool(five_d)
+        self.pixel_means = np.asarray(pixel_means, dtype=np.float64)
+        F = int(frames_u8.shape[0])
+        self.N = F // self.T
+        self.shape = (self.N, 3, self.T) + self.pad_hw if self.five_d else (F, 3) + self.pad_hw
+        self.device = frames_u8.device
+
+    def data_ptr(self):
+        return self.frames.data_ptr()
+
+    def materialise(self):
+        """The fp32 blob dat_preprocess_frames writes for these frames: [N, 3, T, H, W], or [F, 3, H, W] for 2D models."""
+        import torch
+        out = torch.empty((self.N, 3, self.T) + self.pad_hw, dtype=torch.float32, device=self.frames.device)
+        data = _preprocess_into(self.frames, self.T, self.scale, self.pixel_means, self.out_hw, self.pad_hw, out)
+        return data if self.five_d else data.view((self.N * self.T, 3) + self.pad_hw)
+
+
+def _preprocess_into(frames, T, scale, pixel_means, out_hw, pad_hw, out):
+    import ctypes as C
+    from detectandtrack_amd.ops import hip_ops as ops
+    F, h, w, _ = [int(v) for v in frames.shape]
+    means = (C.c_double * 3)(*[float(v) for v in np.asarray(pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    ops.ctx().call('dat_preprocess_frames', ops._stream(), ops._ptr(frames), F, int(T), h, w, C.c_double(scale), C.c_double(scale),
+                   int(out_hw[0]), int(out_hw[1]), int(pad_hw[0]), int(pad_hw[1]), means, ops._ptr(out))
+    return out
+
+
+def frames_to_blob_on_device(frames_u8, num_frames, out=None, lazy=False):
     """prep_im_for_blob + im_list_to_blob for frames that are already on the GPU as a uint8 [F, h, w, 3] tensor (round 3: a clip is
     uploaded as 3 bytes per source pixel and prepared by dat_preprocess_frames, bit-identical to the host path).
     Returns (data blob fp32 [F / num_frames, 3, num_frames, H, W] -- or [F, 3, H, W] for 2D models --, scale, im_info rows)."""
@@ -58,7 +94,15 @@ def frames_to_blob_on_device(frames_u8, num_frames, out=None):
     h, w = int(frames_u8.shape[1]), int(frames_u8.shape[2])
     scale = test_scale((h, w), cfg.TEST.SCALES[0], cfg.TEST.MAX_SIZE)
     T = int(num_frames) if cfg.MODEL.VIDEO_ON else 1
-    data, _ = ops.preprocess_frames(frames_u8, T, scale, cfg.PIXEL_MEANS, int(cfg.FPN.COARSEST_STRIDE) if cfg.FPN.FPN_ON else 0, out=out)
+    pad = int(cfg.FPN.COARSEST_STRIDE) if cfg.FPN.FPN_ON else 0
+    if lazy and cfg.HIP.get('STEM_FROM_UINT8', True):
+        # the blob is described, not written: the fused stem reads the uint8 frames (FrameBlob)
+        oh, ow = int(np.rint(h * scale)), int(np.rint(w * scale))
+        ph, pw = (oh, ow) if not pad else (int(np.ceil(oh / float(pad)) * pad), int(np.ceil(ow / float(pad)) * pad))
+        fb = FrameBlob(frames_u8, T, scale, (oh, ow), (ph, pw), cfg.MODEL.VIDEO_ON, cfg.PIXEL_MEANS)
+        im_info = np.tile(np.array([[ph, pw, scale]], dtype=np.float64), (fb.N if cfg.MODEL.VIDEO_ON else int(frames_u8.shape[0]), 1))
+        return fb, scale, im_info
+    data, _ = ops.preprocess_frames(frames_u8, T, scale, cfg.PIXEL_MEANS, pad, out=out)
     n = data.shape[0]
     # (float64 rows: the `im_info` BLOB is their float32 rounding -- whoever feeds it converts --, the scale column also travels to the device
     #  glue, which divides the boxes by the double like the reference)

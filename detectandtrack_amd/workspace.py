@@ -55,6 +55,10 @@ class Workspace(object):
     # ---- reference workspace API -------------------------------------------------------------------------------
     def FeedBlob(self, name, arr):
         name = _unscoped(name)
+        if getattr(arr, 'materialise', None) is not None and hasattr(arr, 'frames'):
+            # utils.blob.FrameBlob: the `data` blob described by the uploaded uint8 frames (the fused stem reads them directly)
+            self.blobs[name] = Blob(arr, 'u8frames', N=arr.N, T=arr.T, C=3, five_d=arr.five_d)
+            return
         if isinstance(arr, torch.Tensor):
             t = arr.to(self.device)
         else:
@@ -68,6 +72,8 @@ class Workspace(object):
         if name in self.params and name not in self.blobs:
             return self.params[name]
         b = self.blobs[name]
+        if b.kind == 'u8frames':        # (never materialised on the hot path: the blob as dat_preprocess_frames writes it)
+            return b.t.materialise().cpu().numpy()
         if b.kind == 'fmap':
             t = b.t
             if b.tsel is not None:      # lazy key-frame slice: pick frame k of every clip now
@@ -530,11 +536,18 @@ class Executor(object):
         ws, a, dt = self.ws, op.args, _dt(self.ws)
         assert a['kernels'] == [1, 7, 7] and a['strides'] == [2, 2] and a['pads'] == [0, 3, 3] and a['dim_in'] == 3, \
             'the network input must feed the [1,7,7]/[1,2,2] stem conv (ResNet3D.py:258)'
-        data = xin.t
-        five_d = data.dim() == 5
-        if not five_d:
-            data = data[:, :, None]
-        n, _, t, h, w = data.shape
+        frames = None
+        if xin.kind == 'u8frames':      # the uploaded uint8 frames stand for the blob (utils.blob.FrameBlob)
+            frames, five_d = xin.t, xin.t.five_d
+            n, t = frames.N, frames.T
+            if not five_d:
+                n, t = n * t, 1
+        else:
+            data = xin.t
+            five_d = data.dim() == 5
+            if not five_d:
+                data = data[:, :, None]
+            n, _, t, h, w = data.shape
 
         def build():
             scale = ws.dev_param(a['scale']) if a['scale'] else None
@@ -543,11 +556,17 @@ class Executor(object):
         layer = self._layer(i, build)
         # (the fused stem kernel is not a conv3d_igemm launch: it is not part of the bench's per-launch conv log)
         pool = self._stem_pool_op(i, op)
+        if frames is not None and (pool is None or not cfg.HIP.get('STEM_FROM_UINT8', True)):
+            data = frames.materialise()     # no fused stem + pool here: the blob after all (dat_preprocess_frames)
+            data = data if data.dim() == 5 else data[:, :, None]
+            frames = None
         if pool is not None:           # conv1 has one reader, pool1: one kernel, conv1 never written (cfg.HIP.FUSE_STEM_POOL)
             pi, pop = pool
             self._skip.add(pi)
             ws.blobs.pop(op.outputs[0], None)
-            ws.blobs[pop.outputs[0]] = Blob(layer.pooled(data.float()), 'fmap', n, t, a['dim_out'], dt, five_d)
+            # (round 6: from the uint8 frames when that is what was fed -- the fp32 blob is then never written; bit-identical pool1)
+            y = layer.pooled_u8(frames) if frames is not None else layer.pooled(data.float())
+            ws.blobs[pop.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)
             return
         y = layer(data.float())
         ws.blobs[op.outputs[0]] = Blob(y, 'fmap', n, t, a['dim_out'], dt, five_d)

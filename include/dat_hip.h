@@ -347,6 +347,14 @@ int dat_stem_conv(dat_ctx* ctx, dat_stream s, int dtype, const float* data, cons
  * Bit-identical to dat_stem_conv followed by dat_maxpool_hw(k 3, stride 2, pad 1). */
 int dat_stem_conv_pool(dat_ctx* ctx, dat_stream s, int dtype, const float* data, const void* w_packed, const float* scale,
                        const float* bias, int relu, int N, int T, int H, int W, void* out_pool);
+/* The same launch fed from the UPLOADED uint8 frames (round 6): frames = DEVICE uint8 [n_frames, h, w, 3] (BGR, HWC), the geometry arguments
+ * of dat_preprocess_frames (fx = fy = the test scale, out_h x out_w the resized image, pad_h x pad_w the blob).  The patch loader computes the
+ * value the `data` blob would hold -- dat_preprocess_frames' arithmetic, bit for bit -- so pool1 is IDENTICAL to dat_preprocess_frames +
+ * dat_stem_conv_pool and the fp32 blob (12 bytes per network pixel) is never written or read.  out_pool [n_frames, Hp, Wp, 64] in frame
+ * order (frame n*T + t of the blob is input frame n*T + t).  The frames allocation must be readable up to the next multiple of 4 bytes. */
+int dat_stem_conv_pool_u8(dat_ctx* ctx, dat_stream s, int dtype, const unsigned char* frames, int n_frames, int h, int w, double fx, double fy,
+                          int out_h, int out_w, int pad_h, int pad_w, const double* pixel_means, const void* w_packed, const float* scale,
+                          const float* bias, int relu, void* out_pool);
 
 /* ---- gradient exchange of data-parallel training (lib/modeling/model_builder.py:938-942: NCCLAllreduce / muji.Allreduce over the
  * parameter gradients; losses are pre-divided by NUM_GPUS, so the reduction is a plain sum).  Thin wrappers over RCCL (loaded on first

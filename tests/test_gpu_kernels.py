@@ -1433,7 +1433,7 @@ LW_CASES = [
     ('k512_c128', 2, 192, 200, 512, 128, 1, True, 0, True),                 # res3_x_branch2a
     ('k128_c512_sum', 2, 192, 200, 128, 512, 1, True, 1, True),             # res3_x_branch2c + Sum + ReLU: two passes of 256 channels
     ('k256_c256_up2', 2, 192, 200, 256, 256, 1, False, 2, False),           # FPN P2 lateral of R-50 + top-down Sum
-    ('k512_c256_up2_parts2', 2, 192, 200, 512, 256, 1, False, 2, False),    # P3 lateral: weights 256 KB -> two cout parts
+    ('k512_c256_up2_parts2', 2, 128, 160, 512, 256, 1, False, 2, False),    # P3 lateral: weights 256 KB -> two cout parts (on a map too small for the K-streaming kernel, which takes it otherwise)
     ('k256_c512_s2_parts2', 2, 384, 400, 256, 512, 2, False, 0, True),      # res3_0_branch1: stride 2, two cout parts
     ('k256_c128_s2', 2, 384, 400, 256, 128, 2, True, 0, True),              # res3_0_branch2a: stride 2 (STRIDE_1X1)
     ('k256_c200_ragged', 2, 191, 201, 256, 200, 1, True, 1, True),          # Cout not a multiple of 32, ragged last tile, odd W
@@ -1496,6 +1496,7 @@ KS_CASES = [
     ('k1024_c256_up2', 2, 192, 200, 1024, 256, 1, False, 2, False),          # FPN P4 lateral + nearest-2x top-down Sum
     ('k1024_c512_sum', 2, 160, 168, 1024, 512, 1, True, 1, True),            # data gradient of a branch2c-shaped layer: Sum + ReLU epilogue
     ('k1088_c200_ragged', 2, 191, 201, 1088, 200, 1, True, 1, True),         # K not a power of two, Cout padded to 256, ragged last tile
+    ('k1024_c256_mask', 2, 160, 168, 1024, 256, 1, False, 3, False),         # data gradient of res4_x_branch2c with the ReLU backward of its input fused (res_mode 3)
 ]
 
 
@@ -1519,13 +1520,17 @@ def test_conv1x1_k_streaming_kernel(ops, case):
     elif res_mode == 2:
         res_small = q(rs.randn(1, Cout, T, Ho // 2, Wo // 2).astype(np.float32))
         res = np.repeat(np.repeat(res_small, 2, axis=3), 2, axis=4)
+    elif res_mode == 3:
+        res = q(rs.randn(1, Cout, T, Ho, Wo).astype(np.float32))             # the MASK: out = mask > 0 ? v : 0
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    ref = _conv_ref(x, w, scale, bias, res, (stride, stride), (0, 0, 0), relu)
+    ref = _conv_ref(x, w, scale, bias, None if res_mode == 3 else res, (stride, stride), (0, 0, 0), relu)
+    if res_mode == 3:
+        ref = np.where(res > 0, ref, 0.0).astype(np.float32)
     layer = ops.ConvLayer(_dev(w), None if scale is None else _dev(scale), _dev(bias), stride=(stride, stride), pads=(0, 0, 0),
                           relu=relu, dtype=1)
     xd = ops.to_ndhwc(_dev(x), 1)
     rd = None
-    if res_mode == 1:
+    if res_mode in (1, 3):
         rd = ops.to_ndhwc(_dev(res), 1, layer.cstride)
     elif res_mode == 2:
         rd = ops.to_ndhwc(_dev(res_small), 1, layer.cstride)
@@ -1546,3 +1551,38 @@ def test_conv1x1_k_streaming_kernel(ops, case):
     assert err < 3e-2 * max(1.0, np.abs(ref).max() / 4)
     if layer.cstride > Cout:          # the padding channels of the blob stay zero
         assert not y[..., Cout:].any()
+
+
+@pytest.mark.parametrize('dtype_name', ['bf16', 'fp32'])
+@pytest.mark.parametrize('h,w,target,max_size,T,stride', [
+    (720, 1280, 800, 1333, 2, 32),      # the benched geometry: x 1.0414 -> 750 x 1333, padded to 768 x 1344
+    (180, 320, 256, 333, 3, 0),         # a shipped 3D config's scale rule on a small frame, unpadded blob with odd width
+    (97, 131, 64, 100, 1, 32),          # DOWN-scaling (x 0.66), odd source size, heavy padding
+    (33, 47, 90, 150, 2, 0),            # x 2.7 up-scaling: long runs of output pixels inside one source cell, borders on every tile
+    (50, 3, 60, 400, 1, 0),             # a three-pixel-wide frame (every column is a border column)
+])
+def test_stem_from_uint8_frames_is_bit_identical_to_the_blob_path(ops, dtype_name, h, w, target, max_size, T, stride):
+    """dat_stem_conv_pool_u8 (round 6: conv1 + AffineChannelNd + ReLU + pool1 straight from the uploaded uint8 frames, the pre-processing
+    arithmetic of lib/utils/blob.py:40-90 evaluated in the stem's patch loader) against dat_preprocess_frames + dat_stem_conv_pool: the
+    SAME pool1, bit for bit -- up- and down-scaling, padded and unpadded blobs, border columns / rows, the last pixel of the buffer."""
+    from detectandtrack_amd.core.config import cfg, reset_cfg
+    from detectandtrack_amd.utils import blob as blob_utils
+    reset_cfg()
+    dt = ops.F32 if dtype_name == 'fp32' else ops.BF16
+    rs = np.random.RandomState(h * 7 + w)
+    F = 2 * T
+    frames = torch.from_numpy(rs.randint(0, 256, (F, h, w, 3)).astype(np.uint8)).cuda()
+    scale = blob_utils.test_scale((h, w), target, max_size)
+    g = torch.Generator().manual_seed(5)
+    wt = (torch.randn((64, 3, 1, 7, 7), generator=g) * 0.05).cuda()
+    sc, bi = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda()
+    layer = ops.StemConv(wt, sc, bi, dt, relu=True)
+    data, (oh, ow) = ops.preprocess_frames(frames, T, scale, cfg.PIXEL_MEANS, stride)
+    ref = layer.pooled(data)
+    fb = blob_utils.FrameBlob(frames, T, scale, (oh, ow), tuple(data.shape[-2:]), True, cfg.PIXEL_MEANS)
+    assert tuple(fb.shape) == tuple(data.shape)
+    got = layer.pooled_u8(fb)
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert torch.equal(got, ref), 'differs in %d of %d elements, max %.3e' % (int((got != ref).sum()), got.numel(),
+                                                                             float((got.float() - ref.float()).abs().max()))
+    assert torch.equal(fb.materialise(), data)
