@@ -851,8 +851,11 @@ def main():
                'ms_per_step': round(1e3 * el_h / a.steps, 3),
                'upload_mb_per_step': round(pipe.upload_bytes / 1e6 / max(a.steps, 1), 2),
                'host_ms_per_step': round(1e3 * pipe.host_enqueue_s / max(a.steps, 1), 3),
-               'path': 'uint8 %dx%dx3 frames in host memory -> pinned buffer (memcpy) -> hipMemcpyAsync on a copy stream -> '
-                       'dat_preprocess_frames (bilinear resize x%.4f, mean subtraction, pad to 32) -> the same hipGraphs' % (src_h, src_w, im_scale)}
+               'path': ('uint8 %dx%dx3 frames in host memory -> pinned buffer (memcpy) -> hipMemcpyAsync on a copy stream -> %s' % (
+                   src_h, src_w, ('the hipGraphs of the forward, whose fused stem reads the uint8 frames and evaluates the pre-processing (bilinear resize x%.4f, '
+                                  'mean subtraction, pad to 32) in its patch loader (dat_stem_conv_pool_u8: the fp32 data blob is never written)' % im_scale)
+                   if os.environ.get('DAT_STEM_FROM_UINT8', '1') != '0' else
+                   ('dat_preprocess_frames (bilinear resize x%.4f, mean subtraction, pad to 32) -> the same hipGraphs' % im_scale)))}
         _dbg('h2d region done')
     if train:
         start_profilers()

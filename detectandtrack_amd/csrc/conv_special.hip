@@ -563,6 +563,7 @@ struct PwKsParams {
     int ncb;                    // cout blocks of 256
     int kchunks, mb_total;      // Cin / 64; Cout_pad / 32
     unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo)
+    int ablate;                 // DEBUG (DAT_CONV_ABLATE): 1 no input-row copies after the first chunks, 2 no weight copies, 4 no MFMAs
 };
 
 constexpr int KS_THREADS = 512;
@@ -653,9 +654,9 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
     int xi = 0;                                         // kc % 3
     for (int kc = 0; kc < p.kchunks; ++kc) {
         const int x2 = xi >= 1 ? xi - 1 : 2;            // (kc + 2) % 3
-        KS_DMA_W(kc + 1, (kc + 1) & 1);
-        KS_DMA_X(kc + 2, x2);
-        KS_COMPUTE(xi, kc & 1);
+        if (!(p.ablate & 2)) KS_DMA_W(kc + 1, (kc + 1) & 1);
+        if (!(p.ablate & 1)) KS_DMA_X(kc + 2, x2);
+        if (!(p.ablate & 4)) KS_COMPUTE(xi, kc & 1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
         xi = xi == 2 ? 0 : xi + 1;
@@ -1185,6 +1186,7 @@ int launch_pwks(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     p.ncb = cp.Cout_pad / 256; p.kchunks = cp.Cin / 64; p.mb_total = cp.Cout_pad / 32;
     p.how = (unsigned)(cp.Ho * cp.Wo);
     p.wo_magic = cp.Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.Wo - 1) / (unsigned)cp.Wo);
+    p.ablate = ctx->dbg_ablate;
     const long long blocks = cdiv_ll(p.npos, 256) * p.ncb;
     DAT_ENFORCE(ctx, blocks > 0 && blocks < (1ll << 31), "conv1x1_ks: grid of %lld blocks unsupported", blocks);
     const size_t lds = (size_t)3 * KS_XBYTES + 2 * KS_WBYTES;     // 160 KB: three input buffers, two weight buffers (the epilogue reuses them)
