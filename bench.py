@@ -1261,6 +1261,8 @@ def other_configs():
             p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
             d = json.loads(p.stdout.decode().strip().splitlines()[-1])
             res[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'workload': d['config']['workload']}
+            if name == 'reference_2d_best_r101':
+                res[name]['unit'] = 'frames/s'     # (a clip of this model is ONE frame: VIDEO.NUM_FRAMES 1)
             rl = d.get('roofline') or {}
             if rl:      # the configuration's own roofline: dominant MFMA kernel, whole step, and the HBM-bound 1x1 class in GB/s
                 res[name]['roofline'] = {k: rl.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'launches_per_step',
