@@ -25,6 +25,12 @@ PARITY STATUS (what pins each restatement; generators and fixtures are committed
     with this package's INTER_CUBIC restatement in place of the absent cv2.resize; the OpenCV resamplers themselves
     (`oracle.resize`) are restated from the published algorithm and pinned by exact-rational known answers.
   * legacy RoIAlign, ConvTranspose k4 s2 p1: known answers worked by hand (tests/test_oracle_golden.py).
+  * round 6: the keypoint OUTPUT function of a 3D head in both settings of KRCNN.NO_3D_DECONV_TIME_TO_CH (`Net.kps_outputs_tube`): the
+    WIRING is pinned to the reference's own add_heatmap_outputs run on the recorder (tests/golden/reference_heatmap_outputs.json); what
+    `group = T` computes inside Caffe2's ConvTranspose is not (both readings are restated: grouped filter / full brew filter).  The 2D
+    C4 functions (`rpn_c4_2d`, `box_head_c4_2d`, `kps_head_c4_2d`: the graph of configs/video/3d/01_R-18_*.yaml) follow
+    model_builder.py:500-609 (nd=False), ResNet.py:268-287 and keypoint_rcnn_heads.py:39-69.  The DATASET layer is product code pinned
+    directly to the reference (tests/test_dataset_cpu.py), not an oracle restatement.
   * conv / RoIAlign / deconv / FC / loss graph as a whole (`oracle.net3d`, `oracle.train_ref`): PARITY UNPINNED -- the
     arithmetic lives in Caffe2 @ b4e1588 (+ cuDNN 7.1.2), which is not in /root/reference and cannot be built here
     (SURVEY.md F1/F7, section 8c).  The restatement follows the public operator semantics at the reference's call sites;
