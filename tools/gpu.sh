@@ -11,7 +11,7 @@
 #   pmc[:bench args]        three separate --pmc passes (MFMA busy / FETCH_SIZE / WRITE_SIZE; --kernel-trace only) of a --pipeline 1 run
 #   trace[:bench args]      rocprofv3 --kernel-trace of a short --pipeline 1 run (-> <name>_kernel_trace.csv; tools/probes/trace_iter.py lists one iteration)
 #   smoke                   __graft_entry__.smoke()
-#   py:<script;args>        python <script> <args>   (-> py_<n>.log)
+#   py:<script;args>        python <script> <args>   (-> py_<n>.log; args are eval'ed: -k;'"a;or;b"' keeps an expression together)
 #   env:<NAME=V;NAME2=V2>   export for the stages that follow (A/B pairs inside one call);  unset:<NAME;NAME2>
 # Environment switches (DAT_*) are inherited, so A/B pairs are two stages in one call:  DAT_X=1 bash tools/gpu.sh ...
 # Allocation-poison pass of the suite (tests/conftest.py, csrc/c_api.hip):  DAT_POISON=1 DAT_WS_POISON=1 bash tools/gpu.sh <tag> tests
@@ -49,7 +49,7 @@ for st in "$@"; do
     smoke)  (cd $R && timeout -s KILL 600 python -c "import __graft_entry__ as g; g.smoke()" > $o/smoke.log 2>&1; tail -2 $o/smoke.log) ;;
     env)    for kv in $args; do export "$kv"; done ;;
     unset)  for kv in $args; do unset "$kv"; done ;;
-    py)     (cd $R && timeout -s KILL 900 python $args > $o/py_$n.log 2>&1; echo "rc $?" >> $o/py_$n.log; tail -25 $o/py_$n.log) ;;
+    py)     (cd $R && eval "timeout -s KILL 900 python $args" > $o/py_$n.log 2>&1; echo "rc $?" >> $o/py_$n.log; tail -25 $o/py_$n.log) ;;
     *)      echo "unknown stage $name" ;;
     esac
 done
