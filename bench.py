@@ -944,13 +944,20 @@ def main():
     dom_fl, dom_ms, dom_n, dom_bytes = by_tag[dom_tag]
     if a.dump_convs:
         agg = {}
-        for (tag, _, ms), (name, fl, _b) in zip(records, conv_log):
-            e = agg.setdefault(name, [0.0, 0.0, tag, 0])
+        for (tag, _, ms), (name, fl, nb) in zip(records, conv_log):
+            e = agg.setdefault(name, [0.0, 0.0, tag, 0, 0.0])
             e[0] += fl
             e[1] += ms
             e[3] += 1
-        for name, (fl, ms, tag, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s' % (name, tag, ms / prof_steps, fl / ms / 1e9 if ms > 0 else 0),
+            e[4] += nb
+        # per layer: the rate, the algorithmic HBM rate (input + weights + residual + output once), and the roofline that bounds the
+        # layer at its arithmetic intensity -- min(MFMA peak, intensity x HBM peak) -- with the fraction of it reached
+        for name, (fl, ms, tag, cnt, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            tf = fl / ms / 1e9 if ms > 0 else 0
+            roof = min(PEAK_BF16_TFLOPS if a.dtype != 'fp32' else PEAK_F32_TFLOPS, fl / nb * PEAK_HBM_GBS / 1e3) if nb > 0 else 0
+            print('%-40s tag %7d %8.3f ms/step %8.1f TFLOP/s %7.0f GB/s  roof %6.0f TFLOP/s (%s) frac %.2f' % (
+                name, tag, ms / prof_steps, tf, nb / ms / 1e6 if ms > 0 else 0, roof,
+                'hbm' if roof < (PEAK_BF16_TFLOPS if a.dtype != 'fp32' else PEAK_F32_TFLOPS) else 'mfma', tf / roof if roof > 0 else 0),
                   file=sys.stderr)
     all_fl = sum(c[1] for c in conv_log)
     all_ms = sum(ms for _, _, ms in records)

@@ -47,8 +47,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
 // pieces, 32 consecutive rows (= lanes of a fragment) per 512-byte run.
 template <int DT>
 __device__ __forceinline__ void pack_tile(const float* __restrict__ w, void* __restrict__ out, int Cout_real, int Cin_real, int ntap,
-                                          int Cout_pad, int Cin, int frag, int dgrad, const float* __restrict__ scale, int co0, int ci0) {
-    constexpr int CT = 32, CIT = 16;
+                                          int Cout_pad, int Cin, int frag, int dgrad, const float* __restrict__ scale, int co0, int ci0,
+                                          int CIT) {
+    // CIT: input channels of the tile (16 | 32 | 64, pack_cit): pointwise layers -- most of a bottleneck network's parameters -- get
+    // 256-byte source runs and 8 KB per block instead of 64-byte runs and 2 KB
+    constexpr int CT = 32;
     (void)CT;
     constexpr int CK = Mma<DT>::CK, EPS = 16 / ElemOf<DT>::size;
     extern __shared__ float tile[];                    // [CT co][CIT ci][ntap], rows padded by one float: the store phase reads with
@@ -106,7 +109,7 @@ __device__ __forceinline__ void pack_tile(const float* __restrict__ w, void* __r
         }
     }
     __syncthreads();
-    constexpr int SL = CIT / EPS;                      // 16-byte pieces per row of the tile
+    const int SL = CIT / EPS;                          // 16-byte pieces per row of the tile
     const int npieces = ntap * SL * CT;
     for (int id = tid; id < npieces; id += 256) {
         const int co_l = id % CT, r = id / CT, sl = r % SL, tap = r / SL;
@@ -136,25 +139,31 @@ template <int DT>
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout_real,
                                                                  int Cin_real, int ntap, int Cout_pad, int Cin, int frag, int dgrad,
                                                                  const float* __restrict__ scale) {
-    pack_tile<DT>(w, out, Cout_real, Cin_real, ntap, Cout_pad, Cin, frag, dgrad, scale, blockIdx.x * 32, blockIdx.y * 16);
+    pack_tile<DT>(w, out, Cout_real, Cin_real, ntap, Cout_pad, Cin, frag, dgrad, scale, blockIdx.x * 32, blockIdx.y * 16, 16);
 }
 
 // Batched re-pack (training): after an SGD step every trainable layer and its data-gradient twin is re-packed from the fp32 masters --
 // ~100 launches of 3-20 us each, 1.75 ms of a 23 ms iteration.  One launch over a table of entries: block b belongs to the entry whose
-// [tile0, tile0 + tiles) range holds it (binary search over <= a few hundred entries of uniform loads).
+// [tile0, tile0 + tiles) range holds it.  The entry is found with ONE round of loads -- every thread tests one entry, the block counts
+// the entries that start at or before it -- where a binary search chained ~8 dependent L2 round trips in front of a block that moves 3 KB
+// (round 6: the re-pack of R-50 ran at 0.34 TB/s, 0.44 ms per iteration, most of it this search and 2-KB tiles at 2 blocks per CU: the
+// launches are now grouped by tap count on the host, so a pointwise entry no longer reserves the 55 KB of LDS a 27-tap tile needs).
 template <int DT>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const dat_pack_item* __restrict__ items, int n) {
     const int b = blockIdx.x;
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        cnt += __syncthreads_count(i < n && items[i].tile0 <= b);
     }
-    const dat_pack_item it = items[lo];
+    const dat_pack_item it = items[cnt - 1];          // (tile0 ascending from 0: cnt >= 1)
     const int local = b - it.tile0;
     const int bx = local % it.tiles_x, by = local / it.tiles_x;
-    pack_tile<DT>(it.w, it.packed, it.rows, it.cols, it.ntap, it.cout_pad, it.cin, it.frag, it.dgrad, it.scale, bx * 32, by * 16);
+    pack_tile<DT>(it.w, it.packed, it.rows, it.cols, it.ntap, it.cout_pad, it.cin, it.frag, it.dgrad, it.scale, bx * 32, by * it.cit, it.cit);
 }
+
+// input channels per tile of a batched entry: as many as keep the tile (32 rows x cit x taps floats) at or below ~37 KB
+__host__ __device__ inline int pack_cit(int ntap) { return ntap <= 4 ? 64 : ntap <= 9 ? 32 : 16; }
 
 // stem packing (see dat_hip.h: dat_stem_pack): one thread = one 16-byte group of output channels
 template <int DT>
@@ -272,28 +281,32 @@ int dat_conv3d_pack_item(dat_ctx* ctx, const dat_conv_desc* d, const float* w, i
     if (dgrad) DAT_ENFORCE(ctx, rows_real <= d->Cout && cols_real <= d->Cin, "conv3d_pack_item: forward dims exceed the data-gradient descriptor");
     else DAT_ENFORCE(ctx, rows_real <= d->Cout && cols_real <= d->Cin, "conv3d_pack_item: real dims exceed descriptor");
     const int ntap = d->KT * d->KH * d->KW;
-    DAT_ENFORCE(ctx, (size_t)32 * (16 * ntap + 1) * sizeof(float) <= 160 * 1024, "conv3d_pack_item: %d taps exceed the LDS tile", ntap);
+    const int cit = pack_cit(ntap);
+    DAT_ENFORCE(ctx, (size_t)32 * (cit * ntap + 1) * sizeof(float) <= 128 * 1024, "conv3d_pack_item: %d taps exceed the LDS tile", ntap);
+    DAT_ENFORCE(ctx, d->Cin % cit == 0, "conv3d_pack_item: Cin %d is not a multiple of the %d-channel tile", d->Cin, cit);
     item->w = w; item->packed = packed; item->scale = scale;
     item->rows = rows_real; item->cols = cols_real; item->ntap = ntap;
     item->cout_pad = cout_pad_of(d); item->cin = d->Cin;
     item->frag = weights_direct(ctx, d) ? 1 : 0;
     item->dgrad = dgrad ? 1 : 0; item->dtype = d->dtype;
-    item->tile0 = 0; item->tiles_x = item->cout_pad / 32;
-    return item->tiles_x * (d->Cin / 16);
+    item->tile0 = 0; item->tiles_x = item->cout_pad / 32; item->cit = cit;
+    return item->tiles_x * (d->Cin / cit);
 }
 
 int dat_conv3d_pack_weights_batch(dat_ctx* ctx, dat_stream s, const dat_pack_item* items_dev, int n, int total_blocks, int max_ntap,
                                   int dtype) {
     DAT_ENFORCE(ctx, items_dev && n > 0 && total_blocks > 0 && max_ntap > 0, "conv3d_pack_weights_batch: empty batch");
     DAT_ENFORCE(ctx, dtype == DAT_F32 || dtype == DAT_BF16, "conv3d_pack_weights_batch: bad dtype %d", dtype);
-    const size_t lds = (size_t)32 * (16 * max_ntap + 1) * sizeof(float);
-    DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv3d_pack_weights_batch: %d taps exceed the LDS tile", max_ntap);
+    size_t lds = 0;                                    // the largest tile an entry of <= max_ntap taps can have
+    for (int t = 1; t <= max_ntap; ++t) lds = std::max(lds, (size_t)32 * (pack_cit(t) * t + 1) * sizeof(float));
+    // (128 KiB: the block count of the entry search takes a few bytes of static LDS, so the full 160 KiB cannot be dynamic)
+    DAT_ENFORCE(ctx, lds <= 128 * 1024, "conv3d_pack_weights_batch: %d taps exceed the LDS tile", max_ntap);
     int rc;
     if (dtype == DAT_BF16) {
-        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_BF16>, 160 * 1024)) != DAT_OK) return rc;
+        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_BF16>, 128 * 1024)) != DAT_OK) return rc;
         hipLaunchKernelGGL(pack_weights_batch_kernel<DAT_BF16>, dim3(total_blocks), dim3(256), lds, (hipStream_t)s, items_dev, n);
     } else {
-        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_F32>, 160 * 1024)) != DAT_OK) return rc;
+        if ((rc = dat_ensure_lds(ctx, (const void*)pack_weights_batch_kernel<DAT_F32>, 128 * 1024)) != DAT_OK) return rc;
         hipLaunchKernelGGL(pack_weights_batch_kernel<DAT_F32>, dim3(total_blocks), dim3(256), lds, (hipStream_t)s, items_dev, n);
     }
     DAT_CHECK_LAUNCH(ctx, "pack_weights_batch");

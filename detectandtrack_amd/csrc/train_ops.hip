@@ -404,6 +404,7 @@ struct Wgrad9Params {
     int ablate;           // DEBUG (DAT_WGRAD_ABLATE): 1 no global loads, 2 no LDS fragment reads / MFMAs, 4 no final atomics / stores
     const char* zeros;    // >= 16 zero bytes in global memory (LDS-DMA source of halo / out-of-range pieces)
     int atomic;           // add into G with atomics (K split, or a caller-owned accumulator) instead of storing
+    int xcd;              // XCD-aware block order (DAT_WGRAD_XCD): consecutive logical blocks share an XCD's L2
 };
 
 constexpr int W9_PITCH = 192;
@@ -575,6 +576,15 @@ __global__ __launch_bounds__(NT * SUB, SUB == 1 ? 2 : 1) void wgrad_dma9_kernel(
     const int sub = SUB == 1 ? 0 : wave_all >> 2, wave = wave_all & 3;
     const int wave_m = wave & 1, wave_n = wave >> 1;
     unsigned bid = blockIdx.x;
+    if (p.xcd) {
+        // Blocks go to the XCDs round-robin (block i -> XCD i % 8), and the blocks that read the same operand chunks at the same time are the
+        // (kt, ci tile) / (kt, co tile) neighbours of one K range: consecutive ids.  Unmapped, the 12 readers of a g chunk (4 ci tiles x 3 kt) sit
+        // on 8 different L2s and the chunk crosses the fabric ~7 times; mapped (the bijection of conv3d_igemm_kernel), XCD x runs the
+        // consecutive logical ids [x * n / 8, (x + 1) * n / 8).
+        const unsigned nx = 8, q = gridDim.x / nx, r = gridDim.x % nx;
+        const unsigned xcd = bid % nx, k = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const int kt = bid % p.KT; bid /= p.KT;
     const int ci_t = bid % p.n_ci_tiles; bid /= p.n_ci_tiles;
     const int co_t = bid % p.n_co_tiles;
@@ -1534,6 +1544,7 @@ static int wgrad_impl(dat_ctx* ctx, dat_stream s_, const dat_conv_desc* d, const
             if (q.atomic && !acc_mode && hipMemsetAsync(Gt, 0, g_elems * sizeof(float), st) != hipSuccess)
                 DAT_FAIL(ctx, DAT_ERR_LAUNCH, "conv3d_wgrad: memset failed");
             q.zeros = (const char*)ctx->zeros;
+            q.xcd = ctx->dbg_wgrad_xcd != 0;
             const bool ilv = ctx->dbg_wgrad_ilv != 0;
             const void* fn;
             if (sub2) {

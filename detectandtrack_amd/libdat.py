@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
 
 class PackItem(C.Structure):
     _fields_ = [('w', C.c_void_p), ('packed', C.c_void_p), ('scale', C.c_void_p)] + \
-               [(n, C.c_int) for n in ('rows', 'cols', 'ntap', 'cout_pad', 'cin', 'frag', 'dgrad', 'dtype', 'tile0', 'tiles_x')]
+               [(n, C.c_int) for n in ('rows', 'cols', 'ntap', 'cout_pad', 'cin', 'frag', 'dgrad', 'dtype', 'tile0', 'tiles_x', 'cit')]
 
 
 class WFinishItem(C.Structure):

@@ -482,23 +482,31 @@ class PackBatch(object):
         assert layers and len({l.dtype for l in layers}) == 1
         self.layers = list(layers)
         self.dtype = layers[0].dtype
-        items = (L.PackItem * len(layers))()
-        total, self.max_ntap = 0, 0
-        for i, l in enumerate(layers):
-            d = l.desc(1, 1, 8, 8)
-            n = L.lib().dat_conv3d_pack_item(ctx().h, C.byref(d), _ptr(l.w_src), l.cout_real, l.cin_real, int(l.is_dgrad),
-                                             _ptr(l.dgrad_scale) if l.is_dgrad else None, _ptr(l.packed), C.byref(items[i]))
-            if n <= 0:
-                ctx().check(n if n < 0 else -1)
-            items[i].tile0 = total
-            total += n
-            self.max_ntap = max(self.max_ntap, items[i].ntap)
-        self.total = total
-        raw = np.frombuffer(items, dtype=np.uint8).copy()
-        self.table = torch.from_numpy(raw).to(layers[0].packed.device)
+        # one launch per tap count: the kernel's LDS tile is sized by the largest entry of a launch, and a pointwise entry (most of a
+        # bottleneck network's parameters) beside a 27-tap one would run at the 27-tap tile's two blocks per CU
+        groups = {}
+        for l in layers:
+            groups.setdefault(l.kt * l.kh * l.kw, []).append(l)
+        self.launches = []       # (device table, entries, blocks, taps)
+        for ntap in sorted(groups):
+            grp = groups[ntap]
+            items = (L.PackItem * len(grp))()
+            total = 0
+            for i, l in enumerate(grp):
+                d = l.desc(1, 1, 8, 8)
+                n = L.lib().dat_conv3d_pack_item(ctx().h, C.byref(d), _ptr(l.w_src), l.cout_real, l.cin_real, int(l.is_dgrad),
+                                                 _ptr(l.dgrad_scale) if l.is_dgrad else None, _ptr(l.packed), C.byref(items[i]))
+                if n <= 0:
+                    ctx().check(n if n < 0 else -1)
+                assert items[i].ntap == ntap
+                items[i].tile0 = total
+                total += n
+            raw = np.frombuffer(items, dtype=np.uint8).copy()
+            self.launches.append((torch.from_numpy(raw).to(layers[0].packed.device), len(grp), total, ntap))
 
     def run(self):
-        ctx().call('dat_conv3d_pack_weights_batch', _stream(), _ptr(self.table), len(self.layers), self.total, self.max_ntap, self.dtype)
+        for table, n, total, ntap in self.launches:
+            ctx().call('dat_conv3d_pack_weights_batch', _stream(), _ptr(table), n, total, ntap, self.dtype)
         for l in self.layers:
             if l.bias_src is not None:
                 l.bias[:l.cout_real] = l.bias_src.float()

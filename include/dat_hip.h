@@ -132,6 +132,7 @@ typedef struct dat_pack_item {
     const float* scale;
     int rows, cols, ntap, cout_pad, cin, frag, dgrad, dtype;
     int tile0, tiles_x;
+    int cit;                 /* input channels per block tile (set by dat_conv3d_pack_item: 64 / 32 / 16 by tap count) */
 } dat_pack_item;
 int dat_conv3d_pack_item(dat_ctx* ctx, const dat_conv_desc* d, const float* w, int rows_real, int cols_real, int dgrad, const float* scale,
                          void* packed, dat_pack_item* item);

@@ -269,7 +269,8 @@ def test_batched_weight_repack_equals_per_layer_packing(ops, dtype):
     counts and channel paddings) leaves every packed buffer bit-identical to the per-layer dat_conv3d_pack_weights[_dgrad]."""
     g = torch.Generator().manual_seed(7)
     specs = [((128, 64, 3, 3, 3), False), ((256, 128, 1, 1, 1), False), ((64, 64, 1, 3, 3), False), ((12, 200, 1, 1, 1), False),
-             ((128, 64, 3, 3, 3), True), ((96, 256, 1, 3, 3), True)]
+             ((128, 64, 3, 3, 3), True), ((96, 256, 1, 3, 3), True), ((512, 256, 1, 1, 1), True), ((1024, 256, 1, 1, 1), False),
+             ((64, 256, 3, 1, 1), False), ((40, 72, 1, 1, 1), True)]
     layers, masters = [], []
     for shape, dgrad in specs:
         w = (torch.randn(shape, generator=g) * 0.1).cuda()

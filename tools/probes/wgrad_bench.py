@@ -185,7 +185,7 @@ elif len(_s.argv) > 1 and _s.argv[1] == 'pw':     # round 5: pointwise layers of
         print('%-34s worst max-abs difference to the first run / max-abs: %.3g' % (name, worst))
 elif len(_s.argv) > 1 and _s.argv[1] == 'ablate':
     LAYERS[:] = LAYERS[:5]
-    for ab in (0, 1, 2, 4, 3, 7):
+    for ab in (0, 1, 2, 4, 3, 5, 6, 7):
         fresh({'DAT_WGRAD_DIRECT': '1', 'DAT_WGRAD_ABLATE': str(ab)}, 'abl%d' % ab)
 else:
     fresh({'DAT_WGRAD_DIRECT': '0'}, 'repack')
