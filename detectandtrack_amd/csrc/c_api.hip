@@ -68,6 +68,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_wgrad_sub = env_int("DAT_WGRAD_SUB", 2);
         c->dbg_wgrad_ilv = env_int("DAT_WGRAD_ILV", 1);
         c->dbg_wgrad_xcd = env_int("DAT_WGRAD_XCD", 0);
+        c->dbg_pw_xcd = env_int("DAT_CONV_PW_XCD", 1);
         c->dbg_wgrad_pw = env_int("DAT_WGRAD_PW", 1);
         c->dbg_kps_sep = env_int("DAT_KPS_DECODE_SEP", 1);
         c->dbg_linear = env_int("DAT_CONV_LINEAR", 1);

@@ -509,12 +509,16 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
     char* const ybase = p.y + tile_pos * p.out_cs * OES;
     const char* const rbase = p.res_mode == 2 ? p.res + (size_t)f * (p.Ho >> 1) * (p.Wo >> 1) * p.out_cs * OES
                                               : p.res + tile_pos * p.out_cs * OES;
+    const char* const abase = p.res2 + tile_pos * p.out_cs * OES;      // (mode 4 only)
     float* const pbase = part_mode ? p.part + ((size_t)split * npos_all + tile_pos) * p.Cout : nullptr;
     // Residual rows (Sum shortcuts, the top-down map of the FPN laterals) are fetched one position group AHEAD of their use: a load
     // issued where its value is added costs a full memory round trip per store group -- with a top-down map the 64 -> 256 lateral
     // took 0.188 ms (cold caches) against 0.108 ms without one, for 66 MB of extra reads.
     constexpr int NQ = 32 / PPI;
-    const bool res_pre = p.res_mode && !part_mode && (p.out_cs & 7) == 0 && c_st + CPL <= p.Cout;   // whole 16-byte pieces
+    // (mode 4 -- sum with the output's present contents, masked -- takes the load-at-use path below: it reaches this kernel only for shapes the
+    //  1x1 kernels do not take, and a second prefetch ring would cost every variant of this kernel 32-64 registers)
+    const bool m4 = p.res_mode == 4;
+    const bool res_pre = p.res_mode && !m4 && !part_mode && (p.out_cs & 7) == 0 && c_st + CPL <= p.Cout;   // whole 16-byte pieces
     uint4 rq[2][NQ];
     auto res_fetch = [&](int j, uint4* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -577,6 +581,25 @@ __global__ __launch_bounds__(NTHREADS, (MinWaves<BP, NTAP>::value)) void conv3d_
                 } else {
                     v[0] = res_combine(v[0], __uint_as_float(r.x), p.res_mode); v[1] = res_combine(v[1], __uint_as_float(r.y), p.res_mode);
                     v[2] = res_combine(v[2], __uint_as_float(r.z), p.res_mode); v[3] = res_combine(v[3], __uint_as_float(r.w), p.res_mode);
+                }
+            } else if (m4) {
+                const unsigned off = (lpos * (unsigned)p.out_cs + (unsigned)c_st) * (unsigned)OES;
+                const char* rp = rbase + off;
+                const char* ap = abase + off;
+                if (ODT == DAT_BF16) {
+#pragma unroll
+                    for (int e4 = 0; e4 < CPL / 4; ++e4)
+                        if (e4 * 4 < nch) {
+                            const uint2 r = *(const uint2*)(rp + e4 * 8), o = *(const uint2*)(ap + e4 * 8);
+                            v[e4 * 4 + 0] = res_combine4(v[e4 * 4 + 0], bf2f((uint16_t)(o.x & 0xffff)), bf2f((uint16_t)(r.x & 0xffff)));
+                            v[e4 * 4 + 1] = res_combine4(v[e4 * 4 + 1], bf2f((uint16_t)(o.x >> 16)), bf2f((uint16_t)(r.x >> 16)));
+                            v[e4 * 4 + 2] = res_combine4(v[e4 * 4 + 2], bf2f((uint16_t)(o.y & 0xffff)), bf2f((uint16_t)(r.y & 0xffff)));
+                            v[e4 * 4 + 3] = res_combine4(v[e4 * 4 + 3], bf2f((uint16_t)(o.y >> 16)), bf2f((uint16_t)(r.y >> 16)));
+                        }
+                } else {
+                    const float4 r = *(const float4*)rp, o = *(const float4*)ap;
+                    v[0] = res_combine4(v[0], o.x, r.x); v[1] = res_combine4(v[1], o.y, r.y);
+                    v[2] = res_combine4(v[2], o.z, r.z); v[3] = res_combine4(v[3], o.w, r.w);
                 }
             } else if (p.res_mode) {
                 unsigned rpos = lpos;
@@ -648,7 +671,7 @@ template <int DT>
 __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit, size_t npos, int Cout, int out_cs,
                                      const float* __restrict__ scale, const float* __restrict__ bias,
                                      const char* __restrict__ res, int res_mode, int frames, int Ho, int Wo, int relu,
-                                     char* __restrict__ y, char* __restrict__ y_split = nullptr) {
+                                     char* y, char* __restrict__ y_split = nullptr, const char* res2 = nullptr) {
     const int c4 = Cout >> 2;
     const size_t total = npos * c4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -671,7 +694,19 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int ksplit,
                 const size_t f = q / Ho;
                 rpos = (f * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1);
             }
-            if (DT == DAT_BF16) {
+            if (res_mode == 4) {          // sum with the addend `res2` (may be y: each element is read and written by this thread), masked by `res`
+                if (DT == DAT_BF16) {
+                    const uint2 r = *(const uint2*)(res + (rpos * out_cs + c) * 2), o = *(const uint2*)(res2 + (opos * out_cs + c) * 2);
+                    v[0] = res_combine4(v[0], bf2f((uint16_t)(o.x & 0xffff)), bf2f((uint16_t)(r.x & 0xffff)));
+                    v[1] = res_combine4(v[1], bf2f((uint16_t)(o.x >> 16)), bf2f((uint16_t)(r.x >> 16)));
+                    v[2] = res_combine4(v[2], bf2f((uint16_t)(o.y & 0xffff)), bf2f((uint16_t)(r.y & 0xffff)));
+                    v[3] = res_combine4(v[3], bf2f((uint16_t)(o.y >> 16)), bf2f((uint16_t)(r.y >> 16)));
+                } else {
+                    const float4 r = *(const float4*)(res + (rpos * out_cs + c) * 4), o = *(const float4*)(res2 + (opos * out_cs + c) * 4);
+                    v[0] = res_combine4(v[0], o.x, r.x); v[1] = res_combine4(v[1], o.y, r.y);
+                    v[2] = res_combine4(v[2], o.z, r.z); v[3] = res_combine4(v[3], o.w, r.w);
+                }
+            } else if (DT == DAT_BF16) {
                 const uint2 r = *(const uint2*)(res + (rpos * out_cs + c) * 2);
                 v[0] = res_combine(v[0], bf2f((uint16_t)(r.x & 0xffff)), res_mode); v[1] = res_combine(v[1], bf2f((uint16_t)(r.x >> 16)), res_mode);
                 v[2] = res_combine(v[2], bf2f((uint16_t)(r.y & 0xffff)), res_mode); v[3] = res_combine(v[3], bf2f((uint16_t)(r.y >> 16)), res_mode);
@@ -896,7 +931,7 @@ int launch_conv(dat_ctx* ctx, hipStream_t st, ConvParams& p, int bp_log2, int ks
         const size_t tot = npos * (p.Cout >> 2);
         const int blocks = (int)std::min<size_t>((tot + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(splitk_finish_kernel<ODT>, dim3(blocks), dim3(256), 0, st, (const float*)p.part, p.ksplit, npos, p.Cout,
-                           p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y, ODT == DAT_F32 && DT == DAT_BF16 ? p.y_split : nullptr);
+                           p.out_cs, p.scale, p.bias, p.res, p.res_mode, p.frames, p.Ho, p.Wo, p.relu, p.y, ODT == DAT_F32 && DT == DAT_BF16 ? p.y_split : nullptr, p.res2);
     }
     DAT_CHECK_LAUNCH(ctx, "conv3d_igemm");
     return DAT_OK;
@@ -927,7 +962,7 @@ double dat_conv3d_flops(const dat_conv_desc* d, int Cin_real, int Cout_real) {
 }
 
 static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
-                           const float* scale, const float* bias, const void* residual, void* y, void* y_split);
+                           const float* scale, const float* bias, const void* residual, void* y, void* y_split, const void* addend = nullptr);
 
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
                    const float* scale, const float* bias, const void* residual, void* y) {
@@ -942,8 +977,15 @@ int dat_conv3d_fwd_x3(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const 
     return conv3d_fwd_impl(ctx, s, d, x_split, w_packed, scale, bias, residual, y, y_split);
 }
 
+int dat_conv3d_fwd_sum_mask(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                            const float* scale, const float* bias, const void* addend, const void* mask, void* y) {
+    DAT_ENFORCE(ctx, d && d->res_mode == 4, "conv3d_fwd_sum_mask: the descriptor's res_mode must be 4");
+    DAT_ENFORCE(ctx, addend && mask, "conv3d_fwd_sum_mask: null addend / mask");
+    return conv3d_fwd_impl(ctx, s, d, x, w_packed, scale, bias, mask, y, nullptr, addend);
+}
+
 static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
-                           const float* scale, const float* bias, const void* residual, void* y, void* y_split) {
+                           const float* scale, const float* bias, const void* residual, void* y, void* y_split, const void* addend) {
     DAT_ENFORCE(ctx, d && x && w_packed && y, "conv3d_fwd: null argument");
     DAT_ENFORCE(ctx, d->dtype == DAT_F32 || d->dtype == DAT_BF16 || d->dtype == DAT_BF16X3, "conv3d_fwd: bad dtype %d", d->dtype);
     const bool x3 = d->dtype == DAT_BF16X3;
@@ -953,7 +995,8 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     DAT_ENFORCE(ctx, d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_cstride >= d->Cout,
                 "conv3d_fwd: Cout %d / out_cstride %d must be multiples of 4", d->Cout, d->out_cstride);
     DAT_ENFORCE(ctx, d->frames % d->T == 0, "conv3d_fwd: frames %d not a multiple of T %d", d->frames, d->T);
-    DAT_ENFORCE(ctx, d->res_mode >= 0 && d->res_mode <= 3, "conv3d_fwd: res_mode %d", d->res_mode);
+    DAT_ENFORCE(ctx, d->res_mode >= 0 && d->res_mode <= 4, "conv3d_fwd: res_mode %d", d->res_mode);
+    DAT_ENFORCE(ctx, d->res_mode != 4 || (!x3 && !y_split && addend), "conv3d_fwd: res_mode 4 (sum + mask) goes through dat_conv3d_fwd_sum_mask, bf16 / fp32 only");
     DAT_ENFORCE(ctx, d->res_mode == 0 || residual, "conv3d_fwd: res_mode %d needs a residual pointer", d->res_mode);
     // full-length outputs need "same" temporal padding; an explicit output-frame window may use any pad_t (taps that
     // fall outside [0, T) read zeros) -- e.g. KT == T, pad_t == 0, window {0}: a 1x1 conv over time-moved-to-channels
@@ -963,7 +1006,7 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const char*)x; p.w = (const char*)w_packed; p.scale = scale; p.bias = bias;
-    p.res = (const char*)residual; p.y = (char*)y; p.y_split = (char*)y_split;
+    p.res = (const char*)residual; p.res2 = (const char*)addend; p.y = (char*)y; p.y_split = (char*)y_split;
     p.zeros = (const char*)ctx->zeros;
     p.clk = ctx->prof_enabled ? (unsigned long long*)((char*)ctx->zeros + 256) : nullptr;
     p.in_lo = d->in_tn > 0 ? d->in_t0 : 0;
@@ -1052,7 +1095,7 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     if (bt_eligible(ctx, d)) bt_tile_twl(p, &bt_blocks);
     const long long ncu = ctx_num_cu(ctx), bt_rounds = cdiv_ll(bt_blocks, ncu);
     const bool bt_fits = ctx->dbg_bt >= 2 ? bt_blocks * 2 >= 3 * ncu : (bt_blocks >= 4 * ncu && bt_blocks * 100 >= bt_rounds * ncu * 95);
-    const bool mask_mode = d->res_mode == 3;     // only the generic kernel's epilogue knows the masking combine
+    const bool mask_mode = d->res_mode >= 3;     // the masking combines (3: mask, 4: in-place sum + mask) live in the generic kernel and the lw / ks 1x1 kernels
     if (bt_fits && ksplit == 1 && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 2560 + d->dtype;
         rc = launch_bt(ctx, st, p);
@@ -1062,7 +1105,8 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     } else if (pwks_eligible(ctx, d) && !force_bp && !force_ks && !x3) {       // (its epilogue knows the masking combine too)
         tag = 256 * 10000 + 340 + d->dtype;     // (the K-streaming 1x1 kernel: 256 positions x 256 channels per block)
         rc = launch_pwks(ctx, st, p);
-    } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {
+    } else if (pwlw_eligible(ctx, d) && !force_bp && !force_ks && d->res_mode != 3) {   // (knows the sum + mask combine; plain mask layers -- K >= 512 data
+                                                                                        //  gradients of `branch2c` on small maps -- measured faster on the generic kernel)
         tag = 256 * 10000 + 330 + d->dtype;     // (the weights-in-LDS 1x1 kernel: 32 positions per wave tile)
         rc = launch_pwlw(ctx, st, p, d);
     } else if (ws64_eligible(ctx, d) && !force_bp && !force_ks && !mask_mode) {

@@ -30,6 +30,7 @@ struct ConvParams {
     const float* scale;
     const float* bias;
     const char* res;
+    const char* res2;          // res_mode 4: the addend (the other gradient contribution; may be y itself: every element is read and written by one thread)
     char* y;
     char* y_split;              // bf16x3 mode only (ODT fp32): also write the hi / lo bf16 split of y (pixel pitch 2 * out_cs bf16, dat_split_bf16x2's layout) -- the
                                 // next conv then needs no split pre-pass; NULL = off
@@ -93,6 +94,10 @@ template <> struct Mma<DAT_F32> {
 // ReLU backward of the conv's INPUT blob fused into the data-gradient conv (round 3: `res` is the forward input x = relu(...) of the
 // conv whose data gradient the launch computes; training.py bwd_Conv)
 __device__ __forceinline__ float res_combine(float v, float r, int mode) { return mode == 3 ? (r > 0.f ? v : 0.f) : v + r; }
+// mode 4 (round 6): SUM + MASK -- out = m > 0 ? v + old : 0, where `old` is the addend operand (the other contribution to the gradient of a
+// residual block's output; it may be the output tensor itself) and `m` the residual operand (that block output y = relu(...)): the data-gradient
+// conv of the LAST reader of y finishes the sum and applies y's ReLU backward in one epilogue (dat_conv3d_fwd_sum_mask; training.py bwd_Conv)
+__device__ __forceinline__ float res_combine4(float v, float old, float m) { return m > 0.f ? v + old : 0.f; }
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row * ROWB) + (((slot ^ (row >> 1)) & 7) << 4); }
 

@@ -385,6 +385,7 @@ struct PwLwParams {
     const float* scale;
     const float* bias;
     const char* res;
+    const char* res2;           // res_mode 4: the addend
     char* y;
     unsigned npos;              // output positions: frames * Ho * Wo
     int Ho, Wo, H, W, stride;
@@ -393,9 +394,12 @@ struct PwLwParams {
     int ntiles;                 // wave tiles of 32 positions
     unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo)
     int nsplit, mb_total;       // cout parts; Cout_pad / 32
+    int xcd;                    // XCD-aware block -> (part, stream) map (the launcher sets it when the grid is a multiple of 8 * nsplit)
 };
 
-template <int KC, int MBW, int NPASS>
+// M4 = 1: the instantiation for res_mode 4 only (in-place sum + mask: two operand rows per store group) -- separate, so that the other modes
+// keep their register allocation (the two-pass variants sit at 256 + 196 registers already)
+template <int KC, int MBW, int NPASS, int M4 = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv1x1_lw_kernel(const PwLwParams p) {
     constexpr int EPITCH = 32 * 4 + 16;                 // fp32 transpose row of one position: 32 channels + pad
     constexpr int MBP = MBW * NPASS;                    // 32-row blocks of a block's cout part
@@ -404,7 +408,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, n = lane & 31;
-    const int part = blockIdx.x % p.nsplit;
+    // block -> (cout part, tile stream).  The parts of a layer read the SAME input tiles; blocks go to the XCDs round-robin (block b -> XCD
+    // b % 8), so with part = b % nsplit the readers of a tile sat on different XCDs and every part fetched the tile through its own L2 (res4
+    // `branch2c`, four parts: 264 MB of input reads for 66 MB of input).  XCD-aware (p.xcd, grid a multiple of 8 x nsplit): the k-th block of an
+    // XCD serves part k % nsplit of stream (k / nsplit) * 8 + xcd -- all parts of a stream on one L2, launched back to back.
+    int part = blockIdx.x % p.nsplit, stream = blockIdx.x / p.nsplit;
+    if (p.xcd) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        part = k % p.nsplit;
+        stream = (k / p.nsplit) * 8 + xcd;
+    }
     char* const wl = smem;                              // [kc][MBP][ks][lane][16 B]
     float* const sbl = (float*)(smem + WBYTES);         // scale[MBP * 32], bias[MBP * 32] of the part's channels
     char* const est = smem + WBYTES + MBP * 32 * 8 + wave * (32 * EPITCH);
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
     // store phase: lane = 8 channels (sq) of one of 16 positions per round
     const int sq = lane & 3, spl = lane >> 2;
     const int nwaves = (gridDim.x / p.nsplit) * 4;
-    int tile = (blockIdx.x / p.nsplit) * 4 + wave;
+    int tile = stream * 4 + wave;
     uint4 bcur[KC * 4], bnext[KC * 4];
 #define LW_LOAD(DST_, TILE_)                                                                                          \
     {                                                                                                                 \
@@ -449,7 +462,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         bool live[2];
         // ALL residual rows of the tile are requested now, before its MFMAs: one wave per SIMD has nothing else to hide their latency
         // behind, and a load issued between the stores would make its wait a wait for those stores
+        // mode 4 (SUM with the addend rows + MASK by the residual operand: two rows per store group) is fetched PER
+        // PASS, at its start: the addend into rr[0], the mask into rr[1] (two-pass variants: no register left for four prefetched sets) or rm
         uint4 rr[NPASS][MBW][2];
+        uint4 rm[NPASS == 1 ? MBW : 1][2];
+        constexpr bool m4 = M4 != 0;                // (the launcher picks the instantiation by p.res_mode)
+        const char* rb[2];
+        const char* ab[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const unsigned pos = pos0 + (unsigned)(r * 16 + spl);
@@ -462,18 +481,32 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                     const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
                     rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
                 }
-                const char* rb = p.res + ((size_t)rpos * (unsigned)p.out_cs) * 2u;
+                rb[r] = p.res + ((size_t)rpos * (unsigned)p.out_cs) * 2u;
+                ab[r] = p.res2 + ((size_t)pc * (unsigned)p.out_cs) * 2u;
+                if (!m4) {
 #pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass)
+                    for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
-                    for (int mb = 0; mb < MBW; ++mb) {
-                        const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
-                        rr[pass][mb][r] = *(const uint4*)(rb + c * 2u);
-                    }
+                        for (int mb = 0; mb < MBW; ++mb) {
+                            const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
+                            rr[pass][mb][r] = *(const uint4*)(rb[r] + c * 2u);
+                        }
+                }
             }
         }
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
+            if (m4) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
+                        rr[0][mb][r] = *(const uint4*)(ab[r] + c * 2u);
+                        if (NPASS == 1) rm[NPASS == 1 ? mb : 0][r] = *(const uint4*)(rb[r] + c * 2u);
+                        else rr[NPASS - 1][mb][r] = *(const uint4*)(rb[r] + c * 2u);
+                    }
+            }
             f32x16_t acc[MBW];
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb)
@@ -511,13 +544,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                     float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-                    if (p.res_mode) {
+                    if (m4) {
+                        const uint4 qa = rr[0][mb][r], qm = NPASS == 1 ? rm[NPASS == 1 ? mb : 0][r] : rr[NPASS - 1][mb][r];
+                        const uint32_t au[4] = {qa.x, qa.y, qa.z, qa.w}, mu[4] = {qm.x, qm.y, qm.z, qm.w};
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            v[2 * e2] = res_combine4(v[2 * e2], bf2f((uint16_t)(au[e2] & 0xffff)), bf2f((uint16_t)(mu[e2] & 0xffff)));
+                            v[2 * e2 + 1] = res_combine4(v[2 * e2 + 1], bf2f((uint16_t)(au[e2] >> 16)), bf2f((uint16_t)(mu[e2] >> 16)));
+                        }
+                    } else if (p.res_mode) {            // modes 1 / 2: Sum; mode 3: MASK (res_combine)
                         const uint4 q = rr[pass][mb][r];
                         const uint32_t ru[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int e2 = 0; e2 < 4; ++e2) {
-                            v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
-                            v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
+                            v[2 * e2] = res_combine(v[2 * e2], bf2f((uint16_t)(ru[e2] & 0xffff)), p.res_mode);
+                            v[2 * e2 + 1] = res_combine(v[2 * e2 + 1], bf2f((uint16_t)(ru[e2] >> 16)), p.res_mode);
                         }
                     }
                     if (p.relu) {
@@ -555,6 +596,7 @@ struct PwKsParams {
     const float* scale;
     const float* bias;
     const char* res;
+    const char* res2;           // res_mode 4: the addend
     char* y;
     unsigned npos;              // output positions: frames * Ho * Wo
     int Ho, Wo, H, W, stride;
@@ -564,6 +606,7 @@ struct PwKsParams {
     int kchunks, mb_total;      // Cin / 64; Cout_pad / 32
     unsigned how, wo_magic;     // Ho * Wo; ceil(2^32 / Wo)
     int ablate;                 // DEBUG (DAT_CONV_ABLATE): 1 no input-row copies after the first chunks, 2 no weight copies, 4 no MFMAs
+    int xcd;                    // XCD-aware block order (more than one cout block)
 };
 
 constexpr int KS_THREADS = 512;
@@ -577,8 +620,16 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, n = lane & 31;
-    const int cb = blockIdx.x % p.ncb;
-    const unsigned pos0 = (blockIdx.x / p.ncb) * 256u;
+    // block -> (position tile, cout block): the cout blocks of a tile read the same input rows, so they must share an L2 -- consecutive LOGICAL
+    // ids on one XCD (the bijection of conv3d_igemm_kernel; hardware block b runs on XCD b % 8), not consecutive hardware ids
+    unsigned bid = blockIdx.x;
+    if (p.xcd) {
+        const unsigned nx = 8, q = gridDim.x / nx, r = gridDim.x % nx;
+        const unsigned xcd = bid % nx, k = bid / nx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int cb = bid % p.ncb;
+    const unsigned pos0 = (bid / p.ncb) * 256u;
     const int wq = wave & 3, ph = wave >> 2;            // cout quarter (row blocks 2 wq, 2 wq + 1) / position half (tiles 4 ph .. 4 ph + 3)
     // ---- chunk copies by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass; one wave instruction lands 64 x 16 B =
     // 8 input rows, lane-linear, so the XOR swizzle of the fragment reads is applied on the SOURCE side: lane (row, physical slot) fetches the
@@ -682,7 +733,7 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned tile0 = pos0 + (unsigned)(ph * 128 + j * 32);
-        uint4 rr[4];
+        uint4 rr[4], ra[4];
         if (p.res_mode) {                               // residual rows of the tile requested before the transpose
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -694,6 +745,8 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
                     rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
                 }
                 rr[r] = *(const uint4*)(p.res + ((size_t)rpos * (unsigned)p.out_cs + cres) * 2u);
+                // mode 4: the addend (the other gradient contribution; when it is y itself, the row is read here and overwritten below by this same lane)
+                if (p.res_mode == 4) ra[r] = *(const uint4*)(p.res2 + ((size_t)pc * (unsigned)p.out_cs + cres) * 2u);
             }
         }
 #pragma unroll
@@ -711,7 +764,14 @@ __global__ __launch_bounds__(KS_THREADS) void conv1x1_ks_kernel(const PwKsParams
             float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-            if (p.res_mode) {                           // modes 1 / 2: Sum; mode 3: MASK by the forward input of the conv whose data gradient this is
+            if (p.res_mode == 4) {                      // mode 4: SUM with the output's present contents, MASKED by the residual operand
+                const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w}, au[4] = {ra[r].x, ra[r].y, ra[r].z, ra[r].w};
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    v[2 * e2] = res_combine4(v[2 * e2], bf2f((uint16_t)(au[e2] & 0xffff)), bf2f((uint16_t)(ru[e2] & 0xffff)));
+                    v[2 * e2 + 1] = res_combine4(v[2 * e2 + 1], bf2f((uint16_t)(au[e2] >> 16)), bf2f((uint16_t)(ru[e2] >> 16)));
+                }
+            } else if (p.res_mode) {                    // modes 1 / 2: Sum; mode 3: MASK by the forward input of the conv whose data gradient this is
                 const uint32_t ru[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
@@ -1124,6 +1184,11 @@ bool pwlw_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
 
 template <int KC, int MBW, int NPASS>
 static int launch_pwlw_t(dat_ctx* ctx, hipStream_t st, const PwLwParams& p, unsigned grid, size_t lds) {
+    if (p.res_mode == 4) {
+        if (dat_ensure_lds(ctx, (const void*)conv1x1_lw_kernel<KC, MBW, NPASS, 1>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv1x1_lw_kernel<KC, MBW, NPASS, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);
+        return DAT_OK;
+    }
     if (dat_ensure_lds(ctx, (const void*)conv1x1_lw_kernel<KC, MBW, NPASS>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
     hipLaunchKernelGGL((conv1x1_lw_kernel<KC, MBW, NPASS>), dim3(grid), dim3(NTHREADS), lds, st, p);
     return DAT_OK;
@@ -1132,7 +1197,7 @@ static int launch_pwlw_t(dat_ctx* ctx, hipStream_t st, const PwLwParams& p, unsi
 int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_conv_desc* d) {
     ctx_num_cu(ctx);
     PwLwParams p;
-    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y; p.res2 = cp.res2;
     p.npos = (unsigned)((long long)cp.frames * cp.Ho * cp.Wo);
     p.Ho = cp.Ho; p.Wo = cp.Wo; p.H = cp.H; p.W = cp.W; p.stride = cp.sh;
     p.in_cs = cp.Cin; p.out_cs = cp.out_cs; p.cout = cp.Cout; p.relu = cp.relu; p.res_mode = cp.res_mode;
@@ -1144,6 +1209,7 @@ int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_co
     const int mbw = kc <= 4 ? std::min(mbp, 8) : std::min(mbp, 4), npass = mbp / mbw;
     const long long per_part = std::min<long long>(cdiv_ll(p.ntiles, 4), ctx->num_cu / p.nsplit);
     const unsigned grid = (unsigned)(per_part * p.nsplit);
+    p.xcd = ctx->dbg_pw_xcd && p.nsplit > 1 && grid % (8u * (unsigned)p.nsplit) == 0;
     const size_t lds = (size_t)kc * mbp * 4096 + (size_t)mbp * 32 * 8 + 4 * 32 * (32 * 4 + 16);
     DAT_ENFORCE(ctx, lds <= 160 * 1024, "conv1x1_lw: %zu bytes of LDS", lds);
     int rc = DAT_ERR_UNSUPPORTED;
@@ -1179,7 +1245,7 @@ bool pwks_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
 int launch_pwks(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     ctx_num_cu(ctx);
     PwKsParams p;
-    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y;
+    p.x = cp.x; p.w = cp.w; p.scale = cp.scale; p.bias = cp.bias; p.res = cp.res; p.y = cp.y; p.res2 = cp.res2;
     p.npos = (unsigned)((long long)cp.frames * cp.Ho * cp.Wo);
     p.Ho = cp.Ho; p.Wo = cp.Wo; p.H = cp.H; p.W = cp.W; p.stride = cp.sh;
     p.in_cs = cp.Cin; p.out_cs = cp.out_cs; p.cout = cp.Cout; p.relu = cp.relu; p.res_mode = cp.res_mode;
@@ -1187,6 +1253,7 @@ int launch_pwks(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     p.how = (unsigned)(cp.Ho * cp.Wo);
     p.wo_magic = cp.Wo == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.Wo - 1) / (unsigned)cp.Wo);
     p.ablate = ctx->dbg_ablate;
+    p.xcd = ctx->dbg_pw_xcd && p.ncb > 1;
     const long long blocks = cdiv_ll(p.npos, 256) * p.ncb;
     DAT_ENFORCE(ctx, blocks > 0 && blocks < (1ll << 31), "conv1x1_ks: grid of %lld blocks unsupported", blocks);
     const size_t lds = (size_t)3 * KS_XBYTES + 2 * KS_WBYTES;     // 160 KB: three input buffers, two weight buffers (the epilogue reuses them)

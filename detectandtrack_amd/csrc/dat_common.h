@@ -45,6 +45,7 @@ struct dat_ctx {
     int dbg_wgrad_sub;                      // DAT_WGRAD_SUB (default 2): 2 = eight-wave blocks of the nine-tap weight-gradient kernel (two K ranges per block, added through LDS)
     int dbg_wgrad_ilv;                      // DAT_WGRAD_ILV (default 1): 1 = LDS-DMA pieces of the next-but-one chunk issued between the MFMA groups of the current one
     int dbg_wgrad_xcd;                      // DAT_WGRAD_XCD (default 0): XCD-aware block order of wgrad_dma9_kernel (consecutive logical blocks on one XCD) -- measured neutral (round 6: R-50 iteration 20.22 vs 20.39 ms, R-18 14.60 vs 14.56)
+    int dbg_pw_xcd;                         // DAT_CONV_PW_XCD (default 1): the cout parts / cout blocks of the 1x1 kernels (conv1x1_lw / conv1x1_ks) that read one input tile share an XCD
     int dbg_wgrad_dma;                      // DAT_WGRAD_DMA (default 1): nine-tap weight gradient with LDS-DMA operand staging (three stages) instead of register staging
     int dbg_wgrad_ks;                       // DAT_WGRAD_KS (default 0 = heuristic): forced K split of the nine-tap direct weight-gradient kernel
     int dbg_wgrad_pw;                       // DAT_WGRAD_PW (default 1): eight-wave 64 K-accumulator kernel for pointwise weight gradients (0: the 128 x 128 per-tap kernel; 10 / 20 / 40: forced tile shape)

@@ -276,7 +276,7 @@ class ConvLayer(object):
         return float(b)
 
     def __call__(self, x, T=1, residual=None, res_mode=None, out=None, out_t=None, in_t=None, x_split=None, zero_pad=True,
-                 want_split=False):
+                 want_split=False, addend=None):
         """out_t = (t0, n): only output frames t0..t0+n-1 of every clip are computed and stored.
         x_split (bf16x3 layers): the hi / lo split of `x` when the caller already has it (a blob read by several convs is split once)."""
         frames, H, W, cin = x.shape
@@ -293,6 +293,13 @@ class ConvLayer(object):
             # (RPN head -> proposal kernels, cls_score / bbox_pred -> softmax / box decode, the deconv -> kps_finalize) -- no fill launch
             alloc = torch.zeros if (self.cstride != self.cout and zero_pad) else torch.empty
             out = alloc((oframes, ho, wo, self.cstride), dtype=x.dtype, device=x.device)
+        if res_mode == 4:       # out = residual > 0 ? conv + addend : 0 (training: dat_conv3d_fwd_sum_mask; `addend` may be `out`)
+            assert not self.x3 and addend is not None and residual is not None
+            assert addend.shape == out.shape == residual.shape and addend.dtype == out.dtype == residual.dtype
+            assert addend.is_contiguous() and residual.is_contiguous() and out.is_contiguous()
+            ctx().call('dat_conv3d_fwd_sum_mask', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
+                       _ptr(self.bias), _ptr(addend), _ptr(residual), _ptr(out))
+            return out
         if not self.x3:
             ctx().call('dat_conv3d_fwd', _stream(), C.byref(d), _ptr(x), _ptr(self.packed), _ptr(self.scale),
                        _ptr(self.bias), _ptr(residual), _ptr(out))
@@ -402,7 +409,8 @@ class ConvGrad(object):
     def data(self, g, T, H, W, accumulate_into=None, g_frames=None, mask=None, inplace=True):
         """g [frames,Ho,Wo,g_cstride] -> dL/dx [frames,H,W,round64(Cin)] (added to `accumulate_into` when given).  mask: the conv's
         forward input x = relu(...) in the shape of dL/dx -- the ReLU backward of x's producer is applied in this conv's epilogue
-        (dL/dx := x > 0 ? dL/dx : 0, res_mode 3), which saves that producer's elementwise mask pass."""
+        (dL/dx := x > 0 ? dL/dx : 0, res_mode 3), which saves that producer's elementwise mask pass.  mask AND accumulate_into: the sum
+        with the other contribution and the mask in one epilogue (res_mode 4)."""
         if self._data_layer is None:
             # flipped / transposed / scale-folded weights are packed straight from the forward master (no ATen flip, mul, copy)
             pads = (self.kt - 1 - self.pads[0], self.kh - 1 - self.pads[1], self.kw - 1 - self.pads[2])
@@ -420,8 +428,13 @@ class ConvGrad(object):
             gz = g
         lay = self._data_layer
         in_t = g_frames if (g_frames is not None and frames == T) else None   # zero frames of g: their temporal taps are skipped
+        if accumulate_into is not None and mask is not None:
+            # the LAST contribution to the gradient of x = relu(...): sum into `accumulate_into` and apply the ReLU backward of x's producer in the
+            # same epilogue (res_mode 4: out = x > 0 ? conv + out : 0, in place)
+            # (inplace=False: into a new tensor -- a queued weight-gradient job still reads `accumulate_into`)
+            assert mask.is_contiguous() and mask.dtype == gz.dtype and mask.shape == accumulate_into.shape
+            return lay(gz, T=T, residual=mask, res_mode=4, addend=accumulate_into, out=accumulate_into if inplace else None, in_t=in_t)
         if accumulate_into is not None:
-            assert mask is None
             # inplace=False: the sum goes to a NEW tensor (`accumulate_into` is read as the residual and left untouched -- somebody else,
             # a queued weight-gradient job, still needs its present contents)
             return lay(gz, T=T, residual=accumulate_into, res_mode=1, out=accumulate_into if inplace else None, in_t=in_t)

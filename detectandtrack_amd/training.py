@@ -51,11 +51,12 @@ class TrainExecutor(Executor):
         self.accumulate_all = False   # the arena already holds gradients of an earlier clip (Trainer.step(zero_grad=False)): add, never overwrite
         self._iter_cache = {}           # per backward pass: objects several ops build from the same weights (see backward)
         self._last_masked = False       # set by _take_grad: the gradient just taken already carries its producer's ReLU mask
+        self._ncontrib = {}             # blob name -> gradient contributions received so far (entries of self.grads may be sums of several)
         self._trainable_set = None
         self._readers = {}
         for o in net.ops:
             res = o.args.get('residual') if isinstance(o.args, dict) else None
-            for b in list(o.inputs) + ([res] if res else []):
+            for b in set(list(o.inputs) + ([res] if res else [])):      # (a fused Sum lists its residual among the inputs AND in its args: one reader)
                 self._readers[b] = self._readers.get(b, 0) + 1
         self.losses = {}         # loss blob name -> fp32 CUDA scalar tensor
         self.metrics = {}
@@ -209,11 +210,13 @@ class TrainExecutor(Executor):
         """masked: the ReLU backward of `name`'s producer is already applied to `t` (fused into the data-gradient conv that made it).
         The flag travels WITH the entry (tensor, first frame, masked) -- not in a side table keyed by id(tensor)."""
         self.grads.setdefault(name, []).append((t, lo, bool(masked)))
+        self._ncontrib[name] = self._ncontrib.get(name, 0) + 1
 
     def _take_grad(self, name, dtype):
         """-> (dy, lo) with dy in the activation dtype covering frames [lo, lo + dy.shape[0]), or (None, 0).  `self._last_masked`
         says whether the returned gradient already carries the ReLU mask of `name`'s producer (a single, masked contribution)."""
         lst = self.grads.pop(name, None)
+        self._ncontrib.pop(name, None)
         self._last_masked = False
         if not lst:
             return None, 0
@@ -300,6 +303,7 @@ class TrainExecutor(Executor):
                 on_op_done(i)
         self._finish_deferred()
         self.grads.clear()
+        self._ncontrib.clear()
 
     def _flush_pw(self):
         """Run the queued pointwise weight gradients (one grouped launch per tile class) and drop the references that kept their operands alive."""
@@ -432,11 +436,22 @@ class TrainExecutor(Executor):
             # (byte-range overlap with BOTH operands of every queued job -- an offset view or the x operand would have slipped past
             #  an equality test of the g operand's start pointer)
             held = into is not None and any(_bytes_overlap(into, j[1]) or _bytes_overlap(into, j[2]) for _, j in self._pw_pending)
+            # ... and when this conv is the LAST of the blob's readers to contribute (a residual block's output: read by the next block's
+            # first conv and by its shortcut), the same epilogue applies the ReLU backward of the blob's producer to the finished sum
+            # (dat_conv3d_fwd_sum_mask, round 6): that producer's elementwise mask pass (three passes over the block output) goes
+            if (into is not None and cfg.HIP.get('FUSE_RELU_BWD', True) and cfg.HIP.get('FUSE_RELU_SUM_BWD', True) and _SUM_FUSE_ENV and prod is not None and
+                    prod.type == 'Conv' and isinstance(prod.args, dict) and prod.args.get('relu') and
+                    self._readers.get(op.inputs[0], 0) == 2 and self._ncontrib.get(op.inputs[0], 0) == 1 and
+                    xin.keyframe is None and not xin.t2c and x_win.is_contiguous() and tuple(x_win.shape) == tuple(into.shape) and
+                    x_win.dtype == into.dtype):
+                mask = x_win
             dx = cg.data(g_emb, Tw, H, W, accumulate_into=into, g_frames=(lo - ilo, n) if xin.N == 1 else None, mask=mask, inplace=not held)
             if into is None:
                 self._add_grad(op.inputs[0], dx, ilo, masked=mask is not None)
-            elif held:
-                self.grads[op.inputs[0]] = [(dx, ilo, False)]
+            else:
+                self._ncontrib[op.inputs[0]] = self._ncontrib.get(op.inputs[0], 0) + 1
+                if held or mask is not None:
+                    self.grads[op.inputs[0]] = [(dx, ilo, mask is not None)]
 
     def _bwd_rpn_head(self, i):
         ws = self.ws
@@ -730,6 +745,9 @@ class TrainExecutor(Executor):
     # ---- update ---------------------------------------------------------------------------------------------------------------
     def loss_values(self):
         return {k: float(v.item()) for k, v in self.losses.items()}
+
+
+_SUM_FUSE_ENV = os.environ.get('DAT_FUSE_RELU_SUM_BWD', '1') != '0'       # experiment switch for same-box A/B runs (cfg.HIP.FUSE_RELU_SUM_BWD is the setting)
 
 
 def _bytes_overlap(a, b):

@@ -100,7 +100,8 @@ typedef struct {
     int pad_t, pad_h, pad_w; /* symmetric explicit pads, Caffe2 `pads=2*[..]` */
     int relu;                /* fused Relu */
     int res_mode;            /* 0 none | 1 residual same shape | 2 residual at (h/2, w/2) (nearest 2x) | 3 MASK: y = residual > 0 ? v : 0
-                                (ReLU backward fused into a data-gradient conv: residual = the forward input of the conv, same shape as y) */
+                                (ReLU backward fused into a data-gradient conv: residual = the forward input of the conv, same shape as y)
+                                | 4 SUM + MASK: y = mask > 0 ? v + addend : 0 (dat_conv3d_fwd_sum_mask only) */
     int out_t0, out_tn;      /* out_tn > 0: write only output frames t in [out_t0, out_t0+out_tn) of every clip, stored
                                 compactly as [N*out_tn, Ho, Wo, C] (the frames a following SliceKeyFrame keeps,
                                 FPN3D.py:170-183 'slice-center'); out_tn == 0: all T frames.  residual (if any) is
@@ -142,6 +143,12 @@ int dat_conv3d_pack_weights_batch(dat_ctx* ctx, dat_stream s, const dat_pack_ite
  * scale/bias: fp32 [Cout].  residual: same dtype/stride as y. */
 int dat_conv3d_fwd(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
                    const float* scale, const float* bias, const void* residual, void* y);
+/* res_mode 4 (training; replaces the Sum of the two gradient contributions of a residual block's output + the ReLU gradient of that
+ * output, i.e. what Caffe2's AddGradientOperators emits for lib/modeling/ResNet3D.py:21-87 -- a SumOp and a ReluGradient -- around the
+ * ConvGradient of the block's first conv):  y = mask > 0 ? act-free(conv(x, w)*scale + bias) + addend : 0.
+ * addend, mask: same dtype / shape / channel stride as y; addend may BE y (in place).  bf16 / fp32. */
+int dat_conv3d_fwd_sum_mask(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, const void* x, const void* w_packed,
+                            const float* scale, const float* bias, const void* addend, const void* mask, void* y);
 /* bf16x3 mode (d->dtype == DAT_BF16X3) with the operand split fused into the producer: the same launch also writes the
  * hi / lo bf16 split of y (dat_split_bf16x2's layout, pixel pitch 2 * out_cstride) into y_split, bit-identical to
  * dat_split_bf16x2(y) -- the next conv reads it without a split pre-pass.  y_split may be NULL (then == dat_conv3d_fwd);

@@ -1350,6 +1350,61 @@ def test_relu_mask_in_the_data_gradient_epilogue_is_bit_identical_to_the_separat
     assert (fused != 0).any() and ((x == 0) & (plain != 0)).any()            # the mask really removed something
 
 
+SUM_MASK_SHAPES = [
+    # forward conv (cin, cout, kernel, stride), gradient map T, H, W, dtypes -- and the kernel its data gradient takes
+    ((64, 128, (3, 3, 3), (1, 1)), (4, 14, 18), ('bf16', 'fp32')),        # generic implicit GEMM (split-K on this small map)
+    ((128, 64, (1, 3, 3), (2, 2)), (4, 14, 18), ('bf16', 'fp32')),        # strided: zero-insertion + generic kernel
+    ((200, 256, (1, 1, 1), (1, 1)), (4, 14, 18), ('bf16', 'fp32')),       # pointwise on a small map, padded channels [200, 256)
+    ((512, 128, (1, 1, 1), (1, 1)), (4, 128, 160), ('bf16',)),            # res3 `branch2a`: 128 -> 512, weights-in-LDS kernel, two passes
+    ((1024, 256, (1, 1, 1), (1, 1)), (2, 128, 160), ('bf16',)),           # res4 `branch2a`: 256 -> 1024, weights-in-LDS kernel, four cout parts
+    ((2048, 512, (1, 1, 1), (1, 1)), (2, 96, 160), ('bf16',)),            # res5 `branch2a`: 512 -> 2048, K-streaming kernel
+]
+
+
+@pytest.mark.parametrize('inplace', [True, False])
+@pytest.mark.parametrize('case', [(s_, m_, d_) for s_, m_, ds in SUM_MASK_SHAPES for d_ in ds],
+                         ids=lambda c: '%dto%d_k%d%d%d_s%d_%s' % (c[0][0], c[0][1], c[0][2][0], c[0][2][1], c[0][2][2], c[0][3][0], c[2]))
+def test_sum_and_relu_mask_in_the_data_gradient_epilogue_is_bit_identical_to_the_separate_passes(ops, case, inplace):
+    """training.py FUSE_RELU_SUM_BWD (round 6): for a blob with two readers -- a residual block's output -- the data-gradient conv of
+    the reader that contributes LAST adds the other contribution and applies the ReLU backward of the blob's producer in its own epilogue
+    (`dat_conv3d_fwd_sum_mask`, res_mode 4: dx = x > 0 ? conv + other : 0).  It must give bit for bit what the three-launch path gives
+    -- the data gradient summed into the other contribution (res_mode 1), then `dat_relu_bias_bwd` masking by x -- in place and into a
+    new tensor (the other contribution still read by a queued weight-gradient job), on every kernel that takes such a layer."""
+    (cin, cout, k, stride), (T, H, W), dtype_name = case
+    dt = ops.BF16 if dtype_name == 'bf16' else ops.F32
+    tdt = ops.tdtype(dt)
+    g_ = torch.Generator(device='cuda').manual_seed(cin * 7 + cout)
+    w = torch.randn((cout, cin) + k, device='cuda', generator=g_) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5
+    scale = torch.rand(cout, device='cuda', generator=g_) + 0.5
+    pads = (k[0] // 2, k[1] // 2, k[2] // 2)
+    cs_in, cs_out = ops.round_up(cin, 64), ops.round_up(cout, 64)
+    Ho, Wo = (H + 2 * pads[1] - k[1]) // stride[0] + 1, (W + 2 * pads[2] - k[2]) // stride[1] + 1
+    x = torch.relu(torch.randn((T, H, W, cs_in), device='cuda', generator=g_)).to(tdt)       # the block output: a ReLU output
+    x[..., cin:] = 0
+    g = torch.randn((T, Ho, Wo, cs_out), device='cuda', generator=g_).to(tdt)
+    g[..., cout:] = 0
+    other = torch.randn((T, H, W, cs_in), device='cuda', generator=g_).to(tdt)               # the shortcut's contribution
+    other[..., cin:] = 0
+    cg = ops.ConvGrad(w, scale, stride, pads, dt, cs_in, cs_out)
+    prof = ops.ConvProfiler(capacity=8)
+    summed = cg.data(g, T, H, W, accumulate_into=other.clone())
+    three = ops.relu_bias_bwd(summed, x, dt, cin, relu=True)
+    into = other.clone()
+    prof.start()
+    fused = cg.data(g, T, H, W, accumulate_into=into, mask=x.contiguous(), inplace=inplace)
+    tags = [t for t, _, _ in prof.stop()]
+    assert (fused.data_ptr() == into.data_ptr()) == inplace
+    if not inplace:
+        assert torch.equal(into, other), 'the contribution a queued job still reads was modified'
+    assert torch.equal(fused, three), 'differs in %d elements (kernel tags %r)' % (int((fused != three).sum()), tags)
+    assert float(fused[..., cin:].abs().max()) == 0.0 if cs_in > cin else True
+    assert (fused != 0).any() and ((x == 0) & (summed != 0)).any()
+    if (H, W) == (128, 160) and cin in (512, 1024):
+        assert tags == [2560331], tags          # the weights-in-LDS 1x1 kernel
+    if cin == 2048:
+        assert tags == [2560341], tags          # the K-streaming 1x1 kernel
+
+
 @pytest.mark.parametrize('dtype,direct', [('fp32', False), ('bf16', False), ('bf16', True)])
 def test_overlapped_exchange_over_rccl_with_one_rank_is_the_identity(monkeypatch, dtype, direct):
     """The RCCL side of the overlapped gradient exchange on the one GPU a test box has: a process group of ONE rank (backend nccl =

@@ -1008,7 +1008,7 @@ def test_gradient_contributions_of_a_blob_are_summed_over_their_frame_windows():
     g = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g)
     for dt, tdt in ((ops.F32, torch.float32), (ops.BF16, torch.bfloat16)):
-        ex = types.SimpleNamespace(grads={}, _last_masked=False)
+        ex = types.SimpleNamespace(grads={}, _last_masked=False, _ncontrib={})
         take = lambda name: training.TrainExecutor._take_grad(ex, name, dt)
         assert take('none') == (None, 0)
         # one contribution: the tensor itself, the mask flag survives
