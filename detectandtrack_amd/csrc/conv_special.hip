@@ -473,7 +473,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int r = 0; r < 2; ++r) {
             const unsigned pos = pos0 + (unsigned)(r * 16 + spl);
             live[r] = pos < p.npos;
-            if (p.res_mode) {
+            if (m4) {
+                const unsigned pc = min(pos, p.npos - 1u);
+                rb[r] = p.res + ((size_t)pc * (unsigned)p.out_cs) * 2u;
+                ab[r] = p.res2 + ((size_t)pc * (unsigned)p.out_cs) * 2u;
+            } else if (p.res_mode) {
                 const unsigned pc = min(pos, p.npos - 1u);
                 unsigned rpos = pc;
                 if (p.res_mode == 2) {       // nearest-2x up-sampled coarser map (FPN top-down, FPN3D.py:186-222)
@@ -481,17 +485,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                     const unsigned oh = __umulhi(rem, p.wo_magic), ow = rem - oh * (unsigned)p.Wo;
                     rpos = (fr * (unsigned)(p.Ho >> 1) + (oh >> 1)) * (unsigned)(p.Wo >> 1) + (ow >> 1);
                 }
-                rb[r] = p.res + ((size_t)rpos * (unsigned)p.out_cs) * 2u;
-                ab[r] = p.res2 + ((size_t)pc * (unsigned)p.out_cs) * 2u;
-                if (!m4) {
+                const char* rbl = p.res + ((size_t)rpos * (unsigned)p.out_cs) * 2u;
 #pragma unroll
-                    for (int pass = 0; pass < NPASS; ++pass)
+                for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
-                        for (int mb = 0; mb < MBW; ++mb) {
-                            const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
-                            rr[pass][mb][r] = *(const uint4*)(rb[r] + c * 2u);
-                        }
-                }
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        const unsigned c = (unsigned)min(c_part0 + (pass * MBW + mb) * 32 + sq * 8, p.out_cs - 8);
+                        rr[pass][mb][r] = *(const uint4*)(rbl + c * 2u);
+                    }
             }
         }
 #pragma unroll
@@ -552,13 +553,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                             v[2 * e2] = res_combine4(v[2 * e2], bf2f((uint16_t)(au[e2] & 0xffff)), bf2f((uint16_t)(mu[e2] & 0xffff)));
                             v[2 * e2 + 1] = res_combine4(v[2 * e2 + 1], bf2f((uint16_t)(au[e2] >> 16)), bf2f((uint16_t)(mu[e2] >> 16)));
                         }
-                    } else if (p.res_mode) {            // modes 1 / 2: Sum; mode 3: MASK (res_combine)
+                    } else if (p.res_mode) {            // modes 1 / 2: Sum (mode 3 layers stay on the generic kernel: dat_conv3d_fwd's dispatcher)
                         const uint4 q = rr[pass][mb][r];
                         const uint32_t ru[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int e2 = 0; e2 < 4; ++e2) {
-                            v[2 * e2] = res_combine(v[2 * e2], bf2f((uint16_t)(ru[e2] & 0xffff)), p.res_mode);
-                            v[2 * e2 + 1] = res_combine(v[2 * e2 + 1], bf2f((uint16_t)(ru[e2] >> 16)), p.res_mode);
+                            v[2 * e2] += bf2f((uint16_t)(ru[e2] & 0xffff));
+                            v[2 * e2 + 1] += bf2f((uint16_t)(ru[e2] >> 16));
                         }
                     }
                     if (p.relu) {
