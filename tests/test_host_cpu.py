@@ -1279,7 +1279,8 @@ def test_cfg_has_every_key_and_default_of_the_real_reference_config():
     assert not missing, 'reference config keys without a counterpart: %s' % missing
     extra = sorted(k for k in set(mine) - set(ref) if not k.startswith('HIP.'))
     assert not extra, 'keys the reference does not have (outside HIP.*): %s' % extra
-    site_paths = {'EXT_PATHS.POSEVAL_CODE_PATH', 'VOC_DIR'}
+    site_paths = {'EXT_PATHS.POSEVAL_CODE_PATH', 'VOC_DIR', 'ROOT_DIR'}     # (ROOT_DIR = wherever the tree lies: checked on the next line)
+    assert os.path.realpath(mine['ROOT_DIR']) == os.path.realpath(REPO)
     diff = [(k, ref[k], mine[k]) for k in sorted(ref) if k not in site_paths and json.loads(json.dumps(mine[k])) != ref[k]]
     assert not diff, 'defaults that differ from the reference: %s' % diff[:10]
     assert cfg.RPN.ON is False
