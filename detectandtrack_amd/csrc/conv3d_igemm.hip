@@ -1094,7 +1094,7 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     long long bt_blocks = 0;
     if (bt_eligible(ctx, d)) bt_tile_twl(p, &bt_blocks);
     const long long ncu = ctx_num_cu(ctx), bt_rounds = cdiv_ll(bt_blocks, ncu);
-    const bool bt_fits = ctx->dbg_bt >= 2 ? bt_blocks * 2 >= 3 * ncu : (bt_blocks * 100 >= 390 * ncu && bt_blocks * 100 >= bt_rounds * ncu * 95);   // (3.9: conv_rpn_fpn2 at 4 clips is 1 008 blocks on 256 CUs)
+    const bool bt_fits = ctx->dbg_bt >= 2 ? bt_blocks * 2 >= 3 * ncu : (bt_blocks * 100 >= (long long)ctx->dbg_bt_min * ncu && bt_blocks * 100 >= bt_rounds * ncu * 95);   // (3.9: conv_rpn_fpn2 at 4 clips is 1 008 blocks on 256 CUs)
     const bool mask_mode = d->res_mode >= 3;     // the masking combines (3: mask, 4: in-place sum + mask) live in the generic kernel and the lw / ks 1x1 kernels
     if (bt_fits && ksplit == 1 && !force_bp && !force_ks && !mask_mode) {
         tag = 256 * 10000 + 2560 + d->dtype;
