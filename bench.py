@@ -893,6 +893,8 @@ def main():
             _dbg('graph sequential pass done')
         seq = ClipPipeline(model, w0, 1, graph=False, keep_results=False)   # eager, per-launch events: the durations the roofline is computed from
         seq.slots = [pipe.slots[0]]
+        with torch.cuda.stream(st0):        # one forward at a time from here on: the persistent kernels get the whole chip back (in the timed
+            ops.persistent_share(100)       # region they ran on cfg.HIP.PERSISTENT_CU_SHARE percent of it, beside the other forwards)
         w0.conv_log = []
         with torch.cuda.stream(st0):
             pr = ops.ConvProfiler(capacity=cap)
@@ -1148,6 +1150,8 @@ def main():
                    'forwards_in_flight': 1 if train else a.pipeline, 'clips_in_flight': 1 if train else a.pipeline * clips_per_step,
                    'keyframe_dce': bool(a.keyframe_dce),
                    'hip_graph': bool(graph_on),
+                   # share of the CUs the persistent HBM-bound conv kernels take while several forwards are in flight (cfg.HIP.PERSISTENT_CU_SHARE)
+                   'persistent_kernel_cu_share_percent': 100 if train else int(getattr(pipe, 'persistent_share', 100)),
                    # since round 4 the benched graphs read the caller's resident input buffers IN PLACE (rounds 1-3 copied the 99 MB
                    # per clip device-to-device into a private graph input first): `value` is not comparable with rounds 1-3 by that copy
                    'resident_input': bool(resident_in) if not train else True,

@@ -264,6 +264,9 @@ def _build_defaults():
     # communication stream while the backward of the earlier layers continues (training.py); False = one exchange after the backward
     # FUSE_RELU_BWD (training): the ReLU backward of a blob with ONE reader is applied in the epilogue of that reader's data-gradient
     # conv (dat_conv3d_fwd res_mode 3) instead of a separate elementwise pass; identical gradients
+    # PERSISTENT_CU_SHARE (pipelined inference engine, round 6): percent of the CUs the persistent HBM-bound conv kernels (one block per CU) take
+    # while SEVERAL forwards are in flight (core/pipeline.py, depth >= 2): the other forwards' MFMA-bound kernels run beside them on the CUs
+    # they leave (same box: R-50 forward +0.8 %, 2d_best +1.4 %, R-18 +0.3 %; a lone forward or a training iteration keeps 100)
     # FUSE_RELU_SUM_BWD (training, round 6): for a blob with TWO readers (a residual block's output) the data-gradient conv of the reader that
     # contributes last adds the other contribution AND applies the ReLU backward in its epilogue (dat_conv3d_fwd_sum_mask, res_mode 4)
     # WGRAD_PW_BATCH (training, with DEFER_WGRAD_FINISH): the weight gradients of up to this many POINTWISE convs (1 x 1 x 1) are queued and
@@ -280,7 +283,7 @@ def _build_defaults():
     # creates the full [T*C, T*K, 4, 4] filter) would execute -- the argument is dropped and the deconv is dense over T*C -> T*K channels
     c.HIP = AttrDict({'DTYPE': 'bf16', 'KEYFRAME_DCE': False, 'DEVICE_KPS_DECODE': True, 'FRAME_TRUNK_CACHE': 0,
                       'DEVICE_BOX_RESULTS': True, 'FUSE_STEM_POOL': True, 'RCCL_DIRECT': False,
-                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'FUSE_RELU_SUM_BWD': True, 'DET_SPARE_ROWS': 4,
+                      'PIPELINE_DEPTH': 4, 'CLIP_GRAPH': True, 'IMS_PER_FORWARD': 1, 'FUSE_RELU_BWD': True, 'FUSE_RELU_SUM_BWD': True, 'PERSISTENT_CU_SHARE': 50, 'DET_SPARE_ROWS': 4,
                       'DEFER_WGRAD_FINISH': True, 'MAX_GRAPHS_PER_SLOT': 6, 'PAD_TAIL_FORWARD': True,
                       'OVERLAP_ALLREDUCE': True, 'WGRAD_PW_BATCH': 16, 'DEVICE_ROI_SAMPLING': True, 'DECONV_GROUP_IGNORED': False, 'STEM_FROM_UINT8': True})
     return c

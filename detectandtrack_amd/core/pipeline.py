@@ -46,6 +46,12 @@ def _cu_masked_stream(spec):
     return torch.cuda.ExternalStream(st.value)
 
 
+def _set_share(stream, percent):
+    from detectandtrack_amd.ops import hip_ops as ops
+    with torch.cuda.stream(stream):
+        ops.persistent_share(max(1, min(100, int(percent))))
+
+
 class _Slot(object):
     __slots__ = ('ws', 'stream', 'event', 'copy_event', 'graphs', 'pinned', 'dev_u8', 'u8', 'data', 'live', 'gather_event')
     _made = 0
@@ -205,6 +211,12 @@ class ClipPipeline(object):
         self.graphs_captured = self.graphs_evicted = 0
         self.model, self.depth = model, depth
         self.slots = [_Slot(ws if i == 0 else ws.fork()) for i in range(depth)]
+        # several forwards in flight: their persistent HBM-bound conv kernels take a share of the CUs (cfg.HIP.PERSISTENT_CU_SHARE) so that
+        # the other forwards' MFMA-bound kernels run beside them; a lone forward keeps the whole chip.  (Set on every slot's own context:
+        # pooled stream handles recur, so depth 1 resets it.)
+        self.persistent_share = int(os.environ.get('DAT_PERSISTENT_CU_SHARE', cfg.HIP.get('PERSISTENT_CU_SHARE', 100))) if depth >= 2 else 100
+        for s_ in self.slots:
+            _set_share(s_.stream, self.persistent_share)
         self.copy_stream = torch.cuda.Stream()
         self.free = list(range(depth))
         self.use_graph = bool(graph)
@@ -312,6 +324,7 @@ class ClipPipeline(object):
         want = max(int(cfg.HIP.FRAME_TRUNK_CACHE), 2 * B * T)
         if self.trunk is None:
             self.trunk = FrameTrunkCache(self.model, self.slots[0].ws, want)
+            _set_share(self.trunk.stream, self.persistent_share)     # (the prefix runs beside the slots' forwards)
         tr = self.trunk
         if (tr.pool is not None and (h, w) != tr._hw) or want > tr.capacity:
             # frames of another size (the next video) or a larger forward: one pool holds one geometry.  Finish what is in flight (results are

@@ -73,6 +73,7 @@ int dat_ctx_create(dat_ctx** out, int device) {
         c->dbg_kps_sep = env_int("DAT_KPS_DECODE_SEP", 1);
         c->dbg_linear = env_int("DAT_CONV_LINEAR", 1);
         c->dbg_order = env_int("DAT_CONV_ORDER", 0);
+        c->dbg_persist_pct = env_int("DAT_PERSIST_PCT", 100);
         c->dbg_bt_min = env_int("DAT_CONV_BT_MIN", 390);   // smallest grid of the big-tile kernel, in hundredths of a round of the CUs
         c->dbg_bt = env_int("DAT_CONV_BT", 1);   // round 6: on for grids of >= 3.9 even rounds (FPN P2 output conv, conv_rpn_fpn2): +1.3 % on the R-18 forward, same box
         c->dbg_roi_fold = env_int("DAT_ROI_BWD_FOLD", 1);

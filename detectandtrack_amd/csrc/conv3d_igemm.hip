@@ -1175,6 +1175,13 @@ static int conv3d_fwd_impl(dat_ctx* ctx, dat_stream s, const dat_conv_desc* d, c
     return rc;
 }
 
+int dat_conv3d_persistent_share(dat_ctx* ctx, int percent) {
+    if (!ctx) return DAT_ERR_ARG;
+    DAT_ENFORCE(ctx, percent >= 1 && percent <= 100, "conv3d_persistent_share: %d percent out of range", percent);
+    ctx->dbg_persist_pct = percent;
+    return DAT_OK;
+}
+
 int dat_conv3d_tune_plan(dat_ctx* ctx, int positions_per_block, int ksplit) {
     if (!ctx) return DAT_ERR_ARG;
     DAT_ENFORCE(ctx, (positions_per_block == 0 || positions_per_block == 128 || positions_per_block == 256) && ksplit >= 0 && ksplit <= 8,

@@ -1071,6 +1071,15 @@ bool ws64_eligible(const dat_ctx* ctx, const dat_conv_desc* d) {
            d->out_tn <= 0 && d->out_cstride % 8 == 0 && weights_direct(ctx, d);
 }
 
+// CUs a persistent HBM-bound kernel (one block per CU) takes: all of them, or DAT_PERSIST_PCT percent (an experiment: does leaving CUs to the
+// other forwards' MFMA kernels raise the step rate?), rounded down to a multiple of `mult`
+int ctx_num_cu(dat_ctx* ctx);
+static long long persist_cus(dat_ctx* ctx, int mult) {
+    long long n = ctx_num_cu(ctx);
+    if (ctx->dbg_persist_pct > 0 && ctx->dbg_persist_pct < 100) n = std::max<long long>(mult, n * ctx->dbg_persist_pct / 100 / mult * mult);
+    return n;
+}
+
 int ctx_num_cu(dat_ctx* ctx) {
     if (ctx->num_cu == 0) {
         int dev = 0, n = 0;
@@ -1145,7 +1154,7 @@ int launch_pw256(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     p.ntiles = (int)ntiles;
     p.hw = (unsigned)(cp.H * cp.W);
     p.w_magic = cp.W == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)cp.W - 1) / (unsigned)cp.W);
-    const unsigned grid = (unsigned)std::min<long long>(cdiv_ll(ntiles, 4), ctx_num_cu(ctx));
+    const unsigned grid = (unsigned)std::min<long long>(cdiv_ll(ntiles, 4), persist_cus(ctx, 8));
     const size_t lds = (size_t)4 * 32 * (256 * 4 + 16);
     if (dat_ensure_lds(ctx, (const void*)conv1x1_k64_c256_ws_kernel, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
     hipLaunchKernelGGL(conv1x1_k64_c256_ws_kernel, dim3(grid), dim3(NTHREADS), lds, st, p);
@@ -1208,7 +1217,7 @@ int launch_pwlw(dat_ctx* ctx, hipStream_t st, const ConvParams& cp, const dat_co
     p.nsplit = lw_nsplit(d); p.mb_total = cp.Cout_pad / 32;
     const int kc = cp.Cin / 64, mbp = p.mb_total / p.nsplit;
     const int mbw = kc <= 4 ? std::min(mbp, 8) : std::min(mbp, 4), npass = mbp / mbw;
-    const long long per_part = std::min<long long>(cdiv_ll(p.ntiles, 4), ctx->num_cu / p.nsplit);
+    const long long per_part = std::min<long long>(cdiv_ll(p.ntiles, 4), persist_cus(ctx, 8 * p.nsplit) / p.nsplit);
     const unsigned grid = (unsigned)(per_part * p.nsplit);
     p.xcd = ctx->dbg_pw_xcd && p.nsplit > 1 && grid % (8u * (unsigned)p.nsplit) == 0;
     const size_t lds = (size_t)kc * mbp * 4096 + (size_t)mbp * 32 * 8 + 4 * 32 * (32 * 4 + 16);
@@ -1287,7 +1296,7 @@ int launch_ws64(dat_ctx* ctx, hipStream_t st, const ConvParams& cp) {
     p.ntiles = (int)best_tiles;
     const int npiece = ((th + 2) * (tw + 2) * 8 + 63) / 64;
     const size_t lds = (size_t)2 * npiece * 1024 + 4 * 32 * (64 * 4 + 16);
-    const unsigned grid = (unsigned)std::min<long long>(best_tiles, ctx->num_cu);
+    const unsigned grid = (unsigned)std::min<long long>(best_tiles, persist_cus(ctx, 8));
     if (best_twl == 5) {
         if (dat_ensure_lds(ctx, (const void*)conv3x3_c64_ws_kernel<5>, 160 * 1024) != DAT_OK) return DAT_ERR_LAUNCH;
         hipLaunchKernelGGL(conv3x3_c64_ws_kernel<5>, dim3(grid), dim3(NTHREADS), lds, st, p);

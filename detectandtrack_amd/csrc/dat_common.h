@@ -36,6 +36,7 @@ struct dat_ctx {
     int dbg_pack_simple;                    // DAT_PACK_SIMPLE (default 0): element-wise weight packing instead of the LDS-tiled kernel
     int dbg_linear;                         // DAT_CONV_LINEAR (default 1): linear position tiling of small maps (RoI-head 3x3 convs on 14 x 14 maps); 5 = also the 320-position one-block-per-CU tiles
     int dbg_order;                          // DAT_CONV_ORDER (default 0): block order of the implicit-GEMM conv inside an XCD's queue, 0 patch-sharing, 1 weight-stationary (less fabric traffic, slower)
+    int dbg_persist_pct;                    // DAT_PERSIST_PCT (default 100): percent of the CUs the persistent HBM-bound conv kernels take (experiment)
     int dbg_bt_min;                         // DAT_CONV_BT_MIN (default 390): the big-tile kernel takes grids of at least this many hundredths of a round of the CUs
     int dbg_bt;                             // DAT_CONV_BT (default 1 = on for evenly filling grids of >= 3.9 rounds; 0 = off): big-tile (256 x 256, one wave per SIMD) kernel for 3x3 layers with 256-channel-multiple outputs and an evenly filling grid; 2 = for every grid of >= 1.5 blocks per CU (tests)
     int dbg_ws64;                           // DAT_CONV_WS64 (default 1): weights-stationary persistent kernel for 3x3 64 -> 64 bf16 layers

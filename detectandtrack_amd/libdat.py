@@ -104,6 +104,7 @@ _PROTOS = {
     'dat_conv3d_fwd_x3': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     'dat_conv3d_fwd_sum_mask': (_i, [_p, _p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p]),
     'dat_conv3d_tune_plan': (_i, [_p, _i, _i]),
+    'dat_conv3d_persistent_share': (_i, [_p, _i]),
     'dat_conv3d_flops': (_d, [C.POINTER(ConvDesc), _i, _i]),
     'dat_stem_pack': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'dat_stem_weights': (_i, [_p, _p, _p, _i, _p]),

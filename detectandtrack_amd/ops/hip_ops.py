@@ -89,6 +89,12 @@ def tune_plan(positions_per_block, ksplit):
     return L._lib.dat_conv3d_tune_plan(ctx().h, int(positions_per_block), int(ksplit))
 
 
+def persistent_share(percent):
+    """dat_conv3d_persistent_share on the context of the current (device, stream): the share of the CUs the persistent HBM-bound conv
+    kernels launched on THAT context take (core/pipeline.py lowers it while several forwards are in flight)."""
+    ctx().call('dat_conv3d_persistent_share', int(percent))
+
+
 # ---- toy + AffineChannelNd (the reference's own native ops) ---------------------------------------
 def zero_even(x):
     """In-place ZeroEven on a 1-D fp32 tensor (lib/ops/zero_even_op.cc:17-30 semantics)."""

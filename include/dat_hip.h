@@ -341,6 +341,11 @@ int dat_kps_finalize(dat_ctx* ctx, dat_stream s, int dtype, const void* sub, int
  * Per-context state (no process globals): other contexts / devices of the process are unaffected.  Used by
  * tools/tune_plan.py to check the model against measured per-layer timings. */
 int dat_conv3d_tune_plan(dat_ctx* ctx, int positions_per_block, int ksplit);
+/* Engine hook (not a reference interface): the share of the CUs the PERSISTENT HBM-bound conv kernels (one block per CU: res2's 3x3
+ * convs, the 64 -> 256 lateral, the weights-in-LDS 1x1 kernel) launched ON THIS CONTEXT take, 1..100 percent (default 100, or
+ * DAT_PERSIST_PCT).  An engine that keeps several forwards in flight on their own streams lowers it so that the other forwards'
+ * MFMA-bound kernels find free CUs beside them (core/pipeline.py: cfg.HIP.PERSISTENT_CU_SHARE); results do not depend on it. */
+int dat_conv3d_persistent_share(dat_ctx* ctx, int percent);
 
 /* ---- conv1, fused (ResNet3D.py:258-262): ConvNd [1,7,7] / [1,2,2] / pad [0,3,3] on `data` fp32 [N,3,T,H,W] + AffineChannelNd
  * (scale, bias: fp32 [64] or NULL) + ReLU -> out [N*T, Ho, Wo, 64] in `dtype`; weights packed once by

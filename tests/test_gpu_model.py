@@ -728,3 +728,30 @@ def test_pipeline_graphs_that_read_resident_inputs_in_place():
     same(run(a, True), ref[2])
     same(run(b, False), ref[1])                         # the copying path: a third graph with a private input
     assert pipe.graphs_captured == 3
+
+
+@pytest.mark.gpu
+def test_persistent_kernel_cu_share_does_not_change_results():
+    """cfg.HIP.PERSISTENT_CU_SHARE (dat_conv3d_persistent_share, round 6): the pipelined engine gives the persistent HBM-bound conv kernels
+    (res2's 3x3 convs, the P2 lateral, the weights-in-LDS 1x1 kernel) half of the CUs while several forwards are in flight.  Only the grid
+    of those kernels changes: a layer's output is bit-identical at 100, 50 and 13 percent, one and two cout parts, with a residual."""
+    from detectandtrack_amd.ops import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    cases = [(64, 64, (1, 3, 3), (0, 1, 1), False), (64, 256, (1, 1, 1), (0, 0, 0), True), (256, 64, (1, 1, 1), (0, 0, 0), False),
+             (256, 1024, (1, 1, 1), (0, 0, 0), True)]
+    T, H, W = 2, 96, 168
+    for cin, cout, k, pads, with_res in cases:
+        w = (torch.randn((cout, cin) + k, generator=g) * (2.0 / (cin * k[1] * k[2])) ** 0.5).cuda()
+        layer = ops.ConvLayer(w, None, torch.zeros(cout).cuda(), stride=(1, 1), pads=pads, relu=True, dtype=ops.BF16)
+        x = torch.randn((T, H, W, cin), generator=g).bfloat16().cuda()
+        res = torch.randn((T, H, W, cout), generator=g).bfloat16().cuda() if with_res else None
+        outs = []
+        try:
+            for pct in (100, 50, 13):
+                ops.persistent_share(pct)
+                outs.append(layer(x, T=T, residual=res).clone())
+        finally:
+            ops.persistent_share(100)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (cin, cout, k)
+    with pytest.raises(Exception):
+        ops.persistent_share(0)
